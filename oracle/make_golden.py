@@ -1,0 +1,321 @@
+"""Generate tests/golden/*.npz from the upstream reference and validate the oracle against it.
+
+TEST INFRASTRUCTURE -- runs only in the build container (needs /root/reference):
+
+    python oracle/make_golden.py            # check oracle vs reference, then (re)write fixtures
+
+A fixture is data only: seeds / small inputs and the reference's outputs.  Inputs that are large
+are regenerated from a seed by `oracle/synth.py` (the build's own generator) on both sides.
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refshim  # noqa: E402
+import prifit_oracle as orc  # noqa: E402
+import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@contextlib.contextmanager
+def fixed_randint(values):
+    """Make the reference's `torch.randint(0, N, (B,))` (pointnet_util.py:75) return chosen starts."""
+    queue = [v.clone() for v in values]
+    real = torch.randint
+
+    def fake(*a, **k):
+        return queue.pop(0)
+
+    torch.randint = fake
+    try:
+        yield
+    finally:
+        torch.randint = real
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print("  wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def eq(a, b, what):
+    assert torch.equal(a, b), "MISMATCH (exact) " + what
+    print("  ok (bit-exact)  " + what)
+
+
+def close(a, b, what, rtol=1e-5, atol=1e-6):
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, "MISMATCH %s: max|diff|=%g (ref max %g)" % (what, err, ref)
+    print("  ok (%.1e)      %s" % (err, what))
+
+
+# ----------------------------------------------------------------------------------------------
+def golden_index_ops():
+    """FPS / ball query / 3-NN / square_distance on both synthetic distributions."""
+    pu = refshim.ref("models.pointnet_util")
+    print("[index ops]")
+    for kind in ("cube", "surface"):
+        for N, tag in ((2048, "n2048"), (1024, "n1024")):
+            B = 4
+            seed = {"cube": 1, "surface": 2}[kind] * 10 + (N // 1024)
+            xyz = torch.from_numpy(synth.cloud(kind, B, N, seed))
+            start1 = torch.from_numpy(synth.fps_start(B, N, seed))
+            with fixed_randint([start1]):
+                f1 = pu.farthest_point_sample(xyz, 512)
+            eq(orc.farthest_point_sample(xyz, 512, start1), f1, f"fps torch {kind} {tag}")
+            eq(orc.c_farthest_point_sample(xyz, 512, start1), f1, f"fps C     {kind} {tag}")
+            c1 = pu.index_points(xyz, f1)
+            start2 = torch.from_numpy(synth.fps_start(B, 512, seed + 100))
+            with fixed_randint([start2]):
+                f2 = pu.farthest_point_sample(c1, 128)
+            eq(orc.c_farthest_point_sample(c1, 128, start2), f2, f"fps2 C    {kind} {tag}")
+            c2 = pu.index_points(c1, f2)
+            out = {"seed": seed, "start1": start1, "fps1": f1.to(torch.int16), "start2": start2,
+                   "fps2": f2.to(torch.int16)}
+            # MSG radii (sa1 on xyz/c1, sa2 on c1/c2) + SSG radii (cfg 1)
+            cases = [("sa1", xyz, c1, [(0.1, 32), (0.2, 64), (0.4, 128), (0.2, 32)]),
+                     ("sa2", c1, c2, [(0.4, 64), (0.8, 128), (0.4, 64)])]
+            for lname, pts, ctr, rs in cases:
+                for (r, k) in rs:
+                    g = pu.query_ball_point(r, k, pts, ctr)
+                    eq(orc.query_ball_point(r, k, pts, ctr), g, f"ball torch {kind} {tag} {lname} r={r}")
+                    eq(orc.c_query_ball_point(r, k, pts, ctr), g, f"ball C     {kind} {tag} {lname} r={r}")
+                    # store a checksum + a slice (full tensors are large): rows 0..63 of each shape
+                    out[f"ball_{lname}_{r}_{k}_head"] = g[:, :64].to(torch.int16)
+                    out[f"ball_{lname}_{r}_{k}_sum"] = g.sum(dim=(1, 2))
+                    out[f"ball_{lname}_{r}_{k}_wsum"] = (g * (torch.arange(k) + 1)).sum(dim=(1, 2))
+            # 3-NN as in fp1 (xyz <- c1) and fp2 (c1 <- c2)
+            for lname, a, b in (("fp1", xyz, c1), ("fp2", c1, c2)):
+                d = pu.square_distance(a, b)
+                eq(orc.square_distance(a, b), d, f"sqdist torch {kind} {tag} {lname}")
+                eq(orc.c_square_distance(a, b), d, f"sqdist C     {kind} {tag} {lname}")
+                ds, ix = d.sort(dim=-1)
+                ds, ix = ds[:, :, :3], ix[:, :, :3]
+                d3, i3 = orc.c_three_nn(a, b)
+                eq(i3, ix, f"3nn idx C {kind} {tag} {lname}")
+                eq(d3, ds, f"3nn d   C {kind} {tag} {lname}")
+                out[f"nn3_{lname}_idx"] = ix.to(torch.int16)
+                out[f"nn3_{lname}_d"] = ds
+            out["sqdist_fp2_head"] = pu.square_distance(c1, c2)[:2, :128]
+            save(f"index_{kind}_{tag}", **out)
+
+
+def copy_state(dst, src):
+    missing = dst.load_state_dict(src.state_dict(), strict=True)
+    return missing
+
+
+def golden_modules():
+    """SA-MSG / SA(group_all) / FP modules: fwd outputs + grads with shared seeded parameters."""
+    pu = refshim.ref("models.pointnet_util")
+    print("[modules]")
+    B, N = 2, 512
+    seed = 5
+    xyz = torch.from_numpy(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
+    feat = torch.from_numpy(synth.features(B, N, 16, seed)).transpose(1, 2).contiguous()
+    start = torch.from_numpy(synth.fps_start(B, N, seed))
+
+    torch.manual_seed(11)
+    ref_sa = pu.PointNetSetAbstractionMsg(64, [0.2, 0.4], [8, 16], 16, [[16, 32], [16, 24, 32]])
+    synth.perturb_bn(ref_sa, 3)
+    my_sa = orc.OracleSetAbstractionMsg(64, [0.2, 0.4], [8, 16], 16, [[16, 32], [16, 24, 32]])
+    copy_state(my_sa, ref_sa)
+    f_ref = feat.clone().requires_grad_(True)
+    with fixed_randint([start]):
+        rx, rp = ref_sa(xyz, f_ref)
+    gout = torch.from_numpy(synth.features(B, 64, rp.shape[1], seed + 1)).transpose(1, 2)
+    (rp * gout).sum().backward()
+    f_my = feat.clone().requires_grad_(True)
+    mx, mp = my_sa(xyz, f_my, start)
+    (mp * gout).sum().backward()
+    eq(mx, rx, "sa_msg new_xyz")
+    close(mp, rp, "sa_msg out")
+    close(f_my.grad, f_ref.grad, "sa_msg dfeat", rtol=1e-4)
+    gw = {k: p.grad for k, p in ref_sa.named_parameters()}
+    # conv biases feed a train-mode BN, so their true gradient is 0 and what is left is rounding
+    # noise: use an absolute tolerance scaled by the largest gradient of the module.
+    gmax = max(v.abs().max().item() for v in gw.values())
+    for k, p in my_sa.named_parameters():
+        close(p.grad, gw[k], "sa_msg d" + k, rtol=2e-4, atol=2e-5 * gmax)
+    save("module_sa_msg", seed=seed, start=start, new_xyz=rx, out=rp, dfeat=f_ref.grad,
+         running_mean_00=ref_sa.bn_blocks[0][0].running_mean, running_var_00=ref_sa.bn_blocks[0][0].running_var,
+         **{"g_" + k: v for k, v in gw.items()})
+
+    # group_all SA
+    torch.manual_seed(12)
+    ref_ga = pu.PointNetSetAbstraction(None, None, None, 16 + 3, [32, 64], True)
+    synth.perturb_bn(ref_ga, 4)
+    my_ga = orc.OracleSetAbstraction(None, None, None, 16 + 3, [32, 64], True)
+    copy_state(my_ga, ref_ga)
+    f_ref = feat.clone().requires_grad_(True)
+    _, rp = ref_ga(xyz, f_ref)
+    g2 = torch.from_numpy(synth.features(B, 1, 64, seed + 2)).transpose(1, 2)
+    (rp * g2).sum().backward()
+    f_my = feat.clone().requires_grad_(True)
+    _, mp = my_ga(xyz, f_my)
+    (mp * g2).sum().backward()
+    close(mp, rp, "sa_all out")
+    close(f_my.grad, f_ref.grad, "sa_all dfeat", rtol=1e-4)
+    save("module_sa_all", seed=seed, out=rp, dfeat=f_ref.grad,
+         **{"g_" + k: p.grad for k, p in ref_ga.named_parameters()})
+
+    # SSG SA (cfg 1 concat order)
+    torch.manual_seed(13)
+    ref_ss = pu.PointNetSetAbstraction(64, 0.3, 16, 16 + 3, [32, 64], False)
+    synth.perturb_bn(ref_ss, 5)
+    my_ss = orc.OracleSetAbstraction(64, 0.3, 16, 16 + 3, [32, 64], False)
+    copy_state(my_ss, ref_ss)
+    f_ref = feat.clone().requires_grad_(True)
+    with fixed_randint([start]):
+        rx, rp = ref_ss(xyz, f_ref)
+    g3 = torch.from_numpy(synth.features(B, 64, 64, seed + 3)).transpose(1, 2)
+    (rp * g3).sum().backward()
+    f_my = feat.clone().requires_grad_(True)
+    mx, mp = my_ss(xyz, f_my, start)
+    (mp * g3).sum().backward()
+    eq(mx, rx, "sa_ssg new_xyz")
+    close(mp, rp, "sa_ssg out")
+    close(f_my.grad, f_ref.grad, "sa_ssg dfeat", rtol=1e-4)
+    save("module_sa_ssg", seed=seed, start=start, out=rp, dfeat=f_ref.grad,
+         **{"g_" + k: p.grad for k, p in ref_ss.named_parameters()})
+
+    # FP (3-NN branch and S==1 branch)
+    torch.manual_seed(14)
+    S = 64
+    xyz2 = xyz[:, :, :S].contiguous()
+    p1 = torch.from_numpy(synth.features(B, N, 8, seed + 4)).transpose(1, 2).contiguous()
+    p2 = torch.from_numpy(synth.features(B, S, 24, seed + 5)).transpose(1, 2).contiguous()
+    ref_fp = pu.PointNetFeaturePropagation(32, [32, 16])
+    synth.perturb_bn(ref_fp, 6)
+    my_fp = orc.OracleFeaturePropagation(32, [32, 16])
+    copy_state(my_fp, ref_fp)
+    a1, a2 = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    ro = ref_fp(xyz, xyz2, a1, a2)
+    g4 = torch.from_numpy(synth.features(B, N, 16, seed + 6)).transpose(1, 2)
+    (ro * g4).sum().backward()
+    b1, b2 = p1.clone().requires_grad_(True), p2.clone().requires_grad_(True)
+    mo = my_fp(xyz, xyz2, b1, b2)
+    (mo * g4).sum().backward()
+    close(mo, ro, "fp out")
+    close(b1.grad, a1.grad, "fp dpoints1", rtol=1e-4)
+    close(b2.grad, a2.grad, "fp dpoints2", rtol=1e-4)
+    save("module_fp", seed=seed, out=ro, dpoints1=a1.grad, dpoints2=a2.grad,
+         **{"g_" + k: p.grad for k, p in ref_fp.named_parameters()})
+
+    p2g = p2[:, :, :1].contiguous()
+    a1, a2 = p1.clone().requires_grad_(True), p2g.clone().requires_grad_(True)
+    ro = ref_fp(xyz, xyz2[:, :, :1], a1, a2)
+    (ro * g4).sum().backward()
+    b1, b2 = p1.clone().requires_grad_(True), p2g.clone().requires_grad_(True)
+    mo = my_fp(xyz, xyz2[:, :, :1], b1, b2)
+    (mo * g4).sum().backward()
+    close(mo, ro, "fp(S=1) out")
+    close(b2.grad, a2.grad, "fp(S=1) dpoints2", rtol=1e-4)
+    save("module_fp_s1", seed=seed, out=ro, dpoints2=a2.grad)
+
+
+def golden_model():
+    """Full MSG part-seg network, B=2 x 2048, supervised step (train_partseg_shapenet.py:382-399)."""
+    print("[model]")
+    M = refshim.ref("models.pretrain_pointnet2_part_seg_msg")
+    B, N = 2, 2048
+    seed = 7
+    torch.manual_seed(21)
+    ref_net = M.get_model(50)
+    synth.xavier_like_trainer(ref_net)
+    synth.perturb_bn(ref_net, 8)
+    my_net = orc.OracleMSGPartSeg(50)
+    copy_state(my_net, ref_net)
+    for net in (ref_net, my_net):
+        net.train()
+        net.drop1.eval()  # compare with dropout off, BN in train mode
+    xyz = torch.from_numpy(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
+    cls = torch.zeros(B, 1, 16)
+    cls[:, 0, 3] = 1.0
+    target = torch.from_numpy(synth.labels(B, N, 50, seed))
+    s1 = torch.from_numpy(synth.fps_start(B, N, seed))
+    s2 = torch.from_numpy(synth.fps_start(B, 512, seed + 100))
+    with fixed_randint([s1, s2]):
+        rseg, (rl1, rl2, rl3), rfeat, _, _ = ref_net(xyz, cls)
+    rloss = M.get_loss()(rseg.contiguous().view(-1, 50), target.view(-1), None)
+    rloss.backward()
+    mseg, (ml1, ml2, ml3), mfeat, _, _ = my_net(xyz, cls, fps_start=(s1, s2))
+    mloss = orc.seg_loss(mseg.contiguous().view(-1, 50), target.view(-1))
+    mloss.backward()
+    close(mseg, rseg, "model seg log-probs", rtol=1e-4, atol=1e-5)
+    close(mfeat, rfeat, "model feat", rtol=1e-4, atol=1e-5)
+    close(ml3, rl3, "model l3", rtol=1e-4, atol=1e-5)
+    close(mloss, rloss, "model CE loss", rtol=1e-5)
+    rg = {k: p.grad for k, p in ref_net.named_parameters()}
+    gmax = max(v.abs().max().item() for v in rg.values() if v is not None)
+    gn = {}
+    for k, p in my_net.named_parameters():
+        if rg[k] is None:
+            assert p.grad is None or p.grad.abs().max() == 0, k
+            continue
+        gn[k] = rg[k].norm().item()
+        # Whole-network gradients are only reproducible to ~1e-2 in fp32: 1e-5 forward differences
+        # (summation order) flip a few ReLU masks / max-pool winners, and the CE gradient sums cancel
+        # heavily.  Measured here: reference-fp32 vs an fp64 run of this oracle differs by 2.5e-3 on
+        # sa1.conv_blocks.0.0.weight.  Per-module fixtures (module_*.npz) carry the tight tolerances.
+        if k.endswith(".bias") and ("conv" in k) and k != "conv2.bias":
+            continue  # bias in front of a train-mode BN: true gradient is 0, value is noise
+        rel = ((p.grad - rg[k]).norm() / rg[k].norm()).item()
+        assert rel < 3e-2, (k, rel)
+    names = sorted(gn)
+    save("model_msg_sup", seed=seed, s1=s1, s2=s2, loss=rloss.detach(), seg_head=rseg[:, :64].detach(),
+         seg_sum=rseg.detach().sum(dim=1), feat_head=rfeat[:, :, :64].detach(), l3=rl3.detach(),
+         l2_head=rl2[:, :, :16].detach(), grad_names=np.array(names), grad_norms=np.array([gn[k] for k in names]),
+         g_conv2_weight=rg["conv2.weight"], g_sa1_first=rg["sa1.conv_blocks.0.0.weight"],
+         g_fp1_last=rg["fp1.mlp_convs.1.weight"])
+
+    # cfg 1: SSG plumbing case, 4 x 1024 (models/pointnet2_part_seg_ssg.py)
+    S = refshim.ref("models.pointnet2_part_seg_ssg")
+    torch.manual_seed(22)
+    ssg = S.get_model(50)
+    ssg.train()
+    ssg.drop1.eval()
+    xyz4 = torch.from_numpy(synth.cloud("cube", 4, 1024, 9)).transpose(1, 2).contiguous()
+    t1 = torch.from_numpy(synth.fps_start(4, 1024, 9))
+    t2 = torch.from_numpy(synth.fps_start(4, 512, 109))
+    with fixed_randint([t1, t2]):
+        sseg, sl3 = ssg(xyz4, torch.zeros(4, 1, 16))
+    torch.manual_seed(22)  # same construction order => same seeded init (checked here)
+    my_ssg = orc.OracleSSGPartSeg(50)
+    for (ka, va), (kb, vb) in zip(ssg.named_parameters(), my_ssg.named_parameters()):
+        assert ka == kb and torch.equal(va, vb), ka
+    my_ssg.train()
+    my_ssg.drop1.eval()
+    oseg, ol3 = my_ssg(xyz4, torch.zeros(4, 1, 16), fps_start=(t1, t2))
+    close(oseg, sseg, "ssg seg log-probs", rtol=1e-4, atol=1e-5)
+    close(ol3, sl3, "ssg l3", rtol=1e-4, atol=1e-5)
+    save("model_ssg", seed=9, s1=t1, s2=t2, seg_sum=sseg.detach().sum(dim=1), l3=sl3.detach())
+
+
+if __name__ == "__main__":
+    assert refshim.available(), "needs the reference tree"
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["index", "modules", "model", "fit"]
+    if "index" in which:
+        golden_index_ops()
+    if "modules" in which:
+        golden_modules()
+    if "model" in which:
+        golden_model()
+    if "fit" in which:
+        import make_golden_fit
+        make_golden_fit.run(save, eq, close)
+    print("all oracle-vs-reference checks passed; fixtures under", GOLD)

@@ -1,0 +1,99 @@
+"""Seeded synthetic inputs (numpy default_rng) shared by the oracle, the tests and bench.py.
+
+TEST/BENCH INFRASTRUCTURE: pure data generation, no reference code and no model code.
+Distributions follow SURVEY.md section 8(d):
+  cube     xyz ~ U[-1,1]^3                      (BASELINE.json wording: synthetic clouds)
+  surface  points on a random ellipsoid surface, centred and scaled to the unit ball
+           (what ShapeNet clouds look like after data_utils/ShapeNetDataLoader.py:17-22)
+  blobs    8 Gaussian blobs (sigma .08) with centres ~ U[-.8,.8]^3: gives non-trivial clusters
+"""
+import numpy as np
+
+
+def cloud(kind, B, N, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "cube":
+        return rng.uniform(-1.0, 1.0, size=(B, N, 3)).astype(np.float32)
+    if kind == "surface":
+        out = np.empty((B, N, 3), dtype=np.float32)
+        for b in range(B):
+            axes = rng.uniform(0.3, 1.0, size=3)
+            v = rng.normal(size=(N, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            p = v * axes
+            p -= p.mean(axis=0, keepdims=True)
+            p /= np.sqrt((p ** 2).sum(axis=1)).max()
+            out[b] = p.astype(np.float32)
+        return out
+    if kind == "blobs":
+        out = np.empty((B, N, 3), dtype=np.float32)
+        for b in range(B):
+            centres = rng.uniform(-0.8, 0.8, size=(8, 3))
+            lab = rng.integers(0, 8, size=N)
+            out[b] = (centres[lab] + 0.08 * rng.normal(size=(N, 3))).astype(np.float32)
+        return out
+    raise ValueError(kind)
+
+
+def blobs_with_labels(B, N, seed, K=8, sigma=0.08):
+    """Blob cloud plus the generating label of every point (for prototype embeddings)."""
+    rng = np.random.default_rng(seed)
+    pts = np.empty((B, N, 3), dtype=np.float32)
+    labs = np.empty((B, N), dtype=np.int64)
+    for b in range(B):
+        centres = rng.uniform(-0.8, 0.8, size=(K, 3))
+        lab = rng.integers(0, K, size=N)
+        pts[b] = (centres[lab] + sigma * rng.normal(size=(N, 3))).astype(np.float32)
+        labs[b] = lab
+    return pts, labs
+
+
+def prototype_embedding(labels, D, seed, K=8, noise=0.01):
+    """normalize(proto[label] + noise * N(0,1)), proto = normalised N(0,1)[K, D]."""
+    rng = np.random.default_rng(seed)
+    proto = rng.normal(size=(K, D))
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    e = proto[labels] + noise * rng.normal(size=labels.shape + (D,))
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    return e.astype(np.float32)
+
+
+def fps_start(B, N, seed):
+    return np.random.default_rng(seed + 7919).integers(0, N, size=B).astype(np.int64)
+
+
+def features(B, N, C, seed):
+    return np.random.default_rng(seed + 104729).normal(size=(B, N, C)).astype(np.float32)
+
+
+def labels(B, N, num_classes, seed):
+    return np.random.default_rng(seed + 1299709).integers(0, num_classes, size=(B, N)).astype(np.int64)
+
+
+def uniform01(shape, seed):
+    return np.random.default_rng(seed + 15485863).uniform(0.0, 1.0, size=shape).astype(np.float32)
+
+
+def perturb_bn(module, seed):
+    """Give every BatchNorm non-trivial affine parameters (incl. negative gammas) and running stats,
+    so that parity tests exercise the gamma<0 pooling branch and the running-stat update."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def xavier_like_trainer(module):
+    """train_partseg_shapenet.py:240-247: xavier_normal_ on Conv2d/Linear weights, zero bias."""
+    import torch
+
+    for m in module.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+            torch.nn.init.xavier_normal_(m.weight.data)
+            torch.nn.init.constant_(m.bias.data, 0.0)
