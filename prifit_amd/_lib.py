@@ -1,0 +1,73 @@
+"""ctypes binding of libprifit_hip.so (the C ABI declared in include/prifit_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a call returns a non-zero
+code, a RuntimeError is raised.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprifit_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "prifit_hip.h")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_D = ctypes.c_double
+_LL = ctypes.c_longlong
+
+_dll = None
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Names of every `int prifit_*(...)` entry point declared in the public header."""
+    with open(header_path) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"^\s*int\s+(prifit_\w+)\s*\(", text, flags=re.M)))
+
+
+def dll():
+    global _dll
+    if _dll is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libprifit_hip.so is not built (%s). Run `python -m prifit_amd.build` "
+                "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+        _dll = ctypes.CDLL(LIB_PATH)
+        for name in declared_symbols():
+            fn = getattr(_dll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = ctypes.c_int
+    return _dll
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def call(name, *args):
+    """Invoke an entry point; raises on a non-zero return code."""
+    rc = getattr(dll(), name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (name, rc))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("prifit_amd ops need device tensors (HIP backend only, no CPU path)")
+
+
+def cf(t):
+    """contiguous fp32"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,499 @@
+// PointNet++ index / grouping kernels for gfx950 (wave64).  Compiled with -ffp-contract=off; every
+// distance uses explicit __f*_rn intrinsics so that the rounding sequence equals the reference's
+// PyTorch-CPU arithmetic (see oracle/prifit_oracle.c for the scalar statement of the same recipes).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// bit-exact distance recipes
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float norm2_3(float x, float y, float z)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
+// models/pointnet_util.py:37-39: -2 * (K=3 fma-chain dot) + |src|^2 + |dst|^2
+__device__ __forceinline__ float sqdist_expanded(float sx, float sy, float sz, float ss, float dx,
+                                                 float dy, float dz, float dd)
+{
+    float t = __fmul_rn(sx, dx);
+    t = __fmaf_rn(sy, dy, t);
+    t = __fmaf_rn(sz, dz, t);
+    return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, t), ss), dd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// farthest point sampling: one 256-thread workgroup per shape, points in registers, cloud copy in
+// LDS for the centroid broadcast, packed (distance, ~index) keys reduced by wave shuffles + LDS.
+// ---------------------------------------------------------------------------------------------
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz, int N, int npoint,
+                                                  const int64_t *__restrict__ start_idx,
+                                                  int64_t *__restrict__ out_idx,
+                                                  float *__restrict__ new_xyz)
+{
+    extern __shared__ float s_xyz[];  // [N*3] then 8 x u64 slots
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float *P = xyz + (size_t)b * N * 3;
+    for (int i = tid; i < N * 3; i += 256) s_xyz[i] = P[i];
+    unsigned long long *slots =
+        reinterpret_cast<unsigned long long *>(s_xyz + ((N * 3 + 1) & ~1));
+    __syncthreads();
+
+    float px[PPT], py[PPT], pz[PPT], mind[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        int n = tid + 256 * j;
+        bool ok = n < N;
+        px[j] = ok ? s_xyz[n * 3 + 0] : 0.f;
+        py[j] = ok ? s_xyz[n * 3 + 1] : 0.f;
+        pz[j] = ok ? s_xyz[n * 3 + 2] : 0.f;
+        mind[j] = 1e10f;
+    }
+    int far = (int)start_idx[b];
+    for (int it = 0; it < npoint; ++it) {
+        const float cx = s_xyz[far * 3 + 0], cy = s_xyz[far * 3 + 1], cz = s_xyz[far * 3 + 2];
+        if (tid == 0) {
+            out_idx[(size_t)b * npoint + it] = far;
+            if (new_xyz) {
+                float *o = new_xyz + ((size_t)b * npoint + it) * 3;
+                o[0] = cx; o[1] = cy; o[2] = cz;
+            }
+        }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            int n = tid + 256 * j;
+            float dx = __fsub_rn(px[j], cx), dy = __fsub_rn(py[j], cy), dz = __fsub_rn(pz[j], cz);
+            float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            mind[j] = d < mind[j] ? d : mind[j];
+            // distances are >= 0, so the IEEE bit pattern orders like the value; ~index makes the
+            // lowest index win among equal distances (torch.max returns the first maximum).
+            unsigned long long key = ((unsigned long long)__float_as_uint(mind[j]) << 32) |
+                                     (unsigned)(0xffffffffu - (unsigned)n);
+            key = n < N ? key : 0ull;
+            best = key > best ? key : best;
+        }
+        best = wave_max_u64(best);
+        unsigned long long *sl = slots + (it & 1) * 4;
+        if ((tid & 63) == 0) sl[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long a = sl[0], c = sl[1], e = sl[2], g = sl[3];
+        a = a > c ? a : c;
+        e = e > g ? e : g;
+        a = a > e ? a : e;
+        far = (int)(0xffffffffu - (unsigned)(a & 0xffffffffu));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ball query: one wave per query point, all radii in one pass, ordered ballot compaction
+// (first nsample in-ball indices in ascending order, padded with the first: pointnet_util.py:100-106)
+// ---------------------------------------------------------------------------------------------
+struct BallArgs {
+    float r2[4];
+    int nsample[4];
+    void *out[4];
+};
+
+constexpr int BQ_TILE = 2048;   // points staged in LDS per pass (32 KiB as float4)
+constexpr int BQ_QPW = 4;       // queries per wave
+constexpr int BQ_QPB = 4 * BQ_QPW;
+
+template <int R, typename IdxT>
+__global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ xyz,
+                                                         const float *__restrict__ new_xyz, int N,
+                                                         int S, BallArgs args)
+{
+    __shared__ float4 s_pts[BQ_TILE];
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *P = xyz + (size_t)b * N * 3;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW], qq[BQ_QPW];
+    int cnt[BQ_QPW][R], first[BQ_QPW][R];
+    int qid[BQ_QPW];
+#pragma unroll
+    for (int q = 0; q < BQ_QPW; ++q) {
+        qid[q] = blockIdx.x * BQ_QPB + wave * BQ_QPW + q;
+        int s = qid[q] < S ? qid[q] : S - 1;
+        const float *Q = new_xyz + ((size_t)b * S + s) * 3;
+        qx[q] = Q[0]; qy[q] = Q[1]; qz[q] = Q[2];
+        qq[q] = norm2_3(qx[q], qy[q], qz[q]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cnt[q][r] = 0; first[q][r] = N; }
+    }
+
+    for (int base = 0; base < N; base += BQ_TILE) {
+        const int tn = min(BQ_TILE, N - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += 256) {
+            float x = P[(size_t)(base + i) * 3 + 0], y = P[(size_t)(base + i) * 3 + 1],
+                  z = P[(size_t)(base + i) * 3 + 2];
+            s_pts[i] = make_float4(x, y, z, norm2_3(x, y, z));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BQ_QPW; ++q) {
+            if (qid[q] >= S) continue;
+            for (int c = 0; c < tn; c += 64) {
+                bool done = true;
+#pragma unroll
+                for (int r = 0; r < R; ++r) done = done && (cnt[q][r] >= args.nsample[r]);
+                if (done) break;  // wave-uniform
+                const int i = c + lane;
+                const bool inb = i < tn;
+                float4 p = s_pts[inb ? i : 0];
+                float d = sqdist_expanded(qx[q], qy[q], qz[q], qq[q], p.x, p.y, p.z, p.w);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool pred = inb && !(d > args.r2[r]);
+                    const unsigned long long m = __ballot(pred);
+                    if (m == 0ull) continue;
+                    if (cnt[q][r] == 0) first[q][r] = base + c + __builtin_ctzll(m);
+                    const int pos = cnt[q][r] + __popcll(m & lt_mask);
+                    const int K = args.nsample[r];
+                    if (pred && pos < K)
+                        reinterpret_cast<IdxT *>(args.out[r])[((size_t)b * S + qid[q]) * K + pos] =
+                            (IdxT)(base + i);
+                    cnt[q][r] += __popcll(m);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BQ_QPW; ++q) {
+        if (qid[q] >= S) continue;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int K = args.nsample[r];
+            IdxT *o = reinterpret_cast<IdxT *>(args.out[r]) + ((size_t)b * S + qid[q]) * K;
+            for (int k = cnt[q][r] + lane; k < K; k += 64) o[k] = (IdxT)first[q][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// three nearest neighbours (thread per query, candidate cloud staged in LDS)
+// ---------------------------------------------------------------------------------------------
+constexpr int NN_TILE = 2048;
+
+__global__ __launch_bounds__(256) void three_nn_kernel(const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2, int N, int S,
+                                                       int32_t *__restrict__ idx,
+                                                       float *__restrict__ dist,
+                                                       float *__restrict__ weight)
+{
+    __shared__ float4 s_pts[NN_TILE];
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = n < N;
+    const float *Q = xyz1 + ((size_t)b * N + (ok ? n : 0)) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    const float qq = norm2_3(qx, qy, qz);
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0;
+    const float *P = xyz2 + (size_t)b * S * 3;
+    for (int base = 0; base < S; base += NN_TILE) {
+        const int tn = min(NN_TILE, S - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += 256) {
+            float x = P[(size_t)(base + i) * 3], y = P[(size_t)(base + i) * 3 + 1],
+                  z = P[(size_t)(base + i) * 3 + 2];
+            s_pts[i] = make_float4(x, y, z, norm2_3(x, y, z));
+        }
+        __syncthreads();
+        for (int i = 0; i < tn; ++i) {
+            const float4 p = s_pts[i];
+            const float d = sqdist_expanded(qx, qy, qz, qq, p.x, p.y, p.z, p.w);
+            const int s = base + i;
+            if (d < d2) {  // strict: equal distances keep the earlier (lower) index
+                if (d < d1) {
+                    d2 = d1; i2 = i1;
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = s; }
+                    else { d1 = d; i1 = s; }
+                } else { d2 = d; i2 = s; }
+            }
+        }
+    }
+    if (!ok) return;
+    const size_t o = ((size_t)b * N + n) * 3;
+    idx[o] = i0; idx[o + 1] = i1; idx[o + 2] = i2;
+    if (dist) { dist[o] = d0; dist[o + 1] = d1; dist[o + 2] = d2; }
+    // pointnet_util.py:295-297: recip = 1/(d + 1e-8); weight = recip / sum(recip)
+    const float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
+    const float r1 = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f));
+    const float r2 = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+    const float nrm = __fadd_rn(__fadd_rn(r0, r1), r2);
+    weight[o] = __fdiv_rn(r0, nrm);
+    weight[o + 1] = __fdiv_rn(r1, nrm);
+    weight[o + 2] = __fdiv_rn(r2, nrm);
+}
+
+__global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ dst, int S,
+                                                              int N, float *__restrict__ out)
+{
+    const int b = blockIdx.z, s = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float *Q = src + ((size_t)b * S + s) * 3;
+    const float *P = dst + ((size_t)b * N + n) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2], px = P[0], py = P[1], pz = P[2];
+    out[((size_t)b * S + s) * N + n] =
+        sqdist_expanded(qx, qy, qz, norm2_3(qx, qy, qz), px, py, pz, norm2_3(px, py, pz));
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouping gather / scatter-add, 3-NN interpolation (bandwidth kernels)
+// ---------------------------------------------------------------------------------------------
+// Vector path: C % 4 == 0, order 0 ([feat, rel, pad]), ld_out % 4 == 0.  One float4 per thread,
+// consecutive threads write consecutive float4s of the output (fully coalesced stores); the feature
+// rows are read as whole contiguous rows.
+__global__ __launch_bounds__(256) void group_gather_vec_kernel(
+    const float4 *__restrict__ feat, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int32_t *__restrict__ idx, int N, int S, int K, int C4, int V, long long total_vec,
+    float4 *__restrict__ out)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total_vec;
+         id += (long long)gridDim.x * 256) {
+        const long long row = id / V;
+        const int v = (int)(id - row * V);
+        const long long bs = row / K;  // b*S + s
+        const int b = (int)(bs / S);
+        const int n = idx[row];
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 0 && n < N) {
+            if (v < C4) {
+                val = feat[((size_t)b * N + n) * C4 + v];
+            } else if (v == C4) {
+                const float *p = xyz + ((size_t)b * N + n) * 3;
+                const float *c = new_xyz + (size_t)bs * 3;
+                val = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f);
+            }
+        }
+        out[id] = val;
+    }
+}
+
+// Scalar path: any C / order / ld_out.
+__global__ __launch_bounds__(256) void group_gather_scalar_kernel(
+    const float *__restrict__ feat, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int32_t *__restrict__ idx, int N, int S, int K, int C, int order, int ld, long long total,
+    float *__restrict__ out)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total;
+         id += (long long)gridDim.x * 256) {
+        const long long row = id / ld;
+        const int c = (int)(id - row * ld);
+        const long long bs = row / K;
+        const int b = (int)(bs / S);
+        const int n = idx[row];
+        float val = 0.f;
+        if (n >= 0 && n < N) {
+            int fc, rc;  // feature column / rel column, -1 if this output column is neither
+            if (order == 0) { fc = c < C ? c : -1; rc = (c >= C && c < C + 3) ? c - C : -1; }
+            else { rc = c < 3 ? c : -1; fc = (c >= 3 && c < C + 3) ? c - 3 : -1; }
+            if (fc >= 0) val = feat[((size_t)b * N + n) * C + fc];
+            else if (rc >= 0) val = xyz[((size_t)b * N + n) * 3 + rc] - new_xyz[(size_t)bs * 3 + rc];
+        }
+        out[id] = val;
+    }
+}
+
+// dfeat[b, idx, c] += gout[row, col0 + c]; one lane per float so that each wave-instruction adds
+// 256 contiguous bytes (the shape that runs at the chip-wide float-atomic rate).
+__global__ __launch_bounds__(256) void group_scatter_add_kernel(
+    const float *__restrict__ gout, int ld, int col0, const int32_t *__restrict__ idx, int N, int S,
+    int K, int C, long long total, float *__restrict__ dfeat)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total;
+         id += (long long)gridDim.x * 256) {
+        const long long row = id / C;
+        const int c = (int)(id - row * C);
+        const int b = (int)(row / ((long long)S * K));
+        const int n = idx[row];
+        if (n >= 0 && n < N) unsafeAtomicAdd(dfeat + ((size_t)b * N + n) * C + c, gout[row * ld + col0 + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_kernel(
+    const float *__restrict__ points2, const int32_t *__restrict__ idx, const float *__restrict__ w,
+    int N, int S, int C, int ld, int col0, long long total, float *__restrict__ out)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total;
+         id += (long long)gridDim.x * 256) {
+        const long long row = id / C;  // b*N + n
+        const int c = (int)(id - row * C);
+        const int b = (int)(row / N);
+        const int32_t *ii = idx + row * 3;
+        const float *ww = w + row * 3;
+        const float *P = points2 + (size_t)b * S * C;
+        // (p0*w0 + p1*w1) + p2*w2, the order of torch.sum over the 3-slot axis (pointnet_util.py:298)
+        float acc = P[(size_t)ii[0] * C + c] * ww[0];
+        acc += P[(size_t)ii[1] * C + c] * ww[1];
+        acc += P[(size_t)ii[2] * C + c] * ww[2];
+        out[row * ld + col0 + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_bwd_kernel(
+    const float *__restrict__ gout, int ld, int col0, const int32_t *__restrict__ idx,
+    const float *__restrict__ w, int N, int S, int C, long long total, float *__restrict__ dp2)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total;
+         id += (long long)gridDim.x * 256) {
+        const long long row = id / C;
+        const int c = (int)(id - row * C);
+        const int b = (int)(row / N);
+        const float g = gout[row * ld + col0 + c];
+        float *D = dp2 + (size_t)b * S * C;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) unsafeAtomicAdd(D + (size_t)idx[row * 3 + j] * C + c, g * w[row * 3 + j]);
+    }
+}
+
+static inline int grid_for(long long total, int per_block = 256, int cap = 256 * 16)
+{
+    long long g = (total + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int prifit_version(const char **arch)
+{
+    if (arch) *arch = "gfx950";
+    return 100;
+}
+
+int prifit_fps(const float *xyz, int B, int N, int npoint, const int64_t *start_idx, int64_t *out_idx,
+               float *new_xyz, void *stream)
+{
+    if (!xyz || !start_idx || !out_idx || B <= 0 || N <= 0 || npoint <= 0 || N > 4096)
+        return PRIFIT_EINVAL;
+    const size_t lds = (size_t)((N * 3 + 1) & ~1) * sizeof(float) + 8 * sizeof(unsigned long long);
+    hipStream_t st = as_stream(stream);
+    const int ppt = (N + 255) / 256;
+#define FPS_LAUNCH(P) \
+    hipLaunchKernelGGL((fps_kernel<P>), dim3(B), dim3(256), lds, st, xyz, N, npoint, start_idx, out_idx, new_xyz)
+    if (ppt <= 1) FPS_LAUNCH(1);
+    else if (ppt <= 2) FPS_LAUNCH(2);
+    else if (ppt <= 4) FPS_LAUNCH(4);
+    else if (ppt <= 8) FPS_LAUNCH(8);
+    else FPS_LAUNCH(16);
+#undef FPS_LAUNCH
+    return prifit_check_launch();
+}
+
+int prifit_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, int R,
+                      const float *radius2, const int *nsample, void *const *out, int idx64, void *stream)
+{
+    if (!xyz || !new_xyz || !radius2 || !nsample || !out || B <= 0 || N <= 0 || S <= 0 || R < 1 || R > 4)
+        return PRIFIT_EINVAL;
+    BallArgs a;
+    for (int r = 0; r < 4; ++r) {
+        a.r2[r] = r < R ? radius2[r] : 0.f;
+        a.nsample[r] = r < R ? nsample[r] : 0;
+        a.out[r] = r < R ? out[r] : nullptr;
+        if (r < R && (nsample[r] < 1 || nsample[r] > 1024 || !out[r])) return PRIFIT_EINVAL;
+    }
+    dim3 grid((S + BQ_QPB - 1) / BQ_QPB, B), block(256);
+    hipStream_t st = as_stream(stream);
+#define BQ_LAUNCH(RR, T) hipLaunchKernelGGL((ball_query_kernel<RR, T>), grid, block, 0, st, xyz, new_xyz, N, S, a)
+#define BQ_DISPATCH(T)                  \
+    switch (R) {                        \
+        case 1: BQ_LAUNCH(1, T); break; \
+        case 2: BQ_LAUNCH(2, T); break; \
+        case 3: BQ_LAUNCH(3, T); break; \
+        default: BQ_LAUNCH(4, T); break; \
+    }
+    if (idx64) { BQ_DISPATCH(int64_t) } else { BQ_DISPATCH(int32_t) }
+#undef BQ_DISPATCH
+#undef BQ_LAUNCH
+    return prifit_check_launch();
+}
+
+int prifit_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int32_t *idx, float *dist,
+                    float *weight, void *stream)
+{
+    if (!xyz1 || !xyz2 || !idx || !weight || B <= 0 || N <= 0 || S < 3) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((N + 255) / 256, B), dim3(256), 0, as_stream(stream), xyz1,
+                       xyz2, N, S, idx, dist, weight);
+    return prifit_check_launch();
+}
+
+int prifit_square_distance(const float *src, const float *dst, int B, int S, int N, float *out, void *stream)
+{
+    if (!src || !dst || !out || B <= 0 || S <= 0 || N <= 0 || S > 65535 || B > 65535) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(square_distance_kernel, dim3((N + 255) / 256, S, B), dim3(256), 0, as_stream(stream),
+                       src, dst, S, N, out);
+    return prifit_check_launch();
+}
+
+int prifit_group_gather(const float *feat, const float *xyz, const float *new_xyz, const int32_t *idx, int B,
+                        int N, int S, int K, int C, int order, int ld_out, float *out, void *stream)
+{
+    if (!xyz || !new_xyz || !idx || !out || (C > 0 && !feat) || B <= 0 || N <= 0 || S <= 0 || K <= 0 ||
+        C < 0 || ld_out < C + 3 || (order != 0 && order != 1))
+        return PRIFIT_EINVAL;
+    const long long rows = (long long)B * S * K;
+    hipStream_t st = as_stream(stream);
+    const bool vec = order == 0 && C > 0 && (C % 4 == 0) && (ld_out % 4 == 0) &&
+                     ((uintptr_t)feat % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (vec) {
+        const int V = ld_out / 4;
+        const long long total = rows * V;
+        hipLaunchKernelGGL(group_gather_vec_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(feat), xyz, new_xyz, idx, N, S, K, C / 4, V,
+                           total, reinterpret_cast<float4 *>(out));
+    } else {
+        const long long total = rows * ld_out;
+        hipLaunchKernelGGL(group_gather_scalar_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st,
+                           feat, xyz, new_xyz, idx, N, S, K, C, order, ld_out, total, out);
+    }
+    return prifit_check_launch();
+}
+
+int prifit_group_scatter_add(const float *gout, int ld_gout, int col0, const int32_t *idx, int B, int N, int S,
+                             int K, int C, float *dfeat, void *stream)
+{
+    if (!gout || !idx || !dfeat || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || col0 < 0 ||
+        ld_gout < col0 + C)
+        return PRIFIT_EINVAL;
+    const long long total = (long long)B * S * K * C;
+    hipLaunchKernelGGL(group_scatter_add_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
+                       as_stream(stream), gout, ld_gout, col0, idx, N, S, K, C, total, dfeat);
+    return prifit_check_launch();
+}
+
+int prifit_three_interpolate(const float *points2, const int32_t *idx, const float *weight, int B, int N, int S,
+                             int C, int ld_out, int col0, float *out, void *stream)
+{
+    if (!points2 || !idx || !weight || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0 || col0 < 0 ||
+        ld_out < col0 + C)
+        return PRIFIT_EINVAL;
+    const long long total = (long long)B * N * C;
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
+                       as_stream(stream), points2, idx, weight, N, S, C, ld_out, col0, total, out);
+    return prifit_check_launch();
+}
+
+int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const int32_t *idx,
+                                 const float *weight, int B, int N, int S, int C, float *dpoints2, void *stream)
+{
+    if (!gout || !idx || !weight || !dpoints2 || B <= 0 || N <= 0 || S <= 0 || C <= 0 || col0 < 0 ||
+        ld_gout < col0 + C)
+        return PRIFIT_EINVAL;
+    const long long total = (long long)B * N * C;
+    hipLaunchKernelGGL(three_interpolate_bwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
+                       as_stream(stream), gout, ld_gout, col0, idx, weight, N, S, C, total, dpoints2);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""Thin functional wrappers over the C ABI: index / grouping ops of the PointNet++ stack.
+
+Every function takes and returns CUDA(HIP) tensors in channels-last layout and launches on the
+current PyTorch stream.  Reference sites are cited per function (paths relative to upstream).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, cf, cur_stream, ptr, require_cuda
+
+
+def farthest_point_sample(xyz, npoint, start_idx=None, return_xyz=False):
+    """models/pointnet_util.py:63-84.  xyz [B,N,3] -> int64 [B,npoint] (bit-exact for a given
+    start_idx; when None a random start is drawn like the reference's torch.randint at :75)."""
+    require_cuda(xyz)
+    xyz = cf(xyz)
+    B, N, _ = xyz.shape
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (B,), dtype=torch.long, device=xyz.device)
+    start_idx = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
+    out = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
+    new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None
+    call("prifit_fps", ptr(xyz), B, N, npoint, ptr(start_idx), ptr(out), ptr(new_xyz), cur_stream())
+    return (out, new_xyz) if return_xyz else out
+
+
+def ball_query_multi(radius_list, nsample_list, xyz, new_xyz, idx64=False):
+    """models/pointnet_util.py:87-107 for several radii in one pass.  Returns a list of
+    [B,S,nsample] index tensors (int32 internally, int64 for the reference-surface API)."""
+    require_cuda(xyz, new_xyz)
+    xyz, new_xyz = cf(xyz), cf(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    outs = []
+    for lo in range(0, len(radius_list), 4):
+        rs = radius_list[lo:lo + 4]
+        ks = nsample_list[lo:lo + 4]
+        R = len(rs)
+        o = [torch.empty(B, S, k, dtype=torch.int64 if idx64 else torch.int32, device=xyz.device) for k in ks]
+        # the reference compares fp32 distances with the python double radius**2, i.e. fp32(radius**2)
+        r2 = (ctypes.c_float * R)(*[float(np.float32(r ** 2)) for r in rs])
+        ns = (ctypes.c_int * R)(*[int(k) for k in ks])
+        op = (ctypes.c_void_p * R)(*[t.data_ptr() for t in o])
+        call("prifit_ball_query", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, op, int(idx64), cur_stream())
+        outs += o
+    return outs
+
+
+def three_nn(xyz1, xyz2, want_dist=False):
+    """models/pointnet_util.py:291-297: 3 nearest of xyz2 for every xyz1 point + normalised
+    inverse-distance weights.  Returns (idx int32 [B,N,3], weight [B,N,3][, dist [B,N,3]])."""
+    require_cuda(xyz1, xyz2)
+    xyz1, xyz2 = cf(xyz1), cf(xyz2)
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    idx = torch.empty(B, N, 3, dtype=torch.int32, device=xyz1.device)
+    w = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
+    d = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device) if want_dist else None
+    call("prifit_three_nn", ptr(xyz1), ptr(xyz2), B, N, S, ptr(idx), ptr(d), ptr(w), cur_stream())
+    return (idx, w, d) if want_dist else (idx, w)
+
+
+def square_distance(src, dst):
+    """models/pointnet_util.py:19-40 (expanded form, bitwise)."""
+    require_cuda(src, dst)
+    src, dst = cf(src), cf(dst)
+    B, S, _ = src.shape
+    N = dst.shape[1]
+    out = torch.empty(B, S, N, dtype=torch.float32, device=src.device)
+    call("prifit_square_distance", ptr(src), ptr(dst), B, S, N, ptr(out), cur_stream())
+    return out
+
+
+def group_gather(feat, xyz, new_xyz, idx, order=0, ld_out=None):
+    """models/pointnet_util.py:243-249 / :127-133.  Returns [B*S*K, ld_out] rows
+    [feat, rel_xyz, 0..] (order 0, MSG) or [rel_xyz, feat, 0..] (order 1, SSG)."""
+    require_cuda(xyz, new_xyz, idx)
+    B, N, _ = xyz.shape
+    _, S, K = idx.shape
+    C = 0 if feat is None else feat.shape[-1]
+    if ld_out is None:
+        ld_out = (C + 3 + 3) // 4 * 4
+    out = torch.empty(B * S * K, ld_out, dtype=torch.float32, device=xyz.device)
+    call("prifit_group_gather", ptr(feat), ptr(xyz), ptr(new_xyz), ptr(idx), B, N, S, K, C, order, ld_out,
+         ptr(out), cur_stream())
+    return out
+
+
+def group_scatter_add(gout, col0, idx, B, N, C, dfeat=None):
+    """Backward of the feature columns of group_gather: returns dfeat [B,N,C]."""
+    _, S, K = idx.shape
+    if dfeat is None:
+        dfeat = torch.zeros(B, N, C, dtype=torch.float32, device=gout.device)
+    call("prifit_group_scatter_add", ptr(gout), gout.stride(0), col0, ptr(idx), B, N, S, K, C, ptr(dfeat),
+         cur_stream())
+    return dfeat
+
+
+def three_interpolate(points2, idx, weight, out=None, col0=0):
+    """models/pointnet_util.py:298.  points2 [B,S,C] -> out[(b,n), col0:col0+C]."""
+    B, S, C = points2.shape
+    N = idx.shape[1]
+    if out is None:
+        out = torch.empty(B * N, C, dtype=torch.float32, device=points2.device)
+    call("prifit_three_interpolate", ptr(points2), ptr(idx), ptr(weight), B, N, S, C, out.stride(0), col0,
+         ptr(out), cur_stream())
+    return out
+
+
+def three_interpolate_bwd(gout, col0, idx, weight, B, S, C):
+    N = idx.shape[1]
+    dp2 = torch.zeros(B, S, C, dtype=torch.float32, device=gout.device)
+    call("prifit_three_interpolate_bwd", ptr(gout), gout.stride(0), col0, ptr(idx), ptr(weight), B, N, S, C,
+         ptr(dp2), cur_stream())
+    return dp2
