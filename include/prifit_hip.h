@@ -98,6 +98,98 @@ int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const
                                  const float *weight, int B, int N, int S, int C, float *dpoints2,
                                  void *stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* dense contraction on the matrix cores (fp32 in / fp32 accumulate MFMA, exact f32)            */
+/* ------------------------------------------------------------------------------------------ */
+
+#define PRIFIT_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T  (both operands k-contiguous)            */
+#define PRIFIT_GEMM_NN 1 /* C[M,N] = A[M,K] . B[K,N]                                             */
+#define PRIFIT_GEMM_TN 2 /* C[M,N] = A[K,M]^T . B[K,N]  (reduction over the leading index)      */
+#define PRIFIT_EPI_NONE 0     /* C = acc (+ bias)                                                */
+#define PRIFIT_EPI_CHORD 1    /* C = 2 - 2*acc            (src/mean_shift.py:154,168,185)        */
+#define PRIFIT_EPI_MSKERNEL 2 /* C = exp(clamp(-(2-2*acc)/b^2/2, -13, 75)), b = epi_batch_scalar[z]
+                                 (src/mean_shift.py:65-68 with src/guard.py:6-11)                 */
+
+/* Batched GEMM with fused prologue/epilogue.  Replaces every conv1x1 of the shared per-position
+ * MLPs (models/pointnet_util.py:195-199, :252-256, :310-313; models/pointnet2_part_seg_msg.py:88,
+ * :109,:128) and their autograd, and the N x N x D products of src/mean_shift.py:65,73,154,168,185.
+ *   lda/ldb/ldc: row strides; strideA/B/C: batch strides (elements); grid z = batch * splitk.
+ *   a_scale/a_shift (both or neither): operand A is read as max(a*scale[c]+shift[c], 0) with c the
+ *     index along A's contiguous dimension (k for NT/NN, m for TN) -- the train-mode BatchNorm+ReLU
+ *     of the producing layer applied on load.  b_scale/b_shift: the same for B (c = k for NT, n else).
+ *   bias [N] or NULL.  col_stats [ceil(M/tile_m)][2][N] or NULL: per-M-tile partial column sums
+ *     and sums of squares of the stored C (batch == 1, splitk == 1 only).
+ *   splitk > 1: the K range is split over workgroups and C is accumulated with float atomics
+ *     (C must be initialised by the caller; epilogue must be PRIFIT_EPI_NONE).
+ * 16-byte vector loads are used when pointers, strides and contiguous extents are multiples of 4
+ * floats; any other shape takes a scalar-load path. */
+int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long lda, long long strideA,
+                    const float *B, long long ldb, long long strideB, float *C, long long ldc,
+                    long long strideC, int batch, int splitk, const float *a_scale,
+                    const float *a_shift, const float *b_scale, const float *b_shift,
+                    const float *bias, float *col_stats, int epilogue,
+                    const float *epi_batch_scalar, void *stream);
+
+/* Rows of C covered by one col_stats slab of prifit_gemm_f32 (its M tile). */
+int prifit_gemm_tile_m(int N);
+
+/* ------------------------------------------------------------------------------------------ */
+/* train-mode BatchNorm + ReLU + group max-pool around the GEMMs                                */
+/* (matrices are [P, ld] channels-last, C % 4 == 0, rows 16-byte aligned)                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Rows reduced into one partial slab by the *_reduce / col_stats kernels below. */
+int prifit_reduce_rows_per_slab(void);
+
+/* slab [ceil(P/rows_per_slab)][2][C] = per-block column (sum, sum of squares) of Y. */
+int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream);
+
+/* Batch statistics -> affine form of BatchNorm (torch.nn.BatchNorm{1,2}d in train mode, as used at
+ * models/pointnet_util.py:198,254,312): mean/var over `count` positions from the partial slabs,
+ * scale = gamma*invstd, shift = beta - mean*scale; running stats (may be NULL) updated with
+ * `momentum` and the unbiased variance. */
+int prifit_bn_finalize(const float *slab, int nslab, int C, double count, const float *gamma,
+                       const float *beta, float eps, float momentum, float *running_mean,
+                       float *running_var, float *scale, float *shift, float *mean, float *invstd,
+                       void *stream);
+
+/* out = max(Y*scale + shift, 0): F.relu(bn(.)) materialised (module outputs). */
+int prifit_affine_relu(const float *Y, long long ldy, const float *scale, const float *shift, int P,
+                       int C, float *out, long long ldo, void *stream);
+
+/* torch.max(relu(bn(Y)), dim=K)[0] (models/pointnet_util.py:199,256): Y [G*K, ldy] -> out [G, ldo],
+ * arg [G, C] = index k of the first maximum. */
+int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const float *shift, int G, int K,
+                    int C, float *out, long long ldo, int32_t *arg, void *stream);
+
+/* Backward of relu(bn(Y)) given G = dL/d(relu output): partial slabs of m1 = sum(G*mask) and
+ * m2 = sum(G*mask*yhat). */
+int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy,
+                              const float *scale, const float *shift, const float *mean,
+                              const float *invstd, int P, int C, float *slab, void *stream);
+
+/* The same partials when the gradient gp [G, ldgp] arrives through the group max-pool. */
+int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long long ldy,
+                           const int32_t *arg, const float *scale, const float *shift,
+                           const float *mean, const float *invstd, int G, int K, int C, float *slab,
+                           void *stream);
+
+/* m1, m2 -> dgamma, dbeta and the per-channel coefficients of dY = a*(G*mask) + b*Y + d
+ * (training != 0: batch-stat BatchNorm backward; training == 0: running-stat affine). */
+int prifit_bn_bwd_finalize(const float *slab, int nslab, int C, double count, int training,
+                           const float *scale, const float *mean, const float *invstd, float *dgamma,
+                           float *dbeta, float *coef_a, float *coef_b, float *coef_d, void *stream);
+
+int prifit_bn_relu_bwd_apply(const float *G, long long ldg, const float *Y, long long ldy,
+                             const float *scale, const float *shift, const float *coef_a,
+                             const float *coef_b, const float *coef_d, int P, int C, float *dY,
+                             long long ldd, void *stream);
+
+int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long long ldy,
+                          const int32_t *arg, const float *scale, const float *shift,
+                          const float *coef_a, const float *coef_b, const float *coef_d, int G, int K,
+                          int C, float *dY, long long ldd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

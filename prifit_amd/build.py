@@ -21,6 +21,8 @@ ARCH = "gfx950"
 # source -> extra flags
 SOURCES = {
     "pointops.hip": ["-ffp-contract=off"],
+    "gemm.hip": [],
+    "bn.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
           "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,408 @@
+// Train-mode BatchNorm / ReLU / group max-pool kernels of the shared per-position MLP
+// (models/pointnet_util.py:195-199, :252-256, :310-313).  All tensors are channels-last row-major
+// matrices [P, ld] (P positions, C channels, C % 4 == 0, 16-byte aligned rows): every kernel moves
+// float4s with consecutive lanes on consecutive channels, and per-channel reductions are done as
+// per-block partial slabs [nblk][2][C] finalised in double precision (deterministic, no atomics).
+#include "common.h"
+
+constexpr int RED_ROWS = 512;  // rows of the matrix reduced by one workgroup
+
+__device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// Column-slab reduction skeleton: threads are laid out as (C/4 float4 columns) x (row lanes).
+// f(row, c4, acc0, acc1) accumulates two float4 partials per thread.
+template <typename F>
+__device__ __forceinline__ void column_reduce(int P, int C, float *__restrict__ slab, F f)
+{
+    __shared__ float4 s_red[2][256];
+    const int C4 = C >> 2;
+    const int r_begin = blockIdx.x * RED_ROWS, r_end = min(P, r_begin + RED_ROWS);
+    for (int cbase = 0; cbase < C4; cbase += 256) {
+        const int cols = min(256, C4 - cbase);
+        const int lanes = 256 / cols;  // row lanes
+        const int c4 = cbase + threadIdx.x % cols, rl = threadIdx.x / cols;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (rl < lanes)
+            for (int r = r_begin + rl; r < r_end; r += lanes) f(r, c4, a0, a1);
+        s_red[0][threadIdx.x] = a0;
+        s_red[1][threadIdx.x] = a1;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            float4 t0 = s_red[0][threadIdx.x], t1 = s_red[1][threadIdx.x];
+            for (int l = 1; l < lanes; ++l) {
+                const float4 u0 = s_red[0][threadIdx.x + l * cols], u1 = s_red[1][threadIdx.x + l * cols];
+                t0.x += u0.x; t0.y += u0.y; t0.z += u0.z; t0.w += u0.w;
+                t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
+            }
+            st4g(slab + ((size_t)blockIdx.x * 2 + 0) * C + 4 * c4, t0);
+            st4g(slab + ((size_t)blockIdx.x * 2 + 1) * C + 4 * c4, t1);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+// Reduce the [nslab][2][C] partials -> batch mean / biased var -> scale/shift, running-stat update
+// (torch.nn.BatchNorm semantics: running_var uses the unbiased estimate, momentum m).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ slab, int nslab, int C,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float momentum, float *running_mean,
+                                                          float *running_var, float *__restrict__ scale,
+                                                          float *__restrict__ shift, float *__restrict__ mean_o,
+                                                          float *__restrict__ invstd_o)
+{
+    __shared__ double s_s[4], s_q[4];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nslab; i += 256) {
+        s += (double)slab[((size_t)i * 2 + 0) * C + c];
+        q += (double)slab[((size_t)i * 2 + 1) * C + c];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if ((threadIdx.x & 63) == 0) { s_s[threadIdx.x >> 6] = s; s_q[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = s_s[0] + s_s[1] + s_s[2] + s_s[3];
+        q = s_q[0] + s_q[1] + s_q[2] + s_q[3];
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_o[c] = (float)mean;
+        invstd_o[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// Column sum / sum of squares of a matrix (used when the producer was not a GEMM with fused stats).
+__global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ Y, long long ld, int P, int C,
+                                                        float *__restrict__ slab)
+{
+    column_reduce(P, C, slab, [&](int r, int c4, float4 &a0, float4 &a1) {
+        const float4 y = ld4g(Y + (size_t)r * ld + 4 * c4);
+        a0.x += y.x; a0.y += y.y; a0.z += y.z; a0.w += y.w;
+        a1.x += y.x * y.x; a1.y += y.y * y.y; a1.z += y.z * y.z; a1.w += y.w * y.w;
+    });
+}
+
+// out = max(Y * scale + shift, 0)
+__global__ __launch_bounds__(256) void affine_relu_kernel(const float *__restrict__ Y, long long ldy,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int P, int C4,
+                                                          float *__restrict__ out, long long ldo)
+{
+    const long long total = (long long)P * C4;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long r = id / C4;
+        const int c = (int)(id - r * C4) * 4;
+        const float4 y = ld4g(Y + r * ldy + c), s = ld4g(scale + c), t = ld4g(shift + c);
+        st4g(out + r * ldo + c, make_float4(fmaxf(fmaf(y.x, s.x, t.x), 0.f), fmaxf(fmaf(y.y, s.y, t.y), 0.f),
+                                            fmaxf(fmaf(y.z, s.z, t.z), 0.f), fmaxf(fmaf(y.w, s.w, t.w), 0.f)));
+    }
+}
+
+// Group max-pool of relu(bn(Y)) over the K samples of each group (torch.max(new_points, 2)[0]).
+// Y [G*K, ld]; out [G, ldo] (+col0); arg [G, C] = winning k (first maximum).
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__ Y, long long ldy,
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, int G, int K, int C4,
+                                                       float *__restrict__ out, long long ldo,
+                                                       int32_t *__restrict__ arg)
+{
+    const long long total = (long long)G * C4;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long gidx = id / C4;
+        const int c = (int)(id - gidx * C4) * 4;
+        const float4 s = ld4g(scale + c), t = ld4g(shift + c);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int4 bi = make_int4(0, 0, 0, 0);
+        const float *row = Y + gidx * K * ldy + c;
+        for (int k = 0; k < K; ++k) {
+            const float4 y = ld4g(row + (long long)k * ldy);
+            const float vx = fmaf(y.x, s.x, t.x), vy = fmaf(y.y, s.y, t.y), vz = fmaf(y.z, s.z, t.z),
+                        vw = fmaf(y.w, s.w, t.w);
+            if (vx > best.x) { best.x = vx; bi.x = k; }
+            if (vy > best.y) { best.y = vy; bi.y = k; }
+            if (vz > best.z) { best.z = vz; bi.z = k; }
+            if (vw > best.w) { best.w = vw; bi.w = k; }
+        }
+        st4g(out + gidx * ldo + c,
+             make_float4(fmaxf(best.x, 0.f), fmaxf(best.y, 0.f), fmaxf(best.z, 0.f), fmaxf(best.w, 0.f)));
+        *reinterpret_cast<int4 *>(arg + gidx * (C4 * 4) + c) = bi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// Partials of m1 = sum(G * mask), m2 = sum(G * mask * yhat) with mask = (scale*Y+shift > 0),
+// yhat = (Y - mean) * invstd.
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float *__restrict__ Gr, long long ldg,
+                                                                 const float *__restrict__ Y, long long ldy,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 const float *__restrict__ mean,
+                                                                 const float *__restrict__ invstd, int P, int C,
+                                                                 float *__restrict__ slab)
+{
+    column_reduce(P, C, slab, [&](int r, int c4, float4 &a0, float4 &a1) {
+        const int c = 4 * c4;
+        const float4 g = ld4g(Gr + (size_t)r * ldg + c), y = ld4g(Y + (size_t)r * ldy + c);
+        const float4 s = ld4g(scale + c), t = ld4g(shift + c), mu = ld4g(mean + c), is = ld4g(invstd + c);
+        const float gx = fmaf(y.x, s.x, t.x) > 0.f ? g.x : 0.f, gy = fmaf(y.y, s.y, t.y) > 0.f ? g.y : 0.f,
+                    gz = fmaf(y.z, s.z, t.z) > 0.f ? g.z : 0.f, gw = fmaf(y.w, s.w, t.w) > 0.f ? g.w : 0.f;
+        a0.x += gx; a0.y += gy; a0.z += gz; a0.w += gw;
+        a1.x += gx * ((y.x - mu.x) * is.x); a1.y += gy * ((y.y - mu.y) * is.y);
+        a1.z += gz * ((y.z - mu.z) * is.z); a1.w += gw * ((y.w - mu.w) * is.w);
+    });
+}
+
+// Same partials when the gradient arrives through the group max-pool: only the winning sample of
+// each (group, channel) carries gradient gp[g, c] (and only if the pooled value is > 0).
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__restrict__ gp, long long ldgp,
+                                                              const float *__restrict__ Y, long long ldy,
+                                                              const int32_t *__restrict__ arg,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd, int G, int K,
+                                                              int C, float *__restrict__ slab)
+{
+    column_reduce(G, C, slab, [&](int gi, int c4, float4 &a0, float4 &a1) {
+        const int c = 4 * c4;
+        const float4 g = ld4g(gp + (size_t)gi * ldgp + c);
+        const int4 k = *reinterpret_cast<const int4 *>(arg + (size_t)gi * C + c);
+        const float *base = Y + (size_t)gi * K * ldy + c;
+        const float yx = base[(size_t)k.x * ldy], yy = base[(size_t)k.y * ldy + 1],
+                    yz = base[(size_t)k.z * ldy + 2], yw = base[(size_t)k.w * ldy + 3];
+        const float4 s = ld4g(scale + c), t = ld4g(shift + c), mu = ld4g(mean + c), is = ld4g(invstd + c);
+        const float gx = fmaf(yx, s.x, t.x) > 0.f ? g.x : 0.f, gy = fmaf(yy, s.y, t.y) > 0.f ? g.y : 0.f,
+                    gz = fmaf(yz, s.z, t.z) > 0.f ? g.z : 0.f, gw = fmaf(yw, s.w, t.w) > 0.f ? g.w : 0.f;
+        a0.x += gx; a0.y += gy; a0.z += gz; a0.w += gw;
+        a1.x += gx * ((yx - mu.x) * is.x); a1.y += gy * ((yy - mu.y) * is.y);
+        a1.z += gz * ((yz - mu.z) * is.z); a1.w += gw * ((yw - mu.w) * is.w);
+    });
+}
+
+// m1, m2 -> dgamma = m2, dbeta = m1 and the coefficients of dY = a * Gmasked + b * Y + d:
+//   train: dY = gamma*invstd * (Gm - m1/n - yhat * m2/n)
+//   eval : dY = gamma*invstd_running * Gm            (b = d = 0)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ slab, int nslab, int C,
+                                                              double count, int training,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd,
+                                                              float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, float *__restrict__ ca,
+                                                              float *__restrict__ cb, float *__restrict__ cd)
+{
+    __shared__ double s_s[4], s_q[4];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nslab; i += 256) {
+        s += (double)slab[((size_t)i * 2 + 0) * C + c];
+        q += (double)slab[((size_t)i * 2 + 1) * C + c];
+    }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if ((threadIdx.x & 63) == 0) { s_s[threadIdx.x >> 6] = s; s_q[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m1 = s_s[0] + s_s[1] + s_s[2] + s_s[3];
+        const double m2 = s_q[0] + s_q[1] + s_q[2] + s_q[3];
+        dgamma[c] = (float)m2;
+        dbeta[c] = (float)m1;
+        const double a = (double)scale[c];  // gamma * invstd
+        ca[c] = (float)a;
+        if (training) {
+            const double is = (double)invstd[c], mu = (double)mean[c];
+            cb[c] = (float)(-a * is * m2 / count);
+            cd[c] = (float)(a * (-m1 / count + mu * is * m2 / count));
+        } else {
+            cb[c] = 0.f;
+            cd[c] = 0.f;
+        }
+    }
+}
+
+// dY = a * (G masked by the ReLU) + b * Y + d
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float *__restrict__ Gr, long long ldg,
+                                                                const float *__restrict__ Y, long long ldy,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift,
+                                                                const float *__restrict__ ca,
+                                                                const float *__restrict__ cb,
+                                                                const float *__restrict__ cd, int P, int C4,
+                                                                float *__restrict__ dY, long long ldd)
+{
+    const long long total = (long long)P * C4;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long r = id / C4;
+        const int c = (int)(id - r * C4) * 4;
+        const float4 g = ld4g(Gr + r * ldg + c), y = ld4g(Y + r * ldy + c);
+        const float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
+        float4 o;
+        o.x = fmaf(a.x, fmaf(y.x, s.x, t.x) > 0.f ? g.x : 0.f, fmaf(b.x, y.x, d.x));
+        o.y = fmaf(a.y, fmaf(y.y, s.y, t.y) > 0.f ? g.y : 0.f, fmaf(b.y, y.y, d.y));
+        o.z = fmaf(a.z, fmaf(y.z, s.z, t.z) > 0.f ? g.z : 0.f, fmaf(b.z, y.z, d.z));
+        o.w = fmaf(a.w, fmaf(y.w, s.w, t.w) > 0.f ? g.w : 0.f, fmaf(b.w, y.w, d.w));
+        st4g(dY + r * ldd + c, o);
+    }
+}
+
+// dY[g,k,c] = a * (k == arg[g,c] && pooled > 0 ? gp[g,c] : 0) + b * Y + d
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float *__restrict__ gp, long long ldgp,
+                                                             const float *__restrict__ Y, long long ldy,
+                                                             const int32_t *__restrict__ arg,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift,
+                                                             const float *__restrict__ ca,
+                                                             const float *__restrict__ cb,
+                                                             const float *__restrict__ cd, int G, int K, int C4,
+                                                             float *__restrict__ dY, long long ldd)
+{
+    const long long total = (long long)G * K * C4;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long r = id / C4;  // g*K + k
+        const int c = (int)(id - r * C4) * 4;
+        const long long gi = r / K;
+        const int k = (int)(r - gi * K);
+        const float4 g = ld4g(gp + gi * ldgp + c), y = ld4g(Y + r * ldy + c);
+        const int4 w = *reinterpret_cast<const int4 *>(arg + gi * (C4 * 4) + c);
+        const float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
+        float4 o;
+        o.x = fmaf(a.x, (k == w.x && fmaf(y.x, s.x, t.x) > 0.f) ? g.x : 0.f, fmaf(b.x, y.x, d.x));
+        o.y = fmaf(a.y, (k == w.y && fmaf(y.y, s.y, t.y) > 0.f) ? g.y : 0.f, fmaf(b.y, y.y, d.y));
+        o.z = fmaf(a.z, (k == w.z && fmaf(y.z, s.z, t.z) > 0.f) ? g.z : 0.f, fmaf(b.z, y.z, d.z));
+        o.w = fmaf(a.w, (k == w.w && fmaf(y.w, s.w, t.w) > 0.f) ? g.w : 0.f, fmaf(b.w, y.w, d.w));
+        st4g(dY + r * ldd + c, o);
+    }
+}
+
+static inline int ew_grid(long long total)
+{
+    long long g = (total + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g > 256 * 32 ? 256 * 32 : g);
+}
+static inline bool bad_mat(const void *p, long long ld, int C)
+{
+    return !p || (C & 3) || (ld & 3) || ((uintptr_t)p & 15) || ld < C;
+}
+
+extern "C" {
+
+int prifit_reduce_rows_per_slab(void) { return RED_ROWS; }
+
+int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream)
+{
+    if (bad_mat(Y, ld, C) || !slab || P <= 0 || C <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(col_stats_kernel, dim3((P + RED_ROWS - 1) / RED_ROWS), dim3(256), 0, as_stream(stream), Y,
+                       ld, P, C, slab);
+    return prifit_check_launch();
+}
+
+int prifit_bn_finalize(const float *slab, int nslab, int C, double count, const float *gamma, const float *beta,
+                       float eps, float momentum, float *running_mean, float *running_var, float *scale,
+                       float *shift, float *mean, float *invstd, void *stream)
+{
+    if (!slab || nslab <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !scale || !shift || !mean || !invstd ||
+        ((running_mean == nullptr) != (running_var == nullptr)))
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), slab, nslab, C, count, gamma,
+                       beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd);
+    return prifit_check_launch();
+}
+
+int prifit_affine_relu(const float *Y, long long ldy, const float *scale, const float *shift, int P, int C,
+                       float *out, long long ldo, void *stream)
+{
+    if (bad_mat(Y, ldy, C) || bad_mat(out, ldo, C) || !scale || !shift || P <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(affine_relu_kernel, dim3(ew_grid((long long)P * (C / 4))), dim3(256), 0, as_stream(stream),
+                       Y, ldy, scale, shift, P, C / 4, out, ldo);
+    return prifit_check_launch();
+}
+
+int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const float *shift, int G, int K, int C,
+                    float *out, long long ldo, int32_t *arg, void *stream)
+{
+    if (bad_mat(Y, ldy, C) || bad_mat(out, ldo, C) || !scale || !shift || !arg || G <= 0 || K <= 0)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((long long)G * (C / 4))), dim3(256), 0, as_stream(stream), Y,
+                       ldy, scale, shift, G, K, C / 4, out, ldo, arg);
+    return prifit_check_launch();
+}
+
+int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy, const float *scale,
+                              const float *shift, const float *mean, const float *invstd, int P, int C,
+                              float *slab, void *stream)
+{
+    if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || !scale || !shift || !mean || !invstd || !slab || P <= 0)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((P + RED_ROWS - 1) / RED_ROWS), dim3(256), 0,
+                       as_stream(stream), G, ldg, Y, ldy, scale, shift, mean, invstd, P, C, slab);
+    return prifit_check_launch();
+}
+
+int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
+                           const float *scale, const float *shift, const float *mean, const float *invstd, int G,
+                           int K, int C, float *slab, void *stream)
+{
+    if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || !arg || !scale || !shift || !mean || !invstd || !slab ||
+        G <= 0 || K <= 0)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((G + RED_ROWS - 1) / RED_ROWS), dim3(256), 0,
+                       as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, mean, invstd, G, K, C, slab);
+    return prifit_check_launch();
+}
+
+int prifit_bn_bwd_finalize(const float *slab, int nslab, int C, double count, int training, const float *scale,
+                           const float *mean, const float *invstd, float *dgamma, float *dbeta, float *coef_a,
+                           float *coef_b, float *coef_d, void *stream)
+{
+    if (!slab || nslab <= 0 || C <= 0 || count <= 0 || !scale || !mean || !invstd || !dgamma || !dbeta ||
+        !coef_a || !coef_b || !coef_d)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), slab, nslab, C, count,
+                       training, scale, mean, invstd, dgamma, dbeta, coef_a, coef_b, coef_d);
+    return prifit_check_launch();
+}
+
+int prifit_bn_relu_bwd_apply(const float *G, long long ldg, const float *Y, long long ldy, const float *scale,
+                             const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                             int P, int C, float *dY, long long ldd, void *stream)
+{
+    if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || bad_mat(dY, ldd, C) || !scale || !shift || !coef_a ||
+        !coef_b || !coef_d || P <= 0)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_grid((long long)P * (C / 4))), dim3(256), 0,
+                       as_stream(stream), G, ldg, Y, ldy, scale, shift, coef_a, coef_b, coef_d, P, C / 4, dY, ldd);
+    return prifit_check_launch();
+}
+
+int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
+                          const float *scale, const float *shift, const float *coef_a, const float *coef_b,
+                          const float *coef_d, int G, int K, int C, float *dY, long long ldd, void *stream)
+{
+    if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || bad_mat(dY, ldd, C) || !arg || !scale || !shift ||
+        !coef_a || !coef_b || !coef_d || G <= 0 || K <= 0)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((long long)G * K * (C / 4))), dim3(256), 0,
+                       as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C / 4,
+                       dY, ldd);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

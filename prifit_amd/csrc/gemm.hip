@@ -1,0 +1,313 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain).
+//
+// One templated kernel serves every dense contraction of the hot path:
+//   NT  C[M,N] = A[M,K] . B[N,K]^T   shared-MLP forward (1x1 conv), S = Z X^T of mean-shift
+//   NN  C[M,N] = A[M,K] . B[K,N]     dA = dY . W, (K X) of mean-shift
+//   TN  C[M,N] = A[K,M]^T . B[K,N]   dW = dY^T . A (split over the reduction), dX of mean-shift
+// with fused prologues (train-mode BatchNorm + ReLU of the producing layer applied while the
+// operand is staged: "normalise on load") and epilogues (bias, per-column sum / sum-of-squares
+// partials for the next BatchNorm, chord-distance and mean-shift kernel transforms).
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN x 32; each wave owns WM x WN = (32*TM) x (32*TN)
+// accumulators (TM*TN f32x16).  Operand tiles are staged global -> registers -> LDS with the next
+// tile's global loads in flight during the MFMAs of the current one.  LDS rows are padded by one
+// 16-byte slot so that the ds_read_b128 fragment reads are bank-conflict free on the 64-bank LDS.
+// Block ids are remapped so that the N-tiles of one M-panel run on the same XCD (shared L2).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { LAY_NT = 0, LAY_NN = 1, LAY_TN = 2 };
+enum { EPI_NONE = 0, EPI_CHORD = 1, EPI_MSKERNEL = 2 };
+
+struct GemmArgs {
+    const float *A, *B;
+    float *C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    long long sA, sB, sC;  // batch strides (elements)
+    int batch, splitk;     // gridDim.z = batch * splitk
+    const float *a_scale, *a_shift;  // prologue on A: a' = max(a*scale[c]+shift[c], 0), c = A's contiguous index
+    const float *b_scale, *b_shift;  // same for B
+    const float *bias;               // [N], added to every row
+    float *stats;                    // [tilesM][2][N] per-column partial (sum, sum of squares) of C
+    int epi;
+    const float *epi_batch_scalar;   // EPI_MSKERNEL: bandwidth b[z]
+    int accumulate;                  // 1: atomicAdd into C (split-K); 0: store
+    int vecA, vecB;                  // 16-byte loads legal for the operand
+};
+
+constexpr int BK = 32;
+constexpr int PAD = 4;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// Stage one operand tile (ROWS x BK, logical [row][k]) from global into registers.
+//  KC = true : stored [R][K] (k contiguous);  KC = false: stored [K][R] (row index contiguous).
+template <int ROWS, bool KC>
+struct TileLoader {
+    static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float *__restrict__ base, long long ld, int r0, int k0, int R,
+                                         int K, bool vec, const float *__restrict__ scale,
+                                         const float *__restrict__ shift)
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + 256 * p;
+            int row, kk, c0;  // tile-local row, tile-local k of element 0, channel of element 0
+            const float *src;
+            bool ok[4];
+            if (KC) {
+                row = id / (BK / 4);
+                kk = (id % (BK / 4)) * 4;
+                src = base + (long long)(r0 + row) * ld + (k0 + kk);
+                c0 = k0 + kk;
+                const bool rok = (r0 + row) < R;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ok[e] = rok && (k0 + kk + e) < K;
+            } else {
+                kk = id / (ROWS / 4);
+                row = (id % (ROWS / 4)) * 4;
+                src = base + (long long)(k0 + kk) * ld + (r0 + row);
+                c0 = r0 + row;
+                const bool kok = (k0 + kk) < K;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ok[e] = kok && (r0 + row + e) < R;
+            }
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec) {
+                if (ok[0]) x = ld4(src);  // vec mode: extents are multiples of 4, so ok[0] == ok[3]
+            } else {
+                if (ok[0]) x.x = src[0];
+                if (ok[1]) x.y = src[1];
+                if (ok[2]) x.z = src[2];
+                if (ok[3]) x.w = src[3];
+            }
+            if (scale) {
+                if (ok[0]) x.x = fmaxf(fmaf(x.x, scale[c0 + 0], shift[c0 + 0]), 0.f);
+                if (ok[1]) x.y = fmaxf(fmaf(x.y, scale[c0 + 1], shift[c0 + 1]), 0.f);
+                if (ok[2]) x.z = fmaxf(fmaf(x.z, scale[c0 + 2], shift[c0 + 2]), 0.f);
+                if (ok[3]) x.w = fmaxf(fmaf(x.w, scale[c0 + 3], shift[c0 + 3]), 0.f);
+            }
+            v[p] = x;
+        }
+    }
+
+    __device__ __forceinline__ void store(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + 256 * p;
+            if (KC) {
+                const int row = id / (BK / 4), kk = (id % (BK / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + row * (BK + PAD) + kk) = v[p];
+            } else {
+                const int kk = id / (ROWS / 4), row = (id % (ROWS / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + kk * (ROWS + PAD) + row) = v[p];
+            }
+        }
+    }
+};
+
+// Fragment of 4 consecutive MFMA k-steps for lane (i, h): k = 8*g + 4*h + j, j = 0..3.
+template <int ROWS, bool KC>
+__device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int row, int g, int h)
+{
+    if (KC) return *reinterpret_cast<const float4 *>(lds + row * (BK + PAD) + g * 8 + h * 4);
+    const float *p = lds + (g * 8 + h * 4) * (ROWS + PAD) + row;
+    return make_float4(p[0], p[ROWS + PAD], p[2 * (ROWS + PAD)], p[3 * (ROWS + PAD)]);
+}
+
+template <int BM, int BN, int WM, int WN, int LAY>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
+{
+    constexpr bool A_KC = (LAY != LAY_TN);
+    constexpr bool B_KC = (LAY == LAY_NT);
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int SZA = A_KC ? BM * (BK + PAD) : BK * (BM + PAD);
+    constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
+    __shared__ __attribute__((aligned(16))) float lds[SZA + SZB];
+    float *As = lds, *Bs = lds + SZA;
+
+    // XCD-aware bijective remap: logical tiles that share an A panel get ids that are consecutive on
+    // one XCD (hardware deals consecutive workgroup ids round-robin over the 8 XCDs).
+    const int tilesN = (g.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, pos = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int tile_m = L / tilesN, tile_n = L - tile_m * tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z / g.splitk, ks = blockIdx.z - z * g.splitk;
+
+    const float *A = g.A + (long long)z * g.sA;
+    const float *B = g.B + (long long)z * g.sB;
+    float *C = g.C + (long long)z * g.sC;
+
+    // K range of this split
+    const int ktiles = (g.K + BK - 1) / BK;
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    TileLoader<BM, A_KC> la;
+    TileLoader<BN, B_KC> lb;
+    if (kt0 < kt1) {
+        la.load(A, g.lda, m0, kt0 * BK, g.M, g.K, g.vecA, g.a_scale, g.a_shift);
+        lb.load(B, g.ldb, n0, kt0 * BK, g.N, g.K, g.vecB, g.b_scale, g.b_shift);
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();  // previous tile's fragment reads are done
+        la.store(As);
+        lb.store(Bs);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            la.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.vecA, g.a_scale, g.a_shift);
+            lb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.vecB, g.b_scale, g.b_shift);
+        }
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = read_frag<BM, A_KC>(As, wm0 + 32 * a + li, gk, lh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, B_KC>(Bs, wn0 + 32 * b + li, gk, lh);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float inv_b2 = 0.f;
+    if (g.epi == EPI_MSKERNEL) { const float bw = g.epi_batch_scalar[z]; inv_b2 = bw * bw; }
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) { csum[b] = 0.f; csq[b] = 0.f; }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn0 + 32 * b + li;
+        const bool cok = col < g.N;
+        const float bias = (g.bias && cok && ks == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (!(cok && row < g.M)) continue;
+                float v = acc[a][b][r] + bias;
+                if (g.epi == EPI_CHORD) {
+                    v = 2.0f - 2.0f * v;                       // src/mean_shift.py:154 / :168
+                } else if (g.epi == EPI_MSKERNEL) {
+                    // src/mean_shift.py:65-68: dist = 2 - 2 s; K = exp(clamp(-dist / b^2 / 2, -13, 75))
+                    const float dist = 2.0f - 2.0f * v;
+                    float t = (-dist / inv_b2) / 2.0f;
+                    t = fminf(fmaxf(t, -13.0f), 75.0f);
+                    v = expf(t);
+                }
+                csum[b] += v;
+                csq[b] += v * v;
+                float *dst = C + (long long)row * g.ldc + col;
+                if (g.accumulate) unsafeAtomicAdd(dst, v);
+                else *dst = v;
+            }
+        }
+    }
+    if (g.stats) {
+        __syncthreads();  // LDS tiles are dead: reuse as [WAVES_M][2][BN]
+        float *red = lds;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            float s = csum[b] + __shfl_xor(csum[b], 32, 64);
+            float q = csq[b] + __shfl_xor(csq[b], 32, 64);
+            if (lh == 0) {
+                red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
+                red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * BN; t += 256) {
+            const int which = t / BN, c = t - which * BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < BM / WM; ++w) s += red[(w * 2 + which) * BN + c];
+            if (n0 + c < g.N) g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmArgs &g, int lay, hipStream_t st)
+{
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
+    dim3 grid(tilesM * tilesN, 1, g.batch * g.splitk), block(256);
+    switch (lay) {
+        case LAY_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY_NT>), grid, block, 0, st, g); break;
+        case LAY_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY_NN>), grid, block, 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY_TN>), grid, block, 0, st, g); break;
+    }
+    return prifit_check_launch();
+}
+
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+int prifit_gemm_tile_m(int N)
+{
+    (void)N;
+    return 128;
+}
+
+int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long lda, long long strideA,
+                    const float *B, long long ldb, long long strideB, float *C, long long ldc,
+                    long long strideC, int batch, int splitk, const float *a_scale, const float *a_shift,
+                    const float *b_scale, const float *b_shift, const float *bias, float *col_stats,
+                    int epilogue, const float *epi_batch_scalar, void *stream)
+{
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0 || layout < 0 || layout > 2 ||
+        epilogue < 0 || epilogue > 2 || (epilogue == EPI_MSKERNEL && !epi_batch_scalar) ||
+        ((a_scale == nullptr) != (a_shift == nullptr)) || ((b_scale == nullptr) != (b_shift == nullptr)) ||
+        (col_stats && (batch != 1 || splitk != 1)) || (epilogue != EPI_NONE && splitk != 1) || (long long)batch * splitk > 65535)
+        return PRIFIT_EINVAL;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.batch = batch; g.splitk = splitk;
+    g.a_scale = a_scale; g.a_shift = a_shift; g.b_scale = b_scale; g.b_shift = b_shift;
+    g.bias = bias; g.stats = col_stats; g.epi = epilogue; g.epi_batch_scalar = epi_batch_scalar;
+    g.accumulate = splitk > 1;
+    // contiguous extents: A is k-contiguous unless TN (then m-contiguous); B is k-contiguous for NT else n-contiguous
+    const int extA = layout == LAY_TN ? M : K, extB = layout == LAY_NT ? K : N;
+    g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0) && (extA % 4 == 0);
+    g.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0) && (extB % 4 == 0);
+    hipStream_t st = as_stream(stream);
+    if (N > 64) return launch_cfg<128, 128, 64, 64>(g, layout, st);
+    if (N > 32) return launch_cfg<128, 64, 32, 64>(g, layout, st);
+    return launch_cfg<128, 32, 32, 32>(g, layout, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+"""MI355X backend behind the call surface of the reference's models/pointnet_util.py.
+
+Same function / class names, constructor arguments, tensor layouts ([B, C, N] in and out) and
+state_dict keys as upstream (models/pointnet_util.py:19-314); every op runs as a hand-written HIP
+kernel through libprifit_hip.so.  There is no CPU fallback: tensors must live on the GPU.
+
+Differences that are deliberate and documented (SURVEY.md section 8a'):
+  * farthest_point_sample / the modules take an optional explicit FPS start index (`fps_start`);
+    when omitted a random start is drawn exactly like upstream (:75);
+  * internally activations are channels-last and input channels are zero-padded to multiples of 4
+    (weights are re-packed on the fly; gradients flow back to the upstream-shaped parameters).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..nn_ops import GroupGatherFn, SharedMLPFn, ThreeInterpolateFn
+
+
+# ------------------------------------------------------------------ functional surface (:19-107)
+def square_distance(src, dst):
+    """upstream :19-40 -- src [B,N,3], dst [B,M,3] -> [B,N,M] (expanded form, bitwise)."""
+    return ops.square_distance(src, dst)
+
+
+def index_points(points, idx):
+    """upstream :43-60 -- points [B,N,C], idx [B,S] or [B,S,K] -> [B,S,(K,)C]."""
+    B = points.shape[0]
+    flat = idx.reshape(B, -1).long()
+    out = torch.gather(points, 1, flat.unsqueeze(-1).expand(-1, -1, points.shape[-1]))
+    return out.reshape(*idx.shape, points.shape[-1])
+
+
+def farthest_point_sample(xyz, npoint, start_idx=None):
+    """upstream :63-84 -- xyz [B,N,3] -> int64 [B,npoint]."""
+    return ops.farthest_point_sample(xyz, npoint, start_idx)
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """upstream :87-107 -- int64 [B,S,nsample]."""
+    return ops.ball_query_multi([radius], [nsample], xyz, new_xyz, idx64=True)[0]
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _pack_weight(conv, perm_slices, kp):
+    """[Cout, Cin(,1,1)] -> [Cout, kp]: columns re-ordered to the internal row layout, zero padded."""
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    parts = [w[:, a:b] for a, b in perm_slices]
+    k = sum(b - a for a, b in perm_slices)
+    if kp > k:
+        parts.append(w.new_zeros(w.shape[0], kp - k))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+
+def _mlp_tensors(convs, bns, first_weight):
+    ts = []
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        w = first_weight if i == 0 else conv.weight.reshape(conv.weight.shape[0], -1)
+        ts += [w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    return ts
+
+
+def _mlp_cfg(bns, pool_K, training):
+    for bn in bns:
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    return {"pool_K": pool_K, "training": training, "eps": bns[0].eps,
+            "momentum": [0.1 if bn.momentum is None else bn.momentum for bn in bns]}
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, fps_start=None):
+    """upstream :110-137 (SSG order [rel_xyz, features]); returns the reference's 4-D tensors."""
+    B, N, C = xyz.shape
+    fps_idx, new_xyz = ops.farthest_point_sample(xyz, npoint, fps_start, return_xyz=True)
+    idx = ops.ball_query_multi([radius], [nsample], xyz, new_xyz)[0]
+    D = 0 if points is None else points.shape[-1]
+    rows = GroupGatherFn.apply(None if points is None else points.contiguous(), xyz.contiguous(), new_xyz, idx, 1,
+                               _pad4(D + 3))
+    new_points = rows[:, :D + 3].reshape(B, npoint, nsample, D + 3)
+    if returnfps:
+        return new_xyz, new_points, index_points(xyz, idx), fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """upstream :140-157."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device, dtype=xyz.dtype)
+    grouped = xyz.view(B, 1, N, C)
+    if points is not None:
+        grouped = torch.cat([grouped, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped
+
+
+# ------------------------------------------------------------------ modules (:160-314)
+class PointNetSetAbstraction(nn.Module):
+    """upstream :160-201 (single-scale or group_all).  state_dict: mlp_convs.i / mlp_bns.i."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.mlp_convs, self.mlp_bns = nn.ModuleList(), nn.ModuleList()
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last = out_channel
+
+    def forward_cl(self, xyz, feats, fps_start=None):
+        """channels-last: xyz [B,N,3], feats [B,N,D] or None -> (new_xyz [B,S,3], out [B,S,C'])."""
+        B, N, _ = xyz.shape
+        D = 0 if feats is None else feats.shape[-1]
+        kp = _pad4(D + 3)
+        if self.group_all:
+            S, K = 1, N
+            new_xyz = torch.zeros(B, 1, 3, device=xyz.device, dtype=xyz.dtype)
+            parts = [xyz] + ([feats] if feats is not None else [])  # :154 order [xyz, features]
+            if kp > D + 3:
+                parts.append(xyz.new_zeros(B, N, kp - D - 3))
+            rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
+            w0 = _pack_weight(self.mlp_convs[0], [(0, D + 3)], kp)
+        else:
+            S, K = self.npoint, self.nsample
+            _, new_xyz = ops.farthest_point_sample(xyz, S, fps_start, return_xyz=True)
+            idx = ops.ball_query_multi([self.radius], [K], xyz, new_xyz)[0]
+            # rows = [features, rel_xyz, pad]; upstream order is [rel_xyz, features] (:131)
+            rows = GroupGatherFn.apply(feats, xyz, new_xyz, idx, 0, kp)
+            w0 = _pack_weight(self.mlp_convs[0], [(3, 3 + D), (0, 3)], kp)
+        out = SharedMLPFn.apply(rows, _mlp_cfg(self.mlp_bns, K, self.training),
+                                *_mlp_tensors(self.mlp_convs, self.mlp_bns, w0))
+        return new_xyz, out.reshape(B, S, -1)
+
+    def forward(self, xyz, points, fps_start=None):
+        """xyz [B,3,N], points [B,D,N] -> (new_xyz [B,3,S], new_points [B,D',S])."""
+        x = xyz.permute(0, 2, 1).contiguous()
+        f = points.permute(0, 2, 1).contiguous() if points is not None else None
+        nx, out = self.forward_cl(x, f, fps_start)
+        return nx.permute(0, 2, 1), out.permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """upstream :204-261.  state_dict: conv_blocks.i.j / bn_blocks.i.j."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super().__init__()
+        self.npoint, self.radius_list, self.nsample_list = npoint, radius_list, nsample_list
+        self.conv_blocks, self.bn_blocks = nn.ModuleList(), nn.ModuleList()
+        for i in range(len(mlp_list)):
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last = in_channel + 3
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward_cl(self, xyz, feats, fps_start=None):
+        B, N, _ = xyz.shape
+        S = self.npoint
+        D = 0 if feats is None else feats.shape[-1]
+        kp = _pad4(D + 3)
+        _, new_xyz = ops.farthest_point_sample(xyz, S, fps_start, return_xyz=True)
+        idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
+        pooled = []
+        for i, K in enumerate(self.nsample_list):
+            rows = GroupGatherFn.apply(feats, xyz, new_xyz, idxs[i], 0, kp)  # [features, rel_xyz] (:247)
+            w0 = _pack_weight(self.conv_blocks[i][0], [(0, D + 3)], kp)
+            pooled.append(SharedMLPFn.apply(rows, _mlp_cfg(self.bn_blocks[i], K, self.training),
+                                            *_mlp_tensors(self.conv_blocks[i], self.bn_blocks[i], w0)))
+        return new_xyz, torch.cat(pooled, dim=-1).reshape(B, S, -1)
+
+    def forward(self, xyz, points, fps_start=None):
+        x = xyz.permute(0, 2, 1).contiguous()
+        f = points.permute(0, 2, 1).contiguous() if points is not None else None
+        nx, out = self.forward_cl(x, f, fps_start)
+        return nx.permute(0, 2, 1), out.permute(0, 2, 1)
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """upstream :264-314.  state_dict: mlp_convs.i / mlp_bns.i."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs, self.mlp_bns = nn.ModuleList(), nn.ModuleList()
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last = out_channel
+
+    def forward_cl(self, xyz1, xyz2, points1, points2):
+        """xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,D1] or None, points2 [B,S,D2] -> [B,N,D']."""
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        D2 = points2.shape[-1]
+        D1 = 0 if points1 is None else points1.shape[-1]
+        if S == 1:
+            interp = points2.expand(B, N, D2).reshape(B * N, D2)
+        else:
+            idx, w = ops.three_nn(xyz1, xyz2)
+            interp = ThreeInterpolateFn.apply(points2, idx, w)
+        kp = _pad4(D1 + D2)
+        # internal row layout [interpolated, points1, pad]; upstream concatenates [points1, interpolated] (:306)
+        parts = [interp]
+        if points1 is not None:
+            parts.append(points1.reshape(B * N, D1))
+        if kp > D1 + D2:
+            parts.append(interp.new_zeros(B * N, kp - D1 - D2))
+        rows = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
+        if len(self.mlp_convs) == 0:
+            return rows[:, :D1 + D2].reshape(B, N, -1)
+        w0 = _pack_weight(self.mlp_convs[0], [(D1, D1 + D2), (0, D1)], kp)
+        out = SharedMLPFn.apply(rows.contiguous(), _mlp_cfg(self.mlp_bns, 0, self.training),
+                                *_mlp_tensors(self.mlp_convs, self.mlp_bns, w0))
+        return out.reshape(B, N, -1)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D,N], points2 [B,D,S] -> [B,D',N]."""
+        p1 = points1.permute(0, 2, 1).contiguous() if points1 is not None else None
+        out = self.forward_cl(xyz1.permute(0, 2, 1).contiguous(), xyz2.permute(0, 2, 1).contiguous(), p1,
+                              points2.permute(0, 2, 1).contiguous())
+        return out.permute(0, 2, 1)

@@ -1,0 +1,253 @@
+"""Autograd functions of the shared per-position MLP stack, built on the C-ABI kernels.
+
+Activations are channels-last matrices [P, C] (P = B*S*K grouped samples or B*N points).  A
+"shared MLP" is the reference's (Conv1x1 -> train-mode BatchNorm -> ReLU) x L chain, optionally
+followed by the max over the K samples of each group (models/pointnet_util.py:195-199,
+:252-256, :310-313).  Here each layer is ONE MFMA GEMM whose prologue applies the previous
+layer's BatchNorm+ReLU while loading ("normalise on load") and whose epilogue emits the partial
+sums for its own BatchNorm, so no normalised activation is ever written to HBM.
+"""
+import ctypes
+
+import torch
+
+from ._lib import call, cur_stream, dll, ptr
+
+NT, NN, TN = 0, 1, 2
+EPI_NONE, EPI_CHORD, EPI_MSKERNEL = 0, 1, 2
+_LL = ctypes.c_longlong
+_F = ctypes.c_float
+_D = ctypes.c_double
+
+
+def _rows_per_slab():
+    return dll().prifit_reduce_rows_per_slab()
+
+
+def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
+         b_affine=None, bias=None, stats=None, epi=EPI_NONE, epi_scalar=None):
+    call("prifit_gemm_f32", layout, M, N, K, ptr(A), _LL(lda), _LL(sA), ptr(B), _LL(ldb), _LL(sB), ptr(C),
+         _LL(ldc), _LL(sC), batch, splitk,
+         ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
+         ptr(b_affine[0]) if b_affine else None, ptr(b_affine[1]) if b_affine else None,
+         ptr(bias), ptr(stats), epi, ptr(epi_scalar), cur_stream())
+
+
+def _splitk_for(P, tiles):
+    """Workgroups along the reduction for dW = dY^T A: aim at ~1024 workgroups, >= 8 k-tiles each."""
+    ktiles = (P + 31) // 32
+    want = max(1, 1024 // max(1, tiles))
+    return int(max(1, min(want, ktiles // 8 if ktiles >= 8 else 1, 4096)))
+
+
+def _weight_grad(dY, P, Cout, Ain, Kin, a_affine):
+    """dW [Cout, Kin] = dY[P, Cout]^T . A[P, Kin] (A optionally normalised on load)."""
+    dW = torch.zeros(Cout, Kin, dtype=torch.float32, device=dY.device)
+    tiles = ((Cout + 127) // 128) * ((Kin + 127) // 128)
+    sk = _splitk_for(P, tiles)
+    if sk == 1:
+        dW = torch.empty_like(dW)
+    gemm(TN, Cout, Kin, P, dY, dY.stride(0), Ain, Ain.stride(0), dW, Kin, splitk=sk, b_affine=a_affine)
+    return dW
+
+
+class SharedMLPFn(torch.autograd.Function):
+    """(conv1x1 + BatchNorm + ReLU) x L [+ max over the K samples of each group].
+
+    apply(x, cfg, *tensors) with, per layer, tensors = (W [Cout, Kin], bias, gamma, beta,
+    running_mean, running_var); cfg = dict(pool_K, training, eps, momentum[list])."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *tensors):
+        L = len(tensors) // 6
+        P, K0 = x.shape
+        dev = x.device
+        training = cfg["training"]
+        tile_m = 128
+        Ys, affines, stats_saved, Ws = [], [], [], []
+        prev, prev_aff = x, None
+        for l in range(L):
+            W, b, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 6]
+            W = W.contiguous()
+            Cout, Kin = W.shape
+            assert Kin == prev.shape[1], (Kin, prev.shape)
+            Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            scale = torch.empty(Cout, dtype=torch.float32, device=dev)
+            shift = torch.empty_like(scale)
+            mean = torch.empty_like(scale)
+            invstd = torch.empty_like(scale)
+            if training:
+                nslab = (P + tile_m - 1) // tile_m
+                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
+                call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
+                     _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
+                     ptr(mean), ptr(invstd), cur_stream())
+            else:
+                gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b)
+                invstd = torch.rsqrt(rvar + cfg["eps"])
+                mean = rmean.clone()
+                scale = gamma * invstd
+                shift = beta - mean * scale
+            Ys.append(Y)
+            Ws.append(W)
+            affines.append((scale, shift))
+            stats_saved.append((mean, invstd))
+            prev, prev_aff = Y, (scale, shift)
+        CL = Ys[-1].shape[1]
+        pool_K = cfg["pool_K"]
+        arg = None
+        if pool_K:
+            G = P // pool_K
+            out = torch.empty(G, CL, dtype=torch.float32, device=dev)
+            arg = torch.empty(G, CL, dtype=torch.int32, device=dev)
+            call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL,
+                 ptr(out), _LL(CL), ptr(arg), cur_stream())
+        else:
+            out = torch.empty(P, CL, dtype=torch.float32, device=dev)
+            call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, ptr(out),
+                 _LL(CL), cur_stream())
+        ctx.cfg = cfg
+        ctx.L = L
+        ctx.saved = (x, Ys, Ws, affines, stats_saved, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cfg, L = ctx.cfg, ctx.L
+        x, Ys, Ws, affines, stats_saved, arg = ctx.saved
+        training = cfg["training"]
+        P = x.shape[0]
+        dev = x.device
+        gout = gout.contiguous()
+        rps = _rows_per_slab()
+        grads = [None] * (6 * L)
+        G_in = gout  # gradient w.r.t. the ReLU output of layer l (or pooled output for the last layer)
+        for l in range(L - 1, -1, -1):
+            Y, W = Ys[l], Ws[l]
+            Cout, Kin = W.shape
+            scale, shift = affines[l]
+            mean, invstd = stats_saved[l]
+            dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+            dbeta = torch.empty_like(dgamma)
+            ca, cb, cd = torch.empty_like(dgamma), torch.empty_like(dgamma), torch.empty_like(dgamma)
+            dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            pooled = (l == L - 1) and cfg["pool_K"]
+            if pooled:
+                K = cfg["pool_K"]
+                G = P // K
+                nslab = (G + rps - 1) // rps
+                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                call("prifit_pool_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
+                     ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, ptr(slab), cur_stream())
+            else:
+                nslab = (P + rps - 1) // rps
+                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                call("prifit_bn_relu_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
+                     ptr(shift), ptr(mean), ptr(invstd), P, Cout, ptr(slab), cur_stream())
+            call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
+                 ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
+            if pooled:
+                call("prifit_pool_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
+                     ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), G, K, Cout, ptr(dY), _LL(Cout),
+                     cur_stream())
+            else:
+                call("prifit_bn_relu_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
+                     ptr(shift), ptr(ca), ptr(cb), ptr(cd), P, Cout, ptr(dY), _LL(Cout), cur_stream())
+            A_in = x if l == 0 else Ys[l - 1]
+            a_aff = None if l == 0 else affines[l - 1]
+            if ctx.needs_input_grad[2 + 6 * l]:
+                grads[6 * l] = _weight_grad(dY, P, Cout, A_in, Kin, a_aff)
+            if ctx.needs_input_grad[2 + 6 * l + 1]:
+                # bias in front of a batch-stat BatchNorm has zero gradient; with running stats it is sum(dY)
+                grads[6 * l + 1] = torch.zeros(Cout, device=dev) if training else dY.sum(dim=0)
+            grads[6 * l + 2] = dgamma
+            grads[6 * l + 3] = dbeta
+            if l > 0 or ctx.needs_input_grad[0]:
+                G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+                gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, G_prev, Kin)
+                G_in = G_prev
+            else:
+                G_in = None
+            del dY
+        return (G_in, None) + tuple(grads)
+
+
+class LinearFn(torch.autograd.Function):
+    """Y = X W^T + b on [P, C] rows (a conv1x1 without BatchNorm: conv2 / extra_conv_emb,
+    models/pointnet2_part_seg_msg.py:109,128)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        W = W.contiguous()
+        P, Kin = x.shape
+        Cout = W.shape[0]
+        Y = torch.empty(P, Cout, dtype=torch.float32, device=x.device)
+        gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=b)
+        ctx.save_for_backward(x, W)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        gy = gy.contiguous()
+        P, Kin = x.shape
+        Cout = W.shape[0]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(P, Kin, dtype=torch.float32, device=x.device)
+            gemm(NN, P, Kin, Cout, gy, Cout, W, Kin, dx, Kin)
+        if ctx.needs_input_grad[1]:
+            dW = _weight_grad(gy, P, Cout, x, Kin, None)
+        if ctx.needs_input_grad[2]:
+            db = gy.sum(dim=0)
+        return dx, dW, db
+
+
+class GroupGatherFn(torch.autograd.Function):
+    """Grouped rows [B*S*K, ld] = [feat[idx], xyz[idx] - centre, 0-pad] (order 0) or
+    [xyz[idx] - centre, feat[idx], 0-pad] (order 1); gradient flows to `feat` only (xyz is data)."""
+
+    @staticmethod
+    def forward(ctx, feat, xyz, new_xyz, idx, order, ld_out):
+        from . import ops
+
+        out = ops.group_gather(feat, xyz, new_xyz, idx, order=order, ld_out=ld_out)
+        ctx.save_for_backward(idx)
+        ctx.meta = (feat.shape, order) if feat is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+
+        if ctx.meta is None or not ctx.needs_input_grad[0]:
+            return (None,) * 6
+        (idx,) = ctx.saved_tensors
+        (B, N, C), order = ctx.meta
+        gout = gout.contiguous()
+        dfeat = ops.group_scatter_add(gout, 0 if order == 0 else 3, idx, B, N, C)
+        return dfeat, None, None, None, None, None
+
+
+class ThreeInterpolateFn(torch.autograd.Function):
+    """interpolated[(b,n), :] = sum_j w[b,n,j] * points2[b, idx[b,n,j], :]"""
+
+    @staticmethod
+    def forward(ctx, points2, idx, weight):
+        from . import ops
+
+        points2 = points2.contiguous()
+        ctx.save_for_backward(idx, weight)
+        ctx.shape = points2.shape
+        return ops.three_interpolate(points2, idx, weight)
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import ops
+
+        idx, weight = ctx.saved_tensors
+        B, S, C = ctx.shape
+        gout = gout.contiguous()
+        return ops.three_interpolate_bwd(gout, 0, idx, weight, B, S, C), None, None

@@ -78,6 +78,10 @@ def group_gather(feat, xyz, new_xyz, idx, order=0, ld_out=None):
     """models/pointnet_util.py:243-249 / :127-133.  Returns [B*S*K, ld_out] rows
     [feat, rel_xyz, 0..] (order 0, MSG) or [rel_xyz, feat, 0..] (order 1, SSG)."""
     require_cuda(xyz, new_xyz, idx)
+    xyz, new_xyz = cf(xyz), cf(new_xyz)
+    feat = None if feat is None else cf(feat)
+    idx = idx.contiguous()
+    assert idx.dtype == torch.int32
     B, N, _ = xyz.shape
     _, S, K = idx.shape
     C = 0 if feat is None else feat.shape[-1]

@@ -1,0 +1,228 @@
+"""GPU parity: MFMA GEMM, shared-MLP autograd, SA / FP modules and the full MSG network vs the oracle
+(torch-CPU restatement) and the golden vectors captured from the reference.
+
+Tolerances (fp32): GEMM 2e-5 relative to |A||B| row/col norms; module outputs 1e-4; module gradients
+2e-4 (+ abs floor scaled by the largest gradient, see oracle/make_golden.py); whole-network gradients
+3e-2 relative norm (fp32 reproducibility limit of the reference itself, measured in make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import prifit_oracle as orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def nn_ops(hiplib):
+    assert torch.cuda.is_available()
+    from prifit_amd import nn_ops as m
+    return m
+
+
+def _rand(shape, seed):
+    return torch.from_numpy(np.random.default_rng(seed).normal(size=shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("lay", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 50, 70), (1000, 196, 324), (64, 32, 6), (37, 129, 515),
+                                   (2048, 2048, 128)])
+def test_gemm_layouts(nn_ops, lay, M, N, K):
+    A = _rand((M, K), 1)
+    B = _rand((N, K), 2)
+    ref = (A.double() @ B.double().T).float()
+    Ad = (A if lay != 2 else A.T.contiguous()).cuda()
+    Bd = (B if lay == 0 else B.T.contiguous()).cuda()
+    C = torch.empty(M, N, device="cuda")
+    nn_ops.gemm(lay, M, N, K, Ad, Ad.stride(0), Bd, Bd.stride(0), C, N)
+    tol = 2e-5 * (A.norm(dim=1, keepdim=True) * B.norm(dim=1).unsqueeze(0))
+    assert ((C.cpu() - ref).abs() <= tol + 1e-6).all()
+
+
+def test_gemm_prologue_bias_stats_splitk_batched(nn_ops):
+    M, N, K = 777, 96, 64
+    A, W = _rand((M, K), 3), _rand((N, K), 4)
+    sc, sh, bias = _rand((K,), 5), _rand((K,), 6), _rand((N,), 7)
+    An = torch.relu(A * sc + sh)
+    ref = (An.double() @ W.double().T).float() + bias
+    Ad, Wd = A.cuda(), W.cuda()
+    C = torch.empty(M, N, device="cuda")
+    nslab = (M + 127) // 128
+    slab = torch.zeros(nslab, 2, N, device="cuda")
+    nn_ops.gemm(0, M, N, K, Ad, K, Wd, K, C, N, a_affine=(sc.cuda(), sh.cuda()), bias=bias.cuda(), stats=slab)
+    torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(slab[:, 0].sum(0).cpu(), ref.sum(0), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(slab[:, 1].sum(0).cpu(), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
+    # TN with prologue on B and split-K (the dW shape): dW = dY^T relu(bn(A))
+    dY = _rand((M, N), 8)
+    refW = (dY.double().T @ An.double()).float()
+    dW = torch.zeros(N, K, device="cuda")
+    nn_ops.gemm(2, N, K, M, dY.cuda(), N, Ad, K, dW, K, splitk=5, b_affine=(sc.cuda(), sh.cuda()))
+    torch.testing.assert_close(dW.cpu(), refW, rtol=1e-4, atol=1e-3)
+    # batched NT with the chord / mean-shift-kernel epilogues
+    Bt, n, d = 3, 200, 128
+    X = torch.nn.functional.normalize(_rand((Bt, n, d), 9), dim=-1)
+    Xd = X.cuda()
+    out = torch.empty(Bt, n, n, device="cuda")
+    nn_ops.gemm(0, n, n, d, Xd, d, Xd, d, out, n, batch=Bt, sA=n * d, sB=n * d, sC=n * n, epi=1)
+    torch.testing.assert_close(out.cpu(), 2 - 2 * X @ X.transpose(1, 2), rtol=1e-5, atol=2e-6)
+    bw = torch.tensor([0.3, 0.5, 0.9])
+    nn_ops.gemm(0, n, n, d, Xd, d, Xd, d, out, n, batch=Bt, sA=n * d, sB=n * d, sC=n * n, epi=2, epi_scalar=bw.cuda())
+    refk = torch.exp(torch.clamp(-(2 - 2 * X @ X.transpose(1, 2)) / (bw.view(3, 1, 1) ** 2) / 2, -13, 75))
+    torch.testing.assert_close(out.cpu(), refk, rtol=2e-5, atol=1e-7)
+
+
+def _run_pair(my, orc_mod, args_gpu, args_cpu, gout, n_out=1, pick=lambda o: o):
+    """Run the HIP module and the oracle module with identical parameters; return outputs+grads."""
+    my.load_state_dict(orc_mod.state_dict())
+    my.cuda().train()
+    orc_mod.train()
+    o_ref = pick(orc_mod(*args_cpu))
+    (o_ref * gout).sum().backward()
+    o_my = pick(my(*args_gpu))
+    (o_my * gout.cuda()).sum().backward()
+    return o_my, o_ref
+
+
+def _check_param_grads(my, ref, rtol=2e-4):
+    rg = {k: p.grad for k, p in ref.named_parameters()}
+    gmax = max(v.abs().max().item() for v in rg.values())
+    for k, p in my.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), rg[k], rtol=rtol, atol=2e-5 * gmax, msg=lambda m: k + ": " + m)
+    for (k, b1), (_, b2) in zip(my.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b1.cpu().float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
+
+
+def test_sa_msg_module(hiplib, golden):
+    from prifit_amd.models import pointnet_util as pu
+    g = golden("module_sa_msg")
+    B, N, seed = 2, 512, int(g["seed"])
+    xyz = _t(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
+    feat = _t(synth.features(B, N, 16, seed)).transpose(1, 2).contiguous()
+    start = _t(g["start"])
+    torch.manual_seed(11)
+    ref = orc.OracleSetAbstractionMsg(64, [0.2, 0.4], [8, 16], 16, [[16, 32], [16, 24, 32]])
+    synth.perturb_bn(ref, 3)
+    my = pu.PointNetSetAbstractionMsg(64, [0.2, 0.4], [8, 16], 16, [[16, 32], [16, 24, 32]])
+    gout = _t(synth.features(B, 64, 64, seed + 1)).transpose(1, 2)
+    f_cpu = feat.clone().requires_grad_(True)
+    f_gpu = feat.cuda().requires_grad_(True)
+    o_my, o_ref = _run_pair(my, ref, (xyz.cuda(), f_gpu, start.cuda()), (xyz, f_cpu, start), gout, pick=lambda o: o[1])
+    torch.testing.assert_close(o_my.cpu(), _t(g["out"]), rtol=1e-4, atol=1e-4)   # vs the reference itself
+    torch.testing.assert_close(o_my.cpu(), o_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(f_gpu.grad.cpu(), _t(g["dfeat"]), rtol=2e-4, atol=1e-5)
+    _check_param_grads(my, ref)
+    torch.testing.assert_close(my.bn_blocks[0][0].running_var.cpu(), _t(g["running_var_00"]), rtol=1e-4, atol=1e-6)
+
+
+def test_sa_group_all_and_ssg(hiplib, golden):
+    from prifit_amd.models import pointnet_util as pu
+    B, N, seed = 2, 512, 5
+    xyz = _t(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
+    feat = _t(synth.features(B, N, 16, seed)).transpose(1, 2).contiguous()
+    start = _t(synth.fps_start(B, N, seed))
+    for name, ctor, bnseed, s, gseed, ncol in (("module_sa_all", (None, None, None, 19, [32, 64], True), 4, 12, 2, 1),
+                                                ("module_sa_ssg", (64, 0.3, 16, 19, [32, 64], False), 5, 13, 3, 64)):
+        g = golden(name)
+        torch.manual_seed(s)
+        ref = orc.OracleSetAbstraction(*ctor)
+        synth.perturb_bn(ref, bnseed)
+        my = pu.PointNetSetAbstraction(*ctor)
+        gout = _t(synth.features(B, ncol, 64, seed + gseed)).transpose(1, 2)
+        f_cpu = feat.clone().requires_grad_(True)
+        f_gpu = feat.cuda().requires_grad_(True)
+        o_my, o_ref = _run_pair(my, ref, (xyz.cuda(), f_gpu, start.cuda()), (xyz, f_cpu, start), gout,
+                                pick=lambda o: o[1])
+        torch.testing.assert_close(o_my.cpu(), _t(g["out"]), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(f_gpu.grad.cpu(), _t(g["dfeat"]), rtol=2e-4, atol=1e-5)
+        _check_param_grads(my, ref)
+
+
+def test_fp_module(hiplib, golden):
+    from prifit_amd.models import pointnet_util as pu
+    B, N, S, seed = 2, 512, 64, 5
+    xyz = _t(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
+    xyz2 = xyz[:, :, :S].contiguous()
+    p1 = _t(synth.features(B, N, 8, seed + 4)).transpose(1, 2).contiguous()
+    p2 = _t(synth.features(B, S, 24, seed + 5)).transpose(1, 2).contiguous()
+    gout = _t(synth.features(B, N, 16, seed + 6)).transpose(1, 2)
+    for name, x2, q2 in (("module_fp", xyz2, p2), ("module_fp_s1", xyz2[:, :, :1].contiguous(), p2[:, :, :1].contiguous())):
+        g = golden(name)
+        torch.manual_seed(14)
+        ref = orc.OracleFeaturePropagation(32, [32, 16])
+        synth.perturb_bn(ref, 6)
+        my = pu.PointNetFeaturePropagation(32, [32, 16])
+        a1, a2 = p1.clone().requires_grad_(True), q2.clone().requires_grad_(True)
+        b1, b2 = p1.cuda().requires_grad_(True), q2.cuda().requires_grad_(True)
+        o_my, o_ref = _run_pair(my, ref, (xyz.cuda(), x2.cuda(), b1, b2), (xyz, x2, a1, a2), gout)
+        torch.testing.assert_close(o_my.cpu(), _t(g["out"]), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b2.grad.cpu(), _t(g["dpoints2"]), rtol=2e-4, atol=1e-5)
+        torch.testing.assert_close(b1.grad.cpu(), a1.grad, rtol=2e-4, atol=1e-5)
+        if name == "module_fp":
+            _check_param_grads(my, ref)
+
+
+def test_eval_mode_matches_oracle(hiplib):
+    from prifit_amd.models import pointnet_util as pu
+    B, N = 2, 256
+    xyz = _t(synth.cloud("cube", B, N, 3)).transpose(1, 2).contiguous()
+    feat = _t(synth.features(B, N, 8, 3)).transpose(1, 2).contiguous()
+    start = _t(synth.fps_start(B, N, 3))
+    torch.manual_seed(5)
+    ref = orc.OracleSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 16], [16, 32]])
+    synth.perturb_bn(ref, 9)
+    my = pu.PointNetSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 16], [16, 32]])
+    my.load_state_dict(ref.state_dict())
+    my.cuda().eval()
+    ref.eval()
+    f_cpu = feat.clone().requires_grad_(True)
+    f_gpu = feat.cuda().requires_grad_(True)
+    o_ref = ref(xyz, f_cpu, start)[1]
+    o_my = my(xyz.cuda(), f_gpu, start.cuda())[1]
+    torch.testing.assert_close(o_my.cpu(), o_ref, rtol=1e-4, atol=1e-5)
+    o_ref.sum().backward()
+    o_my.sum().backward()
+    torch.testing.assert_close(f_gpu.grad.cpu(), f_cpu.grad, rtol=2e-4, atol=1e-5)
+    rg = {k: p.grad for k, p in ref.named_parameters()}
+    for k, p in my.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), rg[k], rtol=2e-4, atol=1e-4, msg=lambda m: k + ": " + m)
+
+
+def test_full_model_supervised_step(hiplib, golden):
+    """train_partseg_shapenet.py:382-399 on B=2 x 2048: loss, log-probs, feat and gradients."""
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    g = golden("model_msg_sup")
+    B, N, seed = 2, 2048, int(g["seed"])
+    torch.manual_seed(21)
+    net = M.get_model(50)
+    synth.xavier_like_trainer(net)
+    synth.perturb_bn(net, 8)
+    net.cuda().train()
+    net.drop1.eval()
+    xyz = _t(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous().cuda()
+    cls = torch.zeros(B, 1, 16, device="cuda")
+    cls[:, 0, 3] = 1.0
+    target = _t(synth.labels(B, N, 50, seed)).cuda()
+    seg, (l1, l2, l3), feat, tl, cl = net(xyz, cls, fps_start=(_t(g["s1"]).cuda(), _t(g["s2"]).cuda()))
+    assert seg.shape == (B, N, 50) and feat.shape == (B, 128, N) and l1.shape == (B, 128, 512) and l3.shape == (B, 1024, 1)
+    loss = M.get_loss()(seg.contiguous().view(-1, 50), target.view(-1), None)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), _t(g["loss"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(seg[:, :64].detach().cpu(), _t(g["seg_head"]), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(feat[:, :, :64].detach().cpu(), _t(g["feat_head"]), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(l3.detach().cpu(), _t(g["l3"]), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(net.conv2.weight.grad.cpu(), _t(g["g_conv2_weight"]), rtol=1e-3, atol=1e-6)
+    norms = dict(zip([str(s) for s in g["grad_names"]], g["grad_norms"]))
+    for k, p in net.named_parameters():
+        if k in norms and norms[k] > 0 and not (k.endswith(".bias") and "conv" in k and k != "conv2.bias"):
+            assert p.grad is not None, k
+            assert abs(p.grad.norm().item() - norms[k]) <= 3e-2 * norms[k], (k, p.grad.norm().item(), norms[k])
+    for k, ref in (("sa1.conv_blocks.0.0.weight", g["g_sa1_first"]), ("fp1.mlp_convs.1.weight", g["g_fp1_last"])):
+        got = dict(net.named_parameters())[k].grad.cpu()
+        rel = (got - _t(ref)).norm() / _t(ref).norm()
+        assert rel < 3e-2, (k, rel)
