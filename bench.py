@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Headline benchmark of the PRIFIT hot path on MI355X (contract: see the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3]
+
+One "step" = one training iteration of the hot path over one batch of B=24 synthetic 2048-point
+clouds per GPU: zero_grad, forward, loss, backward, gradient all-reduce (N>1, RCCL), Adam step.
+  c2: PointNet++-MSG part-seg, segmentation loss only          (BASELINE.json configs[1])
+  c3: c2's network + mean-shift (10 it, <=25 clusters) + ellipsoid fit + convex loss (configs[2],
+      the configuration the metric is quoted on) -- the self-supervised step of
+      train_partseg_shapenet.py:436-451.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU = 24
+NPTS = 2048
+NUM_PARTS = 50
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured by a float4 copy)
+
+
+def make_inputs(workload, rank, device):
+    import synth
+    seed = 1000 * rank  # seed 0 on rank 0
+    if workload == "c2":
+        xyz = torch.from_numpy(synth.cloud("cube", B_PER_GPU, NPTS, seed)).transpose(1, 2).contiguous()
+        d = {"xyz": xyz, "target": torch.from_numpy(synth.labels(B_PER_GPU, NPTS, NUM_PARTS, seed))}
+    else:
+        cham = torch.from_numpy(synth.cloud("blobs", B_PER_GPU, 5000, seed))
+        sel = np.random.default_rng(seed + 1).choice(5000, NPTS, replace=False)
+        d = {"xyz": cham[:, sel].transpose(1, 2).contiguous(), "chamfer": cham.transpose(1, 2).contiguous()}
+    d["cls"] = torch.zeros(B_PER_GPU, 1, 16)
+    d["s1"] = torch.from_numpy(synth.fps_start(B_PER_GPU, NPTS, seed))
+    d["s2"] = torch.from_numpy(synth.fps_start(B_PER_GPU, 512, seed + 100))
+    return {k: v.to(device) for k, v in d.items()}
+
+
+def build_model(device):
+    import synth
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    torch.manual_seed(0)
+    net = M.get_model(NUM_PARTS)
+    synth.xavier_like_trainer(net)  # train_partseg_shapenet.py:240-247
+    return net.to(device).train(), M
+
+
+def cpu_baseline(workload):
+    """The oracle (CPU restatement of the reference, kind "port") on a bounded sample of the same
+    workload: B=4 shapes, 1 warm-up + 2 timed forward+backward passes, all host cores."""
+    import prifit_oracle as orc
+    import synth
+    cores = min(os.cpu_count() or 1, 32)  # torch-CPU oversubscribes badly beyond ~32 threads on these small ops
+    torch.set_num_threads(cores)
+    Bs = 4
+    torch.manual_seed(0)
+    net = orc.OracleMSGPartSeg(NUM_PARTS)
+    synth.xavier_like_trainer(net)
+    net.train()
+    xyz = torch.from_numpy(synth.cloud("cube" if workload == "c2" else "blobs", Bs, NPTS, 0)).transpose(1, 2).contiguous()
+    cls = torch.zeros(Bs, 1, 16)
+    target = torch.from_numpy(synth.labels(Bs, NPTS, NUM_PARTS, 0))
+    s = (torch.from_numpy(synth.fps_start(Bs, NPTS, 0)), torch.from_numpy(synth.fps_start(Bs, 512, 100)))
+    extra = {}
+    if workload == "c3":
+        cham = torch.from_numpy(synth.cloud("blobs", Bs, 5000, 0))
+        sel = np.random.default_rng(1).choice(5000, NPTS, replace=False)
+        xyz = cham[:, sel].transpose(1, 2).contiguous()
+        extra = dict(chamfer_points=cham.transpose(1, 2).contiguous(), include_convex_loss=True, quantile=0.05,
+                     msc_iterations=10, max_num_clusters=25)
+
+    def one():
+        net.zero_grad()
+        out = net(xyz, cls, fps_start=s, **extra)
+        loss = orc.seg_loss(out[0].reshape(-1, NUM_PARTS), target.view(-1)) if workload == "c2" else out[3].mean()
+        loss.backward()
+
+    one()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return {"value": Bs / t, "unit": "shapes/s", "cores": cores, "kind": "port",
+            "sample": "oracle/prifit_oracle.py (torch-CPU restatement, %d threads), B=%d x %d pts, %s step fwd+bwd, "
+                      "median of 2 after 1 warm-up (%.2f s per pass)" % (cores, Bs, NPTS, workload, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("PRIFIT_WORKLOAD", "c2"), choices=["c2", "c3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from prifit_amd import _lib, profiler
+    from prifit_amd.ddp import FlatGradBucket
+    if not os.path.exists(_lib.LIB_PATH):
+        from prifit_amd import build
+        build.build_library()
+
+    net, M = build_model(device)
+    bucket = FlatGradBucket(net)
+    bucket.broadcast_parameters(0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    data = make_inputs(args.workload, rank, device)
+    crit = M.get_loss()
+
+    def step():
+        bucket.zero()
+        if args.workload == "c2":
+            seg = net(data["xyz"], data["cls"], fps_start=(data["s1"], data["s2"]))[0]
+            loss = crit(seg.reshape(-1, NUM_PARTS), data["target"].view(-1), None)
+        else:
+            out = net(data["xyz"], data["cls"], chamfer_points=data["chamfer"], include_convex_loss=True,
+                      quantile=0.05, msc_iterations=10, max_num_clusters=25, fps_start=(data["s1"], data["s2"]))
+            loss = out[3].mean()
+        loss.backward()
+        bucket.allreduce()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    profiler.reset()
+    profiler.enable("*")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    profiler.disable()
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    fams = profiler.collect()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B_PER_GPU * args.steps / elapsed
+        # dominant kernel family by accumulated event time
+        roof = None
+        detail = {}
+        for name, (n, ms, work) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
+            per = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps, "avg_us": 1e3 * ms / max(n, 1)}
+            if name.startswith("gemm"):
+                per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s")
+            else:
+                per.update(bound="hbm", achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            per["frac"] = per["achieved"] / per["peak"]
+            detail[name] = per
+        if detail:
+            dom = next(iter(detail))
+            d = detail[dom]
+            roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
+                    "frac": d["frac"], "traffic": None, "avg_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
+        grp = [detail[k] for k in detail if k in ("ball_query", "group_gather")]
+        grouping = None
+        if grp:
+            ms = sum(g["ms_per_step"] for g in grp)
+            gb = sum(g["achieved"] * g["ms_per_step"] * 1e-3 for g in grp)
+            grouping = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gb / (ms * 1e-3) / HBM_PEAK_GBS, "ms_per_step": ms,
+                        "note": "ball-query + grouping launches, algorithmic bytes of SURVEY.md 8(d)"}
+        line = {
+            "metric": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG+ellipsoid fit",
+            "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"c2": "configs[1]: PointNet++-MSG part-seg, B=24x2048 per GPU, seg loss only, "
+                                          "fwd+bwd+Adam (fit path not yet in the timed step)",
+                                    "c3": "configs[2]: PointNet++-MSG + mean-shift(10 it, <=25 clusters) + ellipsoid "
+                                          "fit + convex loss, B=24x2048 per GPU, fwd+bwd+Adam"}[args.workload],
+                       "global_batch": world * B_PER_GPU, "points": NPTS, "parallelism": "dp%d" % world,
+                       "loss": float(loss.item())},
+            "roofline": roof, "roofline_grouping": grouping, "kernels": detail,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

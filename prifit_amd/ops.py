@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, profiler
 from ._lib import call, cf, cur_stream, ptr, require_cuda
 
 
@@ -44,7 +44,9 @@ def ball_query_multi(radius_list, nsample_list, xyz, new_xyz, idx64=False):
         r2 = (ctypes.c_float * R)(*[float(np.float32(r ** 2)) for r in rs])
         ns = (ctypes.c_int * R)(*[int(k) for k in ks])
         op = (ctypes.c_void_p * R)(*[t.data_ptr() for t in o])
-        call("prifit_ball_query", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, op, int(idx64), cur_stream())
+        # algorithmic bytes: clouds read once, indices written once
+        with profiler.span("ball_query", B * (12.0 * (N + S) + sum(4.0 * S * k for k in ks))):
+            call("prifit_ball_query", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, op, int(idx64), cur_stream())
         outs += o
     return outs
 
@@ -88,8 +90,10 @@ def group_gather(feat, xyz, new_xyz, idx, order=0, ld_out=None):
     if ld_out is None:
         ld_out = (C + 3 + 3) // 4 * 4
     out = torch.empty(B * S * K, ld_out, dtype=torch.float32, device=xyz.device)
-    call("prifit_group_gather", ptr(feat), ptr(xyz), ptr(new_xyz), ptr(idx), B, N, S, K, C, order, ld_out,
-         ptr(out), cur_stream())
+    # algorithmic bytes: feature table read once + grouped rows [S*K, C+3] written once
+    with profiler.span("group_gather", B * (4.0 * N * C + 4.0 * S * K * (C + 3))):
+        call("prifit_group_gather", ptr(feat), ptr(xyz), ptr(new_xyz), ptr(idx), B, N, S, K, C, order, ld_out,
+             ptr(out), cur_stream())
     return out
 
 

@@ -1,0 +1,47 @@
+"""Per-kernel-family timing with HIP events on the launch stream (used by bench.py for the roofline).
+
+When a section is enabled, every launch wrapped by `span(name, work)` is bracketed by two events on
+PyTorch's current stream (the stream the C-ABI kernels are launched on); `work` is the algorithmic
+cost of the launch (flops or bytes).  `collect()` synchronises and returns, per name,
+(launches, total_ms, total_work).  Disabled (the default) it costs one dict lookup per launch.
+"""
+import contextlib
+
+import torch
+
+_enabled = set()
+_records = {}
+
+
+def enable(*names):
+    _enabled.update(names)
+
+
+def disable():
+    _enabled.clear()
+
+
+def reset():
+    _records.clear()
+
+
+@contextlib.contextmanager
+def span(name, work=0.0):
+    if name not in _enabled and "*" not in _enabled:
+        yield
+        return
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    yield
+    b.record()
+    _records.setdefault(name, []).append((a, b, float(work)))
+
+
+def collect():
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in _records.items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        out[name] = (len(recs), ms, sum(w for _, _, w in recs))
+    return out
