@@ -1,0 +1,214 @@
+"""Fitting half of oracle/make_golden.py: mean-shift / nms / membership / ellipsoid fit / SDF /
+analytic chamfer / convex_loss -- oracle vs the imported reference, and golden fixtures.
+
+TEST INFRASTRUCTURE (build container only).  Harness conventions shared by reference and oracle
+so that results are comparable (SURVEY.md 8a' q14, q17, q19, 8c):
+  * the covariance noise `torch.rand(3,3)` (src/ellipsoid_fitting.py:38) is replaced by ONE fixed
+    matrix R for every cluster (cluster order is rounding noise, so per-cluster noise cannot be shared);
+  * SVD column signs are pinned by `canonical_signs` on both sides;
+  * the trimesh surface sampler is replaced by the build's Fibonacci (U,V) table on both sides;
+  * clusters are compared in a partition-canonical order (ascending smallest member index).
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import refshim  # noqa: E402
+import prifit_oracle as orc  # noqa: E402
+import synth  # noqa: E402
+
+
+def fit_inputs(B, N, D, seed, M=5000, noise=0.03):
+    """Blob cloud (targets M points, model input = fixed N-subset) + prototype embedding.
+    noise=0.03 gives 8 clusters with SOFT memberships (max weight ~0.9), i.e. non-trivial gradients;
+    the survey's 0.01 saturates the membership clamp and leaves gradients of 1e-8."""
+    cham, lab = synth.blobs_with_labels(B, M, seed)
+    sel = np.random.default_rng(seed + 1).choice(M, N, replace=False)
+    pts = cham[:, sel]
+    emb = synth.prototype_embedding(lab[:, sel], D, seed + 2, noise=noise)
+    return torch.from_numpy(pts), torch.from_numpy(cham), torch.from_numpy(emb)
+
+
+def canonical_order(labels, K):
+    """Order of clusters by ascending smallest member index (partition-canonical)."""
+    first = []
+    for k in range(K):
+        idx = torch.nonzero(labels == k)
+        first.append(idx.min().item() if idx.numel() else 10 ** 9)
+    return torch.tensor(np.argsort(np.array(first), kind="stable"))
+
+
+def same_partition(la, lb):
+    """True if two labelings induce the same partition."""
+    pairs = torch.unique(torch.stack([la, lb], 1), dim=0)
+    return pairs.shape[0] == torch.unique(la).shape[0] == torch.unique(lb).shape[0]
+
+
+@contextlib.contextmanager
+def patched(obj, name, value):
+    old = getattr(obj, name)
+    setattr(obj, name, value)
+    try:
+        yield
+    finally:
+        setattr(obj, name, old)
+
+
+def run(save, eq, close):
+    print("[fit]")
+    MS = refshim.ref("src.mean_shift")
+    EF = refshim.ref("src.ellipsoid_fitting")
+    EU = refshim.ref("src.ellipsoid_utils")
+    CL = refshim.ref("convex_loss")
+    UT = refshim.ref("src.utils")
+    ms = MS.MeanShift()
+    B, N, D, seed = 2, 2048, 128, 31
+    pts, cham, emb = fit_inputs(B, N, D, seed)
+    R = torch.from_numpy(synth.uniform01((3, 3), seed))
+    q, iters = 0.05, 10
+
+    # ---- bandwidth / mean-shift iterations / nms / membership, per shape
+    out = {"seed": seed, "R": R}
+    G = torch.from_numpy(synth.features(B, N, D, seed + 3))
+    for b in range(B):
+        X = emb[b]
+        with torch.no_grad():
+            bw_r = ms.compute_bandwidth(X, N, q)
+        bw_o = orc.compute_bandwidth(X, q)
+        close(bw_o, bw_r, f"bandwidth b={b}", rtol=1e-6)
+        Xr = X.clone().requires_grad_(True)
+        Zr, _ = ms.mean_shift_(Xr, bw_r, iterations=iters)
+        (Zr * G[b]).sum().backward()
+        Xo = X.clone().requires_grad_(True)
+        Zo = orc.mean_shift_iterations(Xo, bw_r, iters)
+        (Zo * G[b]).sum().backward()
+        close(Zo, Zr, f"mean_shift_ Z b={b}", rtol=1e-5, atol=1e-6)
+        close(Xo.grad, Xr.grad, f"mean_shift_ dX b={b}", rtol=1e-3, atol=1e-5 * Xr.grad.abs().max().item())
+        with torch.no_grad():
+            cr, ir, lr = ms.nms(Zr.detach(), Zr.detach(), bw_r)
+            co, io, lo = orc.nms(Zr.detach(), Zr.detach(), bw_r)
+        eq(io, ir, f"nms ids b={b} (same input)")
+        eq(lo, lr, f"nms labels b={b} (same input)")
+        Wr = ms.membership(cr, X, bw_r)
+        Wo = orc.membership(co, X, bw_r)
+        close(Wo, Wr, f"membership b={b}", rtol=1e-5, atol=1e-7)
+        out[f"bw_{b}"] = bw_r
+        out[f"Z_head_{b}"] = Zr.detach()[:64]
+        out[f"Z_colsum_{b}"] = Zr.detach().sum(0)
+        out[f"dX_head_{b}"] = Xr.grad[:64]
+        out[f"dX_norm_{b}"] = Xr.grad.norm()
+        out[f"K_{b}"] = ir.shape[0]
+        out[f"labels_{b}"] = lr.to(torch.int16)
+        order = canonical_order(lr, ir.shape[0])
+        out[f"W_colsum_{b}"] = Wr.detach().t()[:, order].sum(0)
+        out[f"W_head_{b}"] = Wr.detach().t()[:64][:, order]
+    save("fit_meanshift", **out)
+
+    # ---- ellipsoid fit: soft weights from the clustering + a hard one-hot known-answer case
+    def ref_customsvd_canonical(M):
+        U, S, V = refshim.ref("src.fitting_utils").customsvd(M)
+        s = orc.canonical_signs(V).view(1, 3)
+        return U * s, S, V * s
+
+    Ws_r, labs_r = EU.clustering(emb, num_samples=N, quantile=q, iterations=iters, max_num_clusters=25)
+    Ws_o, labs_o, info_o = orc.clustering(emb, q, iters, 25)
+    out = {"seed": seed, "R": R}
+    for b in range(B):
+        assert same_partition(labs_r[b], labs_o[b]), "label partition differs"
+        print(f"  ok partition      clustering labels b={b} (K={Ws_r[b].shape[1]})")
+    Wr = [w.detach().clone().requires_grad_(True) for w in Ws_r]
+    with patched(torch, "rand", lambda *a, **k: R.clone()), patched(EF, "customsvd", ref_customsvd_canonical):
+        params_r = EF.weighted_ellipsoid_fitting_batch(pts, Wr)
+    Wo = [w.detach().clone().requires_grad_(True) for w in Ws_r]
+    table = [[R] * w.shape[1] for w in Wo]
+    params_o = orc.fit_ellipsoids_batch(pts, Wo, table, canonical=True)
+    gr = torch.from_numpy(synth.features(1, 32, 15, seed + 4))[0]
+    for b in range(B):
+        assert len(params_r[b]) == len(params_o[b]) == Wr[b].shape[1]
+        lr_ = sum((p[0] * gr[k, 0:3]).sum() + (p[1] * gr[k, 3:12].view(3, 3)).sum() + (p[2] * gr[k, 12:15]).sum()
+                  for k, p in enumerate(params_r[b]))
+        lo_ = sum((p[0] * gr[k, 0:3]).sum() + (p[1] * gr[k, 3:12].view(3, 3)).sum() + (p[2] * gr[k, 12:15]).sum()
+                  for k, p in enumerate(params_o[b]))
+        lr_.backward()
+        lo_.backward()
+        for k, (a, o) in enumerate(zip(params_r[b], params_o[b])):
+            close(o[0], a[0], f"fit r b={b} k={k}", rtol=1e-5, atol=1e-6)
+            close(o[1], a[1], f"fit V b={b} k={k}", rtol=1e-4, atol=1e-5)
+            close(o[2], a[2], f"fit c b={b} k={k}", rtol=1e-5, atol=1e-6)
+        close(Wo[b].grad, Wr[b].grad, f"fit dW b={b}", rtol=1e-3, atol=1e-5 * Wr[b].grad.abs().max().item())
+        out[f"W_{b}"] = Ws_r[b].detach().to(torch.float32)
+        out[f"r_{b}"] = torch.stack([p[0] for p in params_r[b]]).detach()
+        out[f"V_{b}"] = torch.stack([p[1] for p in params_r[b]]).detach()
+        out[f"c_{b}"] = torch.stack([p[2] for p in params_r[b]]).detach()
+        out[f"dW_{b}"] = Wr[b].grad
+    out["grad_seed_table"] = gr
+    save("fit_ellipsoid", **out)
+
+    # ---- SDF + analytic chamfer with the shared sampler
+    def ref_sample(self, a, b_, c, center, transformation, n=500):
+        U, V = orc.fibonacci_uv(int(n))
+        p = self.uniform_sample_points_on_ellipsoid(U, V, a, b_, c)
+        return p @ transformation.T + center, None
+
+    SE = refshim.ref("src.sample_ellipsoid")
+    with patched(SE.SampleEllipsoid, "sample", ref_sample):
+        samples_r = EU.sample_from_pred_params(params_r, 500)
+    samples_o = orc.sample_from_params(params_o)
+    for b in range(B):
+        close(samples_o[b], samples_r[b], f"sampled points b={b}", rtol=1e-5, atol=1e-6)
+    l_r = UT.analytic_chamfer_distance(params_r, samples_r, cham)
+    l_o, parts = orc.analytic_chamfer(params_o, samples_o, cham)
+    close(l_o, l_r, "analytic chamfer", rtol=1e-5)
+    sdf_r = CL.compute_sdf_ellipsoids_batch(cham, params_r)
+    save("fit_chamfer", seed=seed, loss=l_r.detach(), dist_st=torch.stack([p[0] for p in parts]),
+         sdf_ts=torch.stack([p[1] for p in parts]), nsamples=np.array([s.shape[0] for s in samples_r]),
+         sdf_head=torch.stack([torch.stack(s, 1)[:256] for s in sdf_r]).detach())
+
+    # ---- full convex_loss (B=2), gradient w.r.t. the embedding
+    Xr = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    with patched(torch, "rand", lambda *a, **k: R.clone()), patched(EF, "customsvd", ref_customsvd_canonical), \
+            patched(SE.SampleEllipsoid, "sample", ref_sample):
+        tot_r, ch_r, prm_r, lab_r = CL.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xr, quantile=q,
+                                                   iterations=iters, max_num_clusters=25)
+    tot_r.sum().backward()
+    Xo = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    tot_o, ch_o, prm_o, lab_o = orc.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xo, quantile=q,
+                                                iterations=iters, max_num_clusters=25,
+                                                rand_table=[[R] * 64] * B, canonical=True)
+    tot_o.sum().backward()
+    close(tot_o, tot_r, "convex_loss total", rtol=1e-5)
+    close(Xo.grad, Xr.grad, "convex_loss dX", rtol=2e-3, atol=1e-3 * Xr.grad.abs().max().item())
+    save("fit_convex_loss", seed=seed, R=R, total=tot_r.detach(), chamfer=ch_r.detach(),
+         K=np.array([len(p) for p in prm_r]), labels=torch.stack(lab_r).to(torch.int16),
+         dX_norm=Xr.grad.norm(), dX_head=Xr.grad[:, :, :32].contiguous())
+
+    # ---- known-answer test data: hard weights on analytic ellipsoid surfaces (fitting.py / ellipsoid_fitting_numpy.py:36-45)
+    rng = np.random.default_rng(77)
+    pts_k, W_k, abc_k, ctr_k = [], [], [], []
+    for k in range(3):
+        abc = rng.integers(2, 20, size=3).astype(np.float64)
+        U, V = orc.fibonacci_uv(500)
+        p = np.stack([abc[0] * np.cos(U) * np.sin(V), abc[1] * np.sin(U) * np.sin(V), abc[2] * np.cos(V)], 1)
+        th = rng.uniform(0, 2 * np.pi)
+        Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        ctr = rng.uniform(0, 1, size=3) * abc.max()
+        pts_k.append(p @ Rz + ctr)
+        w = np.zeros((500, 3), np.float32)
+        w[:, k] = 1
+        W_k.append(w)
+        abc_k.append(abc)
+        ctr_k.append(ctr)
+    pk = torch.from_numpy(np.concatenate(pts_k).astype(np.float32))[None]
+    wk = torch.from_numpy(np.concatenate(W_k))
+    with patched(torch, "rand", lambda *a, **k: R.clone()):
+        prm = EF.weighted_ellipsoid_fitting_batch(pk, [wk])
+    for k, (r, V, c) in enumerate(prm[0]):
+        assert np.allclose(np.sort(r.numpy()), np.sort(abc_k[k]), rtol=2e-2), (r, abc_k[k])
+    save("fit_kat", points=pk, W=wk, abc=np.array(abc_k), centres=np.array(ctr_k), R=R,
+         r_ref=torch.stack([p[0] for p in prm[0]]), c_ref=torch.stack([p[2] for p in prm[0]]))
