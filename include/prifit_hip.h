@@ -109,6 +109,8 @@ int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const
 #define PRIFIT_EPI_CHORD 1    /* C = 2 - 2*acc            (src/mean_shift.py:154,168,185)        */
 #define PRIFIT_EPI_MSKERNEL 2 /* C = exp(clamp(-(2-2*acc)/b^2/2, -13, 75)), b = epi_batch_scalar[z]
                                  (src/mean_shift.py:65-68 with src/guard.py:6-11)                 */
+#define PRIFIT_EPI_MSBWD 3    /* C = acc * aux / b^2 where aux > exp(-13), else 0: autograd of the
+                                 line above (aux = the forward kernel matrix, indexed like C)     */
 
 /* Batched GEMM with fused prologue/epilogue.  Replaces every conv1x1 of the shared per-position
  * MLPs (models/pointnet_util.py:195-199, :252-256, :310-313; models/pointnet2_part_seg_msg.py:88,
@@ -119,8 +121,9 @@ int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const
  *     of the producing layer applied on load.  b_scale/b_shift: the same for B (c = k for NT, n else).
  *   bias [N] or NULL.  col_stats [ceil(M/tile_m)][2][N] or NULL: per-M-tile partial column sums
  *     and sums of squares of the stored C (batch == 1, splitk == 1 only).
- *   splitk > 1: the K range is split over workgroups and C is accumulated with float atomics
- *     (C must be initialised by the caller; epilogue must be PRIFIT_EPI_NONE).
+ *   accumulate != 0: C += result (C initialised by the caller).  splitk > 1: the K range is split
+ *     over workgroups which add with float atomics (needs accumulate != 0 and PRIFIT_EPI_NONE).
+ *   epi_aux / ld_aux / stride_aux: second matrix read by PRIFIT_EPI_MSBWD.
  * 16-byte vector loads are used when pointers, strides and contiguous extents are multiples of 4
  * floats; any other shape takes a scalar-load path. */
 int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long lda, long long strideA,
@@ -128,7 +131,8 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     long long strideC, int batch, int splitk, const float *a_scale,
                     const float *a_shift, const float *b_scale, const float *b_shift,
                     const float *bias, float *col_stats, int epilogue,
-                    const float *epi_batch_scalar, void *stream);
+                    const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
+                    long long stride_aux, int accumulate, void *stream);
 
 /* Rows of C covered by one col_stats slab of prifit_gemm_f32 (its M tile). */
 int prifit_gemm_tile_m(int N);
@@ -189,6 +193,92 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
                           const int32_t *arg, const float *scale, const float *shift,
                           const float *coef_a, const float *coef_b, const float *coef_d, int G, int K,
                           int C, float *dY, long long ldd, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* mean-shift clustering on the unit hypersphere (src/mean_shift.py)                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out[row] = k-th smallest entry (1-based) of row `row` of M [rows, C], C <= 4096: the
+ * torch.topk(dist, k, largest=False)[0][:, -1] of compute_bandwidth, src/mean_shift.py:156-158. */
+int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float *out, void *stream);
+
+/* One mean-shift update, src/mean_shift.py:70-82.  O [rows, Dp] = K . [X | 1 | 0-pad] (column D is the
+ * kernel row sum), Z [rows, D] the current points: out = normalize(Z + (O[:, :D]/O[:, D] - Z)),
+ * nrm [rows] = the norm before normalisation. */
+int prifit_meanshift_update_fwd(const float *O, int Dp, const float *Z, int D, long long rows,
+                                float *out, float *nrm, void *stream);
+
+/* Autograd of the update: g = dL/d(out) -> gO [rows, Dp] = dL/dO (column D = gradient of the row sum). */
+int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O,
+                                int Dp, int D, long long rows, float *gO, void *stream);
+
+/* Non-maximum suppression, src/mean_shift.py:162-202 called as nms(Z, Z, b) (:44).
+ * dist [B,N,N] = 2 - 2 Z Z^T, Z [B,N,D], bw [B].  Outputs: owner [B,N] (nearest centre of each point),
+ * counts [B,N], flags [B,N] (scratch), ids [B,cap] ascending kept centre ids, count [B] = number of kept
+ * centres (may exceed cap: only the first cap ids are stored), labels [B,N] = argmax_k <Z[ids[k]], z_j>
+ * over the stored centres, used [B,cap] = 1 where label k occurs. */
+int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap,
+               int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count,
+               int32_t *labels, int32_t *used, void *stream);
+
+/* Soft membership, src/mean_shift.py:230-247.  dots [B,N,KM] = <x_j, centre_k> (raw), bw [B], gmax [B] =
+ * max over live (k, j) of dots / bw^2 (detached): W [B,N,KM] = softmax-like weights, 0 for k >= count[b]. */
+int prifit_membership_fwd(const float *dots, const float *bw, const float *gmax, const int32_t *count,
+                          int B, int N, int KM, float *W, void *stream);
+int prifit_membership_bwd(const float *gW, const float *W, const float *dots, const float *bw,
+                          const float *gmax, const int32_t *count, int B, int N, int KM, float *gdots,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* weighted ellipsoid fit and analytic-chamfer loss terms                                       */
+/* (fixed capacity: KM <= 64 cluster slots per shape, live when k < count[b] and valid[b][k])   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Floats of saved state per (shape, cluster) written by the forward fit for its backward. */
+int prifit_fit_state_floats(void);
+
+/* src/ellipsoid_fitting.py:19-69 + principal_axis_ellipsoid(mode="slow") :119-141, one workgroup per
+ * (shape, cluster).  points [B,N,3], W [B,N,KM]; rnd = the U[0,1) 3x3 matrices of :38, element (b,k)
+ * at rnd + b*rnd_stride_b + k*rnd_stride_k (strides 0 share one matrix).  canonical_signs != 0 pins the
+ * SVD column signs (largest component positive).  Outputs r [B,KM,3] semi-axes, V [B,KM,3,3] principal
+ * axes (after the reflection fix :133-135), c [B,KM,3], valid [B,KM] (0 where S0/S2 > 1e5, :43). */
+int prifit_ellipsoid_fit_fwd(const float *points, const float *W, const int32_t *count, const float *rnd,
+                             long long rnd_stride_b, long long rnd_stride_k, int canonical_signs, int B,
+                             int N, int KM, float *r, float *V, float *c, int32_t *valid, float *state,
+                             void *stream);
+
+/* (g_r, g_V, g_c) -> gW [B,N,KM]: through the extents, the reflection fix, CustomSVD.backward
+ * (src/fitting_utils.py:67-139), the covariance (+noise) and the weighted centre. */
+int prifit_ellipsoid_fit_bwd(const float *points, const float *W, const int32_t *count,
+                             const int32_t *valid, const float *rnd, long long rnd_stride_b,
+                             long long rnd_stride_k, const float *state, const float *g_r,
+                             const float *g_V, const float *g_c, int B, int N, int KM, float *gW,
+                             void *stream);
+
+/* convex_loss.py:313-328 + src/utils.py:410-411: for every target point the ellipsoid with the smallest
+ * |sdf|; arg [B,M] its slot (-1: none), fval [B,M] the signed value, sum_sq [B] = sum of squares. */
+int prifit_ellipsoid_sdf_fwd(const float *targets, int B, int M, const float *r, const float *V,
+                             const float *c, const int32_t *valid, int KM, int32_t *arg, float *fval,
+                             float *sum_sq, void *stream);
+/* g_{r,V,c} += gscale[b] * d(sum_sq[b]) / d{r,V,c}  (outputs initialised by the caller). */
+int prifit_ellipsoid_sdf_bwd(const float *targets, int B, int M, const float *r, const float *V,
+                             const float *c, const int32_t *arg, const float *gscale, int KM, float *g_r,
+                             float *g_V, float *g_c, void *stream);
+
+/* src/ellipsoid_utils.py:87-107: n [B,KM] surface samples per ellipsoid (round(10000*area/sum area),
+ * <=0 -> 100), off [B,KM+1] exclusive prefix (off[KM] = total, clipped to cap). */
+int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n,
+                         int32_t *off, void *stream);
+
+/* Surface samples on the Fibonacci (U,V) table evaluated as src/sample_ellipsoid.py:55-63, their exact
+ * nearest target (src/utils.py:413-416): nn_idx [B,cap], sum_d2 [B] = sum of squared distances. */
+int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n,
+                         const int32_t *off, int B, int KM, const float *targets, int M, int cap,
+                         int32_t *nn_idx, float *sum_d2, void *stream);
+int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n,
+                         const int32_t *off, int B, int KM, const float *targets, int M, int cap,
+                         const int32_t *nn_idx, const float *gscale, float *g_r, float *g_V, float *g_c,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,8 @@ SOURCES = {
     "pointops.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "bn.hip": [],
+    "meanshift.hip": [],
+    "fit.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
           "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,714 @@
+// Weighted ellipsoid fitting and the analytic-chamfer loss terms (src/ellipsoid_fitting.py,
+// src/fitting_utils.py, src/ellipsoid_utils.py, src/sample_ellipsoid.py, convex_loss.py, src/utils.py).
+//
+// Fixed-capacity layout: every shape owns KM cluster slots; slot k of shape b is live when
+// k < count[b] and valid[b][k] != 0 (ill-conditioned fits are dropped by a validity flag instead of
+// the reference's -1 sentinel).  One workgroup per (shape, cluster) for the fit: the ten weighted
+// moments (sum w, sum w p, sum w q q^T) are block reductions, the 3x3 SVD and its custom backward run
+// in one lane in double precision, the extent pass is a block (value, index) max/min reduction.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// block reductions (256 threads)
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float *s_buf /* [4*NV] */)
+{
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_f32(v[i]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s_buf[(threadIdx.x >> 6) * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = (s_buf[i] + s_buf[NV + i]) + (s_buf[2 * NV + i] + s_buf[3 * NV + i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 SVD in double (Jacobi eigen-decomposition of M^T M), singular values descending.
+// ---------------------------------------------------------------------------------------------
+__device__ void svd3(const double M[3][3], double U[3][3], double S[3], double V[3][3])
+{
+    double A[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += M[k][i] * M[k][j];
+            A[i][j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {  // A <- A J
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {  // A <- J^T A
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double lam[3] = {A[0][0], A[1][1], A[2][2]};
+    int ord[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (lam[ord[j]] < lam[ord[j + 1]]) { int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
+    double Vs[3][3];
+    for (int j = 0; j < 3; ++j) {
+        S[j] = sqrt(lam[ord[j]] > 0 ? lam[ord[j]] : 0.0);
+        for (int i = 0; i < 3; ++i) Vs[i][j] = V[i][ord[j]];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = Vs[i][j];
+    for (int j = 0; j < 3; ++j) {
+        const double inv = S[j] > 1e-300 ? 1.0 / S[j] : 0.0;
+        for (int i = 0; i < 3; ++i) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += M[i][k] * V[k][j];
+            U[i][j] = s * inv;
+        }
+    }
+}
+
+// saved-state layout per (b, k): 48 floats
+//  [0..2] centre, [3] sw, [4..12] cov (row-major 3x3), [13..21] U, [22..24] S, [25..33] V (canonical, before
+//  the determinant flip), [34] flip (0/1), [35..40] extreme indices as float bits (imax0..2, imin0..2)
+constexpr int FIT_STATE = 48;
+
+__global__ __launch_bounds__(256) void ellipsoid_fit_fwd_kernel(
+    const float *__restrict__ pts, const float *__restrict__ W, const int32_t *__restrict__ count,
+    const float *__restrict__ rnd, long long rnd_stride_b, long long rnd_stride_k, int canonical, int N, int KM,
+    float *__restrict__ r_o, float *__restrict__ V_o, float *__restrict__ c_o, int32_t *__restrict__ valid_o,
+    float *__restrict__ state)
+{
+    __shared__ float s_buf[4 * 6];
+    __shared__ float s_par[16];
+    __shared__ unsigned long long s_ext[4 * 6];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t slot = (size_t)b * KM + k;
+    if (k >= count[b]) {
+        if (tid == 0) valid_o[slot] = 0;
+        if (tid < 3) { r_o[slot * 3 + tid] = 0.f; c_o[slot * 3 + tid] = 0.f; }
+        if (tid < 9) V_o[slot * 9 + tid] = (tid % 4 == 0) ? 1.f : 0.f;
+        return;
+    }
+    const float *P = pts + (size_t)b * N * 3;
+    const float *Wk = W + (size_t)b * N * KM + k;
+    // pass 1: sum w, sum w p
+    float a1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < N; i += 256) {
+        const float w = Wk[(size_t)i * KM];
+        a1[0] += w; a1[1] += w * P[i * 3]; a1[2] += w * P[i * 3 + 1]; a1[3] += w * P[i * 3 + 2];
+    }
+    block_sum<4>(a1, s_buf);
+    const float sw = a1[0];
+    const float cx = a1[1] / sw, cy = a1[2] / sw, cz = a1[3] / sw;
+    // pass 2: weighted second moments about the centre
+    float a2[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < N; i += 256) {
+        const float w = Wk[(size_t)i * KM];
+        const float x = P[i * 3] - cx, y = P[i * 3 + 1] - cy, z = P[i * 3 + 2] - cz;
+        a2[0] += w * x * x; a2[1] += w * x * y; a2[2] += w * x * z;
+        a2[3] += w * y * y; a2[4] += w * y * z; a2[5] += w * z * z;
+    }
+    block_sum<6>(a2, s_buf);
+    float *st = state + slot * FIT_STATE;
+    if (tid == 0) {
+        const float cov[3][3] = {{a2[0] / sw, a2[1] / sw, a2[2] / sw},
+                                 {a2[1] / sw, a2[3] / sw, a2[4] / sw},
+                                 {a2[2] / sw, a2[4] / sw, a2[5] / sw}};
+        float mean = 0.f;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) mean += cov[i][j];
+        mean /= 9.f;
+        const float *R = rnd + b * rnd_stride_b + k * rnd_stride_k;
+        double M[3][3], U[3][3], S[3], V[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M[i][j] = (double)(cov[i][j] + 1e-4f * mean * R[i * 3 + j]);
+        svd3(M, U, S, V);
+        const int ok = !((float)S[0] / (float)S[2] > 1e5f);  // src/ellipsoid_fitting.py:43
+        if (canonical)
+            for (int j = 0; j < 3; ++j) {
+                int im = 0;
+                for (int i = 1; i < 3; ++i)
+                    if (fabs(V[i][j]) > fabs(V[im][j])) im = i;
+                if (V[im][j] < 0)
+                    for (int i = 0; i < 3; ++i) { V[i][j] = -V[i][j]; U[i][j] = -U[i][j]; }
+            }
+        const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) -
+                           V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                           V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+        const int flip = det < 0;
+        st[0] = cx; st[1] = cy; st[2] = cz; st[3] = sw;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                st[4 + i * 3 + j] = cov[i][j];
+                st[13 + i * 3 + j] = (float)U[i][j];
+                st[25 + i * 3 + j] = (float)V[i][j];
+                const float vp = (float)((j == 2 && flip) ? -V[i][j] : V[i][j]);
+                s_par[i * 3 + j] = vp;
+                V_o[slot * 9 + i * 3 + j] = vp;
+            }
+        for (int j = 0; j < 3; ++j) st[22 + j] = (float)S[j];
+        st[34] = (float)flip;
+        valid_o[slot] = ok;
+        c_o[slot * 3] = cx; c_o[slot * 3 + 1] = cy; c_o[slot * 3 + 2] = cz;
+    }
+    __syncthreads();
+    // pass 3: extents of the weight-scaled points along the principal axes (principal_axis_ellipsoid, "slow")
+    float vp[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) vp[i] = s_par[i];
+    // keys: (order-preserving float image << 32) | ~index  -> max key = first maximum; for the minimum the
+    // float image is inverted
+    unsigned long long kmax[3] = {0ull, 0ull, 0ull}, kmin[3] = {0ull, 0ull, 0ull};
+    for (int i = tid; i < N; i += 256) {
+        const float w = Wk[(size_t)i * KM];
+        const float x = (P[i * 3] - cx) * w, y = (P[i * 3 + 1] - cy) * w, z = (P[i * 3 + 2] - cz) * w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t = x * vp[a] + y * vp[3 + a] + z * vp[6 + a];
+            unsigned u = __float_as_uint(t);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            const unsigned long long lo = (unsigned)(0xffffffffu - (unsigned)i);
+            const unsigned long long k1 = ((unsigned long long)u << 32) | lo;
+            const unsigned long long k2 = ((unsigned long long)(~u) << 32) | lo;
+            kmax[a] = k1 > kmax[a] ? k1 : kmax[a];
+            kmin[a] = k2 > kmin[a] ? k2 : kmin[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { kmax[a] = wave_max_u64(kmax[a]); kmin[a] = wave_max_u64(kmin[a]); }
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_ext[(tid >> 6) * 6 + a] = kmax[a]; s_ext[(tid >> 6) * 6 + 3 + a] = kmin[a]; }
+    __syncthreads();
+    if (tid < 3) {
+        unsigned long long m1 = 0ull, m2 = 0ull;
+        for (int w = 0; w < 4; ++w) {
+            m1 = s_ext[w * 6 + tid] > m1 ? s_ext[w * 6 + tid] : m1;
+            m2 = s_ext[w * 6 + 3 + tid] > m2 ? s_ext[w * 6 + 3 + tid] : m2;
+        }
+        unsigned u1 = (unsigned)(m1 >> 32), u2 = ~(unsigned)(m2 >> 32);
+        u1 = (u1 & 0x80000000u) ? (u1 & 0x7fffffffu) : ~u1;
+        u2 = (u2 & 0x80000000u) ? (u2 & 0x7fffffffu) : ~u2;
+        const float mx = __uint_as_float(u1), mn = __uint_as_float(u2);
+        r_o[slot * 3 + tid] = fabsf(mx - mn) / 2.0f;
+        st[35 + tid] = __int_as_float((int)(0xffffffffu - (unsigned)(m1 & 0xffffffffu)));
+        st[38 + tid] = __int_as_float((int)(0xffffffffu - (unsigned)(m2 & 0xffffffffu)));
+    }
+}
+
+// Backward: (g_r, g_Vp, g_c) -> dL/dW[:, k].
+__global__ __launch_bounds__(256) void ellipsoid_fit_bwd_kernel(
+    const float *__restrict__ pts, const float *__restrict__ W, const int32_t *__restrict__ count,
+    const int32_t *__restrict__ valid, const float *__restrict__ rnd, long long rnd_stride_b,
+    long long rnd_stride_k, const float *__restrict__ state, const float *__restrict__ g_r,
+    const float *__restrict__ g_V, const float *__restrict__ g_c, int N, int KM, float *__restrict__ gW)
+{
+    __shared__ float s_g[9 + 1 + 3 + 6];  // g_cov, tr(g_cov^T cov), g_c_total, sparse g_w
+    __shared__ int s_idx[6];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const size_t slot = (size_t)b * KM + k;
+    float *gWk = gW + (size_t)b * N * KM + k;
+    if (k >= count[b] || !valid[slot]) {
+        for (int i = tid; i < N; i += 256) gWk[(size_t)i * KM] = 0.f;
+        return;
+    }
+    const float *P = pts + (size_t)b * N * 3;
+    const float *Wk = W + (size_t)b * N * KM + k;
+    const float *st = state + slot * FIT_STATE;
+    const float cx = st[0], cy = st[1], cz = st[2], sw = st[3];
+    if (tid == 0) {
+        double U[3][3], S[3], V[3][3], Vp[3][3], cov[3][3], gVp[3][3], gcen[3], gw_sp[6];
+        const int flip = st[34] != 0.f;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                cov[i][j] = st[4 + i * 3 + j];
+                U[i][j] = st[13 + i * 3 + j];
+                V[i][j] = st[25 + i * 3 + j];
+                Vp[i][j] = (j == 2 && flip) ? -V[i][j] : V[i][j];
+                gVp[i][j] = g_V[slot * 9 + i * 3 + j];
+            }
+        for (int j = 0; j < 3; ++j) { S[j] = st[22 + j]; gcen[j] = g_c[slot * 3 + j]; }
+        // extents: r_a = |max_a - min_a| / 2, gradient to the two extreme rows of each axis
+        for (int a = 0; a < 3; ++a) {
+            const int im[2] = {__float_as_int(st[35 + a]), __float_as_int(st[38 + a])};
+            double tv[2], q[2][3], ww[2];
+            for (int e = 0; e < 2; ++e) {
+                const int i = im[e];
+                ww[e] = Wk[(size_t)i * KM];
+                q[e][0] = (double)P[i * 3] - cx; q[e][1] = (double)P[i * 3 + 1] - cy; q[e][2] = (double)P[i * 3 + 2] - cz;
+                tv[e] = ww[e] * (q[e][0] * Vp[0][a] + q[e][1] * Vp[1][a] + q[e][2] * Vp[2][a]);
+            }
+            const double sgn = (tv[0] - tv[1]) > 0 ? 1.0 : ((tv[0] - tv[1]) < 0 ? -1.0 : 0.0);
+            for (int e = 0; e < 2; ++e) {
+                const double coef = (e == 0 ? 1.0 : -1.0) * sgn * (double)g_r[slot * 3 + a] / 2.0;
+                const double proj = q[e][0] * Vp[0][a] + q[e][1] * Vp[1][a] + q[e][2] * Vp[2][a];
+                gw_sp[e * 3 + a] = coef * proj;
+                for (int d = 0; d < 3; ++d) {
+                    gcen[d] -= coef * ww[e] * Vp[d][a];      // q = p - c
+                    gVp[d][a] += coef * ww[e] * q[e][d];
+                }
+                s_idx[e * 3 + a] = im[e];
+            }
+        }
+        // through the determinant flip back to the SVD's V
+        double gV[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) gV[i][j] = (j == 2 && flip) ? -gVp[i][j] : gVp[i][j];
+        // CustomSVD backward (src/fitting_utils.py:67-105) with dL/dS = 0, dL/dU ignored
+        double Kc[3][3], A1[3][3], sym[3][3], T[3][3], Gm[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                if (i == j) { Kc[i][j] = 0.0; continue; }
+                const double diff = S[i] - S[j];
+                const double sg = diff > 0 ? 1.0 : (diff < 0 ? -1.0 : 0.0);
+                const double kneg = sg * fmax(fabs(diff), 1e-6);
+                Kc[i][j] = (1.0 / kneg) * (1.0 / (S[i] + S[j]));
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int d = 0; d < 3; ++d) s += V[d][i] * gV[d][j];
+                A1[i][j] = Kc[j][i] * s;  // K^T * (V^T gV)
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) sym[i][j] = (A1[i][j] + A1[j][i]) / 2.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int d = 0; d < 3; ++d) s += U[i][d] * S[d] * sym[d][j];
+                T[i][j] = s;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int d = 0; d < 3; ++d) s += T[i][d] * V[j][d];
+                Gm[i][j] = 2.0 * s;
+            }
+        // M = cov + 1e-4 * mean(cov) * R
+        const float *R = rnd + b * rnd_stride_b + k * rnd_stride_k;
+        double gR = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) gR += Gm[i][j] * (double)R[i * 3 + j];
+        double tr = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const double gc = Gm[i][j] + 1e-4 * gR / 9.0;
+                s_g[i * 3 + j] = (float)gc;
+                tr += gc * cov[i][j];
+            }
+        s_g[9] = (float)tr;
+        for (int d = 0; d < 3; ++d) s_g[10 + d] = (float)gcen[d];
+        for (int e = 0; e < 6; ++e) s_g[13 + e] = (float)gw_sp[e];
+    }
+    __syncthreads();
+    float gc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gc[i] = s_g[i];
+    const float tr = s_g[9], gx = s_g[10], gy = s_g[11], gz = s_g[12];
+    for (int i = tid; i < N; i += 256) {
+        const float x = P[i * 3] - cx, y = P[i * 3 + 1] - cy, z = P[i * 3 + 2] - cz;
+        const float quad = x * (gc[0] * x + gc[1] * y + gc[2] * z) + y * (gc[3] * x + gc[4] * y + gc[5] * z) +
+                           z * (gc[6] * x + gc[7] * y + gc[8] * z);
+        float v = (quad - tr) / sw + (gx * x + gy * y + gz * z) / sw;
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            if (s_idx[e] == i) v += s_g[13 + e];
+        gWk[(size_t)i * KM] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ellipsoid SDF of the target points, min over ellipsoids of |sdf|, squared (convex_loss.py:313-328,
+// src/utils.py:410-411).  One thread per target point, parameters in LDS.
+// ---------------------------------------------------------------------------------------------
+struct EllParam { float r[3]; float V[9]; float c[3]; };
+
+__device__ __forceinline__ float sdf_eval(const EllParam &e, float px, float py, float pz, float q[3], float &k0,
+                                          float &k1)
+{
+    const float dx = px - e.c[0], dy = py - e.c[1], dz = pz - e.c[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[a] = e.V[a] * dx + e.V[3 + a] * dy + e.V[6 + a] * dz;  // V^T (p - c)
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float u = q[a] / (e.r[a] + 1e-6f), v = q[a] / (e.r[a] * e.r[a] + 1e-6f);
+        s0 += u * u;
+        s1 += v * v;
+    }
+    k0 = sqrtf(s0);
+    k1 = sqrtf(s1);
+    return k0 * (k0 - 1.0f) / (k1 + 1e-6f);
+}
+
+constexpr int KM_MAX = 64;
+
+__global__ __launch_bounds__(256) void sdf_fwd_kernel(const float *__restrict__ tgt, int M,
+                                                      const float *__restrict__ r, const float *__restrict__ V,
+                                                      const float *__restrict__ c,
+                                                      const int32_t *__restrict__ valid, int KM,
+                                                      int32_t *__restrict__ arg, float *__restrict__ fval,
+                                                      float *__restrict__ sum_o)
+{
+    __shared__ EllParam s_e[KM_MAX];
+    __shared__ int s_ok[KM_MAX];
+    __shared__ float s_red[4];
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < KM; k += 256) {
+        const size_t s = (size_t)b * KM + k;
+        s_ok[k] = valid[s];
+        for (int i = 0; i < 3; ++i) { s_e[k].r[i] = r[s * 3 + i]; s_e[k].c[i] = c[s * 3 + i]; }
+        for (int i = 0; i < 9; ++i) s_e[k].V[i] = V[s * 9 + i];
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float best = INFINITY, bf = 0.f;
+    int bk = -1;
+    if (m < M) {
+        const float *p = tgt + ((size_t)b * M + m) * 3;
+        const float px = p[0], py = p[1], pz = p[2];
+        for (int k = 0; k < KM; ++k) {
+            if (!s_ok[k]) continue;
+            float q[3], k0, k1;
+            const float f = sdf_eval(s_e[k], px, py, pz, q, k0, k1);
+            if (fabsf(f) < best) { best = fabsf(f); bf = f; bk = k; }
+        }
+        arg[(size_t)b * M + m] = bk;
+        fval[(size_t)b * M + m] = bf;
+    }
+    float v = (m < M && bk >= 0) ? bf * bf : 0.f;
+    v = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(sum_o + b, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+}
+
+// d(sum f^2)/d(r, V, c), scaled per shape by gscale[b]
+__global__ __launch_bounds__(256) void sdf_bwd_kernel(const float *__restrict__ tgt, int M,
+                                                      const float *__restrict__ r, const float *__restrict__ V,
+                                                      const float *__restrict__ c,
+                                                      const int32_t *__restrict__ arg,
+                                                      const float *__restrict__ gscale, int KM,
+                                                      float *__restrict__ g_r, float *__restrict__ g_V,
+                                                      float *__restrict__ g_c)
+{
+    __shared__ EllParam s_e[KM_MAX];
+    __shared__ float s_acc[KM_MAX * 15];
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < KM; k += 256) {
+        const size_t s = (size_t)b * KM + k;
+        for (int i = 0; i < 3; ++i) { s_e[k].r[i] = r[s * 3 + i]; s_e[k].c[i] = c[s * 3 + i]; }
+        for (int i = 0; i < 9; ++i) s_e[k].V[i] = V[s * 9 + i];
+    }
+    for (int i = threadIdx.x; i < KM * 15; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < M) {
+        const int k = arg[(size_t)b * M + m];
+        if (k >= 0) {
+            const EllParam &e = s_e[k];
+            const float *p = tgt + ((size_t)b * M + m) * 3;
+            float q[3], k0, k1;
+            const float f = sdf_eval(e, p[0], p[1], p[2], q, k0, k1);
+            const float gf = gscale[b] * 2.0f * f;
+            const float den = k1 + 1e-6f;
+            const float df0 = (2.0f * k0 - 1.0f) / den, df1 = -k0 * (k0 - 1.0f) / (den * den);
+            float gq[3];
+            float *acc = s_acc + k * 15;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float ra = e.r[a] + 1e-6f, rb = e.r[a] * e.r[a] + 1e-6f;
+                const float u = q[a] / ra, v = q[a] / rb;
+                const float dk0dq = k0 > 0.f ? u / (k0 * ra) : 0.f, dk1dq = k1 > 0.f ? v / (k1 * rb) : 0.f;
+                const float dk0dr = k0 > 0.f ? -u * u / (k0 * ra) : 0.f;
+                const float dk1dr = k1 > 0.f ? -2.0f * e.r[a] * v * v / (k1 * rb) : 0.f;
+                gq[a] = gf * (df0 * dk0dq + df1 * dk1dq);
+                atomicAdd(acc + a, gf * (df0 * dk0dr + df1 * dk1dr));
+            }
+            const float d[3] = {p[0] - e.c[0], p[1] - e.c[1], p[2] - e.c[2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float gc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    atomicAdd(acc + 3 + i * 3 + a, d[i] * gq[a]);  // q_a = sum_i V[i][a] d_i
+                    gc -= e.V[i * 3 + a] * gq[a];
+                }
+                atomicAdd(acc + 12 + i, gc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KM * 15; i += 256) {
+        const float v = s_acc[i];
+        if (v == 0.f) continue;
+        const int k = i / 15, j = i % 15;
+        const size_t s = (size_t)b * KM + k;
+        if (j < 3) unsafeAtomicAdd(g_r + s * 3 + j, v);
+        else if (j < 12) unsafeAtomicAdd(g_V + s * 9 + (j - 3), v);
+        else unsafeAtomicAdd(g_c + s * 3 + (j - 12), v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// surface sampling budget (src/ellipsoid_utils.py:87-107, :157-159)
+// ---------------------------------------------------------------------------------------------
+__global__ void sample_budget_kernel(const float *__restrict__ r, const int32_t *__restrict__ valid, int KM,
+                                     int cap, int32_t *__restrict__ n_o, int32_t *__restrict__ off_o)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double area[KM_MAX];
+    double total = 0.0;
+    for (int k = 0; k < KM; ++k) {
+        area[k] = 0.0;
+        if (!valid[(size_t)b * KM + k]) continue;
+        const float a = r[((size_t)b * KM + k) * 3], bb = r[((size_t)b * KM + k) * 3 + 1],
+                    cc = r[((size_t)b * KM + k) * 3 + 2];
+        const float p = 1.585f;
+        const float s = powf(a * bb, p) + powf(bb * cc, p) + powf(cc * a, p);
+        area[k] = (double)(4.0f * 3.142f * powf(s, 1.0f / p));
+        total += area[k];
+    }
+    int off = 0;
+    for (int k = 0; k < KM; ++k) {
+        int n = 0;
+        if (valid[(size_t)b * KM + k]) {
+            n = (int)rint(10000.0 * (area[k] / total));  // np.round: half to even
+            if (n <= 0) n = 100;
+            if (off + n > cap) n = cap - off;
+        }
+        n_o[(size_t)b * KM + k] = n;
+        off_o[(size_t)b * (KM + 1) + k] = off;
+        off += n;
+    }
+    off_o[(size_t)b * (KM + 1) + KM] = off;
+}
+
+__device__ __forceinline__ void fib_dir(int j, int n, float &cu, float &su, float &cv, float &sv)
+{
+    const double z = 1.0 - (2.0 * (double)j + 1.0) / (double)n;
+    double ip;
+    const double lon = 6.283185307179586 * modf((double)j * 0.6180339887498949, &ip);
+    cu = (float)cos(lon); su = (float)sin(lon);
+    cv = (float)z; sv = (float)sqrt(fmax(0.0, 1.0 - z * z));
+}
+
+constexpr int NN_TILE_T = 1024;
+
+// Sample s of shape b: point on ellipsoid k(s), nearest target, squared distance (src/utils.py:413-416).
+__global__ __launch_bounds__(256) void sample_nn_fwd_kernel(
+    const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
+    const int32_t *__restrict__ n_k, const int32_t *__restrict__ off_k, int KM, const float *__restrict__ tgt,
+    int M, int cap, int32_t *__restrict__ nn_idx, float *__restrict__ sum_o)
+{
+    __shared__ float4 s_t[NN_TILE_T];
+    __shared__ float s_red[4];
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int32_t *off = off_k + (size_t)b * (KM + 1);
+    const int total = off[KM];
+    if (blockIdx.x * 256 >= total) return;  // block-uniform
+    const bool act = s < total;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (act) {
+        int k = 0;
+        while (k + 1 < KM && s >= off[k + 1]) ++k;
+        const size_t sl = (size_t)b * KM + k;
+        float cu, su, cv, sv;
+        fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
+        const float ex = r[sl * 3] * cu * sv, ey = r[sl * 3 + 1] * su * sv, ez = r[sl * 3 + 2] * cv;
+        const float *Vk = V + sl * 9;
+        px = Vk[0] * ex + Vk[1] * ey + Vk[2] * ez + c[sl * 3];
+        py = Vk[3] * ex + Vk[4] * ey + Vk[5] * ez + c[sl * 3 + 1];
+        pz = Vk[6] * ex + Vk[7] * ey + Vk[8] * ez + c[sl * 3 + 2];
+    }
+    float best = INFINITY;
+    int bi = 0;
+    const float *T = tgt + (size_t)b * M * 3;
+    for (int base = 0; base < M; base += NN_TILE_T) {
+        const int tn = min(NN_TILE_T, M - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn; i += 256)
+            s_t[i] = make_float4(T[(size_t)(base + i) * 3], T[(size_t)(base + i) * 3 + 1],
+                                 T[(size_t)(base + i) * 3 + 2], 0.f);
+        __syncthreads();
+        for (int i = 0; i < tn; ++i) {
+            const float4 t = s_t[i];
+            const float dx = px - t.x, dy = py - t.y, dz = pz - t.z;
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; bi = base + i; }
+        }
+    }
+    if (act) nn_idx[(size_t)b * cap + s] = bi;
+    float v = act ? best : 0.f;
+    v = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(sum_o + b, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+}
+
+__global__ __launch_bounds__(256) void sample_nn_bwd_kernel(
+    const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
+    const int32_t *__restrict__ n_k, const int32_t *__restrict__ off_k, int KM, const float *__restrict__ tgt,
+    int M, int cap, const int32_t *__restrict__ nn_idx, const float *__restrict__ gscale,
+    float *__restrict__ g_r, float *__restrict__ g_V, float *__restrict__ g_c)
+{
+    __shared__ float s_acc[KM_MAX * 15];
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int32_t *off = off_k + (size_t)b * (KM + 1);
+    const int total = off[KM];
+    if (blockIdx.x * 256 >= total) return;
+    for (int i = threadIdx.x; i < KM * 15; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    if (s < total) {
+        int k = 0;
+        while (k + 1 < KM && s >= off[k + 1]) ++k;
+        const size_t sl = (size_t)b * KM + k;
+        float cu, su, cv, sv;
+        fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
+        const float dir[3] = {cu * sv, su * sv, cv};
+        const float e[3] = {r[sl * 3] * dir[0], r[sl * 3 + 1] * dir[1], r[sl * 3 + 2] * dir[2]};
+        const float *Vk = V + sl * 9;
+        const float *t = tgt + ((size_t)b * M + nn_idx[(size_t)b * cap + s]) * 3;
+        float gs[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float p = Vk[i * 3] * e[0] + Vk[i * 3 + 1] * e[1] + Vk[i * 3 + 2] * e[2] + c[sl * 3 + i];
+            gs[i] = gscale[b] * 2.0f * (p - t[i]);
+        }
+        float *acc = s_acc + k * 15;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float ge = Vk[j] * gs[0] + Vk[3 + j] * gs[1] + Vk[6 + j] * gs[2];  // (V^T g_s)[j]
+            atomicAdd(acc + j, ge * dir[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) atomicAdd(acc + 3 + i * 3 + j, gs[i] * e[j]);
+            atomicAdd(acc + 12 + i, gs[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KM * 15; i += 256) {
+        const float v = s_acc[i];
+        if (v == 0.f) continue;
+        const int k = i / 15, j = i % 15;
+        const size_t sl = (size_t)b * KM + k;
+        if (j < 3) unsafeAtomicAdd(g_r + sl * 3 + j, v);
+        else if (j < 12) unsafeAtomicAdd(g_V + sl * 9 + (j - 3), v);
+        else unsafeAtomicAdd(g_c + sl * 3 + (j - 12), v);
+    }
+}
+
+extern "C" {
+
+int prifit_fit_state_floats(void) { return FIT_STATE; }
+
+int prifit_ellipsoid_fit_fwd(const float *points, const float *W, const int32_t *count, const float *rnd,
+                             long long rnd_stride_b, long long rnd_stride_k, int canonical_signs, int B, int N,
+                             int KM, float *r, float *V, float *c, int32_t *valid, float *state, void *stream)
+{
+    if (!points || !W || !count || !rnd || !r || !V || !c || !valid || !state || B <= 0 || N <= 0 || KM <= 0 ||
+        KM > KM_MAX)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(ellipsoid_fit_fwd_kernel, dim3(KM, B), dim3(256), 0, as_stream(stream), points, W, count,
+                       rnd, rnd_stride_b, rnd_stride_k, canonical_signs, N, KM, r, V, c, valid, state);
+    return prifit_check_launch();
+}
+
+int prifit_ellipsoid_fit_bwd(const float *points, const float *W, const int32_t *count, const int32_t *valid,
+                             const float *rnd, long long rnd_stride_b, long long rnd_stride_k, const float *state,
+                             const float *g_r, const float *g_V, const float *g_c, int B, int N, int KM, float *gW,
+                             void *stream)
+{
+    if (!points || !W || !count || !valid || !rnd || !state || !g_r || !g_V || !g_c || !gW || B <= 0 || N <= 0 ||
+        KM <= 0 || KM > KM_MAX)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(ellipsoid_fit_bwd_kernel, dim3(KM, B), dim3(256), 0, as_stream(stream), points, W, count,
+                       valid, rnd, rnd_stride_b, rnd_stride_k, state, g_r, g_V, g_c, N, KM, gW);
+    return prifit_check_launch();
+}
+
+int prifit_ellipsoid_sdf_fwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                             const int32_t *valid, int KM, int32_t *arg, float *fval, float *sum_sq, void *stream)
+{
+    if (!targets || !r || !V || !c || !valid || !arg || !fval || !sum_sq || B <= 0 || M <= 0 || KM <= 0 ||
+        KM > KM_MAX)
+        return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sum_sq, 0, sizeof(float) * B, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    hipLaunchKernelGGL(sdf_fwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, targets, M, r, V, c, valid, KM,
+                       arg, fval, sum_sq);
+    return prifit_check_launch();
+}
+
+int prifit_ellipsoid_sdf_bwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                             const int32_t *arg, const float *gscale, int KM, float *g_r, float *g_V, float *g_c,
+                             void *stream)
+{
+    if (!targets || !r || !V || !c || !arg || !gscale || !g_r || !g_V || !g_c || B <= 0 || M <= 0 || KM <= 0 ||
+        KM > KM_MAX)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(sdf_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), targets, M, r, V,
+                       c, arg, gscale, KM, g_r, g_V, g_c);
+    return prifit_check_launch();
+}
+
+int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n, int32_t *off,
+                         void *stream)
+{
+    if (!r || !valid || !n || !off || B <= 0 || KM <= 0 || KM > KM_MAX || cap <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(sample_budget_kernel, dim3(B), dim3(64), 0, as_stream(stream), r, valid, KM, cap, n, off);
+    return prifit_check_launch();
+}
+
+int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+                         int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
+                         void *stream)
+{
+    if (!r || !V || !c || !n || !off || !targets || !nn_idx || !sum_d2 || B <= 0 || KM <= 0 || KM > KM_MAX ||
+        M <= 0 || cap <= 0)
+        return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(sum_d2, 0, sizeof(float) * B, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    hipLaunchKernelGGL(sample_nn_fwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, st, r, V, c, n, off, KM,
+                       targets, M, cap, nn_idx, sum_d2);
+    return prifit_check_launch();
+}
+
+int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+                         int B, int KM, const float *targets, int M, int cap, const int32_t *nn_idx,
+                         const float *gscale, float *g_r, float *g_V, float *g_c, void *stream)
+{
+    if (!r || !V || !c || !n || !off || !targets || !nn_idx || !gscale || !g_r || !g_V || !g_c || B <= 0 ||
+        KM <= 0 || KM > KM_MAX || M <= 0 || cap <= 0)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(sample_nn_bwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, as_stream(stream), r, V, c,
+                       n, off, KM, targets, M, cap, nn_idx, gscale, g_r, g_V, g_c);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

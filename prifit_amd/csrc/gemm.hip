@@ -18,7 +18,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { LAY_NT = 0, LAY_NN = 1, LAY_TN = 2 };
-enum { EPI_NONE = 0, EPI_CHORD = 1, EPI_MSKERNEL = 2 };
+enum { EPI_NONE = 0, EPI_CHORD = 1, EPI_MSKERNEL = 2, EPI_MSBWD = 3 };
 
 struct GemmArgs {
     const float *A, *B;
@@ -32,8 +32,10 @@ struct GemmArgs {
     const float *bias;               // [N], added to every row
     float *stats;                    // [tilesM][2][N] per-column partial (sum, sum of squares) of C
     int epi;
-    const float *epi_batch_scalar;   // EPI_MSKERNEL: bandwidth b[z]
-    int accumulate;                  // 1: atomicAdd into C (split-K); 0: store
+    const float *epi_batch_scalar;   // EPI_MSKERNEL / EPI_MSBWD: bandwidth b[z]
+    const float *aux;                // EPI_MSBWD: the forward kernel matrix, indexed like C
+    long long ldaux, sAux;
+    int accumulate;                  // 1: C += result (atomics when split-K); 0: store
     int vecA, vecB;                  // 16-byte loads legal for the operand
 };
 
@@ -203,7 +205,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float inv_b2 = 0.f;
-    if (g.epi == EPI_MSKERNEL) { const float bw = g.epi_batch_scalar[z]; inv_b2 = bw * bw; }
+    if (g.epi == EPI_MSKERNEL || g.epi == EPI_MSBWD) { const float bw = g.epi_batch_scalar[z]; inv_b2 = bw * bw; }
+    const float kmin = expf(-13.0f);  // value of a kernel entry whose exponent hit the lower clamp
     float csum[TN], csq[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) { csum[b] = 0.f; csq[b] = 0.f; }
@@ -227,12 +230,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
                     float t = (-dist / inv_b2) / 2.0f;
                     t = fminf(fmaxf(t, -13.0f), 75.0f);
                     v = expf(t);
+                } else if (g.epi == EPI_MSBWD) {
+                    // backward of K = exp(clamp((s-1)/b^2)): dL/ds = dL/dK * K / b^2, zero where clamped
+                    const float kf = g.aux[(long long)z * g.sAux + (long long)row * g.ldaux + col];
+                    v = kf > kmin ? v * kf / inv_b2 : 0.f;
                 }
                 csum[b] += v;
                 csq[b] += v * v;
                 float *dst = C + (long long)row * g.ldc + col;
-                if (g.accumulate) unsafeAtomicAdd(dst, v);
-                else *dst = v;
+                if (g.accumulate) {
+                    if (g.splitk > 1) unsafeAtomicAdd(dst, v);
+                    else *dst += v;
+                } else *dst = v;
             }
         }
     }
@@ -286,10 +295,12 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     const float *B, long long ldb, long long strideB, float *C, long long ldc,
                     long long strideC, int batch, int splitk, const float *a_scale, const float *a_shift,
                     const float *b_scale, const float *b_shift, const float *bias, float *col_stats,
-                    int epilogue, const float *epi_batch_scalar, void *stream)
+                    int epilogue, const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
+                    long long stride_aux, int accumulate, void *stream)
 {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0 || layout < 0 || layout > 2 ||
-        epilogue < 0 || epilogue > 2 || (epilogue == EPI_MSKERNEL && !epi_batch_scalar) ||
+        epilogue < 0 || epilogue > 3 || (epilogue >= EPI_MSKERNEL && !epi_batch_scalar) ||
+        (epilogue == EPI_MSBWD && !epi_aux) || (splitk > 1 && !accumulate) ||
         ((a_scale == nullptr) != (a_shift == nullptr)) || ((b_scale == nullptr) != (b_shift == nullptr)) ||
         (col_stats && (batch != 1 || splitk != 1)) || (epilogue != EPI_NONE && splitk != 1) || (long long)batch * splitk > 65535)
         return PRIFIT_EINVAL;
@@ -299,7 +310,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.batch = batch; g.splitk = splitk;
     g.a_scale = a_scale; g.a_shift = a_shift; g.b_scale = b_scale; g.b_shift = b_shift;
     g.bias = bias; g.stats = col_stats; g.epi = epilogue; g.epi_batch_scalar = epi_batch_scalar;
-    g.accumulate = splitk > 1;
+    g.accumulate = accumulate; g.aux = epi_aux; g.ldaux = ld_aux; g.sAux = stride_aux;
     // contiguous extents: A is k-contiguous unless TN (then m-contiguous); B is k-contiguous for NT else n-contiguous
     const int extA = layout == LAY_TN ? M : K, extB = layout == LAY_NT ? K : N;
     g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0) && (extA % 4 == 0);

@@ -1,0 +1,377 @@
+// Mean-shift clustering on the unit hypersphere (src/mean_shift.py): the bandwidth / assignment /
+// update kernels around the N x N x D GEMMs (which run on the MFMA GEMM of gemm.hip).
+// All kernels are bandwidth- or latency-class: one wave per matrix row, coalesced row reads,
+// wave-shuffle reductions.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// k-th smallest entry of every row (torch.topk(dist, k, largest=False)[0][:, -1], mean_shift.py:156-158)
+// One wave per row; the row lives in registers (C <= 64*VPT) and a 32-step MSB-first radix
+// select over the order-preserving integer image of the floats finds the exact k-th value.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2key(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restrict__ M, long long rows, int C,
+                                                           int k, float *__restrict__ out)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *r = M + row * C;
+    unsigned key[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int c = lane + 64 * j;
+        key[j] = c < C ? f2key(r[c]) : 0xffffffffu;  // padding sorts last
+    }
+    unsigned prefix = 0;
+    int kk = k;  // 1-based rank among the remaining candidates
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned hi_mask = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j)
+            cnt += ((key[j] & hi_mask) == prefix && !((key[j] >> bit) & 1u)) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (kk > cnt) { kk -= cnt; prefix |= (1u << bit); }
+    }
+    if (lane == 0) out[row] = key2f(prefix);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mean-shift update (mean_shift.py:70-82): O = K [X | 1]  ->  Mv = O[:D] / O[D];
+// new = Z + (Mv - Z); out = new / ||new||.  One wave per point.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ms_update_fwd_kernel(const float *__restrict__ O, int Dp,
+                                                            const float *__restrict__ Z, int D, long long rows,
+                                                            float *__restrict__ out, float *__restrict__ nrm_o)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *o = O + row * Dp;
+    const float *z = Z + row * D;
+    const float dinv = 1.0f / o[D];  // D = 1 / sum(K, 1)
+    float nv[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        float v = 0.f;
+        if (c < D) {
+            const float zz = z[c];
+            const float m = o[c] * dinv - zz;
+            v = zz + m;
+        }
+        nv[j] = v;
+        ss += v * v;
+    }
+    ss = wave_sum_f32(ss);
+    const float n = sqrtf(ss);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        if (c < D) out[row * D + c] = nv[j] / n;
+    }
+    if (lane == 0) nrm_o[row] = n;
+}
+
+// Backward of the update: given g = dL/d(out) produce dL/dO (Dp columns: the last live column is the
+// gradient w.r.t. the row sum; padding columns are zero).  dL/dZ through "Z + (Mv - Z)" is exactly 0.
+__global__ __launch_bounds__(256) void ms_update_bwd_kernel(const float *__restrict__ g,
+                                                            const float *__restrict__ out,
+                                                            const float *__restrict__ nrm,
+                                                            const float *__restrict__ O, int Dp, int D,
+                                                            long long rows, float *__restrict__ gO)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *o = O + row * Dp;
+    const float rinv = 1.0f / o[D];
+    const float ninv = 1.0f / nrm[row];
+    float gg[4], oo[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        gg[j] = c < D ? g[row * D + c] : 0.f;
+        oo[j] = c < D ? out[row * D + c] : 0.f;
+        dot += gg[j] * oo[j];
+    }
+    dot = wave_sum_f32(dot);
+    float gr = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        if (c < D) {
+            const float gnew = (gg[j] - oo[j] * dot) * ninv;  // through the normalisation
+            const float mv = o[c] * rinv;
+            gO[row * Dp + c] = gnew * rinv;                  // d/dO[c] of O[c]/r
+            gr -= gnew * mv;
+        }
+    }
+    gr = wave_sum_f32(gr);
+    for (int c = D + lane; c < Dp; c += 64) gO[row * Dp + c] = c == D ? gr * rinv : 0.f;  // d/dr of O/r
+}
+
+// ---------------------------------------------------------------------------------------------
+// nms (mean_shift.py:162-202) on the chord-distance matrix dist = 2 - 2 Z Z^T  [B, N, N]
+// ---------------------------------------------------------------------------------------------
+// owner[j] = argmin_i dist[i][j] (first minimum).  dist is bitwise symmetric (same fma chain), so the
+// column argmin is read as a row argmin; counts[owner] += 1.
+__global__ __launch_bounds__(256) void nms_owner_kernel(const float *__restrict__ dist, int N, long long rows,
+                                                        int32_t *__restrict__ owner, int32_t *__restrict__ counts)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *r = dist + row * N;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < N; c += 64) {
+        const float v = r[c];
+        if (v < best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        owner[row] = bi;
+        atomicAdd(counts + (row / N) * N + bi, 1);
+    }
+}
+
+// For every centre u that owns >= 1 point: chosen[u] = argmax_j (dist[u][j] < b ? counts[j] : 0), first max.
+__global__ __launch_bounds__(256) void nms_pick_kernel(const float *__restrict__ dist,
+                                                       const int32_t *__restrict__ counts,
+                                                       const float *__restrict__ bw, int N, long long rows,
+                                                       int32_t *__restrict__ flags)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long b = row / N;
+    if (counts[row] == 0) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const float *r = dist + row * N;
+    const int32_t *cn = counts + b * N;
+    const float thr = bw[b];
+    int best = 0, bi = 0x7fffffff;
+    for (int c = lane; c < N; c += 64) {
+        const int v = r[c] < thr ? cn[c] : 0;
+        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) flags[b * N + bi] = 1;
+}
+
+// Ordered compaction of the flagged centre ids (torch.unique sorts ascending): ids[b][0..count) and count[b].
+__global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t *__restrict__ flags, int N, int cap,
+                                                          int32_t *__restrict__ ids, int32_t *__restrict__ count)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < N; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const bool f = c < N && flags[(long long)b * N + c] != 0;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (f && pos < cap) ids[(long long)b * cap + pos] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[b] = s_base;
+    for (int k = s_base + threadIdx.x; k < cap; k += 256) ids[(long long)b * cap + k] = 0;
+}
+
+// labels[j] = argmax_k <centre_k, z_j> (first max) with centre_k = Z[ids[k]]; used[b][label] = 1.
+// One wave per point; D <= 256.
+__global__ __launch_bounds__(256) void nms_labels_kernel(const float *__restrict__ Z, int N, int D,
+                                                         const int32_t *__restrict__ ids,
+                                                         const int32_t *__restrict__ count, int cap,
+                                                         long long rows, int32_t *__restrict__ labels,
+                                                         int32_t *__restrict__ used)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long b = row / N;
+    const int lane = threadIdx.x & 63;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = (lane + 64 * j) < D ? Z[row * D + lane + 64 * j] : 0.f;
+    const int K = min(count[b], cap);
+    float best = -INFINITY;
+    int bk = 0;
+    for (int k = 0; k < K; ++k) {
+        const float *c = Z + (b * N + ids[b * cap + k]) * D;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (lane + 64 * j) < D ? x[j] * c[lane + 64 * j] : 0.f;
+        s = wave_sum_f32(s);
+        if (s > best) { best = s; bk = k; }
+    }
+    if (lane == 0) {
+        labels[row] = bk;
+        used[b * cap + bk] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// membership (mean_shift.py:230-247): sim = <centre_k, x_j> / b^2 - gmax; e = exp(clamp(sim, -13, 75));
+// W[j][k] = e_k / sum_k e_k for k < count, 0 otherwise.  dots [B, N, KM] are raw dot products.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void membership_fwd_kernel(const float *__restrict__ dots,
+                                                             const float *__restrict__ bw,
+                                                             const float *__restrict__ gmax,
+                                                             const int32_t *__restrict__ count, int N, int KM,
+                                                             long long rows, float *__restrict__ W)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const long long b = row / N;
+    const int K = min(count[b], KM);
+    const float b2 = bw[b] * bw[b];
+    const float gm = gmax[b];
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float s = dots[row * KM + k] / b2 - gm;
+        sum += expf(fminf(fmaxf(s, -13.f), 75.f));
+    }
+    for (int k = 0; k < KM; ++k) {
+        float w = 0.f;
+        if (k < K) {
+            const float s = dots[row * KM + k] / b2 - gm;
+            w = expf(fminf(fmaxf(s, -13.f), 75.f)) / sum;
+        }
+        W[row * KM + k] = w;
+    }
+}
+
+// g_dots[j][k] = dL/d(raw dot): (gW_k - sum_k' gW_k' W_k') * W_k * [not clamped] / b^2
+__global__ __launch_bounds__(256) void membership_bwd_kernel(const float *__restrict__ gW,
+                                                             const float *__restrict__ W,
+                                                             const float *__restrict__ dots,
+                                                             const float *__restrict__ bw,
+                                                             const float *__restrict__ gmax,
+                                                             const int32_t *__restrict__ count, int N, int KM,
+                                                             long long rows, float *__restrict__ gdots)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const long long b = row / N;
+    const int K = min(count[b], KM);
+    const float b2 = bw[b] * bw[b];
+    const float gm = gmax[b];
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += gW[row * KM + k] * W[row * KM + k];
+    for (int k = 0; k < KM; ++k) {
+        float v = 0.f;
+        if (k < K) {
+            const float s = dots[row * KM + k] / b2 - gm;
+            if (s >= -13.f && s <= 75.f) v = (gW[row * KM + k] - dot) * W[row * KM + k] / b2;
+        }
+        gdots[row * KM + k] = v;
+    }
+}
+
+extern "C" {
+
+int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float *out, void *stream)
+{
+    if (!M || !out || rows <= 0 || C <= 0 || k < 1 || k > C || C > 4096) return PRIFIT_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (C <= 512) hipLaunchKernelGGL((kth_smallest_kernel<8>), grid, block, 0, st, M, rows, C, k, out);
+    else if (C <= 1024) hipLaunchKernelGGL((kth_smallest_kernel<16>), grid, block, 0, st, M, rows, C, k, out);
+    else if (C <= 2048) hipLaunchKernelGGL((kth_smallest_kernel<32>), grid, block, 0, st, M, rows, C, k, out);
+    else hipLaunchKernelGGL((kth_smallest_kernel<64>), grid, block, 0, st, M, rows, C, k, out);
+    return prifit_check_launch();
+}
+
+int prifit_meanshift_update_fwd(const float *O, int Dp, const float *Z, int D, long long rows, float *out,
+                                float *nrm, void *stream)
+{
+    if (!O || !Z || !out || !nrm || rows <= 0 || D <= 0 || D > 256 || Dp <= D) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(ms_update_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), O,
+                       Dp, Z, D, rows, out, nrm);
+    return prifit_check_launch();
+}
+
+int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O, int Dp, int D,
+                                long long rows, float *gO, void *stream)
+{
+    if (!g || !out || !nrm || !O || !gO || rows <= 0 || D <= 0 || D > 256 || Dp <= D) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(ms_update_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), g,
+                       out, nrm, O, Dp, D, rows, gO);
+    return prifit_check_launch();
+}
+
+int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap, int32_t *owner,
+               int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count, int32_t *labels, int32_t *used,
+               void *stream)
+{
+    if (!dist || !Z || !bw || !owner || !counts || !flags || !ids || !count || !labels || !used || B <= 0 ||
+        N <= 0 || D <= 0 || D > 256 || cap <= 0)
+        return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const long long rows = (long long)B * N;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(flags, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)B * cap, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist, N, rows, owner, counts);
+    hipLaunchKernelGGL(nms_pick_kernel, grid, block, 0, st, dist, counts, bw, N, rows, flags);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(B), block, 0, st, flags, N, cap, ids, count);
+    hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, Z, N, D, ids, count, cap, rows, labels, used);
+    return prifit_check_launch();
+}
+
+int prifit_membership_fwd(const float *dots, const float *bw, const float *gmax, const int32_t *count, int B,
+                          int N, int KM, float *W, void *stream)
+{
+    if (!dots || !bw || !gmax || !count || !W || B <= 0 || N <= 0 || KM <= 0) return PRIFIT_EINVAL;
+    const long long rows = (long long)B * N;
+    hipLaunchKernelGGL(membership_fwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), dots, bw, gmax, count, N, KM, rows, W);
+    return prifit_check_launch();
+}
+
+int prifit_membership_bwd(const float *gW, const float *W, const float *dots, const float *bw, const float *gmax,
+                          const int32_t *count, int B, int N, int KM, float *gdots, void *stream)
+{
+    if (!gW || !W || !dots || !bw || !gmax || !count || !gdots || B <= 0 || N <= 0 || KM <= 0)
+        return PRIFIT_EINVAL;
+    const long long rows = (long long)B * N;
+    hipLaunchKernelGGL(membership_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), gW, W, dots, bw, gmax, count, N, KM, rows, gdots);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""Autograd functions of the fitting path: batched mean-shift clustering, soft membership, weighted
+ellipsoid fit and the analytic-chamfer loss terms, on the C-ABI kernels.
+
+Everything is batched over the B shapes of a GPU with fixed-capacity cluster slots (KM per shape,
+validity masks instead of the reference's python lists / -1 sentinels), so one forward+backward of
+the loss is a fixed sequence of launches with a single host read-back (the cluster-count check of
+src/ellipsoid_utils.py:19-27).  Reference sites are cited per function (paths relative to upstream).
+"""
+import ctypes
+
+import torch
+
+from . import profiler
+from ._lib import call, cur_stream, dll, ptr
+from .nn_ops import EPI_CHORD, EPI_MSBWD, EPI_MSKERNEL, NN, NT, TN, gemm
+
+_LL = ctypes.c_longlong
+KM = 32          # cluster slots per shape (>= max_num_clusters = 25, src/ellipsoid_utils.py:6)
+NMS_CAP = 64     # centre ids kept by nms before the cluster-count check
+SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106)
+
+
+def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
+    gemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch=batch, sA=sA, sB=sB, sC=sC, **kw)
+
+
+def chord_matrix(A, B_):
+    """2 - 2 A B^T for unit rows (src/mean_shift.py:154,168,185).  A [B,N,D], B_ [B,M,D] -> [B,N,M]."""
+    Bt, N, D = A.shape
+    M = B_.shape[1]
+    out = torch.empty(Bt, N, M, dtype=torch.float32, device=A.device)
+    _bgemm(NT, N, M, D, A, D, B_, D, out, M, Bt, N * D, M * D, N * M, epi=EPI_CHORD)
+    return out
+
+
+def compute_bandwidth(X, quantile):
+    """src/mean_shift.py:138-160 with num_samples == N, batched: X [B,N,D] (unit rows) -> bw [B]."""
+    Bt, N, D = X.shape
+    dist = chord_matrix(X, X)
+    k = int(quantile * N)
+    kth = torch.empty(Bt * N, dtype=torch.float32, device=X.device)
+    call("prifit_kth_smallest_rows", ptr(dist), _LL(Bt * N), N, k, ptr(kth), cur_stream())
+    return torch.sqrt(torch.clamp(kth, min=1e-6)).view(Bt, N).mean(dim=1)
+
+
+class MeanShiftFn(torch.autograd.Function):
+    """src/mean_shift.py:50-84 (gaussian kernel, delta = 1), all shapes at once.
+
+    forward: Z_0 = X; per iteration K = exp(clamp((Z X^T - 1)/b^2)) (MFMA GEMM with the kernel transform in
+    its epilogue), O = K [X | 1] (second GEMM: the ones column yields the row sums), Z <- normalize(O/rowsum).
+    backward: four GEMMs per iteration (dK through the saved K in the epilogue, dZ, and two dX terms)."""
+
+    @staticmethod
+    def forward(ctx, X, bw, iterations):
+        X = X.contiguous()
+        Bt, N, D = X.shape
+        Dp = D + 4
+        dev = X.device
+        Xa = torch.zeros(Bt, N, Dp, dtype=torch.float32, device=dev)
+        Xa[:, :, :D] = X
+        Xa[:, :, D] = 1.0
+        Z = X.clone()
+        saved = []
+        for _ in range(iterations):
+            Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
+            _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
+            O = torch.empty(Bt, N, Dp, dtype=torch.float32, device=dev)
+            _bgemm(NN, N, Dp, N, Kmat, N, Xa, Dp, O, Dp, Bt, N * N, N * Dp, N * Dp)
+            Zn = torch.empty_like(Z)
+            nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+            call("prifit_meanshift_update_fwd", ptr(O), Dp, ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm), cur_stream())
+            saved.append((Z, Kmat, O, Zn, nrm))
+            Z = Zn
+        ctx.saved = (X, Xa, bw, saved)
+        return Z
+
+    @staticmethod
+    def backward(ctx, g):
+        X, Xa, bw, saved = ctx.saved
+        Bt, N, D = X.shape
+        Dp = D + 4
+        dev = X.device
+        g = g.contiguous()
+        gX = torch.zeros(Bt, N, D, dtype=torch.float32, device=dev)
+        gS = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
+        gO = torch.empty(Bt, N, Dp, dtype=torch.float32, device=dev)
+        for Z, Kmat, O, Zn, nrm in reversed(saved):
+            call("prifit_meanshift_update_bwd", ptr(g), ptr(Zn), ptr(nrm), ptr(O), Dp, D, _LL(Bt * N), ptr(gO),
+                 cur_stream())
+            # dL/dS = (gO [X|1]^T) * K / b^2 where the clamp is inactive
+            _bgemm(NT, N, N, Dp, gO, Dp, Xa, Dp, gS, N, Bt, N * Dp, N * Dp, N * N, epi=EPI_MSBWD, epi_scalar=bw,
+                   aux=Kmat, ld_aux=N, s_aux=N * N)
+            gZ = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
+            _bgemm(NN, N, D, N, gS, N, X, D, gZ, D, Bt, N * N, N * D, N * D)                      # dZ = dS X
+            _bgemm(TN, N, D, N, gS, N, Z, D, gX, D, Bt, N * N, N * D, N * D, accumulate=True)     # dX += dS^T Z
+            _bgemm(TN, N, D, N, Kmat, N, gO, Dp, gX, D, Bt, N * N, N * Dp, N * D, accumulate=True)  # dX += K^T dO
+            g = gZ
+        gX += g  # Z_0 = X.clone()
+        return gX, None, None
+
+
+def nms(Z, bw):
+    """src/mean_shift.py:162-202 as called at :44 (centers = X = shifted points), batched.
+    Returns ids [B,NMS_CAP] (ascending kept centre ids), count [B], labels [B,N], used [B,NMS_CAP]."""
+    Bt, N, D = Z.shape
+    dev = Z.device
+    dist = chord_matrix(Z, Z)
+    i32 = dict(dtype=torch.int32, device=dev)
+    owner = torch.empty(Bt, N, **i32)
+    counts = torch.empty(Bt, N, **i32)
+    flags = torch.empty(Bt, N, **i32)
+    ids = torch.empty(Bt, NMS_CAP, **i32)
+    count = torch.empty(Bt, **i32)
+    labels = torch.empty(Bt, N, **i32)
+    used = torch.empty(Bt, NMS_CAP, **i32)
+    call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(owner), ptr(counts), ptr(flags), ptr(ids),
+         ptr(count), ptr(labels), ptr(used), cur_stream())
+    return ids, count, labels, used
+
+
+class MembershipFn(torch.autograd.Function):
+    """src/mean_shift.py:230-247, batched: centres [B,KM,D], X [B,N,D] -> W [B,N,KM] (0 for k >= count)."""
+
+    @staticmethod
+    def forward(ctx, centres, X, bw, count):
+        centres, X = centres.contiguous(), X.contiguous()
+        Bt, N, D = X.shape
+        K = centres.shape[1]
+        dev = X.device
+        dots = torch.empty(Bt, N, K, dtype=torch.float32, device=dev)
+        _bgemm(NT, N, K, D, X, D, centres, D, dots, K, Bt, N * D, K * D, N * K)
+        live = torch.arange(K, device=dev).view(1, 1, K) < count.view(Bt, 1, 1)
+        gmax = dots.masked_fill(~live, float("-inf")).amax(dim=(1, 2)) / (bw * bw)  # global max, detached (:242)
+        W = torch.empty_like(dots)
+        call("prifit_membership_fwd", ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(W), cur_stream())
+        ctx.save_for_backward(centres, X, bw, count, dots, gmax, W)
+        return W
+
+    @staticmethod
+    def backward(ctx, gW):
+        centres, X, bw, count, dots, gmax, W = ctx.saved_tensors
+        Bt, N, D = X.shape
+        K = centres.shape[1]
+        gW = gW.contiguous()
+        gd = torch.empty_like(dots)
+        call("prifit_membership_bwd", ptr(gW), ptr(W), ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(gd),
+             cur_stream())
+        gc = torch.empty_like(centres)
+        _bgemm(TN, K, D, N, gd, K, X, D, gc, D, Bt, N * K, N * D, K * D)     # dcentres = gd^T X
+        gX = torch.empty_like(X)
+        _bgemm(NN, N, D, K, gd, K, centres, D, gX, D, Bt, N * K, K * D, N * D)  # dX = gd centres
+        return gc, gX, None, None
+
+
+class EllipsoidFitFn(torch.autograd.Function):
+    """src/ellipsoid_fitting.py:19-69,104-141, one workgroup per (shape, cluster).
+    points [B,N,3], W [B,N,KM], count [B], rnd [3,3] | [B,KM,3,3] -> r [B,KM,3], V [B,KM,3,3], c [B,KM,3], valid."""
+
+    @staticmethod
+    def forward(ctx, points, W, count, rnd, canonical):
+        points, W, rnd = points.contiguous(), W.contiguous(), rnd.contiguous()
+        Bt, N, _ = points.shape
+        K = W.shape[2]
+        dev = points.device
+        sb, sk = (0, 0) if rnd.dim() == 2 else (K * 9, 9)
+        r = torch.empty(Bt, K, 3, dtype=torch.float32, device=dev)
+        V = torch.empty(Bt, K, 3, 3, dtype=torch.float32, device=dev)
+        c = torch.empty(Bt, K, 3, dtype=torch.float32, device=dev)
+        valid = torch.empty(Bt, K, dtype=torch.int32, device=dev)
+        state = torch.zeros(Bt, K, dll().prifit_fit_state_floats(), dtype=torch.float32, device=dev)
+        call("prifit_ellipsoid_fit_fwd", ptr(points), ptr(W), ptr(count), ptr(rnd), _LL(sb), _LL(sk), int(canonical),
+             Bt, N, K, ptr(r), ptr(V), ptr(c), ptr(valid), ptr(state), cur_stream())
+        ctx.save_for_backward(points, W, count, rnd, state, valid)
+        ctx.strides = (sb, sk)
+        ctx.mark_non_differentiable(valid)
+        return r, V, c, valid
+
+    @staticmethod
+    def backward(ctx, g_r, g_V, g_c, _gvalid):
+        points, W, count, rnd, state, valid = ctx.saved_tensors
+        Bt, N, _ = points.shape
+        K = W.shape[2]
+        sb, sk = ctx.strides
+        gW = torch.empty_like(W)
+        call("prifit_ellipsoid_fit_bwd", ptr(points), ptr(W), ptr(count), ptr(valid), ptr(rnd), _LL(sb), _LL(sk),
+             ptr(state), ptr(g_r.contiguous()), ptr(g_V.contiguous()), ptr(g_c.contiguous()), Bt, N, K, ptr(gW),
+             cur_stream())
+        return None, gW, None, None, None
+
+
+class SdfLossFn(torch.autograd.Function):
+    """sum over target points of (min_k |sdf_k|)^2 per shape (convex_loss.py:313-328, src/utils.py:410-411)."""
+
+    @staticmethod
+    def forward(ctx, targets, r, V, c, valid):
+        targets, r, V, c = targets.contiguous(), r.contiguous(), V.contiguous(), c.contiguous()
+        Bt, M, _ = targets.shape
+        K = r.shape[1]
+        dev = targets.device
+        arg = torch.empty(Bt, M, dtype=torch.int32, device=dev)
+        fval = torch.empty(Bt, M, dtype=torch.float32, device=dev)
+        s = torch.empty(Bt, dtype=torch.float32, device=dev)
+        call("prifit_ellipsoid_sdf_fwd", ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(arg),
+             ptr(fval), ptr(s), cur_stream())
+        ctx.save_for_backward(targets, r, V, c, arg)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        targets, r, V, c, arg = ctx.saved_tensors
+        Bt, M, _ = targets.shape
+        K = r.shape[1]
+        g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
+        call("prifit_ellipsoid_sdf_bwd", ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(arg), ptr(gs.contiguous()),
+             K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
+        return None, g_r, g_V, g_c, None
+
+
+class SampleNNLossFn(torch.autograd.Function):
+    """Surface samples (area-proportional budget, Fibonacci (U,V) table) -> exact nearest target -> sum of
+    squared distances per shape (src/ellipsoid_utils.py:76-130, src/sample_ellipsoid.py:45-63,
+    src/utils.py:413-416).  Returns (sum_d2 [B], total [B] number of samples)."""
+
+    @staticmethod
+    def forward(ctx, r, V, c, valid, targets):
+        targets, r, V, c = targets.contiguous(), r.contiguous(), V.contiguous(), c.contiguous()
+        Bt, M, _ = targets.shape
+        K = r.shape[1]
+        dev = targets.device
+        n = torch.empty(Bt, K, dtype=torch.int32, device=dev)
+        off = torch.empty(Bt, K + 1, dtype=torch.int32, device=dev)
+        call("prifit_sample_budget", ptr(r), ptr(valid), Bt, K, SAMPLE_CAP, ptr(n), ptr(off), cur_stream())
+        nn_idx = torch.empty(Bt, SAMPLE_CAP, dtype=torch.int32, device=dev)
+        s = torch.empty(Bt, dtype=torch.float32, device=dev)
+        with profiler.span("sample_nn", 0.0):
+            call("prifit_sample_nn_fwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M,
+                 SAMPLE_CAP, ptr(nn_idx), ptr(s), cur_stream())
+        total = off[:, K].clone()
+        ctx.save_for_backward(r, V, c, n, off, targets, nn_idx)
+        ctx.mark_non_differentiable(total)
+        return s, total
+
+    @staticmethod
+    def backward(ctx, gs, _gt):
+        r, V, c, n, off, targets, nn_idx = ctx.saved_tensors
+        Bt, M, _ = targets.shape
+        K = r.shape[1]
+        g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
+        call("prifit_sample_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
+             ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
+        return g_r, g_V, g_c, None, None
+
+
+def cluster(X, quantile, iterations, max_num_clusters):
+    """src/ellipsoid_utils.py:9-73 batched: mean-shift + nms with the quantile-doubling retry
+    (one host read-back per round).  X [B,N,D] unit rows.
+    Returns dict(Z, bw, ids [B,KM], count [B], labels [B,N] int64, centres [B,KM,D], W [B,N,KM], quantile list)."""
+    Bt, N, D = X.shape
+    dev = X.device
+    Z_all = [None] * Bt
+    res = {"bw": torch.empty(Bt, device=dev), "ids": torch.zeros(Bt, KM, dtype=torch.int64, device=dev),
+           "count": torch.zeros(Bt, dtype=torch.int32, device=dev),
+           "labels": torch.zeros(Bt, N, dtype=torch.int64, device=dev), "quantile": [quantile] * Bt}
+    pending = torch.arange(Bt, device=dev)
+    q = quantile
+    Zs, idx_sets = [], []
+    while pending.numel():
+        Xp = X if pending.numel() == Bt else X.index_select(0, pending)
+        with torch.no_grad():
+            bw = compute_bandwidth(Xp, q)
+        Z = MeanShiftFn.apply(Xp, bw, iterations)
+        with torch.no_grad():
+            ids, count, labels, used = nms(Z.detach(), bw)
+            nuniq = torch.where(count > NMS_CAP, count, used.sum(dim=1).to(torch.int32))
+            host = torch.stack([count, nuniq]).cpu()  # the one host sync of the round (guard_mean_shift's check)
+        ok = host[1] <= max_num_clusters
+        if bool((ok & (host[0] > KM)).any()):
+            raise RuntimeError("more than %d kept centres with <= %d distinct labels: unsupported corner" % (KM, max_num_clusters))
+        okd = ok.to(dev)
+        sel = pending[okd]
+        if sel.numel():
+            res["bw"][sel] = bw[okd]
+            res["ids"][sel] = ids[okd][:, :KM].long()
+            res["count"][sel] = count[okd]
+            res["labels"][sel] = labels[okd].long()
+            Zs.append(Z[okd] if not bool(ok.all()) else Z)
+            idx_sets.append(sel)
+            for i in sel.tolist():
+                res["quantile"][i] = q
+        pending = pending[~okd]
+        q *= 2
+    if len(Zs) == 1 and idx_sets[0].numel() == Bt:
+        Zfull = Zs[0]
+    else:
+        Zfull = torch.zeros(Bt, N, D, device=dev).index_copy(0, torch.cat(idx_sets), torch.cat(Zs))
+    res["Z"] = Zfull
+    centres = torch.gather(Zfull, 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))  # center = new_X[indices] (:46)
+    res["centres"] = centres
+    res["W"] = MembershipFn.apply(centres, X, res["bw"], res["count"])
+    return res

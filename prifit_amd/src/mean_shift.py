@@ -1,0 +1,53 @@
+"""Call surface of the reference's src/mean_shift.py (class MeanShift) on the MI355X backend.
+Per-shape methods ([N, D] tensors, as upstream) are thin views over the batched kernels."""
+import torch
+
+from .. import fit_ops
+
+
+class MeanShift:
+    def mean_shift(self, X, num_samples, quantile, iterations, kernel_type="gaussian", bw=None, eff=False):
+        """upstream :18-48 -> (center [K,D], bandwidth, labels [N])."""
+        if kernel_type != "gaussian" or eff:
+            raise NotImplementedError("only the gaussian, eff=False path is used by the reference's loss")
+        Xb = X.unsqueeze(0).contiguous()
+        if bw is None:
+            with torch.no_grad():
+                bw = self.compute_bandwidth(X, num_samples, quantile)
+        bwb = bw.reshape(1).to(X.device, torch.float32)
+        Z = fit_ops.MeanShiftFn.apply(Xb, bwb, iterations)
+        with torch.no_grad():
+            ids, count, labels, _ = fit_ops.nms(Z.detach(), bwb)
+        K = int(count.item())
+        if K > fit_ops.NMS_CAP:
+            raise RuntimeError("more than %d clusters" % fit_ops.NMS_CAP)
+        return Z[0][ids[0, :K].long()], bw, labels[0].long()
+
+    def mean_shift_(self, X, b, iterations=10, kernel_type="gaussian"):
+        """upstream :50-84 -> (new_X, X)."""
+        bwb = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(1)
+        return fit_ops.MeanShiftFn.apply(X.unsqueeze(0).contiguous(), bwb, iterations)[0], X
+
+    def compute_bandwidth(self, X, num_samples, quantile):
+        """upstream :138-160 (num_samples must equal N, as in convex_loss.py:68)."""
+        if num_samples != X.shape[0]:
+            raise NotImplementedError("sub-sampled bandwidth estimation")
+        return fit_ops.compute_bandwidth(X.unsqueeze(0).contiguous(), quantile)[0]
+
+    def nms(self, centers, X, b):
+        """upstream :162-202 for centers is X (the only way it is called, :44)."""
+        bwb = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(1)
+        ids, count, labels, _ = fit_ops.nms(X.unsqueeze(0).contiguous(), bwb)
+        K = int(count.item())
+        ids = ids[0, :K].long()
+        return centers[ids], ids, labels[0].long()
+
+    def membership(self, centers, X, bandwidth):
+        """upstream :230-247 -> [K, N]."""
+        K = centers.shape[0]
+        cpad = torch.zeros(1, fit_ops.KM, X.shape[1], device=X.device)
+        cpad[0, :K] = centers
+        W = fit_ops.MembershipFn.apply(cpad, X.unsqueeze(0).contiguous(),
+                                       torch.as_tensor(bandwidth, dtype=torch.float32, device=X.device).reshape(1),
+                                       torch.tensor([K], dtype=torch.int32, device=X.device))
+        return W[0, :, :K].t()

@@ -1,0 +1,254 @@
+"""GPU parity of the fitting path (through the C ABI) vs the oracle and the goldens captured from the
+reference: bandwidth, mean-shift iterations (+autograd), nms, membership, weighted ellipsoid fit
+(+autograd), ellipsoid SDF, surface sampling + nearest target, analytic chamfer, convex_loss.
+
+Tolerances: fp32 fitting residuals 1e-4 (BASELINE.json north_star); cluster ids / order are rounding
+noise in the reference itself, so clusters are compared through the label partition."""
+import numpy as np
+import pytest
+import torch
+
+import prifit_oracle as orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def fit_inputs(B, N, D, seed, M=5000, noise=0.03):
+    cham, lab = synth.blobs_with_labels(B, M, seed)
+    sel = np.random.default_rng(seed + 1).choice(M, N, replace=False)
+    return _t(cham[:, sel]), _t(cham), _t(synth.prototype_embedding(lab[:, sel], D, seed + 2, noise=noise))
+
+
+def same_partition(la, lb):
+    pairs = torch.unique(torch.stack([la.long(), lb.long()], 1), dim=0)
+    return pairs.shape[0] == torch.unique(la).shape[0] == torch.unique(lb).shape[0]
+
+
+@pytest.fixture(scope="module")
+def F(hiplib):
+    assert torch.cuda.is_available()
+    from prifit_amd import fit_ops
+    return fit_ops
+
+
+def test_kth_smallest_and_bandwidth(F, golden):
+    from prifit_amd._lib import call, cur_stream, ptr
+    import ctypes
+    for C, k in ((2048, 102), (1000, 1), (300, 300), (4096, 77)):
+        M = torch.randn(37, C, generator=torch.Generator().manual_seed(C))
+        M[:, 0:C // 2:5] = M[:, 1:C // 2:5][:, : M[:, 0:C // 2:5].shape[1]]  # exact duplicates
+        out = torch.empty(37, device="cuda")
+        call("prifit_kth_smallest_rows", ptr(M.cuda()), ctypes.c_longlong(37), C, k, ptr(out), cur_stream())
+        assert torch.equal(out.cpu(), torch.topk(M, k, dim=1, largest=False)[0][:, -1])
+    g = golden("fit_meanshift")
+    _, _, emb = fit_inputs(2, 2048, 128, int(g["seed"]))
+    bw = F.compute_bandwidth(emb.cuda(), 0.05)
+    torch.testing.assert_close(bw.cpu(), torch.stack([_t(g["bw_0"]), _t(g["bw_1"])]), rtol=1e-5, atol=0)
+
+
+def test_mean_shift_iterations_fwd_bwd(F, golden):
+    g = golden("fit_meanshift")
+    seed = int(g["seed"])
+    _, _, emb = fit_inputs(2, 2048, 128, seed)
+    G = _t(synth.features(2, 2048, 128, seed + 3))
+    bw = torch.stack([_t(g["bw_0"]), _t(g["bw_1"])])
+    X = emb.cuda().requires_grad_(True)
+    Z = F.MeanShiftFn.apply(X, bw.cuda(), 10)
+    (Z * G.cuda()).sum().backward()
+    for b in range(2):
+        torch.testing.assert_close(Z[b, :64].detach().cpu(), _t(g[f"Z_head_{b}"]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(Z[b].detach().sum(0).cpu(), _t(g[f"Z_colsum_{b}"]), rtol=1e-4, atol=1e-3)
+        ref = _t(g[f"dX_head_{b}"])
+        torch.testing.assert_close(X.grad[b, :64].cpu(), ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+        assert abs(X.grad[b].norm().item() - float(g[f"dX_norm_{b}"])) < 2e-3 * float(g[f"dX_norm_{b}"])
+    # small ragged case against the oracle directly (N not a multiple of the tiles, D = 32 as in fitting.py)
+    Xs = torch.nn.functional.normalize(_t(synth.features(1, 300, 32, 5))[0], dim=1)
+    bws = orc.compute_bandwidth(Xs, 0.1)
+    Xo = Xs.clone().requires_grad_(True)
+    Zo = orc.mean_shift_iterations(Xo, bws, 4)
+    Gs = _t(synth.features(1, 300, 32, 6))[0]
+    (Zo * Gs).sum().backward()
+    Xg = Xs.cuda().unsqueeze(0).requires_grad_(True)
+    Zg = F.MeanShiftFn.apply(Xg, bws.reshape(1).cuda(), 4)
+    (Zg[0] * Gs.cuda()).sum().backward()
+    torch.testing.assert_close(Zg[0].detach().cpu(), Zo.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(Xg.grad[0].cpu(), Xo.grad, rtol=2e-3, atol=2e-4 * Xo.grad.abs().max().item())
+
+
+def test_nms_and_membership(F, golden):
+    g = golden("fit_meanshift")
+    seed = int(g["seed"])
+    _, _, emb = fit_inputs(2, 2048, 128, seed)
+    bw = torch.stack([_t(g["bw_0"]), _t(g["bw_1"])])
+    Zo = torch.stack([orc.mean_shift_iterations(emb[b], bw[b], 10) for b in range(2)])
+    ids, count, labels, used = F.nms(Zo.cuda(), bw.cuda())
+    for b in range(2):
+        K = int(count[b])
+        assert K == int(g[f"K_{b}"])
+        assert same_partition(labels[b].cpu(), _t(g[f"labels_{b}"]).long())
+        assert int(used[b].sum()) == K
+        # membership with the HIP-chosen centres vs the oracle on the same centres
+        cen = Zo[b][ids[b, :K].long().cpu()]
+        Wo = orc.membership(cen, emb[b], bw[b])
+        from prifit_amd.src.mean_shift import MeanShift
+        Wg = MeanShift().membership(cen.cuda(), emb[b].cuda(), bw[b].cuda())
+        torch.testing.assert_close(Wg.cpu(), Wo, rtol=1e-4, atol=1e-6)
+        # column sums in partition-canonical order vs the reference's
+        first = [int(torch.nonzero(labels[b].cpu() == k).min()) for k in range(K)]
+        order = torch.tensor(np.argsort(first, kind="stable"))
+        torch.testing.assert_close(Wg.cpu().t()[:, order].sum(0), _t(g[f"W_colsum_{b}"]), rtol=1e-4, atol=1e-2)
+
+
+def test_membership_backward(F):
+    Bt, N, D, K = 2, 500, 32, 5
+    X = torch.nn.functional.normalize(_t(synth.features(Bt, N, D, 1)), dim=-1)
+    cen = torch.nn.functional.normalize(_t(synth.features(Bt, K, D, 2)), dim=-1)
+    bw = torch.tensor([0.7, 0.4])
+    gW = _t(synth.features(Bt, N, K, 3))
+    Xo, co = X.clone().requires_grad_(True), cen.clone().requires_grad_(True)
+    loss = sum((orc.membership(co[b], Xo[b], bw[b]).t() * gW[b]).sum() for b in range(Bt))
+    loss.backward()
+    cpad = torch.zeros(Bt, F.KM, D)
+    cpad[:, :K] = cen
+    Xg, cg = X.cuda().requires_grad_(True), cpad.cuda().requires_grad_(True)
+    W = F.MembershipFn.apply(cg, Xg, bw.cuda(), torch.tensor([K, K], dtype=torch.int32, device="cuda"))
+    gpad = torch.zeros(Bt, N, F.KM)
+    gpad[:, :, :K] = gW
+    (W * gpad.cuda()).sum().backward()
+    torch.testing.assert_close(Xg.grad.cpu(), Xo.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(cg.grad[:, :K].cpu(), co.grad, rtol=1e-3, atol=1e-4)
+    assert cg.grad[:, K:].abs().max().item() == 0
+
+
+def test_ellipsoid_fit_fwd_bwd(F, golden):
+    g = golden("fit_ellipsoid")
+    seed = int(g["seed"])
+    pts, _, _ = fit_inputs(2, 2048, 128, seed)
+    R = _t(g["R"]).cuda()
+    gr = _t(g["grad_seed_table"])
+    from prifit_amd.src.ellipsoid_fitting import weighted_ellipsoid_fitting_batch
+    Ws = [_t(g[f"W_{b}"]).cuda().requires_grad_(True) for b in range(2)]
+    params = weighted_ellipsoid_fitting_batch(pts.cuda(), Ws, rand_table=R, canonical=True)
+    loss = 0
+    for b in range(2):
+        assert len(params[b]) == g[f"r_{b}"].shape[0]
+        for k, (r, V, c) in enumerate(params[b]):
+            torch.testing.assert_close(r.detach().cpu(), _t(g[f"r_{b}"])[k], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(V.detach().cpu(), _t(g[f"V_{b}"])[k], rtol=1e-3, atol=1e-4)
+            torch.testing.assert_close(c.detach().cpu(), _t(g[f"c_{b}"])[k], rtol=1e-4, atol=1e-5)
+            gk = gr[k].cuda()
+            loss = loss + (r * gk[0:3]).sum() + (V * gk[3:12].view(3, 3)).sum() + (c * gk[12:15]).sum()
+    loss.backward()
+    for b in range(2):
+        ref = _t(g[f"dW_{b}"])
+        torch.testing.assert_close(Ws[b].grad.cpu(), ref, rtol=2e-3, atol=1e-4 * ref.abs().max().item())
+
+
+def test_fit_known_answer(F, golden):
+    """hard one-hot weights on analytic ellipsoid surfaces: semi-axes are recovered (fitting.py, ellipsoid_fitting_numpy.py:36-45)."""
+    g = golden("fit_kat")
+    from prifit_amd.src.ellipsoid_fitting import weighted_ellipsoid_fitting_batch
+    prm = weighted_ellipsoid_fitting_batch(_t(g["points"]).cuda(), [_t(g["W"]).cuda()], rand_table=_t(g["R"]).cuda())
+    assert len(prm[0]) == 3
+    for k, (r, V, c) in enumerate(prm[0]):
+        assert np.allclose(np.sort(r.cpu().numpy()), np.sort(g["abc"][k]), rtol=2e-2)
+        torch.testing.assert_close(r.cpu(), _t(g["r_ref"])[k], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(c.cpu(), _t(g["c_ref"])[k], rtol=1e-4, atol=1e-4)
+        assert abs(abs(torch.det(V).item()) - 1) < 1e-4 and torch.det(V).item() > 0
+
+
+def test_sdf_and_sample_chamfer(F, golden):
+    ge, gc = golden("fit_ellipsoid"), golden("fit_chamfer")
+    seed = int(ge["seed"])
+    pts, cham, _ = fit_inputs(2, 2048, 128, seed)
+    K = ge["r_0"].shape[0]
+    r = torch.zeros(2, F.KM, 3); V = torch.eye(3).repeat(2, F.KM, 1, 1); c = torch.zeros(2, F.KM, 3)
+    valid = torch.zeros(2, F.KM, dtype=torch.int32)
+    for b in range(2):
+        r[b, :K], V[b, :K], c[b, :K], valid[b, :K] = _t(ge[f"r_{b}"]), _t(ge[f"V_{b}"]), _t(ge[f"c_{b}"]), 1
+    rg, Vg, cg = (t.cuda().requires_grad_(True) for t in (r, V, c))
+    from prifit_amd.convex_loss import analytic_chamfer_distance
+    loss, (dist_st, sdf_ts) = analytic_chamfer_distance(rg, Vg, cg, valid.cuda(), cham.cuda())
+    torch.testing.assert_close(sdf_ts.detach().cpu(), _t(gc["sdf_ts"]), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dist_st.detach().cpu(), _t(gc["dist_st"]), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(loss.detach().cpu(), _t(gc["loss"]), rtol=1e-4, atol=1e-8)
+    loss.backward()
+    # gradients vs the oracle's autograd on the same parameters
+    ro, Vo, co = r.clone().requires_grad_(True), V.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    params = [[(ro[b, k], Vo[b, k], co[b, k]) for k in range(K)] for b in range(2)]
+    lo, _ = orc.analytic_chamfer(params, orc.sample_from_params(params), cham)
+    lo.backward()
+    for got, ref in ((rg.grad, ro.grad), (Vg.grad, Vo.grad), (cg.grad, co.grad)):
+        torch.testing.assert_close(got.cpu(), ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+
+
+def test_convex_loss_end_to_end(F, golden):
+    g = golden("fit_convex_loss")
+    seed = int(g["seed"])
+    pts, cham, emb = fit_inputs(2, 2048, 128, seed)
+    from prifit_amd.convex_loss import convex_loss
+    X = emb.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    total, l, params, labels, info = convex_loss(pts.permute(0, 2, 1).cuda(), cham.permute(0, 2, 1).cuda(), X,
+                                                 quantile=0.05, iterations=10, max_num_clusters=25,
+                                                 rand_table=_t(g["R"]).cuda(), canonical=True, return_info=True)
+    total.sum().backward()
+    assert total.shape == (1, 1) and l.shape == (1, 1)
+    assert [len(p) for p in params] == list(g["K"])
+    for b in range(2):
+        assert same_partition(labels[b].cpu(), _t(g["labels"])[b].long())
+    torch.testing.assert_close(total.detach().cpu(), _t(g["total"]), rtol=1e-4, atol=1e-7)
+    ref = _t(g["dX_head"])
+    assert abs(X.grad.norm().item() - float(g["dX_norm"])) < 1e-2 * float(g["dX_norm"])
+    torch.testing.assert_close(X.grad[:, :, :32].cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
+
+
+def test_cluster_retry_and_degenerate(F):
+    """quantile-doubling retry (src/ellipsoid_utils.py:19-27) and a shape whose fit is ill-conditioned."""
+    B, N, D = 2, 1024, 32
+    rng = np.random.default_rng(3)
+    # 40 tight prototypes -> more than 25 clusters at a small quantile -> the loop must enlarge the bandwidth
+    proto = rng.normal(size=(40, D)); proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    lab = rng.integers(0, 40, size=(B, N))
+    emb = proto[lab] + 0.003 * rng.normal(size=(B, N, D))
+    emb = _t((emb / np.linalg.norm(emb, axis=-1, keepdims=True)).astype(np.float32))
+    cl = F.cluster(emb.cuda(), 0.01, 5, 25)
+    Ws, labs, info = orc.clustering(emb, 0.01, 5, 25)
+    for b in range(B):
+        assert int(cl["count"][b]) == Ws[b].shape[1] <= 25
+        assert abs(cl["quantile"][b] - info[b]["quantile"]) < 1e-12
+        assert same_partition(cl["labels"][b].cpu(), labs[b])
+    # coplanar points: smallest singular value ~ 0 -> cond > 1e5 -> dropped (valid = 0), loss stays finite
+    pts = _t(synth.cloud("cube", 1, 512, 1)); pts[..., 2] = 0.0
+    W = torch.zeros(1, 512, F.KM); W[:, :, 0] = 1.0
+    r, V, c, valid = F.EllipsoidFitFn.apply(pts.cuda(), W.cuda(), torch.tensor([1], dtype=torch.int32, device="cuda"),
+                                            torch.zeros(3, 3, device="cuda"), True)
+    assert int(valid.sum()) == 0
+    from prifit_amd.convex_loss import analytic_chamfer_distance
+    loss, _ = analytic_chamfer_distance(r, V, c, valid, pts.cuda())
+    assert float(loss) == 0.0
+
+
+def test_model_selfsup_step(hiplib):
+    """train_partseg_shapenet.py:436-451: forward with include_convex_loss, backward reaches extra_conv_emb and sa1."""
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    B, N = 2, 2048
+    pts, cham, _ = fit_inputs(B, N, 128, 3)
+    torch.manual_seed(1)
+    net = M.get_model(50).cuda().train()
+    out = net(pts.permute(0, 2, 1).contiguous().cuda(), torch.zeros(B, 1, 16, device="cuda"),
+              chamfer_points=cham.permute(0, 2, 1).contiguous().cuda(), include_convex_loss=True, quantile=0.05,
+              msc_iterations=10, max_num_clusters=25)
+    assert len(out) == 8 and out[3].shape == (1, 1) and out[4].shape == (1, 1)
+    assert abs(net.beta - 0.99) < 1e-12
+    loss = out[3].mean()
+    assert torch.isfinite(loss)
+    loss.backward()
+    for name in ("extra_conv_emb.weight", "conv1.weight", "sa1.conv_blocks.0.0.weight", "fp1.mlp_convs.0.weight"):
+        gr = dict(net.named_parameters())[name].grad
+        assert gr is not None and torch.isfinite(gr).all(), name
+    assert len(out[5]) == B and out[5][0].shape == (N,) and out[7].shape == (B, 128, N)
