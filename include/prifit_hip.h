@@ -123,7 +123,10 @@ int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const
  *     and sums of squares of the stored C (batch == 1, splitk == 1 only).
  *   accumulate != 0: C += result (C initialised by the caller).  splitk > 1: the K range is split
  *     over workgroups which add with float atomics (needs accumulate != 0 and PRIFIT_EPI_NONE).
- *   epi_aux / ld_aux / stride_aux: second matrix read by PRIFIT_EPI_MSBWD.
+ *   epi_aux / ld_aux / stride_aux: second matrix read by PRIFIT_EPI_MSBWD; epi_row_add [batch][M] (or
+ *     NULL) is added to every element of its row before that transform.
+ *   a_rowsum [batch][M] (or NULL; NT/NN, splitk == 1): receives sum_k A[m][k] of the (prologue-
+ *     transformed) A operand -- the kernel row sums of src/mean_shift.py:70 for free.
  * 16-byte vector loads are used when pointers, strides and contiguous extents are multiples of 4
  * floats; any other shape takes a scalar-load path. */
 int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long lda, long long strideA,
@@ -132,7 +135,8 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     const float *a_shift, const float *b_scale, const float *b_shift,
                     const float *bias, float *col_stats, int epilogue,
                     const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
-                    long long stride_aux, int accumulate, void *stream);
+                    long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
+                    void *stream);
 
 /* Rows of C covered by one col_stats slab of prifit_gemm_f32 (its M tile). */
 int prifit_gemm_tile_m(int N);
@@ -202,15 +206,16 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
  * torch.topk(dist, k, largest=False)[0][:, -1] of compute_bandwidth, src/mean_shift.py:156-158. */
 int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float *out, void *stream);
 
-/* One mean-shift update, src/mean_shift.py:70-82.  O [rows, Dp] = K . [X | 1 | 0-pad] (column D is the
- * kernel row sum), Z [rows, D] the current points: out = normalize(Z + (O[:, :D]/O[:, D] - Z)),
- * nrm [rows] = the norm before normalisation. */
-int prifit_meanshift_update_fwd(const float *O, int Dp, const float *Z, int D, long long rows,
-                                float *out, float *nrm, void *stream);
+/* One mean-shift update, src/mean_shift.py:70-82.  O [rows, D] = K . X, rowsum [rows] = sum_j K[i][j]
+ * (prifit_gemm_f32's a_rowsum), Z [rows, D] the current points:
+ * out = normalize(Z + (O / rowsum - Z)), nrm [rows] = the norm before normalisation. */
+int prifit_meanshift_update_fwd(const float *O, const float *rowsum, const float *Z, int D,
+                                long long rows, float *out, float *nrm, void *stream);
 
-/* Autograd of the update: g = dL/d(out) -> gO [rows, Dp] = dL/dO (column D = gradient of the row sum). */
+/* Autograd of the update: g = dL/d(out) -> gO [rows, D] = dL/dO and g_rowsum [rows] = dL/d(rowsum). */
 int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O,
-                                int Dp, int D, long long rows, float *gO, void *stream);
+                                const float *rowsum, int D, long long rows, float *gO,
+                                float *g_rowsum, void *stream);
 
 /* Non-maximum suppression, src/mean_shift.py:162-202 called as nms(Z, Z, b) (:44).
  * dist [B,N,N] = 2 - 2 Z Z^T, Z [B,N,D], bw [B].  Outputs: owner [B,N] (nearest centre of each point),

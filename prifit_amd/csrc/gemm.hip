@@ -34,6 +34,8 @@ struct GemmArgs {
     int epi;
     const float *epi_batch_scalar;   // EPI_MSKERNEL / EPI_MSBWD: bandwidth b[z]
     const float *aux;                // EPI_MSBWD: the forward kernel matrix, indexed like C
+    const float *row_add;            // EPI_MSBWD: per-row additive term [batch][M] (may be NULL)
+    float *a_rowsum;                 // NN/NT only: sum over k of the staged A rows -> [batch][M] (may be NULL)
     long long ldaux, sAux;
     int accumulate;                  // 1: C += result (atomics when split-K); 0: store
     int vecA, vecB;                  // 16-byte loads legal for the operand
@@ -46,52 +48,50 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 
 // Stage one operand tile (ROWS x BK, logical [row][k]) from global into registers.
 //  KC = true : stored [R][K] (k contiguous);  KC = false: stored [K][R] (row index contiguous).
-template <int ROWS, bool KC>
+//  VEC: 16-byte loads (extents / strides multiples of 4 floats).  AFF: apply max(x*scale[c]+shift[c], 0).
+// Loads are branch-free: out-of-range lanes read a clamped (valid) address and the value is replaced
+// by zero afterwards, so that all loads of a tile are in flight together (hipcc serialises predicated
+// loads with a vmcnt(0) each).
+template <int ROWS, bool KC, bool VEC, bool AFF>
 struct TileLoader {
     static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
     float4 v[NV];
 
     __device__ __forceinline__ void load(const float *__restrict__ base, long long ld, int r0, int k0, int R,
-                                         int K, bool vec, const float *__restrict__ scale,
+                                         int K, const float *__restrict__ scale,
                                          const float *__restrict__ shift)
     {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int id = threadIdx.x + 256 * p;
-            int row, kk, c0;  // tile-local row, tile-local k of element 0, channel of element 0
-            const float *src;
-            bool ok[4];
-            if (KC) {
-                row = id / (BK / 4);
-                kk = (id % (BK / 4)) * 4;
-                src = base + (long long)(r0 + row) * ld + (k0 + kk);
-                c0 = k0 + kk;
-                const bool rok = (r0 + row) < R;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ok[e] = rok && (k0 + kk + e) < K;
+            int gr, gk, c0;  // global row / k of element 0, channel (index along the contiguous dim) of element 0
+            if (KC) { gr = r0 + id / (BK / 4); gk = k0 + (id % (BK / 4)) * 4; c0 = gk; }
+            else { gk = k0 + id / (ROWS / 4); gr = r0 + (id % (ROWS / 4)) * 4; c0 = gr; }
+            const int cext = KC ? K : R;  // extent along the contiguous dimension
+            const bool line_ok = KC ? (gr < R) : (gk < K);
+            const long long line = KC ? (long long)(line_ok ? gr : 0) : (long long)(line_ok ? gk : 0);
+            const float *row = base + line * ld;
+            float4 x;
+            if (VEC) {
+                const bool ok = line_ok && c0 < cext;
+                x = ld4(row + (ok ? c0 : 0));
+                if (AFF) {
+                    const float4 s = ld4(scale + (ok ? c0 : 0)), t = ld4(shift + (ok ? c0 : 0));
+                    x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
+                    x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
+                }
+                if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                kk = id / (ROWS / 4);
-                row = (id % (ROWS / 4)) * 4;
-                src = base + (long long)(k0 + kk) * ld + (r0 + row);
-                c0 = r0 + row;
-                const bool kok = (k0 + kk) < K;
+                float e[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ok[e] = kok && (r0 + row + e) < R;
-            }
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (vec) {
-                if (ok[0]) x = ld4(src);  // vec mode: extents are multiples of 4, so ok[0] == ok[3]
-            } else {
-                if (ok[0]) x.x = src[0];
-                if (ok[1]) x.y = src[1];
-                if (ok[2]) x.z = src[2];
-                if (ok[3]) x.w = src[3];
-            }
-            if (scale) {
-                if (ok[0]) x.x = fmaxf(fmaf(x.x, scale[c0 + 0], shift[c0 + 0]), 0.f);
-                if (ok[1]) x.y = fmaxf(fmaf(x.y, scale[c0 + 1], shift[c0 + 1]), 0.f);
-                if (ok[2]) x.z = fmaxf(fmaf(x.z, scale[c0 + 2], shift[c0 + 2]), 0.f);
-                if (ok[3]) x.w = fmaxf(fmaf(x.w, scale[c0 + 3], shift[c0 + 3]), 0.f);
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = line_ok && (c0 + j) < cext;
+                    const int cc = ok ? c0 + j : 0;
+                    float val = row[cc];
+                    if (AFF) val = fmaxf(fmaf(val, scale[cc], shift[cc]), 0.f);
+                    e[j] = ok ? val : 0.f;
+                }
+                x = make_float4(e[0], e[1], e[2], e[3]);
             }
             v[p] = x;
         }
@@ -122,7 +122,8 @@ __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int r
     return make_float4(p[0], p[ROWS + PAD], p[2 * (ROWS + PAD)], p[3 * (ROWS + PAD)]);
 }
 
-template <int BM, int BN, int WM, int WN, int LAY>
+// VA/VB: vector loads legal for A/B; FA/FB: BatchNorm+ReLU prologue on A/B.
+template <int BM, int BN, int WM, int WN, int LAY, bool VA, bool VB, bool FA, bool FB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
 {
     constexpr bool A_KC = (LAY != LAY_TN);
@@ -169,20 +170,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    TileLoader<BM, A_KC> la;
-    TileLoader<BN, B_KC> lb;
+    TileLoader<BM, A_KC, VA, FA> la;
+    TileLoader<BN, B_KC, VB, FB> lb;
     if (kt0 < kt1) {
-        la.load(A, g.lda, m0, kt0 * BK, g.M, g.K, g.vecA, g.a_scale, g.a_shift);
-        lb.load(B, g.ldb, n0, kt0 * BK, g.N, g.K, g.vecB, g.b_scale, g.b_shift);
+        la.load(A, g.lda, m0, kt0 * BK, g.M, g.K, g.a_scale, g.a_shift);
+        lb.load(B, g.ldb, n0, kt0 * BK, g.N, g.K, g.b_scale, g.b_shift);
     }
+    constexpr int NVA = TileLoader<BM, A_KC, VA, FA>::NV;
+    float rs[NVA];
+#pragma unroll
+    for (int p = 0; p < NVA; ++p) rs[p] = 0.f;
+    const bool want_rowsum = A_KC && g.a_rowsum != nullptr && tile_n == 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         __syncthreads();  // previous tile's fragment reads are done
         la.store(As);
         lb.store(Bs);
+        if (want_rowsum) {
+#pragma unroll
+            for (int p = 0; p < NVA; ++p) rs[p] += (la.v[p].x + la.v[p].y) + (la.v[p].z + la.v[p].w);
+        }
         __syncthreads();
         if (kt + 1 < kt1) {
-            la.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.vecA, g.a_scale, g.a_shift);
-            lb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.vecB, g.b_scale, g.b_shift);
+            la.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.a_scale, g.a_shift);
+            lb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.b_scale, g.b_shift);
         }
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
@@ -203,13 +213,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
         }
     }
 
+    if (want_rowsum) {  // KC staging: float4 p of thread t belongs to row (t + 256 p) / 8; 8 lanes share a row
+#pragma unroll
+        for (int p = 0; p < NVA; ++p) {
+            float v = rs[p];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            const int row = m0 + (threadIdx.x + 256 * p) / (BK / 4);
+            if ((threadIdx.x & 7) == 0 && row < g.M) g.a_rowsum[(long long)z * g.M + row] = v;
+        }
+    }
+
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float inv_b2 = 0.f;
     if (g.epi == EPI_MSKERNEL || g.epi == EPI_MSBWD) { const float bw = g.epi_batch_scalar[z]; inv_b2 = bw * bw; }
-    const float kmin = expf(-13.0f);  // value of a kernel entry whose exponent hit the lower clamp
+    const float rcp_b2 = inv_b2 > 0.f ? 1.0f / inv_b2 : 0.f;
+    const float kmin = __expf(-13.0f);  // value of a kernel entry whose exponent hit the lower clamp
     float csum[TN], csq[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) { csum[b] = 0.f; csq[b] = 0.f; }
+    const bool full_rows = (m0 + BM <= g.M);  // block-uniform: no per-row predicates; columns are per-lane
+    auto transform = [&](float v, float kf) -> float {
+        if (g.epi == EPI_CHORD) {
+            v = 2.0f - 2.0f * v;  // src/mean_shift.py:154 / :168
+        } else if (g.epi == EPI_MSKERNEL) {
+            // src/mean_shift.py:65-68: dist = 2 - 2 s; K = exp(clamp(-dist / b^2 / 2, -13, 75))
+            const float dist = 2.0f - 2.0f * v;
+            float t = (-dist * rcp_b2) * 0.5f;
+            t = fminf(fmaxf(t, -13.0f), 75.0f);
+            v = __expf(t);  // v_exp_f32 path: relative error < 1e-6 on [-13, 75]
+        } else if (g.epi == EPI_MSBWD) {
+            // backward of K = exp(clamp((s-1)/b^2)): dL/ds = dL/dK * K / b^2, zero where clamped
+            v = kf > kmin ? v * kf * rcp_b2 : 0.f;
+        }
+        return v;
+    };
+    const float *AUX = g.epi == EPI_MSBWD ? g.aux + (long long)z * g.sAux : nullptr;
+    const float *RADD = (g.epi == EPI_MSBWD && g.row_add) ? g.row_add + (long long)z * g.M : nullptr;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = n0 + wn0 + 32 * b + li;
@@ -217,31 +258,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
         const float bias = (g.bias && cok && ks == 0) ? g.bias[col] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
+            const int rbase = m0 + wm0 + 32 * a + 4 * lh;
+            if (full_rows) {
+                if (!cok) continue;
+                float kf[16], ra[16];
+                if (g.epi == EPI_MSBWD) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (!(cok && row < g.M)) continue;
-                float v = acc[a][b][r] + bias;
-                if (g.epi == EPI_CHORD) {
-                    v = 2.0f - 2.0f * v;                       // src/mean_shift.py:154 / :168
-                } else if (g.epi == EPI_MSKERNEL) {
-                    // src/mean_shift.py:65-68: dist = 2 - 2 s; K = exp(clamp(-dist / b^2 / 2, -13, 75))
-                    const float dist = 2.0f - 2.0f * v;
-                    float t = (-dist / inv_b2) / 2.0f;
-                    t = fminf(fmaxf(t, -13.0f), 75.0f);
-                    v = expf(t);
-                } else if (g.epi == EPI_MSBWD) {
-                    // backward of K = exp(clamp((s-1)/b^2)): dL/ds = dL/dK * K / b^2, zero where clamped
-                    const float kf = g.aux[(long long)z * g.sAux + (long long)row * g.ldaux + col];
-                    v = kf > kmin ? v * kf / inv_b2 : 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        kf[r] = AUX[(long long)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldaux + col];
+                        ra[r] = RADD ? RADD[rbase + (r & 3) + 8 * (r >> 2)] : 0.f;
+                    }
                 }
-                csum[b] += v;
-                csq[b] += v * v;
-                float *dst = C + (long long)row * g.ldc + col;
-                if (g.accumulate) {
-                    if (g.splitk > 1) unsafeAtomicAdd(dst, v);
-                    else *dst += v;
-                } else *dst = v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    const float v = transform(acc[a][b][r] + bias + (g.epi == EPI_MSBWD ? ra[r] : 0.f),
+                                              g.epi == EPI_MSBWD ? kf[r] : 0.f);
+                    csum[b] += v;
+                    csq[b] += v * v;
+                    float *dst = C + (long long)row * g.ldc + col;
+                    if (g.accumulate) {
+                        if (g.splitk > 1) unsafeAtomicAdd(dst, v);
+                        else *dst += v;
+                    } else *dst = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (!(cok && row < g.M)) continue;
+                    const float kf = g.epi == EPI_MSBWD ? AUX[(long long)row * g.ldaux + col] : 0.f;
+                    const float v = transform(acc[a][b][r] + bias + (RADD ? RADD[row] : 0.f), kf);
+                    csum[b] += v;
+                    csq[b] += v * v;
+                    float *dst = C + (long long)row * g.ldc + col;
+                    if (g.accumulate) {
+                        if (g.splitk > 1) unsafeAtomicAdd(dst, v);
+                        else *dst += v;
+                    } else *dst = v;
+                }
             }
         }
     }
@@ -268,15 +323,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
     }
 }
 
+template <int BM, int BN, int WM, int WN, int LAY, bool VEC>
+static void launch_aff(const GemmArgs &g, dim3 grid, hipStream_t st)
+{
+    // prologue combinations that occur: none, A only (forward / dA never has one), B only (dW)
+    if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, true, false>), grid, dim3(256), 0, st, g);
+    else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, false>), grid, dim3(256), 0, st, g);
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const GemmArgs &g, int lay, hipStream_t st)
 {
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN;
-    dim3 grid(tilesM * tilesN, 1, g.batch * g.splitk), block(256);
+    dim3 grid(tilesM * tilesN, 1, g.batch * g.splitk);
+    const bool vec = g.vecA && g.vecB;  // both or neither (mixed alignment takes the scalar path)
+    if (g.a_scale && g.b_scale) return PRIFIT_EINVAL;
     switch (lay) {
-        case LAY_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY_NT>), grid, block, 0, st, g); break;
-        case LAY_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY_NN>), grid, block, 0, st, g); break;
-        default: hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY_TN>), grid, block, 0, st, g); break;
+        case LAY_NT:
+            if (vec) launch_aff<BM, BN, WM, WN, LAY_NT, true>(g, grid, st);
+            else launch_aff<BM, BN, WM, WN, LAY_NT, false>(g, grid, st);
+            break;
+        case LAY_NN:
+            if (vec) launch_aff<BM, BN, WM, WN, LAY_NN, true>(g, grid, st);
+            else launch_aff<BM, BN, WM, WN, LAY_NN, false>(g, grid, st);
+            break;
+        default:
+            if (vec) launch_aff<BM, BN, WM, WN, LAY_TN, true>(g, grid, st);
+            else launch_aff<BM, BN, WM, WN, LAY_TN, false>(g, grid, st);
+            break;
     }
     return prifit_check_launch();
 }
@@ -296,7 +371,8 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     long long strideC, int batch, int splitk, const float *a_scale, const float *a_shift,
                     const float *b_scale, const float *b_shift, const float *bias, float *col_stats,
                     int epilogue, const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
-                    long long stride_aux, int accumulate, void *stream)
+                    long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
+                    void *stream)
 {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0 || layout < 0 || layout > 2 ||
         epilogue < 0 || epilogue > 3 || (epilogue >= EPI_MSKERNEL && !epi_batch_scalar) ||
@@ -311,14 +387,18 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.a_scale = a_scale; g.a_shift = a_shift; g.b_scale = b_scale; g.b_shift = b_shift;
     g.bias = bias; g.stats = col_stats; g.epi = epilogue; g.epi_batch_scalar = epi_batch_scalar;
     g.accumulate = accumulate; g.aux = epi_aux; g.ldaux = ld_aux; g.sAux = stride_aux;
+    g.row_add = epi_row_add; g.a_rowsum = a_rowsum;
+    if (a_rowsum && (layout == LAY_TN || splitk != 1)) return PRIFIT_EINVAL;
     // contiguous extents: A is k-contiguous unless TN (then m-contiguous); B is k-contiguous for NT else n-contiguous
     const int extA = layout == LAY_TN ? M : K, extB = layout == LAY_NT ? K : N;
     g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0) && (extA % 4 == 0);
     g.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0) && (extB % 4 == 0);
     hipStream_t st = as_stream(stream);
-    if (N > 64) return launch_cfg<128, 128, 64, 64>(g, layout, st);
-    if (N > 32) return launch_cfg<128, 64, 32, 64>(g, layout, st);
-    return launch_cfg<128, 32, 32, 32>(g, layout, st);
+    // N tile: 128 (2x2 waves of 64x64), 96 / 64 / 32 (4 waves stacked along M, each 32 x BN)
+    if (N <= 32) return launch_cfg<128, 32, 32, 32>(g, layout, st);
+    if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
+    if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);
+    return launch_cfg<128, 128, 64, 64>(g, layout, st);
 }
 
 }  // extern "C"

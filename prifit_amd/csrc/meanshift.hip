@@ -49,19 +49,20 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// mean-shift update (mean_shift.py:70-82): O = K [X | 1]  ->  Mv = O[:D] / O[D];
+// mean-shift update (mean_shift.py:70-82): O = K X, rsum = row sums of K  ->  Mv = O / rsum;
 // new = Z + (Mv - Z); out = new / ||new||.  One wave per point.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ms_update_fwd_kernel(const float *__restrict__ O, int Dp,
+__global__ __launch_bounds__(256) void ms_update_fwd_kernel(const float *__restrict__ O,
+                                                            const float *__restrict__ rsum,
                                                             const float *__restrict__ Z, int D, long long rows,
                                                             float *__restrict__ out, float *__restrict__ nrm_o)
 {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float *o = O + row * Dp;
+    const float *o = O + row * D;
     const float *z = Z + row * D;
-    const float dinv = 1.0f / o[D];  // D = 1 / sum(K, 1)
+    const float dinv = 1.0f / rsum[row];  // D = 1 / sum(K, 1)
     float nv[4];
     float ss = 0.f;
 #pragma unroll
@@ -86,19 +87,21 @@ __global__ __launch_bounds__(256) void ms_update_fwd_kernel(const float *__restr
     if (lane == 0) nrm_o[row] = n;
 }
 
-// Backward of the update: given g = dL/d(out) produce dL/dO (Dp columns: the last live column is the
-// gradient w.r.t. the row sum; padding columns are zero).  dL/dZ through "Z + (Mv - Z)" is exactly 0.
+// Backward of the update: given g = dL/d(out) produce dL/dO [rows, D] and dL/d(rsum) [rows].
+// dL/dZ through "Z + (Mv - Z)" is exactly 0.
 __global__ __launch_bounds__(256) void ms_update_bwd_kernel(const float *__restrict__ g,
                                                             const float *__restrict__ out,
                                                             const float *__restrict__ nrm,
-                                                            const float *__restrict__ O, int Dp, int D,
-                                                            long long rows, float *__restrict__ gO)
+                                                            const float *__restrict__ O,
+                                                            const float *__restrict__ rsum, int D,
+                                                            long long rows, float *__restrict__ gO,
+                                                            float *__restrict__ grs)
 {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float *o = O + row * Dp;
-    const float rinv = 1.0f / o[D];
+    const float *o = O + row * D;
+    const float rinv = 1.0f / rsum[row];
     const float ninv = 1.0f / nrm[row];
     float gg[4], oo[4];
     float dot = 0.f;
@@ -117,12 +120,12 @@ __global__ __launch_bounds__(256) void ms_update_bwd_kernel(const float *__restr
         if (c < D) {
             const float gnew = (gg[j] - oo[j] * dot) * ninv;  // through the normalisation
             const float mv = o[c] * rinv;
-            gO[row * Dp + c] = gnew * rinv;                  // d/dO[c] of O[c]/r
+            gO[row * D + c] = gnew * rinv;                   // d/dO[c] of O[c]/r
             gr -= gnew * mv;
         }
     }
     gr = wave_sum_f32(gr);
-    for (int c = D + lane; c < Dp; c += 64) gO[row * Dp + c] = c == D ? gr * rinv : 0.f;  // d/dr of O/r
+    if (lane == 0) grs[row] = gr * rinv;                     // d/dr of O/r
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,21 +318,23 @@ int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float
     return prifit_check_launch();
 }
 
-int prifit_meanshift_update_fwd(const float *O, int Dp, const float *Z, int D, long long rows, float *out,
-                                float *nrm, void *stream)
+int prifit_meanshift_update_fwd(const float *O, const float *rowsum, const float *Z, int D, long long rows,
+                                float *out, float *nrm, void *stream)
 {
-    if (!O || !Z || !out || !nrm || rows <= 0 || D <= 0 || D > 256 || Dp <= D) return PRIFIT_EINVAL;
+    if (!O || !rowsum || !Z || !out || !nrm || rows <= 0 || D <= 0 || D > 256) return PRIFIT_EINVAL;
     hipLaunchKernelGGL(ms_update_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), O,
-                       Dp, Z, D, rows, out, nrm);
+                       rowsum, Z, D, rows, out, nrm);
     return prifit_check_launch();
 }
 
-int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O, int Dp, int D,
-                                long long rows, float *gO, void *stream)
+int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O,
+                                const float *rowsum, int D, long long rows, float *gO, float *g_rowsum,
+                                void *stream)
 {
-    if (!g || !out || !nrm || !O || !gO || rows <= 0 || D <= 0 || D > 256 || Dp <= D) return PRIFIT_EINVAL;
+    if (!g || !out || !nrm || !O || !rowsum || !gO || !g_rowsum || rows <= 0 || D <= 0 || D > 256)
+        return PRIFIT_EINVAL;
     hipLaunchKernelGGL(ms_update_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), g,
-                       out, nrm, O, Dp, D, rows, gO);
+                       out, nrm, O, rowsum, D, rows, gO, g_rowsum);
     return prifit_check_launch();
 }
 

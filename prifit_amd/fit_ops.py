@@ -47,53 +47,56 @@ class MeanShiftFn(torch.autograd.Function):
     """src/mean_shift.py:50-84 (gaussian kernel, delta = 1), all shapes at once.
 
     forward: Z_0 = X; per iteration K = exp(clamp((Z X^T - 1)/b^2)) (MFMA GEMM with the kernel transform in
-    its epilogue), O = K [X | 1] (second GEMM: the ones column yields the row sums), Z <- normalize(O/rowsum).
+    its epilogue), O = K X (second GEMM, which also emits the row sums of K while staging it),
+    Z <- normalize(O/rowsum).
     backward: four GEMMs per iteration (dK through the saved K in the epilogue, dZ, and two dX terms)."""
 
     @staticmethod
     def forward(ctx, X, bw, iterations):
         X = X.contiguous()
         Bt, N, D = X.shape
-        Dp = D + 4
         dev = X.device
-        Xa = torch.zeros(Bt, N, Dp, dtype=torch.float32, device=dev)
-        Xa[:, :, :D] = X
-        Xa[:, :, D] = 1.0
         Z = X.clone()
         saved = []
         for _ in range(iterations):
             Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
             _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
-            O = torch.empty(Bt, N, Dp, dtype=torch.float32, device=dev)
-            _bgemm(NN, N, Dp, N, Kmat, N, Xa, Dp, O, Dp, Bt, N * N, N * Dp, N * Dp)
+            O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
+            rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+            _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X and rowsum(K)
             Zn = torch.empty_like(Z)
             nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
-            call("prifit_meanshift_update_fwd", ptr(O), Dp, ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm), cur_stream())
-            saved.append((Z, Kmat, O, Zn, nrm))
+            call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
+                 cur_stream())
+            saved += [Z, Kmat, O, rsum, Zn, nrm]
             Z = Zn
-        ctx.saved = (X, Xa, bw, saved)
+        # save_for_backward (not a python attribute): the last Zn IS the output, and an attribute would close a
+        # reference cycle output -> grad_fn -> ctx -> output that only the cyclic GC frees (4 GB of K per step)
+        ctx.save_for_backward(X, bw, *saved)
         return Z
 
     @staticmethod
     def backward(ctx, g):
-        X, Xa, bw, saved = ctx.saved
+        X, bw = ctx.saved_tensors[:2]
+        flat = ctx.saved_tensors[2:]
+        saved = [flat[i:i + 6] for i in range(0, len(flat), 6)]
         Bt, N, D = X.shape
-        Dp = D + 4
         dev = X.device
         g = g.contiguous()
         gX = torch.zeros(Bt, N, D, dtype=torch.float32, device=dev)
         gS = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
-        gO = torch.empty(Bt, N, Dp, dtype=torch.float32, device=dev)
-        for Z, Kmat, O, Zn, nrm in reversed(saved):
-            call("prifit_meanshift_update_bwd", ptr(g), ptr(Zn), ptr(nrm), ptr(O), Dp, D, _LL(Bt * N), ptr(gO),
-                 cur_stream())
-            # dL/dS = (gO [X|1]^T) * K / b^2 where the clamp is inactive
-            _bgemm(NT, N, N, Dp, gO, Dp, Xa, Dp, gS, N, Bt, N * Dp, N * Dp, N * N, epi=EPI_MSBWD, epi_scalar=bw,
-                   aux=Kmat, ld_aux=N, s_aux=N * N)
+        gO = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
+        grs = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+        for Z, Kmat, O, rsum, Zn, nrm in reversed(saved):
+            call("prifit_meanshift_update_bwd", ptr(g), ptr(Zn), ptr(nrm), ptr(O), ptr(rsum), D, _LL(Bt * N), ptr(gO),
+                 ptr(grs), cur_stream())
+            # dL/dS = (gO X^T + g_rowsum 1^T) * K / b^2 where the clamp is inactive
+            _bgemm(NT, N, N, D, gO, D, X, D, gS, N, Bt, N * D, N * D, N * N, epi=EPI_MSBWD, epi_scalar=bw,
+                   aux=Kmat, ld_aux=N, s_aux=N * N, row_add=grs)
             gZ = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
             _bgemm(NN, N, D, N, gS, N, X, D, gZ, D, Bt, N * N, N * D, N * D)                      # dZ = dS X
             _bgemm(TN, N, D, N, gS, N, Z, D, gX, D, Bt, N * N, N * D, N * D, accumulate=True)     # dX += dS^T Z
-            _bgemm(TN, N, D, N, Kmat, N, gO, Dp, gX, D, Bt, N * N, N * Dp, N * D, accumulate=True)  # dX += K^T dO
+            _bgemm(TN, N, D, N, Kmat, N, gO, D, gX, D, Bt, N * N, N * D, N * D, accumulate=True)  # dX += K^T dO
             g = gZ
         gX += g  # Z_0 = X.clone()
         return gX, None, None

@@ -27,18 +27,18 @@ def _rows_per_slab():
 
 def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
          b_affine=None, bias=None, stats=None, epi=EPI_NONE, epi_scalar=None, aux=None, ld_aux=0, s_aux=0,
-         accumulate=None):
+         row_add=None, a_rowsum=None, accumulate=None):
     if accumulate is None:
         accumulate = splitk > 1
     # span name = the kernel instantiation (layout, BN tile) so that it lines up with rocprofv3's per-kernel rows
-    with profiler.span("gemm_%s_bn%d" % (("nt", "nn", "tn")[layout], 128 if N > 64 else (64 if N > 32 else 32)),
+    with profiler.span("gemm_%s_bn%d" % (("nt", "nn", "tn")[layout], 32 if N <= 32 else (64 if N <= 64 else (96 if N <= 96 else 128))),
                        2.0 * M * N * K * batch):
         call("prifit_gemm_f32", layout, M, N, K, ptr(A), _LL(lda), _LL(sA), ptr(B), _LL(ldb), _LL(sB), ptr(C),
              _LL(ldc), _LL(sC), batch, splitk,
              ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
              ptr(b_affine[0]) if b_affine else None, ptr(b_affine[1]) if b_affine else None,
-             ptr(bias), ptr(stats), epi, ptr(epi_scalar), ptr(aux), _LL(ld_aux), _LL(s_aux), int(accumulate),
-             cur_stream())
+             ptr(bias), ptr(stats), epi, ptr(epi_scalar), ptr(aux), _LL(ld_aux), _LL(s_aux), ptr(row_add),
+             ptr(a_rowsum), int(accumulate), cur_stream())
 
 
 def _splitk_for(P, tiles):

@@ -1,0 +1,86 @@
+"""CPU: the fitting half of the oracle against the golden vectors captured from the reference
+(oracle/make_golden_fit.py): bandwidth, mean-shift iterations + autograd, nms, membership, weighted
+ellipsoid fit + autograd, analytic chamfer, convex_loss."""
+import numpy as np
+import torch
+
+import prifit_oracle as orc
+import synth
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def fit_inputs(B, N, D, seed, M=5000, noise=0.03):
+    cham, lab = synth.blobs_with_labels(B, M, seed)
+    sel = np.random.default_rng(seed + 1).choice(M, N, replace=False)
+    return _t(cham[:, sel]), _t(cham), _t(synth.prototype_embedding(lab[:, sel], D, seed + 2, noise=noise))
+
+
+def same_partition(la, lb):
+    pairs = torch.unique(torch.stack([la.long(), lb.long()], 1), dim=0)
+    return pairs.shape[0] == torch.unique(la).shape[0] == torch.unique(lb).shape[0]
+
+
+def test_meanshift_pieces(golden):
+    g = golden("fit_meanshift")
+    seed = int(g["seed"])
+    _, _, emb = fit_inputs(2, 2048, 128, seed)
+    G = _t(synth.features(2, 2048, 128, seed + 3))
+    b = 0  # one shape keeps the CPU suite fast
+    X = emb[b].clone().requires_grad_(True)
+    bw = orc.compute_bandwidth(X.detach(), 0.05)
+    torch.testing.assert_close(bw, _t(g["bw_0"]), rtol=1e-6, atol=0)
+    bw = _t(g["bw_0"])  # the fixture's gradients were taken at the reference's bandwidth
+    Z = orc.mean_shift_iterations(X, bw, 10)
+    (Z * G[b]).sum().backward()
+    torch.testing.assert_close(Z[:64].detach(), _t(g["Z_head_0"]), rtol=1e-5, atol=1e-6)
+    ref = _t(g["dX_head_0"])
+    torch.testing.assert_close(X.grad[:64], ref, rtol=1e-3, atol=1e-4 * ref.abs().max().item())
+    _, ids, labels = orc.nms(Z.detach(), Z.detach(), bw)
+    assert ids.shape[0] == int(g["K_0"]) and same_partition(labels, _t(g["labels_0"]).long())
+
+
+def test_fit_and_chamfer(golden):
+    ge, gc = golden("fit_ellipsoid"), golden("fit_chamfer")
+    seed = int(ge["seed"])
+    pts, cham, _ = fit_inputs(2, 2048, 128, seed)
+    R = _t(ge["R"])
+    Ws = [_t(ge[f"W_{b}"]).requires_grad_(True) for b in range(2)]
+    params = orc.fit_ellipsoids_batch(pts, Ws, [[R] * w.shape[1] for w in Ws], canonical=True)
+    gr = _t(ge["grad_seed_table"])
+    loss = 0
+    for b in range(2):
+        for k, (r, V, c) in enumerate(params[b]):
+            torch.testing.assert_close(r.detach(), _t(ge[f"r_{b}"])[k], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(V.detach(), _t(ge[f"V_{b}"])[k], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(c.detach(), _t(ge[f"c_{b}"])[k], rtol=1e-5, atol=1e-6)
+            loss = loss + (r * gr[k, 0:3]).sum() + (V * gr[k, 3:12].view(3, 3)).sum() + (c * gr[k, 12:15]).sum()
+    loss.backward()
+    for b in range(2):
+        ref = _t(ge[f"dW_{b}"])
+        torch.testing.assert_close(Ws[b].grad, ref, rtol=1e-3, atol=1e-5 * ref.abs().max().item())
+    samples = orc.sample_from_params(params)
+    assert [s.shape[0] for s in samples] == list(gc["nsamples"])
+    l, parts = orc.analytic_chamfer(params, samples, cham)
+    torch.testing.assert_close(l.detach(), _t(gc["loss"]), rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(torch.stack([p[0] for p in parts]), _t(gc["dist_st"]), rtol=1e-5, atol=1e-9)
+
+
+def test_known_answer(golden):
+    g = golden("fit_kat")
+    prm = orc.fit_ellipsoids_batch(_t(g["points"]), [_t(g["W"])], [[_t(g["R"])] * 3])
+    for k, (r, V, c) in enumerate(prm[0]):
+        assert np.allclose(np.sort(r.numpy()), np.sort(g["abc"][k]), rtol=2e-2)
+        torch.testing.assert_close(r, _t(g["r_ref"])[k], rtol=1e-5, atol=1e-5)
+
+
+def test_sample_budget_and_table():
+    U, V = orc.fibonacci_uv(1000)
+    assert U.shape == (1000,) and float(V.min()) > 0 and float(V.max()) < np.pi
+    p = torch.stack([torch.cos(U) * torch.sin(V), torch.sin(U) * torch.sin(V), torch.cos(V)], 1)
+    assert p.mean(0).abs().max() < 5e-3  # evenly spread over the sphere
+    params = [(torch.tensor([1.0, 1.0, 1.0]), torch.eye(3), torch.zeros(3)), (torch.tensor([2.0, 2.0, 2.0]), torch.eye(3), torch.zeros(3))]
+    n = orc.sample_budget(params)
+    assert n.sum() == 10000 and abs(n[1] / n[0] - 4.0) < 0.01
