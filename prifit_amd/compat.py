@@ -1,0 +1,38 @@
+"""Drop-in aliasing: make the reference's module paths resolve to the MI355X backend.
+
+    import prifit_amd.compat; prifit_amd.compat.install()
+    MODEL = importlib.import_module("models.pointnet2_part_seg_msg")   # train_partseg_shapenet.py:219
+
+After `install()` the names the reference's trainer / loss import -- `models.pointnet_util`,
+`models.pointnet2_part_seg_msg`, `models.pretrain_pointnet2_part_seg_msg`, `convex_loss`,
+`src.mean_shift`, `src.ellipsoid_fitting`, `src.ellipsoid_utils` -- are this package's modules.
+Nothing is imported from the reference tree."""
+import importlib
+import sys
+import types
+
+_ALIASES = {
+    "models.pointnet_util": "prifit_amd.models.pointnet_util",
+    "models.pointnet_utils": "prifit_amd.models.pointnet_util",
+    "models.pointnet2_part_seg_msg": "prifit_amd.models.pointnet2_part_seg_msg",
+    "models.pretrain_pointnet2_part_seg_msg": "prifit_amd.models.pretrain_pointnet2_part_seg_msg",
+    "convex_loss": "prifit_amd.convex_loss",
+    "src.mean_shift": "prifit_amd.src.mean_shift",
+    "src.ellipsoid_fitting": "prifit_amd.src.ellipsoid_fitting",
+    "src.ellipsoid_utils": "prifit_amd.src.ellipsoid_utils",
+}
+
+
+def install():
+    for pkg in ("models", "src"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []  # namespace-like package
+            sys.modules[pkg] = m
+    for alias, target in _ALIASES.items():
+        mod = importlib.import_module(target)
+        sys.modules[alias] = mod
+        parent, _, leaf = alias.rpartition(".")
+        if parent:
+            setattr(sys.modules[parent], leaf, mod)
+    return sorted(_ALIASES)

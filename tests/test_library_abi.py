@@ -35,3 +35,34 @@ def test_header_is_plain_c():
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-x", "c", "-",
                         "-o", "/dev/null"], input=src, text=True, capture_output=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_compat_aliases_resolve_to_backend(hiplib):
+    """the reference's module paths (train_partseg_shapenet.py:219 importlib.import_module(args.model)) -> this backend"""
+    import importlib
+    import sys
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("models", "src", "convex_loss")}
+    try:
+        from prifit_amd import compat
+        names = compat.install()
+        M = importlib.import_module("models.pointnet2_part_seg_msg")
+        assert M.get_model.__module__.startswith("prifit_amd.") and hasattr(M, "get_loss")
+        pu = importlib.import_module("models.pointnet_util")
+        for n in ("square_distance", "index_points", "farthest_point_sample", "query_ball_point", "sample_and_group",
+                  "sample_and_group_all", "PointNetSetAbstraction", "PointNetSetAbstractionMsg",
+                  "PointNetFeaturePropagation"):
+            assert hasattr(pu, n), n
+        assert hasattr(importlib.import_module("convex_loss"), "convex_loss")
+        assert hasattr(importlib.import_module("src.mean_shift"), "MeanShift")
+        assert len(names) >= 8
+        net = M.get_model(50)
+        keys = set(net.state_dict().keys())
+        for k in ("sa1.conv_blocks.0.0.weight", "sa1.bn_blocks.2.2.running_var", "sa3.mlp_convs.2.bias",
+                  "fp1.mlp_convs.0.weight", "conv1.weight", "bn1.running_mean", "conv2.bias", "extra_conv_emb.weight"):
+            assert k in keys, k
+        assert sum(p.numel() for p in net.parameters()) == 1757470  # SURVEY.md section 6: model size
+    finally:
+        for k in list(sys.modules):
+            if k.split(".")[0] in ("models", "src", "convex_loss"):
+                del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
