@@ -128,7 +128,7 @@ def main():
     net, M = build_model(device)
     bucket = FlatGradBucket(net)
     bucket.broadcast_parameters(0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, fused=True)
     data = make_inputs(args.workload, rank, device)
     crit = M.get_loss()
 

@@ -16,6 +16,7 @@ _ALIASES = {
     "models.pointnet_utils": "prifit_amd.models.pointnet_util",
     "models.pointnet2_part_seg_msg": "prifit_amd.models.pointnet2_part_seg_msg",
     "models.pretrain_pointnet2_part_seg_msg": "prifit_amd.models.pretrain_pointnet2_part_seg_msg",
+    "models.pointnet2_part_seg_ssg": "prifit_amd.models.pointnet2_part_seg_ssg",
     "convex_loss": "prifit_amd.convex_loss",
     "src.mean_shift": "prifit_amd.src.mean_shift",
     "src.ellipsoid_fitting": "prifit_amd.src.ellipsoid_fitting",

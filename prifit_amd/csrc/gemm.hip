@@ -52,9 +52,10 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // Loads are branch-free: out-of-range lanes read a clamped (valid) address and the value is replaced
 // by zero afterwards, so that all loads of a tile are in flight together (hipcc serialises predicated
 // loads with a vmcnt(0) each).
-template <int ROWS, bool KC, bool VEC, bool AFF>
+template <int ROWS, bool KC, bool VEC, bool AFF, int NTH>
 struct TileLoader {
-    static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+    static constexpr int NV = ROWS * BK / 4 / NTH;  // float4 per thread
+    static_assert(NV * NTH * 4 == ROWS * BK, "tile must divide evenly over the threads");
     float4 v[NV];
 
     __device__ __forceinline__ void load(const float *__restrict__ base, long long ld, int r0, int k0, int R,
@@ -63,7 +64,7 @@ struct TileLoader {
     {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            const int id = threadIdx.x + 256 * p;
+            const int id = threadIdx.x + NTH * p;
             int gr, gk, c0;  // global row / k of element 0, channel (index along the contiguous dim) of element 0
             if (KC) { gr = r0 + id / (BK / 4); gk = k0 + (id % (BK / 4)) * 4; c0 = gk; }
             else { gk = k0 + id / (ROWS / 4); gr = r0 + (id % (ROWS / 4)) * 4; c0 = gr; }
@@ -101,7 +102,7 @@ struct TileLoader {
     {
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            const int id = threadIdx.x + 256 * p;
+            const int id = threadIdx.x + NTH * p;
             if (KC) {
                 const int row = id / (BK / 4), kk = (id % (BK / 4)) * 4;
                 *reinterpret_cast<float4 *>(lds + row * (BK + PAD) + kk) = v[p];
@@ -124,13 +125,14 @@ __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int r
 
 // VA/VB: vector loads legal for A/B; FA/FB: BatchNorm+ReLU prologue on A/B.
 template <int BM, int BN, int WM, int WN, int LAY, bool VA, bool VB, bool FA, bool FB>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmArgs g)
 {
+    constexpr int NTH = (BM / WM) * (BN / WN) * 64;
     constexpr bool A_KC = (LAY != LAY_TN);
     constexpr bool B_KC = (LAY == LAY_NT);
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    static_assert(NTH == 256 || NTH == 512, "4 or 8 waves per block");
     constexpr int SZA = A_KC ? BM * (BK + PAD) : BK * (BM + PAD);
     constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
     __shared__ __attribute__((aligned(16))) float lds[SZA + SZB];
@@ -170,13 +172,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    TileLoader<BM, A_KC, VA, FA> la;
-    TileLoader<BN, B_KC, VB, FB> lb;
+    TileLoader<BM, A_KC, VA, FA, NTH> la;
+    TileLoader<BN, B_KC, VB, FB, NTH> lb;
     if (kt0 < kt1) {
         la.load(A, g.lda, m0, kt0 * BK, g.M, g.K, g.a_scale, g.a_shift);
         lb.load(B, g.ldb, n0, kt0 * BK, g.N, g.K, g.b_scale, g.b_shift);
     }
-    constexpr int NVA = TileLoader<BM, A_KC, VA, FA>::NV;
+    constexpr int NVA = TileLoader<BM, A_KC, VA, FA, NTH>::NV;
     float rs[NVA];
 #pragma unroll
     for (int p = 0; p < NVA; ++p) rs[p] = 0.f;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
             v += __shfl_xor(v, 4, 64);
-            const int row = m0 + (threadIdx.x + 256 * p) / (BK / 4);
+            const int row = m0 + (threadIdx.x + NTH * p) / (BK / 4);
             if ((threadIdx.x & 7) == 0 && row < g.M) g.a_rowsum[(long long)z * g.M + row] = v;
         }
     }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g)
             }
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < 2 * BN; t += 256) {
+        for (int t = threadIdx.x; t < 2 * BN; t += NTH) {
             const int which = t / BN, c = t - which * BN;
             float s = 0.f;
 #pragma unroll
@@ -327,9 +329,10 @@ template <int BM, int BN, int WM, int WN, int LAY, bool VEC>
 static void launch_aff(const GemmArgs &g, dim3 grid, hipStream_t st)
 {
     // prologue combinations that occur: none, A only (forward / dA never has one), B only (dW)
-    if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, true, false>), grid, dim3(256), 0, st, g);
-    else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, false>), grid, dim3(256), 0, st, g);
+    const dim3 block((BM / WM) * (BN / WN) * 64);
+    if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, true, false>), grid, block, 0, st, g);
+    else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, false>), grid, block, 0, st, g);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -398,7 +401,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     if (N <= 32) return launch_cfg<128, 32, 32, 32>(g, layout, st);
     if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
     if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);
-    return launch_cfg<128, 128, 64, 64>(g, layout, st);
+    return launch_cfg<128, 128, 32, 64>(g, layout, st);  // 8 waves of 32x64: more waves per SIMD hide the staging waits
 }
 
 }  // extern "C"

@@ -97,7 +97,7 @@ struct BallArgs {
 };
 
 constexpr int BQ_TILE = 2048;   // points staged in LDS per pass (32 KiB as float4)
-constexpr int BQ_QPW = 4;       // queries per wave
+constexpr int BQ_QPW = 1;       // queries per wave (more, shorter waves: the per-query scan is a serial chain)
 constexpr int BQ_QPB = 4 * BQ_QPW;
 
 template <int R, typename IdxT>
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
         for (int r = 0; r < R; ++r) { cnt[q][r] = 0; first[q][r] = N; }
     }
 
+    float r2max = args.r2[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) r2max = fmaxf(r2max, args.r2[r]);
+
     for (int base = 0; base < N; base += BQ_TILE) {
         const int tn = min(BQ_TILE, N - base);
         __syncthreads();
@@ -134,26 +138,31 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
             s_pts[i] = make_float4(x, y, z, norm2_3(x, y, z));
         }
         __syncthreads();
+        // the wave's BQ_QPW queries share every LDS point read (4 independent dependency chains per chunk)
+        for (int c = 0; c < tn; c += 64) {
+            bool all_done = true;
 #pragma unroll
-        for (int q = 0; q < BQ_QPW; ++q) {
-            if (qid[q] >= S) continue;
-            for (int c = 0; c < tn; c += 64) {
-                bool done = true;
+            for (int q = 0; q < BQ_QPW; ++q)
 #pragma unroll
-                for (int r = 0; r < R; ++r) done = done && (cnt[q][r] >= args.nsample[r]);
-                if (done) break;  // wave-uniform
-                const int i = c + lane;
-                const bool inb = i < tn;
-                float4 p = s_pts[inb ? i : 0];
-                float d = sqdist_expanded(qx[q], qy[q], qz[q], qq[q], p.x, p.y, p.z, p.w);
+                for (int r = 0; r < R; ++r) all_done = all_done && (qid[q] >= S || cnt[q][r] >= args.nsample[r]);
+            if (all_done) break;  // wave-uniform
+            const int i = c + lane;
+            const bool inb = i < tn;
+            const float4 p = s_pts[inb ? i : 0];
+#pragma unroll
+            for (int q = 0; q < BQ_QPW; ++q) {
+                if (qid[q] >= S) continue;
+                const float d = sqdist_expanded(qx[q], qy[q], qz[q], qq[q], p.x, p.y, p.z, p.w);
+                // most 64-point chunks contain no point of even the largest ball: one ballot rejects them
+                if (__ballot(inb && !(d > r2max)) == 0ull) continue;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+                    const int K = args.nsample[r];
                     const bool pred = inb && !(d > args.r2[r]);
                     const unsigned long long m = __ballot(pred);
-                    if (m == 0ull) continue;
+                    if (m == 0ull || cnt[q][r] >= K) continue;
                     if (cnt[q][r] == 0) first[q][r] = base + c + __builtin_ctzll(m);
                     const int pos = cnt[q][r] + __popcll(m & lt_mask);
-                    const int K = args.nsample[r];
                     if (pred && pos < K)
                         reinterpret_cast<IdxT *>(args.out[r])[((size_t)b * S + qid[q]) * K + pos] =
                             (IdxT)(base + i);
@@ -248,32 +257,72 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float *__res
 // ---------------------------------------------------------------------------------------------
 // grouping gather / scatter-add, 3-NN interpolation (bandwidth kernels)
 // ---------------------------------------------------------------------------------------------
-// Vector path: C % 4 == 0, order 0 ([feat, rel, pad]), ld_out % 4 == 0.  One float4 per thread,
-// consecutive threads write consecutive float4s of the output (fully coalesced stores); the feature
-// rows are read as whole contiguous rows.
+// Vector path: C % 4 == 0, order 0 ([feat, rel, pad]), ld_out % 4 == 0.  One float4 per lane, consecutive
+// lanes write consecutive float4s of the output (fully coalesced 1 KiB per wave-instruction); every thread
+// keeps GG_UNROLL independent (index -> row -> store) chains in flight to cover the dependent-load latency.
+constexpr int GG_UNROLL = 4;
 __global__ __launch_bounds__(256) void group_gather_vec_kernel(
     const float4 *__restrict__ feat, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const int32_t *__restrict__ idx, int N, int S, int K, int C4, int V, long long total_vec,
     float4 *__restrict__ out)
 {
-    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total_vec;
-         id += (long long)gridDim.x * 256) {
-        const long long row = id / V;
-        const int v = (int)(id - row * V);
-        const long long bs = row / K;  // b*S + s
-        const int b = (int)(bs / S);
-        const int n = idx[row];
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n >= 0 && n < N) {
-            if (v < C4) {
-                val = feat[((size_t)b * N + n) * C4 + v];
-            } else if (v == C4) {
-                const float *p = xyz + ((size_t)b * N + n) * 3;
-                const float *c = new_xyz + (size_t)bs * 3;
-                val = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f);
-            }
+    // 32-bit index arithmetic (the launcher guarantees total_vec < 2^31): 64-bit divisions are emulated
+    const unsigned total = (unsigned)total_vec;
+    for (unsigned base = blockIdx.x * (256u * GG_UNROLL); base < total; base += gridDim.x * (256u * GG_UNROLL)) {
+        unsigned id[GG_UNROLL], bs[GG_UNROLL];
+        int v[GG_UNROLL], n[GG_UNROLL];
+        bool ok[GG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GG_UNROLL; ++u) {
+            id[u] = base + u * 256u + threadIdx.x;
+            ok[u] = id[u] < total;
+            const unsigned row = (ok[u] ? id[u] : 0u) / (unsigned)V;
+            v[u] = (int)((ok[u] ? id[u] : 0u) - row * (unsigned)V);
+            bs[u] = row / (unsigned)K;  // b*S + s
+            n[u] = idx[row];
         }
-        out[id] = val;
+        float4 val[GG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GG_UNROLL; ++u) {
+            const int b = (int)(bs[u] / (unsigned)S);
+            const bool in = n[u] >= 0 && n[u] < N;
+            const int nn = in ? n[u] : 0;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v[u] < C4) {
+                x = feat[((size_t)b * N + nn) * C4 + v[u]];
+            } else if (v[u] == C4) {
+                const float *p = xyz + ((size_t)b * N + nn) * 3;
+                const float *c = new_xyz + (size_t)bs[u] * 3;
+                x = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f);
+            }
+            val[u] = in ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < GG_UNROLL; ++u)
+            if (ok[u]) out[id[u]] = val[u];
+    }
+}
+
+// Narrow rows (SA1: C = 3 features + 3 relative coordinates in an 8-float row): one thread per row, two
+// float4 stores, consecutive lanes on consecutive rows (2 KiB contiguous per wave).
+__global__ __launch_bounds__(256) void group_gather_row8_kernel(
+    const float *__restrict__ feat, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int32_t *__restrict__ idx, int N, int S, int K, int C, unsigned rows, float4 *__restrict__ out)
+{
+    for (unsigned row = blockIdx.x * 256u + threadIdx.x; row < rows; row += gridDim.x * 256u) {
+        const unsigned bs = row / (unsigned)K;
+        const int b = (int)(bs / (unsigned)S);
+        const int n = idx[row];
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (n >= 0 && n < N) {
+            const float *f = feat + ((size_t)b * N + n) * C;
+            for (int c = 0; c < C; ++c) v[c] = f[c];
+            const float *p = xyz + ((size_t)b * N + n) * 3;
+            const float *ctr = new_xyz + (size_t)bs * 3;
+            v[C] = p[0] - ctr[0]; v[C + 1] = p[1] - ctr[1]; v[C + 2] = p[2] - ctr[2];
+        }
+        out[(size_t)row * 2] = make_float4(v[0], v[1], v[2], v[3]);
+        out[(size_t)row * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
     }
 }
 
@@ -445,13 +494,17 @@ int prifit_group_gather(const float *feat, const float *xyz, const float *new_xy
     const long long rows = (long long)B * S * K;
     hipStream_t st = as_stream(stream);
     const bool vec = order == 0 && C > 0 && (C % 4 == 0) && (ld_out % 4 == 0) &&
-                     ((uintptr_t)feat % 16 == 0) && ((uintptr_t)out % 16 == 0);
+                     ((uintptr_t)feat % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                     rows * (ld_out / 4) < 2147483647LL;
     if (vec) {
         const int V = ld_out / 4;
         const long long total = rows * V;
-        hipLaunchKernelGGL(group_gather_vec_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st,
+        hipLaunchKernelGGL(group_gather_vec_kernel, dim3(grid_for(total, 256 * GG_UNROLL, 256 * 16)), dim3(256), 0, st,
                            reinterpret_cast<const float4 *>(feat), xyz, new_xyz, idx, N, S, K, C / 4, V,
                            total, reinterpret_cast<float4 *>(out));
+    } else if (order == 0 && C <= 5 && ld_out == 8 && ((uintptr_t)out % 16 == 0) && rows < 2147483647LL) {
+        hipLaunchKernelGGL(group_gather_row8_kernel, dim3(grid_for(rows, 256, 256 * 16)), dim3(256), 0, st, feat, xyz,
+                           new_xyz, idx, N, S, K, C, (unsigned)rows, reinterpret_cast<float4 *>(out));
     } else {
         const long long total = rows * ld_out;
         hipLaunchKernelGGL(group_gather_scalar_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st,

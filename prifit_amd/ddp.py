@@ -13,6 +13,13 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
+    """Per step: `zero()` before backward, `allreduce()` after it, then `optimizer.step()`.
+
+    Gradients are produced by autograd as ordinary per-parameter tensors (zero() only drops the old
+    ones, so backward *writes* instead of accumulating); `allreduce()` packs them into the flat fp32
+    bucket with one multi-tensor copy, runs ONE all-reduce, scales by 1/world and points every
+    `p.grad` at its slice of the bucket.  With a single rank nothing is copied or exchanged."""
+
     def __init__(self, module, process_group=None):
         self.module = module
         self.group = process_group
@@ -20,38 +27,34 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)  # gradients accumulate in place in the bucket
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
     def zero(self):
-        self.flat.zero_()
-        off = 0
-        for p in self.params:  # re-attach views (a backward may have replaced .grad with a fresh tensor)
-            v = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                p.grad = v
-            off += p.numel()
-
-    def _gather_strays(self):
-        off = 0
         for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = v
-            elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v
-            off += p.numel()
+            p.grad = None
+
+    def pack(self):
+        """Copy the per-parameter gradients into the bucket (zeros for parameters that got none)."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
     def allreduce(self):
-        """Average gradients over ranks (sum all-reduce of the flat bucket, then scale by 1/world)."""
-        self._gather_strays()
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / self.world)
+        """Average gradients over ranks: one sum all-reduce of the flat bucket, then scale by 1/world."""
+        if self.world == 1:
+            return
+        self.pack()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.mul_(1.0 / self.world)
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:

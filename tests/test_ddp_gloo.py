@@ -47,6 +47,7 @@ def _worker(rank, world, port, out):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
+        bucket.pack()
         out.put([t.numpy().copy() for t in gathered] + [bucket.flat.numpy().copy()])  # by value, not shared memory
     dist.destroy_process_group()
 
@@ -82,5 +83,7 @@ def test_single_process_bucket_matches_plain_autograd():
         ref.zero_grad()
         net(x).sum().backward()
         ref(x).sum().backward()
-        bucket.allreduce()
+        bucket.allreduce()  # single rank: gradients stay where autograd put them
+        assert torch.equal(net.weight.grad, ref.weight.grad)
+        bucket.pack()
         assert torch.equal(net.weight.grad, ref.weight.grad) and net.weight.grad.data_ptr() == bucket.flat.data_ptr()

@@ -226,3 +226,22 @@ def test_full_model_supervised_step(hiplib, golden):
         got = dict(net.named_parameters())[k].grad.cpu()
         rel = (got - _t(ref)).norm() / _t(ref).norm()
         assert rel < 3e-2, (k, rel)
+
+
+def test_ssg_model_config1(hiplib, golden):
+    """BASELINE.json configs[0]: PointNet++-SSG part-seg on 4 x 1024 clouds vs the reference's outputs
+    (same seeded init: the parameter containers are constructed in the reference's order)."""
+    from prifit_amd.models import pointnet2_part_seg_ssg as S
+    g = golden("model_ssg")
+    torch.manual_seed(22)
+    net = S.get_model(50)
+    assert sum(p.numel() for p in net.parameters()) == 1411250  # SURVEY.md 8a'' probe
+    net.cuda().train()
+    net.drop1.eval()
+    xyz = _t(synth.cloud("cube", 4, 1024, int(g["seed"]))).transpose(1, 2).contiguous().cuda()
+    seg, l3 = net(xyz, torch.zeros(4, 1, 16, device="cuda"), fps_start=(_t(g["s1"]).cuda(), _t(g["s2"]).cuda()))
+    assert seg.shape == (4, 1024, 50) and l3.shape == (4, 1024, 1)
+    torch.testing.assert_close(l3.detach().cpu(), _t(g["l3"]), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(seg.detach().sum(dim=1).cpu(), _t(g["seg_sum"]), rtol=1e-3, atol=5e-2)
+    S.get_loss()(seg.reshape(-1, 50), torch.zeros(4096, dtype=torch.long, device="cuda")).backward()
+    assert torch.isfinite(net.sa1.mlp_convs[0].weight.grad).all()

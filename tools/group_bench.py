@@ -1,0 +1,29 @@
+"""Micro-benchmark of ball query + grouping at the B=24 MSG shapes (GPU box)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch, synth
+from prifit_amd import ops
+def timed(name, fn, bytes_, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    us = 1e3 * s.elapsed_time(e) / iters
+    print("%-40s %8.1f us  %7.0f GB/s (alg)" % (name, us, bytes_ / us / 1e3))
+B = 24
+for kind in ("cube", "surface"):
+    xyz = torch.from_numpy(synth.cloud(kind, B, 2048, 0)).cuda()
+    _, c1 = ops.farthest_point_sample(xyz, 512, torch.zeros(B, dtype=torch.long, device="cuda"), return_xyz=True)
+    _, c2 = ops.farthest_point_sample(c1, 128, torch.zeros(B, dtype=torch.long, device="cuda"), return_xyz=True)
+    f1 = torch.randn(B, 512, 320, device="cuda")
+    timed(kind + " ball sa1 (3 radii)", lambda: ops.ball_query_multi([.1, .2, .4], [32, 64, 128], xyz, c1), B * (12 * 2560 + 4 * 512 * 224))
+    timed(kind + " ball sa2 (2 radii)", lambda: ops.ball_query_multi([.4, .8], [64, 128], c1, c2), B * (12 * 640 + 4 * 128 * 192))
+    i1 = ops.ball_query_multi([.1, .2, .4], [32, 64, 128], xyz, c1)
+    i2 = ops.ball_query_multi([.4, .8], [64, 128], c1, c2)
+    for K, ii in zip((32, 64, 128), i1):
+        timed(kind + " gather sa1 K=%d (C=3)" % K, lambda ii=ii: ops.group_gather(xyz, xyz, c1, ii, ld_out=8), B * (4 * 512 * K * 6))
+    for K, ii in zip((64, 128), i2):
+        timed(kind + " gather sa2 K=%d (C=320)" % K, lambda ii=ii: ops.group_gather(f1, c1, c2, ii, ld_out=324), B * (4 * 512 * 320 + 4 * 128 * K * 323))
