@@ -161,26 +161,33 @@ int prifit_bn_finalize(const float *slab, int nslab, int C, double count, const 
                        float *running_var, float *scale, float *shift, float *mean, float *invstd,
                        void *stream);
 
-/* out = max(Y*scale + shift, 0): F.relu(bn(.)) materialised (module outputs). */
+/* The kernels below take the normalisation as per-channel tables.  rows_per_sample == 0: ONE table row
+ * [C] for all rows (BatchNorm).  rows_per_sample > 0: tables are [P/rows_per_sample][C] and row r uses
+ * table row r / rows_per_sample (GroupNorm of src/dgcnn.py:157-159: statistics per sample).
+ * slope: negative slope of the activation (0 = ReLU, 0.2 = the LeakyReLU of src/dgcnn.py:162). */
+
+/* out = act(Y*scale + shift): F.relu(bn(.)) materialised (module outputs). */
 int prifit_affine_relu(const float *Y, long long ldy, const float *scale, const float *shift, int P,
-                       int C, float *out, long long ldo, void *stream);
+                       int C, int rows_per_sample, float slope, float *out, long long ldo, void *stream);
 
 /* torch.max(relu(bn(Y)), dim=K)[0] (models/pointnet_util.py:199,256): Y [G*K, ldy] -> out [G, ldo],
  * arg [G, C] = index k of the first maximum. */
 int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const float *shift, int G, int K,
-                    int C, float *out, long long ldo, int32_t *arg, void *stream);
+                    int C, int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg,
+                    void *stream);
 
 /* Backward of relu(bn(Y)) given G = dL/d(relu output): partial slabs of m1 = sum(G*mask) and
  * m2 = sum(G*mask*yhat). */
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy,
                               const float *scale, const float *shift, const float *mean,
-                              const float *invstd, int P, int C, float *slab, void *stream);
+                              const float *invstd, int P, int C, int rows_per_sample, float slope,
+                              float *slab, void *stream);
 
 /* The same partials when the gradient gp [G, ldgp] arrives through the group max-pool. */
 int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long long ldy,
                            const int32_t *arg, const float *scale, const float *shift,
-                           const float *mean, const float *invstd, int G, int K, int C, float *slab,
-                           void *stream);
+                           const float *mean, const float *invstd, int G, int K, int C,
+                           int rows_per_sample, float slope, float *slab, void *stream);
 
 /* m1, m2 -> dgamma, dbeta and the per-channel coefficients of dY = a*(G*mask) + b*Y + d
  * (training != 0: batch-stat BatchNorm backward; training == 0: running-stat affine). */
@@ -190,13 +197,14 @@ int prifit_bn_bwd_finalize(const float *slab, int nslab, int C, double count, in
 
 int prifit_bn_relu_bwd_apply(const float *G, long long ldg, const float *Y, long long ldy,
                              const float *scale, const float *shift, const float *coef_a,
-                             const float *coef_b, const float *coef_d, int P, int C, float *dY,
-                             long long ldd, void *stream);
+                             const float *coef_b, const float *coef_d, int P, int C,
+                             int rows_per_sample, float slope, float *dY, long long ldd, void *stream);
 
 int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long long ldy,
                           const int32_t *arg, const float *scale, const float *shift,
                           const float *coef_a, const float *coef_b, const float *coef_d, int G, int K,
-                          int C, float *dY, long long ldd, void *stream);
+                          int C, int rows_per_sample, float slope, float *dY, long long ldd,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* mean-shift clustering on the unit hypersphere (src/mean_shift.py)                            */
@@ -284,6 +292,23 @@ int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const i
                          const int32_t *off, int B, int KM, const float *targets, int M, int cap,
                          const int32_t *nn_idx, const float *gscale, float *g_r, float *g_V, float *g_c,
                          void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* DGCNN graph ops (src/dgcnn.py, BASELINE.json configs[4])                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* k nearest neighbours in feature space, src/dgcnn.py:9-27: G [B,N,N] = x^T x (raw inner products, from
+ * prifit_gemm_f32), xx [B,N] = |x|^2; idx [B,N,k] = top-k of (-xx_i - (-2 G_ij)) - xx_j, descending,
+ * ties to the lower index.  N <= 4096. */
+int prifit_knn_topk(const float *G, const float *xx, int B, int N, int k, int32_t *idx, void *stream);
+
+/* Edge features, src/dgcnn.py:74-107: out[(b,n,j), :] = [x[b,idx[b,n,j]] - x[b,n], x[b,n], 0-pad],
+ * x [B,N,C] channels-last, out rows of ld_out >= 2C floats. */
+int prifit_edge_gather(const float *x, const int32_t *idx, int B, int N, int C, int k, int ld_out,
+                       float *out, void *stream);
+/* Its autograd: dx [B,N,C] (initialised by the caller) += scatter of gout [B*N*k, ld_gout]. */
+int prifit_edge_scatter(const float *gout, int ld_gout, const int32_t *idx, int B, int N, int C, int k,
+                        float *dx, void *stream);
 
 #ifdef __cplusplus
 }

@@ -305,16 +305,65 @@ def golden_model():
     save("model_ssg", seed=9, s1=t1, s2=t2, seg_sum=sseg.detach().sum(dim=1), l3=sl3.detach())
 
 
+def golden_dgcnn():
+    """config 5: src/dgcnn.DGCNGn (k=20) on B=2 x 1024 points: outputs + gradients."""
+    print("[dgcnn]")
+    D = refshim.ref("src.dgcnn")
+
+    class _TorchProxy:  # src/dgcnn.py:83,122 hard-code torch.device('cuda')
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*a, **k):
+            return torch.device("cpu")
+
+    D.torch = _TorchProxy()
+    B, N, k, seed = 2, 1024, 20, 41
+    torch.manual_seed(31)
+    ref = D.DGCNGn(emb_size=128, num_channels=3, nn_nb=k)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.GroupNorm):
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(m.num_channels)
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+    my = orc.OracleDGCNGn(128, 3, k)
+    assert [kk for kk, _ in my.state_dict().items()] == [kk for kk, _ in ref.state_dict().items()]
+    my.load_state_dict(ref.state_dict())
+    pts = torch.from_numpy(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
+    idx_r = D.knn(pts, k, k)
+    eq(orc.knn(pts, k, k), idx_r, "dgcnn knn (xyz)")
+    ge = torch.from_numpy(synth.features(B, N, 128, seed + 1))
+    gs = torch.from_numpy(synth.features(B, N, 3, seed + 2)).transpose(1, 2)
+    er, sr = ref(pts)
+    ((er * ge).sum() + (sr * gs).sum()).backward()
+    eo, so = my(pts)
+    ((eo * ge).sum() + (so * gs).sum()).backward()
+    close(eo, er, "dgcnn embedding", rtol=1e-5, atol=1e-6)
+    close(so, sr, "dgcnn seg", rtol=1e-5, atol=1e-6)
+    rg = {kk: p.grad for kk, p in ref.named_parameters()}
+    names = sorted(rg)
+    for kk, p in my.named_parameters():
+        close(p.grad, rg[kk], "dgcnn d" + kk, rtol=1e-4, atol=1e-5 * max(v.abs().max().item() for v in rg.values()))
+    save("model_dgcnn", seed=seed, knn_head=idx_r[:, :64].to(torch.int16), knn_sum=idx_r.sum(dim=(1, 2)),
+         emb_head=er[:, :64].detach(), emb_sum=er.detach().sum(dim=1), seg=sr.detach(),
+         grad_names=np.array(names), grad_norms=np.array([rg[n].norm().item() for n in names]),
+         g_enc_conv1=rg["encoder.conv1.0.weight"], g_seg=rg["mlp_segmentation.weight"], g_emb=rg["mlp_seg_prob2.weight"])
+
+
 if __name__ == "__main__":
     assert refshim.available(), "needs the reference tree"
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["index", "modules", "model", "fit"]
+    which = sys.argv[1:] or ["index", "modules", "model", "fit", "dgcnn"]
     if "index" in which:
         golden_index_ops()
     if "modules" in which:
         golden_modules()
     if "model" in which:
         golden_model()
+    if "dgcnn" in which:
+        golden_dgcnn()
     if "fit" in which:
         import make_golden_fit
         make_golden_fit.run(save, eq, close)

@@ -381,6 +381,72 @@ def seg_loss(pred, target):
 
 
 # ----------------------------------------------------------------------------------------------
+# DGCNN backbone with GroupNorm (src/dgcnn.py) -- BASELINE.json configs[4]
+# ----------------------------------------------------------------------------------------------
+def knn(x, k1, k2):
+    """src/dgcnn.py:9-27.  x [B,C,N] -> idx [B,N,k1] (top-k2 of -|xi-xj|^2, every (k2//k1)-th kept)."""
+    keep = np.arange(0, k2, k2 // k1)
+    with torch.no_grad():
+        inner = -2 * torch.matmul(x.transpose(2, 1), x)
+        xx = torch.sum(x ** 2, dim=1, keepdim=True)
+        pairwise = -xx - inner - xx.transpose(2, 1)
+        return pairwise.topk(k=k2, dim=-1)[1][:, :, keep]
+
+
+def graph_feature(x, k1, k2, idx=None):
+    """src/dgcnn.py:74-107: edge features cat(x_j - x_i, x_i) -> [B, 2C, N, k1]."""
+    B, C, N = x.shape
+    if idx is None:
+        idx = knn(x, k1, k2)
+    xt = x.transpose(2, 1).contiguous()
+    nb = gather_rows(xt, idx)                                   # [B,N,k,C]
+    ctr = xt.unsqueeze(2).expand(-1, -1, k1, -1)
+    return torch.cat((nb - ctr, ctr), dim=3).permute(0, 3, 1, 2), idx
+
+
+class OracleDGCNGn(nn.Module):
+    """src/dgcnn.py:149-267 (input_channels=3): DGCNNEncoderGn + segmentation / embedding heads.
+    forward(points [B,3,N]) -> (embedding [B,N,emb], seg [B,3,N])."""
+
+    def __init__(self, emb_size=128, num_channels=3, nn_nb=80, dilation=1):
+        super().__init__()
+        enc = nn.Module()
+        enc.bn1, enc.bn2, enc.bn3 = nn.GroupNorm(2, 64), nn.GroupNorm(2, 64), nn.GroupNorm(2, 128)
+        enc.conv1 = nn.Sequential(nn.Conv2d(num_channels * 2, 64, kernel_size=1, bias=False), enc.bn1, nn.LeakyReLU(0.2))
+        enc.conv2 = nn.Sequential(nn.Conv2d(64 * 2, 64, kernel_size=1, bias=False), enc.bn2, nn.LeakyReLU(0.2))
+        enc.conv3 = nn.Sequential(nn.Conv2d(64 * 2, 128, kernel_size=1, bias=False), enc.bn3, nn.LeakyReLU(0.2))
+        enc.mlp1 = nn.Conv1d(256, 1024, 1)
+        enc.bnmlp1 = nn.GroupNorm(8, 1024)
+        self.encoder = enc
+        self.k, self.dil = nn_nb, dilation
+        self.conv1 = nn.Conv1d(1024 + 256, 512, 1)
+        self.bn1 = nn.GroupNorm(8, 512)
+        self.conv2 = nn.Conv1d(512, 256, 1)
+        self.bn2 = nn.GroupNorm(4, 256)
+        self.mlp_seg_prob1 = nn.Conv1d(256, 256, 1)
+        self.mlp_seg_prob2 = nn.Conv1d(256, emb_size, 1, bias=False)
+        self.bn_seg_prob1 = nn.GroupNorm(4, 256)
+        self.mlp_segmentation = nn.Conv1d(256, 3, 1)
+
+    def forward(self, points):
+        B, _, N = points.shape
+        e, k = self.encoder, self.k
+        x, _ = graph_feature(points, k, k * self.dil)
+        x1 = e.conv1(x).max(dim=-1)[0]
+        x, idx = graph_feature(x1, k, k * self.dil)
+        x2 = e.conv2(x).max(dim=-1)[0]
+        x, _ = graph_feature(x2, k, k, idx=idx)          # third edge conv re-uses the second graph (:191)
+        x3 = e.conv3(x).max(dim=-1)[0]
+        feats = torch.cat((x1, x2, x3), dim=1)
+        x4 = F.relu(e.bnmlp1(e.mlp1(feats))).max(dim=2)[0]
+        x = torch.cat([x4.view(B, 1024, 1).repeat(1, 1, N), feats], 1)
+        x = F.relu(self.bn1(self.conv1(x)))
+        x_all = F.relu(self.bn2(self.conv2(x)))
+        x = F.relu(self.bn_seg_prob1(self.mlp_seg_prob1(x_all)))
+        return self.mlp_seg_prob2(x).permute(0, 2, 1), self.mlp_segmentation(x)
+
+
+# ----------------------------------------------------------------------------------------------
 # mean-shift clustering on the unit hypersphere (src/mean_shift.py)
 # ----------------------------------------------------------------------------------------------
 def guard_exp(x):

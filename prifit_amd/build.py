@@ -25,6 +25,7 @@ SOURCES = {
     "bn.hip": [],
     "meanshift.hip": [],
     "fit.hip": [],
+    "dgcnn.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
           "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -21,6 +21,7 @@ _ALIASES = {
     "src.mean_shift": "prifit_amd.src.mean_shift",
     "src.ellipsoid_fitting": "prifit_amd.src.ellipsoid_fitting",
     "src.ellipsoid_utils": "prifit_amd.src.ellipsoid_utils",
+    "src.dgcnn": "prifit_amd.src.dgcnn",
 }
 
 

@@ -97,19 +97,26 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict_
     });
 }
 
-// out = max(Y * scale + shift, 0)
+// Activation with a negative slope (0: ReLU, 0.2: the LeakyReLU of src/dgcnn.py:162).
+__device__ __forceinline__ float act(float v, float slope) { return v > 0.f ? v : v * slope; }
+// Row offset into the per-sample coefficient tables [samples][C]: rps rows share one table row
+// (rps == 0: one table for everything = BatchNorm; rps = rows per sample = GroupNorm).
+__device__ __forceinline__ long long tab_off(long long row, int rps, int C) { return rps ? (row / rps) * C : 0; }
+
+// out = act(Y * scale + shift)
 __global__ __launch_bounds__(256) void affine_relu_kernel(const float *__restrict__ Y, long long ldy,
                                                           const float *__restrict__ scale,
-                                                          const float *__restrict__ shift, int P, int C4,
-                                                          float *__restrict__ out, long long ldo)
+                                                          const float *__restrict__ shift, int P, int C4, int rps,
+                                                          float slope, float *__restrict__ out, long long ldo)
 {
     const long long total = (long long)P * C4;
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const long long r = id / C4;
         const int c = (int)(id - r * C4) * 4;
-        const float4 y = ld4g(Y + r * ldy + c), s = ld4g(scale + c), t = ld4g(shift + c);
-        st4g(out + r * ldo + c, make_float4(fmaxf(fmaf(y.x, s.x, t.x), 0.f), fmaxf(fmaf(y.y, s.y, t.y), 0.f),
-                                            fmaxf(fmaf(y.z, s.z, t.z), 0.f), fmaxf(fmaf(y.w, s.w, t.w), 0.f)));
+        const long long to = tab_off(r, rps, C4 * 4) + c;
+        const float4 y = ld4g(Y + r * ldy + c), s = ld4g(scale + to), t = ld4g(shift + to);
+        st4g(out + r * ldo + c, make_float4(act(fmaf(y.x, s.x, t.x), slope), act(fmaf(y.y, s.y, t.y), slope),
+                                            act(fmaf(y.z, s.z, t.z), slope), act(fmaf(y.w, s.w, t.w), slope)));
     }
 }
 
@@ -118,14 +125,15 @@ __global__ __launch_bounds__(256) void affine_relu_kernel(const float *__restric
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__ Y, long long ldy,
                                                        const float *__restrict__ scale,
                                                        const float *__restrict__ shift, int G, int K, int C4,
-                                                       float *__restrict__ out, long long ldo,
-                                                       int32_t *__restrict__ arg)
+                                                       int rps, float slope, float *__restrict__ out,
+                                                       long long ldo, int32_t *__restrict__ arg)
 {
     const long long total = (long long)G * C4;
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const long long gidx = id / C4;
         const int c = (int)(id - gidx * C4) * 4;
-        const float4 s = ld4g(scale + c), t = ld4g(shift + c);
+        const long long to = tab_off(gidx * K, rps, C4 * 4) + c;
+        const float4 s = ld4g(scale + to), t = ld4g(shift + to);
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int4 bi = make_int4(0, 0, 0, 0);
         const float *row = Y + gidx * K * ldy + c;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__
             if (vw > best.w) { best.w = vw; bi.w = k; }
         }
         st4g(out + gidx * ldo + c,
-             make_float4(fmaxf(best.x, 0.f), fmaxf(best.y, 0.f), fmaxf(best.z, 0.f), fmaxf(best.w, 0.f)));
+             make_float4(act(best.x, slope), act(best.y, slope), act(best.z, slope), act(best.w, slope)));
         *reinterpret_cast<int4 *>(arg + gidx * (C4 * 4) + c) = bi;
     }
 }
@@ -155,14 +163,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float *__
                                                                  const float *__restrict__ shift,
                                                                  const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd, int P, int C,
-                                                                 float *__restrict__ slab)
+                                                                 int rps, float slope, float *__restrict__ slab)
 {
     column_reduce(P, C, slab, [&](int r, int c4, float4 &a0, float4 &a1) {
         const int c = 4 * c4;
+        const long long to = tab_off(r, rps, C) + c;
         const float4 g = ld4g(Gr + (size_t)r * ldg + c), y = ld4g(Y + (size_t)r * ldy + c);
-        const float4 s = ld4g(scale + c), t = ld4g(shift + c), mu = ld4g(mean + c), is = ld4g(invstd + c);
-        const float gx = fmaf(y.x, s.x, t.x) > 0.f ? g.x : 0.f, gy = fmaf(y.y, s.y, t.y) > 0.f ? g.y : 0.f,
-                    gz = fmaf(y.z, s.z, t.z) > 0.f ? g.z : 0.f, gw = fmaf(y.w, s.w, t.w) > 0.f ? g.w : 0.f;
+        const float4 s = ld4g(scale + to), t = ld4g(shift + to), mu = ld4g(mean + to), is = ld4g(invstd + to);
+        const float gx = fmaf(y.x, s.x, t.x) > 0.f ? g.x : g.x * slope, gy = fmaf(y.y, s.y, t.y) > 0.f ? g.y : g.y * slope,
+                    gz = fmaf(y.z, s.z, t.z) > 0.f ? g.z : g.z * slope, gw = fmaf(y.w, s.w, t.w) > 0.f ? g.w : g.w * slope;
         a0.x += gx; a0.y += gy; a0.z += gz; a0.w += gw;
         a1.x += gx * ((y.x - mu.x) * is.x); a1.y += gy * ((y.y - mu.y) * is.y);
         a1.z += gz * ((y.z - mu.z) * is.z); a1.w += gw * ((y.w - mu.w) * is.w);
@@ -178,18 +187,20 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                                                               const float *__restrict__ shift,
                                                               const float *__restrict__ mean,
                                                               const float *__restrict__ invstd, int G, int K,
-                                                              int C, float *__restrict__ slab)
+                                                              int C, int rps, float slope,
+                                                              float *__restrict__ slab)
 {
     column_reduce(G, C, slab, [&](int gi, int c4, float4 &a0, float4 &a1) {
         const int c = 4 * c4;
+        const long long to = tab_off((long long)gi * K, rps, C) + c;
         const float4 g = ld4g(gp + (size_t)gi * ldgp + c);
         const int4 k = *reinterpret_cast<const int4 *>(arg + (size_t)gi * C + c);
         const float *base = Y + (size_t)gi * K * ldy + c;
         const float yx = base[(size_t)k.x * ldy], yy = base[(size_t)k.y * ldy + 1],
                     yz = base[(size_t)k.z * ldy + 2], yw = base[(size_t)k.w * ldy + 3];
-        const float4 s = ld4g(scale + c), t = ld4g(shift + c), mu = ld4g(mean + c), is = ld4g(invstd + c);
-        const float gx = fmaf(yx, s.x, t.x) > 0.f ? g.x : 0.f, gy = fmaf(yy, s.y, t.y) > 0.f ? g.y : 0.f,
-                    gz = fmaf(yz, s.z, t.z) > 0.f ? g.z : 0.f, gw = fmaf(yw, s.w, t.w) > 0.f ? g.w : 0.f;
+        const float4 s = ld4g(scale + to), t = ld4g(shift + to), mu = ld4g(mean + to), is = ld4g(invstd + to);
+        const float gx = fmaf(yx, s.x, t.x) > 0.f ? g.x : g.x * slope, gy = fmaf(yy, s.y, t.y) > 0.f ? g.y : g.y * slope,
+                    gz = fmaf(yz, s.z, t.z) > 0.f ? g.z : g.z * slope, gw = fmaf(yw, s.w, t.w) > 0.f ? g.w : g.w * slope;
         a0.x += gx; a0.y += gy; a0.z += gz; a0.w += gw;
         a1.x += gx * ((yx - mu.x) * is.x); a1.y += gy * ((yy - mu.y) * is.y);
         a1.z += gz * ((yz - mu.z) * is.z); a1.w += gw * ((yw - mu.w) * is.w);
@@ -245,19 +256,21 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const float *__r
                                                                 const float *__restrict__ ca,
                                                                 const float *__restrict__ cb,
                                                                 const float *__restrict__ cd, int P, int C4,
-                                                                float *__restrict__ dY, long long ldd)
+                                                                int rps, float slope, float *__restrict__ dY,
+                                                                long long ldd)
 {
     const long long total = (long long)P * C4;
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const long long r = id / C4;
         const int c = (int)(id - r * C4) * 4;
+        const long long to = tab_off(r, rps, C4 * 4) + c;
         const float4 g = ld4g(Gr + r * ldg + c), y = ld4g(Y + r * ldy + c);
-        const float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
+        const float4 s = ld4g(scale + to), t = ld4g(shift + to), a = ld4g(ca + to), b = ld4g(cb + to), d = ld4g(cd + to);
         float4 o;
-        o.x = fmaf(a.x, fmaf(y.x, s.x, t.x) > 0.f ? g.x : 0.f, fmaf(b.x, y.x, d.x));
-        o.y = fmaf(a.y, fmaf(y.y, s.y, t.y) > 0.f ? g.y : 0.f, fmaf(b.y, y.y, d.y));
-        o.z = fmaf(a.z, fmaf(y.z, s.z, t.z) > 0.f ? g.z : 0.f, fmaf(b.z, y.z, d.z));
-        o.w = fmaf(a.w, fmaf(y.w, s.w, t.w) > 0.f ? g.w : 0.f, fmaf(b.w, y.w, d.w));
+        o.x = fmaf(a.x, fmaf(y.x, s.x, t.x) > 0.f ? g.x : g.x * slope, fmaf(b.x, y.x, d.x));
+        o.y = fmaf(a.y, fmaf(y.y, s.y, t.y) > 0.f ? g.y : g.y * slope, fmaf(b.y, y.y, d.y));
+        o.z = fmaf(a.z, fmaf(y.z, s.z, t.z) > 0.f ? g.z : g.z * slope, fmaf(b.z, y.z, d.z));
+        o.w = fmaf(a.w, fmaf(y.w, s.w, t.w) > 0.f ? g.w : g.w * slope, fmaf(b.w, y.w, d.w));
         st4g(dY + r * ldd + c, o);
     }
 }
@@ -271,7 +284,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float *__rest
                                                              const float *__restrict__ ca,
                                                              const float *__restrict__ cb,
                                                              const float *__restrict__ cd, int G, int K, int C4,
-                                                             float *__restrict__ dY, long long ldd)
+                                                             int rps, float slope, float *__restrict__ dY,
+                                                             long long ldd)
 {
     const long long total = (long long)G * K * C4;
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
@@ -279,14 +293,15 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float *__rest
         const int c = (int)(id - r * C4) * 4;
         const long long gi = r / K;
         const int k = (int)(r - gi * K);
+        const long long to = tab_off(r, rps, C4 * 4) + c;
         const float4 g = ld4g(gp + gi * ldgp + c), y = ld4g(Y + r * ldy + c);
         const int4 w = *reinterpret_cast<const int4 *>(arg + gi * (C4 * 4) + c);
-        const float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
+        const float4 s = ld4g(scale + to), t = ld4g(shift + to), a = ld4g(ca + to), b = ld4g(cb + to), d = ld4g(cd + to);
         float4 o;
-        o.x = fmaf(a.x, (k == w.x && fmaf(y.x, s.x, t.x) > 0.f) ? g.x : 0.f, fmaf(b.x, y.x, d.x));
-        o.y = fmaf(a.y, (k == w.y && fmaf(y.y, s.y, t.y) > 0.f) ? g.y : 0.f, fmaf(b.y, y.y, d.y));
-        o.z = fmaf(a.z, (k == w.z && fmaf(y.z, s.z, t.z) > 0.f) ? g.z : 0.f, fmaf(b.z, y.z, d.z));
-        o.w = fmaf(a.w, (k == w.w && fmaf(y.w, s.w, t.w) > 0.f) ? g.w : 0.f, fmaf(b.w, y.w, d.w));
+        o.x = fmaf(a.x, k == w.x ? (fmaf(y.x, s.x, t.x) > 0.f ? g.x : g.x * slope) : 0.f, fmaf(b.x, y.x, d.x));
+        o.y = fmaf(a.y, k == w.y ? (fmaf(y.y, s.y, t.y) > 0.f ? g.y : g.y * slope) : 0.f, fmaf(b.y, y.y, d.y));
+        o.z = fmaf(a.z, k == w.z ? (fmaf(y.z, s.z, t.z) > 0.f ? g.z : g.z * slope) : 0.f, fmaf(b.z, y.z, d.z));
+        o.w = fmaf(a.w, k == w.w ? (fmaf(y.w, s.w, t.w) > 0.f ? g.w : g.w * slope) : 0.f, fmaf(b.w, y.w, d.w));
         st4g(dY + r * ldd + c, o);
     }
 }
@@ -327,44 +342,49 @@ int prifit_bn_finalize(const float *slab, int nslab, int C, double count, const 
 }
 
 int prifit_affine_relu(const float *Y, long long ldy, const float *scale, const float *shift, int P, int C,
-                       float *out, long long ldo, void *stream)
+                       int rows_per_sample, float slope, float *out, long long ldo, void *stream)
 {
-    if (bad_mat(Y, ldy, C) || bad_mat(out, ldo, C) || !scale || !shift || P <= 0) return PRIFIT_EINVAL;
+    if (bad_mat(Y, ldy, C) || bad_mat(out, ldo, C) || !scale || !shift || P <= 0 || rows_per_sample < 0)
+        return PRIFIT_EINVAL;
     hipLaunchKernelGGL(affine_relu_kernel, dim3(ew_grid((long long)P * (C / 4))), dim3(256), 0, as_stream(stream),
-                       Y, ldy, scale, shift, P, C / 4, out, ldo);
+                       Y, ldy, scale, shift, P, C / 4, rows_per_sample, slope, out, ldo);
     return prifit_check_launch();
 }
 
 int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const float *shift, int G, int K, int C,
-                    float *out, long long ldo, int32_t *arg, void *stream)
+                    int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, void *stream)
 {
-    if (bad_mat(Y, ldy, C) || bad_mat(out, ldo, C) || !scale || !shift || !arg || G <= 0 || K <= 0)
+    if (bad_mat(Y, ldy, C) || bad_mat(out, ldo, C) || !scale || !shift || !arg || G <= 0 || K <= 0 ||
+        rows_per_sample < 0 || (rows_per_sample % K) != 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((long long)G * (C / 4))), dim3(256), 0, as_stream(stream), Y,
-                       ldy, scale, shift, G, K, C / 4, out, ldo, arg);
+                       ldy, scale, shift, G, K, C / 4, rows_per_sample, slope, out, ldo, arg);
     return prifit_check_launch();
 }
 
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy, const float *scale,
                               const float *shift, const float *mean, const float *invstd, int P, int C,
-                              float *slab, void *stream)
+                              int rows_per_sample, float slope, float *slab, void *stream)
 {
-    if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || !scale || !shift || !mean || !invstd || !slab || P <= 0)
+    if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || !scale || !shift || !mean || !invstd || !slab || P <= 0 ||
+        rows_per_sample < 0 || (rows_per_sample % RED_ROWS) != 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((P + RED_ROWS - 1) / RED_ROWS), dim3(256), 0,
-                       as_stream(stream), G, ldg, Y, ldy, scale, shift, mean, invstd, P, C, slab);
+                       as_stream(stream), G, ldg, Y, ldy, scale, shift, mean, invstd, P, C, rows_per_sample, slope,
+                       slab);
     return prifit_check_launch();
 }
 
 int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
                            const float *scale, const float *shift, const float *mean, const float *invstd, int G,
-                           int K, int C, float *slab, void *stream)
+                           int K, int C, int rows_per_sample, float slope, float *slab, void *stream)
 {
     if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || !arg || !scale || !shift || !mean || !invstd || !slab ||
-        G <= 0 || K <= 0)
+        G <= 0 || K <= 0 || rows_per_sample < 0 || (rows_per_sample % (K * RED_ROWS)) != 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((G + RED_ROWS - 1) / RED_ROWS), dim3(256), 0,
-                       as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, mean, invstd, G, K, C, slab);
+                       as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, mean, invstd, G, K, C, rows_per_sample,
+                       slope, slab);
     return prifit_check_launch();
 }
 
@@ -382,26 +402,28 @@ int prifit_bn_bwd_finalize(const float *slab, int nslab, int C, double count, in
 
 int prifit_bn_relu_bwd_apply(const float *G, long long ldg, const float *Y, long long ldy, const float *scale,
                              const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
-                             int P, int C, float *dY, long long ldd, void *stream)
+                             int P, int C, int rows_per_sample, float slope, float *dY, long long ldd, void *stream)
 {
     if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || bad_mat(dY, ldd, C) || !scale || !shift || !coef_a ||
-        !coef_b || !coef_d || P <= 0)
+        !coef_b || !coef_d || P <= 0 || rows_per_sample < 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_grid((long long)P * (C / 4))), dim3(256), 0,
-                       as_stream(stream), G, ldg, Y, ldy, scale, shift, coef_a, coef_b, coef_d, P, C / 4, dY, ldd);
+                       as_stream(stream), G, ldg, Y, ldy, scale, shift, coef_a, coef_b, coef_d, P, C / 4,
+                       rows_per_sample, slope, dY, ldd);
     return prifit_check_launch();
 }
 
 int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
                           const float *scale, const float *shift, const float *coef_a, const float *coef_b,
-                          const float *coef_d, int G, int K, int C, float *dY, long long ldd, void *stream)
+                          const float *coef_d, int G, int K, int C, int rows_per_sample, float slope, float *dY,
+                          long long ldd, void *stream)
 {
     if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || bad_mat(dY, ldd, C) || !arg || !scale || !shift ||
-        !coef_a || !coef_b || !coef_d || G <= 0 || K <= 0)
+        !coef_a || !coef_b || !coef_d || G <= 0 || K <= 0 || rows_per_sample < 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((long long)G * K * (C / 4))), dim3(256), 0,
                        as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C / 4,
-                       dY, ldd);
+                       rows_per_sample, slope, dY, ldd);
     return prifit_check_launch();
 }
 

@@ -1,0 +1,115 @@
+// DGCNN graph ops (src/dgcnn.py): k-nearest-neighbour selection on a pairwise matrix and the edge-feature
+// gather / scatter of get_graph_feature.  The pairwise inner products come from the MFMA GEMM; the
+// edge convolutions and their GroupNorm run on the GEMM + normalisation kernels of gemm.hip / bn.hip.
+#include "common.h"
+
+// idx[row][0..k) = indices of the k largest v_j = (-xx_i - (-2 G_ij)) - xx_j, descending, ties to the lower
+// index (src/dgcnn.py:15-22: pairwise_distance.topk(k)).  One wave per row, the row lives in registers.
+template <int VPT>
+__global__ __launch_bounds__(256) void knn_topk_kernel(const float *__restrict__ G, const float *__restrict__ xx,
+                                                       int N, long long rows, int k, int32_t *__restrict__ idx)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const long long b = row / N;
+    const float *g = G + row * N;
+    const float *xb = xx + b * N;
+    const float nxi = -xb[row - b * N];
+    float v[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < N ? (nxi - (-2.0f * g[c])) - xb[c] : -INFINITY;
+    }
+    for (int t = 0; t < k; ++t) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j)
+            if (v[j] > best) { best = v[j]; bi = lane + 64 * j; }  // ascending index within the lane: first max
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) idx[row * k + t] = bi;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j)
+            if (lane + 64 * j == bi) v[j] = -INFINITY;
+    }
+}
+
+// rows (b, n, j): [x[b, idx[b,n,j]] - x[b,n] (C), x[b,n] (C), 0-pad]   (src/dgcnn.py:98-105)
+__global__ __launch_bounds__(256) void edge_gather_kernel(const float *__restrict__ x,
+                                                          const int32_t *__restrict__ idx, int N, int C, int k,
+                                                          int ld, long long total, float *__restrict__ out)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long row = id / ld;
+        const int c = (int)(id - row * ld);
+        const long long bn = row / k;  // b*N + n
+        const long long b = bn / N;
+        float val = 0.f;
+        if (c < C) val = x[(b * N + idx[row]) * C + c] - x[bn * C + c];
+        else if (c < 2 * C) val = x[bn * C + (c - C)];
+        out[id] = val;
+    }
+}
+
+// autograd of the gather: dx[b, idx] += g[:C];  dx[b, n] += g[C:2C] - g[:C]
+__global__ __launch_bounds__(256) void edge_scatter_kernel(const float *__restrict__ g, int ld,
+                                                           const int32_t *__restrict__ idx, int N, int C, int k,
+                                                           long long total, float *__restrict__ dx)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long row = id / C;
+        const int c = (int)(id - row * C);
+        const long long bn = row / k;
+        const long long b = bn / N;
+        const float gd = g[row * ld + c], gc = g[row * ld + C + c];
+        unsafeAtomicAdd(dx + (b * N + idx[row]) * C + c, gd);
+        unsafeAtomicAdd(dx + bn * C + c, gc - gd);
+    }
+}
+
+extern "C" {
+
+int prifit_knn_topk(const float *G, const float *xx, int B, int N, int k, int32_t *idx, void *stream)
+{
+    if (!G || !xx || !idx || B <= 0 || N <= 0 || k <= 0 || k > N || N > 4096) return PRIFIT_EINVAL;
+    const long long rows = (long long)B * N;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (N <= 1024) hipLaunchKernelGGL((knn_topk_kernel<16>), grid, block, 0, st, G, xx, N, rows, k, idx);
+    else if (N <= 2048) hipLaunchKernelGGL((knn_topk_kernel<32>), grid, block, 0, st, G, xx, N, rows, k, idx);
+    else hipLaunchKernelGGL((knn_topk_kernel<64>), grid, block, 0, st, G, xx, N, rows, k, idx);
+    return prifit_check_launch();
+}
+
+int prifit_edge_gather(const float *x, const int32_t *idx, int B, int N, int C, int k, int ld_out, float *out,
+                       void *stream)
+{
+    if (!x || !idx || !out || B <= 0 || N <= 0 || C <= 0 || k <= 0 || ld_out < 2 * C) return PRIFIT_EINVAL;
+    const long long total = (long long)B * N * k * ld_out;
+    long long gsz = (total + 255) / 256;
+    if (gsz > 256 * 32) gsz = 256 * 32;
+    hipLaunchKernelGGL(edge_gather_kernel, dim3((unsigned)gsz), dim3(256), 0, as_stream(stream), x, idx, N, C, k,
+                       ld_out, total, out);
+    return prifit_check_launch();
+}
+
+int prifit_edge_scatter(const float *gout, int ld_gout, const int32_t *idx, int B, int N, int C, int k, float *dx,
+                        void *stream)
+{
+    if (!gout || !idx || !dx || B <= 0 || N <= 0 || C <= 0 || k <= 0 || ld_gout < 2 * C) return PRIFIT_EINVAL;
+    const long long total = (long long)B * N * k * C;
+    long long gsz = (total + 255) / 256;
+    if (gsz > 256 * 32) gsz = 256 * 32;
+    hipLaunchKernelGGL(edge_scatter_kernel, dim3((unsigned)gsz), dim3(256), 0, as_stream(stream), gout, ld_gout,
+                       idx, N, C, k, total, dx);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

@@ -109,12 +109,12 @@ class SharedMLPFn(torch.autograd.Function):
             G = P // pool_K
             out = torch.empty(G, CL, dtype=torch.float32, device=dev)
             arg = torch.empty(G, CL, dtype=torch.int32, device=dev)
-            call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL,
+            call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
                  ptr(out), _LL(CL), ptr(arg), cur_stream())
         else:
             out = torch.empty(P, CL, dtype=torch.float32, device=dev)
-            call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, ptr(out),
-                 _LL(CL), cur_stream())
+            call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, 0, _F(0.0),
+                 ptr(out), _LL(CL), cur_stream())
         ctx.cfg = cfg
         ctx.L = L
         ctx.saved = (x, Ys, Ws, affines, stats_saved, arg)
@@ -147,21 +147,21 @@ class SharedMLPFn(torch.autograd.Function):
                 nslab = (G + rps - 1) // rps
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
-                     ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, ptr(slab), cur_stream())
+                     ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, 0, _F(0.0), ptr(slab), cur_stream())
             else:
                 nslab = (P + rps - 1) // rps
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_bn_relu_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
-                     ptr(shift), ptr(mean), ptr(invstd), P, Cout, ptr(slab), cur_stream())
+                     ptr(shift), ptr(mean), ptr(invstd), P, Cout, 0, _F(0.0), ptr(slab), cur_stream())
             call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
                  ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
             if pooled:
                 call("prifit_pool_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
-                     ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), G, K, Cout, ptr(dY), _LL(Cout),
+                     ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), G, K, Cout, 0, _F(0.0), ptr(dY), _LL(Cout),
                      cur_stream())
             else:
                 call("prifit_bn_relu_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
-                     ptr(shift), ptr(ca), ptr(cb), ptr(cd), P, Cout, ptr(dY), _LL(Cout), cur_stream())
+                     ptr(shift), ptr(ca), ptr(cb), ptr(cd), P, Cout, 0, _F(0.0), ptr(dY), _LL(Cout), cur_stream())
             A_in = x if l == 0 else Ys[l - 1]
             a_aff = None if l == 0 else affines[l - 1]
             if ctx.needs_input_grad[2 + 6 * l]:

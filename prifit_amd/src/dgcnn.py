@@ -1,0 +1,303 @@
+"""DGCNN backbone with GroupNorm on the MI355X backend: call surface of the reference's src/dgcnn.py
+(`knn :9-27`, `get_graph_feature :74-107`, `DGCNNEncoderGn :149-222`, `DGCNGn :225-267`) --
+BASELINE.json configs[4].  Same constructor arguments, parameter names (state_dict compatible) and
+outputs: `DGCNGn.forward(points [B,3,N]) -> (embedding [B,N,emb], seg [B,3,N])`.
+
+Every edge convolution is one MFMA GEMM on channels-last edge rows `[x_j - x_i | x_i]`; the GEMM
+epilogue emits per-tile column sums from which the per-sample GroupNorm statistics are formed, and
+GroupNorm + LeakyReLU + the max over the k neighbours run fused in one kernel (per-sample
+coefficient tables).  `get_model(num_part, normal_channel, k)` is the adapter the reference's trainer
+expects for `'dgcnn' in args.model` (train_partseg_shapenet.py:226-228) but never shipped.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import nn_ops
+from .._lib import call, cur_stream, dll, ptr
+from ..nn_ops import NN, NT, TN, LinearFn, gemm
+
+_LL = ctypes.c_longlong
+_F = ctypes.c_float
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _knn_cl(x, k):
+    """x [B,N,C] channels-last -> idx int32 [B,N,k]."""
+    x = x.contiguous()
+    B, N, C = x.shape
+    G = torch.empty(B, N, N, dtype=torch.float32, device=x.device)
+    gemm(NT, N, N, C, x, C, x, C, G, N, batch=B, sA=N * C, sB=N * C, sC=N * N)
+    if C == 3:
+        xx = (x[..., 0] * x[..., 0] + x[..., 1] * x[..., 1]) + x[..., 2] * x[..., 2]
+    else:
+        xx = (x * x).sum(dim=-1)
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    call("prifit_knn_topk", ptr(G), ptr(xx.contiguous()), B, N, k, ptr(idx), cur_stream())
+    return idx
+
+
+def knn(x, k1, k2):
+    """upstream :9-27 -- x [B,C,N] -> idx int64 [B,N,k1] (every (k2//k1)-th of the k2 nearest)."""
+    with torch.no_grad():
+        idx = _knn_cl(x.transpose(1, 2), k2)
+    return idx[:, :, ::k2 // k1].long()
+
+
+class EdgeGatherFn(torch.autograd.Function):
+    """rows [(b,n,j), ld] = [x_j - x_i, x_i, 0-pad]  (upstream :98-105, channels-last)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, ld):
+        x = x.contiguous()
+        B, N, C = x.shape
+        k = idx.shape[2]
+        out = torch.empty(B * N * k, ld, dtype=torch.float32, device=x.device)
+        call("prifit_edge_gather", ptr(x), ptr(idx), B, N, C, k, ld, ptr(out), cur_stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, C, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, C, k = ctx.shape
+        g = g.contiguous()
+        dx = torch.zeros(B, N, C, dtype=torch.float32, device=g.device)
+        call("prifit_edge_scatter", ptr(g), g.stride(0), ptr(idx), B, N, C, k, ptr(dx), cur_stream())
+        return dx, None, None
+
+
+def get_graph_feature(x, k1=20, k2=20, idx=None):
+    """upstream :74-107 -- x [B,C,N] -> (feature [B,2C,N,k1], idx)."""
+    B, C, N = x.shape
+    xt = x.transpose(1, 2).contiguous()
+    if idx is None:
+        idx = knn(x, k1, k2)
+    rows = EdgeGatherFn.apply(xt, idx.int().contiguous(), _pad4(2 * C))
+    return rows[:, :2 * C].reshape(B, N, k1, 2 * C).permute(0, 3, 1, 2), idx
+
+
+class ConvGNActFn(torch.autograd.Function):
+    """conv1x1 (+bias) -> GroupNorm(groups) -> LeakyReLU(slope) [-> max over the K rows of each group].
+
+    x [P, Kin] channels-last rows, `rps` rows per sample (GroupNorm statistics are per sample, upstream
+    :157-159,171,231-246).  apply(x, W [Cout,Kin], bias|None, gamma, beta, cfg) with
+    cfg = dict(groups, rps, slope, pool_K, eps)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, gamma, beta, cfg):
+        x, W = x.contiguous(), W.contiguous()
+        P, Kin = x.shape
+        Cout = W.shape[0]
+        G, rps, slope, pool_K, eps = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"], cfg["eps"]
+        assert P % rps == 0 and rps % 512 == 0 and Cout % G == 0
+        Bs = P // rps
+        dev = x.device
+        Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+        nslab = (P + 127) // 128
+        slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+        gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab)
+        sums = slab.view(Bs, rps // 128, 2, Cout).double().sum(dim=1)            # [Bs, 2, C] per-sample column sums
+        m = float(rps * (Cout // G))
+        s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
+        s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
+        var = (s2 - s1 * s1).clamp_min(0.0)
+        invstd_g = torch.rsqrt(var + eps)
+        mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()       # [Bs, C] tables
+        invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
+        scale = (gamma.unsqueeze(0) * invstd).contiguous()
+        shift = (beta.unsqueeze(0) - mean * scale).contiguous()
+        arg = None
+        if pool_K:
+            Gp = P // pool_K
+            out = torch.empty(Gp, Cout, dtype=torch.float32, device=dev)
+            arg = torch.empty(Gp, Cout, dtype=torch.int32, device=dev)
+            call("prifit_pool_fwd", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope),
+                 ptr(out), _LL(Cout), ptr(arg), cur_stream())
+        else:
+            out = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            call("prifit_affine_relu", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), P, Cout, rps, _F(slope), ptr(out),
+                 _LL(Cout), cur_stream())
+        ctx.cfg = cfg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, W, gamma, Y, scale, shift, mean, invstd, *([arg] if arg is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cfg = ctx.cfg
+        x, W, gamma, Y, scale, shift, mean, invstd = ctx.saved_tensors[:8]
+        arg = ctx.saved_tensors[8] if len(ctx.saved_tensors) > 8 else None
+        P, Kin = x.shape
+        Cout = W.shape[0]
+        G, rps, slope, pool_K = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"]
+        Bs = P // rps
+        dev = x.device
+        gout = gout.contiguous()
+        rows = dll().prifit_reduce_rows_per_slab()
+        if pool_K:
+            Gp = P // pool_K
+            nslab = (Gp + rows - 1) // rows
+            slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+            call("prifit_pool_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+                 ptr(shift), ptr(mean), ptr(invstd), Gp, pool_K, Cout, rps, _F(slope), ptr(slab), cur_stream())
+        else:
+            nslab = (P + rows - 1) // rows
+            slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+            call("prifit_bn_relu_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
+                 ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), cur_stream())
+        S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)              # [Bs, 2, C]: sum Gm, sum Gm*yhat
+        dgamma = S[:, 1].sum(0).float()
+        dbeta = S[:, 0].sum(0).float()
+        m = float(rps * (Cout // G))
+        gd = gamma.double().unsqueeze(0)
+        m1 = (gd * S[:, 0]).view(Bs, G, -1).sum(-1) / m                          # group means of dyhat, dyhat*yhat
+        m2 = (gd * S[:, 1]).view(Bs, G, -1).sum(-1) / m
+        rep = Cout // G
+        m1c, m2c = m1.repeat_interleave(rep, dim=1), m2.repeat_interleave(rep, dim=1)
+        isd, mu = invstd.double(), mean.double()
+        ca = scale.contiguous()
+        cb = (-(isd * isd) * m2c).float().contiguous()
+        cd = (-isd * m1c + mu * isd * isd * m2c).float().contiguous()
+        dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+        if pool_K:
+            call("prifit_pool_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+                 ptr(shift), ptr(ca), ptr(cb), ptr(cd), P // pool_K, pool_K, Cout, rps, _F(slope), ptr(dY), _LL(Cout),
+                 cur_stream())
+        else:
+            call("prifit_bn_relu_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
+                 ptr(ca), ptr(cb), ptr(cd), P, Cout, rps, _F(slope), ptr(dY), _LL(Cout), cur_stream())
+        dW = nn_ops._weight_grad(dY, P, Cout, x, Kin, None) if ctx.needs_input_grad[1] else None
+        db = dY.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+            gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, dx, Kin)
+        return dx, dW, db, dgamma, dbeta, None
+
+
+def _w2d(conv, kp=None):
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    if kp is not None and kp > w.shape[1]:
+        w = torch.cat([w, w.new_zeros(w.shape[0], kp - w.shape[1])], dim=1)
+    return w
+
+
+class DGCNNEncoderGn(nn.Module):
+    def __init__(self, input_channels=3, nn_nb=80, dilation=1):
+        super().__init__()
+        if input_channels != 3:
+            raise NotImplementedError("the normals variant (input_channels=6) is not on the benchmarked path")
+        self.k = nn_nb
+        self.dilation_factor = dilation
+        self.drop = 0.0
+        self.input_channels = input_channels
+        self.bn1 = nn.GroupNorm(2, 64)
+        self.bn2 = nn.GroupNorm(2, 64)
+        self.bn3 = nn.GroupNorm(2, 128)
+        self.conv1 = nn.Sequential(nn.Conv2d(input_channels * 2, 64, kernel_size=1, bias=False), self.bn1,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.conv2 = nn.Sequential(nn.Conv2d(64 * 2, 64, kernel_size=1, bias=False), self.bn2,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.conv3 = nn.Sequential(nn.Conv2d(64 * 2, 128, kernel_size=1, bias=False), self.bn3,
+                                   nn.LeakyReLU(negative_slope=0.2))
+        self.mlp1 = nn.Conv1d(256, 1024, 1)
+        self.bnmlp1 = nn.GroupNorm(8, 1024)
+
+    def _edge_conv(self, feats, idx, seq, N):
+        conv, gn = seq[0], seq[1]
+        C = feats.shape[-1]
+        k = idx.shape[2]
+        ld = _pad4(2 * C)
+        rows = EdgeGatherFn.apply(feats, idx, ld)
+        cfg = {"groups": gn.num_groups, "rps": N * k, "slope": 0.2, "pool_K": k, "eps": gn.eps}
+        return ConvGNActFn.apply(rows, _w2d(conv, ld), None, gn.weight, gn.bias, cfg)   # [B*N, Cout]
+
+    def forward_cl(self, pts):
+        """pts [B,N,3] -> (x4 [B,1024], x_features [B*N,256]) channels-last."""
+        B, N, _ = pts.shape
+        k, k2 = self.k, self.k * self.dilation_factor
+        step = k2 // k
+        with torch.no_grad():
+            idx1 = _knn_cl(pts, k2)[:, :, ::step].contiguous()
+        x1 = self._edge_conv(pts, idx1, self.conv1, N)
+        with torch.no_grad():
+            idx2 = _knn_cl(x1.detach().view(B, N, -1), k2)[:, :, ::step].contiguous()
+        x2 = self._edge_conv(x1.view(B, N, -1), idx2, self.conv2, N)
+        x3 = self._edge_conv(x2.view(B, N, -1), idx2, self.conv3, N)      # re-uses the second graph (:191)
+        feats = torch.cat((x1, x2, x3), dim=1)
+        cfg = {"groups": self.bnmlp1.num_groups, "rps": N, "slope": 0.0, "pool_K": 0, "eps": self.bnmlp1.eps}
+        h = ConvGNActFn.apply(feats, _w2d(self.mlp1), self.mlp1.bias, self.bnmlp1.weight, self.bnmlp1.bias, cfg)
+        x4 = h.view(B, N, -1).max(dim=1)[0]
+        return x4, feats
+
+    def forward(self, x):
+        """x [B,3,N] -> (x4 [B,1024], x_features [B,256,N]) as upstream :171-197."""
+        B, _, N = x.shape
+        x4, feats = self.forward_cl(x.transpose(1, 2).contiguous())
+        return x4, feats.view(B, N, -1).permute(0, 2, 1)
+
+
+class DGCNGn(nn.Module):
+    def __init__(self, emb_size=128, num_channels=3, nn_nb=80, dilation=1):
+        super().__init__()
+        self.encoder = DGCNNEncoderGn(input_channels=num_channels, nn_nb=nn_nb, dilation=dilation)
+        self.drop = 0.0
+        self.conv1 = nn.Conv1d(1024 + 256, 512, 1)
+        self.bn1 = nn.GroupNorm(8, 512)
+        self.conv2 = nn.Conv1d(512, 256, 1)
+        self.bn2 = nn.GroupNorm(4, 256)
+        self.emb_size = emb_size
+        self.mlp_seg_prob1 = nn.Conv1d(256, 256, 1)
+        self.mlp_seg_prob2 = nn.Conv1d(256, self.emb_size, 1, bias=False)
+        self.bn_seg_prob1 = nn.GroupNorm(4, 256)
+        self.mlp_segmentation = nn.Conv1d(256, 3, 1)
+
+    def _block(self, x, conv, gn, N):
+        cfg = {"groups": gn.num_groups, "rps": N, "slope": 0.0, "pool_K": 0, "eps": gn.eps}
+        return ConvGNActFn.apply(x, _w2d(conv), conv.bias, gn.weight, gn.bias, cfg)
+
+    def forward(self, points):
+        B, _, N = points.shape
+        x4, feats = self.encoder.forward_cl(points.transpose(1, 2).contiguous())
+        x = torch.cat([x4.unsqueeze(1).expand(B, N, 1024).reshape(B * N, 1024), feats], dim=1)
+        x = self._block(x, self.conv1, self.bn1, N)
+        x_all = self._block(x, self.conv2, self.bn2, N)
+        x = self._block(x_all, self.mlp_seg_prob1, self.bn_seg_prob1, N)
+        seg = LinearFn.apply(x, _w2d(self.mlp_segmentation), self.mlp_segmentation.bias)
+        emb = LinearFn.apply(x, _w2d(self.mlp_seg_prob2), None)
+        return emb.view(B, N, -1), seg.view(B, N, 3).permute(0, 2, 1)
+
+
+class get_model(nn.Module):
+    """Adapter with the part-seg call surface the trainer expects for `'dgcnn' in args.model`
+    (train_partseg_shapenet.py:226-228): DGCNN embedding (src/dgcnn.py) + convex loss.  The reference ships
+    no such module; outputs follow the 5-tuple of the MSG model with `seg` from DGCNGn's head."""
+
+    def __init__(self, num_part, normal_channel=False, k=20):
+        super().__init__()
+        self.net = DGCNGn(emb_size=128, num_channels=6 if normal_channel else 3, nn_nb=k)
+        self.beta = 1
+
+    def forward(self, xyz, cls_label=None, chamfer_points=0, include_convex_loss=False, quantile=0.01,
+                msc_iterations=5, max_num_clusters=25, fit_inputs=None, **_unused):
+        emb, seg = self.net(xyz)
+        total = torch.zeros(1, device=xyz.device)
+        chamfer = torch.zeros(1, device=xyz.device)
+        extra = ()
+        if include_convex_loss:
+            from ..convex_loss import convex_loss
+            if self.beta > 0.001:
+                self.beta *= 0.99
+            fe = emb.permute(0, 2, 1)
+            total, chamfer, params, labels = convex_loss(xyz, chamfer_points, fe, quantile=quantile,
+                                                         iterations=msc_iterations,
+                                                         max_num_clusters=max_num_clusters, **(fit_inputs or {}))
+            extra = (labels, params, fe)
+        return (F.log_softmax(seg, dim=1).permute(0, 2, 1), None, emb.permute(0, 2, 1), total, chamfer) + extra
