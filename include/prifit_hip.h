@@ -119,7 +119,7 @@ int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const
  *   a_scale/a_shift (both or neither): operand A is read as max(a*scale[c]+shift[c], 0) with c the
  *     index along A's contiguous dimension (k for NT/NN, m for TN) -- the train-mode BatchNorm+ReLU
  *     of the producing layer applied on load.  b_scale/b_shift: the same for B (c = k for NT, n else).
- *   bias [N] or NULL.  col_stats [ceil(M/tile_m)][2][N] or NULL: per-M-tile partial column sums
+ *   bias [N] (element z*bias_batch_stride + n for batch z) or NULL.  col_stats [ceil(M/tile_m)][2][N] or NULL: per-M-tile partial column sums
  *     and sums of squares of the stored C (batch == 1, splitk == 1 only).
  *   accumulate != 0: C += result (C initialised by the caller).  splitk > 1: the K range is split
  *     over workgroups which add with float atomics (needs accumulate != 0 and PRIFIT_EPI_NONE).
@@ -133,7 +133,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     const float *B, long long ldb, long long strideB, float *C, long long ldc,
                     long long strideC, int batch, int splitk, const float *a_scale,
                     const float *a_shift, const float *b_scale, const float *b_shift,
-                    const float *bias, float *col_stats, int epilogue,
+                    const float *bias, long long bias_batch_stride, float *col_stats, int epilogue,
                     const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
                     long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
                     void *stream);
@@ -220,10 +220,32 @@ int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float
 int prifit_meanshift_update_fwd(const float *O, const float *rowsum, const float *Z, int D,
                                 long long rows, float *out, float *nrm, void *stream);
 
-/* Autograd of the update: g = dL/d(out) -> gO [rows, D] = dL/dO and g_rowsum [rows] = dL/d(rowsum). */
+/* Autograd of the update: g = dL/d(out) -> gO = dL/dO (shape b at gO + b*gO_batch_stride, [N, D] rows)
+ * and g_rowsum [B*N] = dL/d(rowsum). */
 int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O,
-                                const float *rowsum, int D, long long rows, float *gO,
-                                float *g_rowsum, void *stream);
+                                const float *rowsum, int D, int B, int N, float *gO,
+                                long long gO_batch_stride, float *g_rowsum, void *stream);
+
+/* Flash-style fused mean-shift iteration for D == 128 (src/mean_shift.py:61-82): one workgroup per 64
+ * points streams the dictionary X through LDS; S = Z X^T, K = exp(clamp((S-1)/b^2)) and O = K X are
+ * chained on the matrix cores without leaving registers, followed by the normalisation epilogue.
+ * Z, X [B,N,128]; bw [B].  Outputs: Znext [B,N,128]; saved for autograd: KT = K^T, element (b, key, query)
+ * at KT[b*stride_kt + key*ld_kt + query] (may be NULL), O [B,N,128] (may be NULL), rowsum [B,N], nrm [B,N]. */
+int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D,
+                               float *KT, long long ld_kt, long long stride_kt, float *Znext, float *O,
+                               float *rowsum, float *nrm, void *stream);
+/* dZ = gS X with gS = (gO X^T + g_rowsum 1^T) * K / b^2 (clamp-masked), same fused data flow;
+ * gST (may be NULL) receives gS^T in the layout of KT (for the dX GEMM). */
+int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, const float *X,
+                                  const float *bw, const float *g_rowsum, const float *KT, long long ld_kt,
+                                  long long stride_kt, float *gST, int B, int N, int D, float *dZ,
+                                  void *stream);
+/* dX += gS^T Z + K^T gO (both uses of the dictionary in one iteration) with gS re-formed in registers,
+ * key-major, N % 4 == 0.  (Alternative to one long-K GEMM on [gS^T | K^T]; kept for N where that buffer
+ * would not fit.) */
+int prifit_meanshift_fused_bwd_dx(const float *gO, const float *Z, const float *X, const float *bw,
+                                  const float *g_rowsum, const float *KT, long long ld_kt,
+                                  long long stride_kt, int B, int N, int D, float *dX, void *stream);
 
 /* Non-maximum suppression, src/mean_shift.py:162-202 called as nms(Z, Z, b) (:44).
  * dist [B,N,N] = 2 - 2 Z Z^T, Z [B,N,D], bw [B].  Outputs: owner [B,N] (nearest centre of each point),

@@ -24,6 +24,7 @@ SOURCES = {
     "gemm.hip": [],
     "bn.hip": [],
     "meanshift.hip": [],
+    "meanshift_fused.hip": [],
     "fit.hip": [],
     "dgcnn.hip": ["-ffp-contract=off"],
 }

@@ -29,7 +29,8 @@ struct GemmArgs {
     int batch, splitk;     // gridDim.z = batch * splitk
     const float *a_scale, *a_shift;  // prologue on A: a' = max(a*scale[c]+shift[c], 0), c = A's contiguous index
     const float *b_scale, *b_shift;  // same for B
-    const float *bias;               // [N], added to every row
+    const float *bias;               // [N] (+ z * bias_stride), added to every row
+    long long bias_stride;
     float *stats;                    // [tilesM][2][N] per-column partial (sum, sum of squares) of C
     int epi;
     const float *epi_batch_scalar;   // EPI_MSKERNEL / EPI_MSBWD: bandwidth b[z]
@@ -49,48 +50,81 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // Stage one operand tile (ROWS x BK, logical [row][k]) from global into registers.
 //  KC = true : stored [R][K] (k contiguous);  KC = false: stored [K][R] (row index contiguous).
 //  VEC: 16-byte loads (extents / strides multiples of 4 floats).  AFF: apply max(x*scale[c]+shift[c], 0).
-// Loads are branch-free: out-of-range lanes read a clamped (valid) address and the value is replaced
-// by zero afterwards, so that all loads of a tile are in flight together (hipcc serialises predicated
-// loads with a vmcnt(0) each).
+// Everything that does not depend on the k-tile (row clamps, row predicates, base pointers, the prologue
+// coefficients when the channel is the row) is computed once in init(); load(kt) is pointer + kt*step.
+// Loads are branch-free: out-of-range lanes read a clamped (valid) address and the value is zeroed
+// afterwards, so all loads of a tile are in flight together (hipcc serialises predicated loads with a
+// vmcnt(0) each).
 template <int ROWS, bool KC, bool VEC, bool AFF, int NTH>
 struct TileLoader {
     static constexpr int NV = ROWS * BK / 4 / NTH;  // float4 per thread
     static_assert(NV * NTH * 4 == ROWS * BK, "tile must divide evenly over the threads");
     float4 v[NV];
+    const float *ptr[NV];   // element 0 of this thread's float4 in k-tile 0 (row / column clamped into range)
+    int klo[NV];            // k index of element 0 inside the tile
+    int c0[NV];             // !KC: channel (= global row index) of element 0
+    unsigned okmask[NV];    // per element: the row / column exists
+    long long step;         // pointer increment per k-tile
+    int K, R, cclamp;
 
-    __device__ __forceinline__ void load(const float *__restrict__ base, long long ld, int r0, int k0, int R,
-                                         int K, const float *__restrict__ scale,
-                                         const float *__restrict__ shift)
+    __device__ __forceinline__ void init(const float *__restrict__ base, long long ld, int r0, int R_, int K_)
     {
+        K = K_; R = R_;
+        step = KC ? (long long)BK : (long long)BK * ld;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int id = threadIdx.x + NTH * p;
-            int gr, gk, c0;  // global row / k of element 0, channel (index along the contiguous dim) of element 0
-            if (KC) { gr = r0 + id / (BK / 4); gk = k0 + (id % (BK / 4)) * 4; c0 = gk; }
-            else { gk = k0 + id / (ROWS / 4); gr = r0 + (id % (ROWS / 4)) * 4; c0 = gr; }
-            const int cext = KC ? K : R;  // extent along the contiguous dimension
-            const bool line_ok = KC ? (gr < R) : (gk < K);
-            const long long line = KC ? (long long)(line_ok ? gr : 0) : (long long)(line_ok ? gk : 0);
-            const float *row = base + line * ld;
+            if (KC) {
+                const int gr = r0 + id / (BK / 4);
+                klo[p] = (id % (BK / 4)) * 4;
+                okmask[p] = gr < R ? 0xFu : 0u;
+                // K < BK: columns beyond K are never valid; keep the pointer inside the row
+                ptr[p] = base + (long long)(gr < R ? gr : 0) * ld + (klo[p] < K ? klo[p] : 0);
+                c0[p] = 0;
+            } else {
+                klo[p] = id / (ROWS / 4);
+                const int gr = r0 + (id % (ROWS / 4)) * 4;
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m |= (gr + j < R) ? (1u << j) : 0u;
+                okmask[p] = m;
+                c0[p] = m ? gr : 0;
+                ptr[p] = base + (long long)klo[p] * ld + c0[p];
+            }
+        }
+    }
+
+    __device__ __forceinline__ void load(int k0, const float *__restrict__ scale, const float *__restrict__ shift)
+    {
+        const int kt = k0 / BK;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            // k validity of this float4 (KC: 4 consecutive k; !KC: one k row)
+            const int gk = k0 + klo[p];
+            const bool kin = gk < K;                       // element 0 (VEC: K % 4 == 0 covers all four)
+            const float *src = ptr[p] + (kin ? (long long)kt * step : 0);
+            if (!KC && !kin && klo[p] >= K) src = ptr[p] - (long long)klo[p] * (step / BK);  // K < BK: stay in row 0
             float4 x;
             if (VEC) {
-                const bool ok = line_ok && c0 < cext;
-                x = ld4(row + (ok ? c0 : 0));
+                x = ld4(src);
                 if (AFF) {
-                    const float4 s = ld4(scale + (ok ? c0 : 0)), t = ld4(shift + (ok ? c0 : 0));
+                    const int cc = KC ? (kin ? gk : 0) : c0[p];
+                    const float4 s = ld4(scale + cc), t = ld4(shift + cc);
                     x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
                     x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
                 }
-                if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(kin && okmask[p])) x = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = line_ok && (c0 + j) < cext;
-                    const int cc = ok ? c0 + j : 0;
-                    float val = row[cc];
-                    if (AFF) val = fmaxf(fmaf(val, scale[cc], shift[cc]), 0.f);
-                    e[j] = ok ? val : 0.f;
+                    const bool ok = KC ? (okmask[p] && (gk + j) < K) : (kin && ((okmask[p] >> j) & 1u));
+                    float val = ok ? src[j] : 0.f;
+                    if (AFF && ok) {
+                        const int cc = KC ? gk + j : c0[p] + j;
+                        val = fmaxf(fmaf(val, scale[cc], shift[cc]), 0.f);
+                    }
+                    e[j] = val;
                 }
                 x = make_float4(e[0], e[1], e[2], e[3]);
             }
@@ -125,7 +159,7 @@ __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int r
 
 // VA/VB: vector loads legal for A/B; FA/FB: BatchNorm+ReLU prologue on A/B.
 template <int BM, int BN, int WM, int WN, int LAY, bool VA, bool VB, bool FA, bool FB>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmArgs g)
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) == 8 ? 6 : 4)) void gemm_kernel(const GemmArgs g)
 {
     constexpr int NTH = (BM / WM) * (BN / WN) * 64;
     constexpr bool A_KC = (LAY != LAY_TN);
@@ -135,8 +169,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     static_assert(NTH == 256 || NTH == 512, "4 or 8 waves per block");
     constexpr int SZA = A_KC ? BM * (BK + PAD) : BK * (BM + PAD);
     constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
-    __shared__ __attribute__((aligned(16))) float lds[SZA + SZB];
-    float *As = lds, *Bs = lds + SZA;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];  // two stages
 
     // XCD-aware bijective remap: logical tiles that share an A panel get ids that are consecutive on
     // one XCD (hardware deals consecutive workgroup ids round-robin over the 8 XCDs).
@@ -174,27 +207,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 
     TileLoader<BM, A_KC, VA, FA, NTH> la;
     TileLoader<BN, B_KC, VB, FB, NTH> lb;
-    if (kt0 < kt1) {
-        la.load(A, g.lda, m0, kt0 * BK, g.M, g.K, g.a_scale, g.a_shift);
-        lb.load(B, g.ldb, n0, kt0 * BK, g.N, g.K, g.b_scale, g.b_shift);
-    }
+    la.init(A, g.lda, m0, g.M, g.K);
+    lb.init(B, g.ldb, n0, g.N, g.K);
     constexpr int NVA = TileLoader<BM, A_KC, VA, FA, NTH>::NV;
     float rs[NVA];
 #pragma unroll
     for (int p = 0; p < NVA; ++p) rs[p] = 0.f;
     const bool want_rowsum = A_KC && g.a_rowsum != nullptr && tile_n == 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        __syncthreads();  // previous tile's fragment reads are done
-        la.store(As);
-        lb.store(Bs);
+
+    // Software pipeline: tile kt is computed from LDS stage s while tile kt+1 travels global -> registers;
+    // it is written to stage s^1 after the MFMAs (nobody reads s^1 any more: the barrier that ended the
+    // previous iteration) and one barrier per k-tile publishes it.
+    if (kt0 < kt1) {
+        la.load(kt0 * BK, g.a_scale, g.a_shift);
+        lb.load(kt0 * BK, g.b_scale, g.b_shift);
+        la.store(lds);
+        lb.store(lds + SZA);
         if (want_rowsum) {
 #pragma unroll
             for (int p = 0; p < NVA; ++p) rs[p] += (la.v[p].x + la.v[p].y) + (la.v[p].z + la.v[p].w);
         }
-        __syncthreads();
-        if (kt + 1 < kt1) {
-            la.load(A, g.lda, m0, (kt + 1) * BK, g.M, g.K, g.a_scale, g.a_shift);
-            lb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, g.b_scale, g.b_shift);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int stage = (kt - kt0) & 1;
+        const float *As = lds + stage * (SZA + SZB), *Bs = As + SZA;
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            la.load((kt + 1) * BK, g.a_scale, g.a_shift);
+            lb.load((kt + 1) * BK, g.b_scale, g.b_shift);
         }
 #pragma unroll
         for (int gk = 0; gk < BK / 8; ++gk) {
@@ -213,6 +254,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
                 }
         }
+        if (more) {
+            float *An = lds + (stage ^ 1) * (SZA + SZB);
+            la.store(An);
+            lb.store(An + SZA);
+            if (want_rowsum) {
+#pragma unroll
+                for (int p = 0; p < NVA; ++p) rs[p] += (la.v[p].x + la.v[p].y) + (la.v[p].z + la.v[p].w);
+            }
+        }
+        __syncthreads();
     }
 
     if (want_rowsum) {  // KC staging: float4 p of thread t belongs to row (t + 256 p) / 8; 8 lanes share a row
@@ -225,6 +276,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             const int row = m0 + (threadIdx.x + NTH * p) / (BK / 4);
             if ((threadIdx.x & 7) == 0 && row < g.M) g.a_rowsum[(long long)z * g.M + row] = v;
         }
+    }
+
+    if (g.epi == 100) {  // timing-only build switch (tools/gemm_bench.py --nostore): price of the epilogue
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[a][b][r]));
+        return;
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -257,7 +318,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int b = 0; b < TN; ++b) {
         const int col = n0 + wn0 + 32 * b + li;
         const bool cok = col < g.N;
-        const float bias = (g.bias && cok && ks == 0) ? g.bias[col] : 0.f;
+        const float bias = (g.bias && cok && ks == 0) ? g.bias[(long long)z * g.bias_stride + col] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int rbase = m0 + wm0 + 32 * a + 4 * lh;
@@ -372,13 +433,13 @@ int prifit_gemm_tile_m(int N)
 int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long lda, long long strideA,
                     const float *B, long long ldb, long long strideB, float *C, long long ldc,
                     long long strideC, int batch, int splitk, const float *a_scale, const float *a_shift,
-                    const float *b_scale, const float *b_shift, const float *bias, float *col_stats,
-                    int epilogue, const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
+                    const float *b_scale, const float *b_shift, const float *bias, long long bias_batch_stride,
+                    float *col_stats, int epilogue, const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
                     long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
                     void *stream)
 {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0 || layout < 0 || layout > 2 ||
-        epilogue < 0 || epilogue > 3 || (epilogue >= EPI_MSKERNEL && !epi_batch_scalar) ||
+        (epilogue != 100 && (epilogue < 0 || epilogue > 3)) || (epilogue >= EPI_MSKERNEL && !epi_batch_scalar) ||
         (epilogue == EPI_MSBWD && !epi_aux) || (splitk > 1 && !accumulate) ||
         ((a_scale == nullptr) != (a_shift == nullptr)) || ((b_scale == nullptr) != (b_shift == nullptr)) ||
         (col_stats && (batch != 1 || splitk != 1)) || (epilogue != EPI_NONE && splitk != 1) || (long long)batch * splitk > 65535)
@@ -388,7 +449,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.batch = batch; g.splitk = splitk;
     g.a_scale = a_scale; g.a_shift = a_shift; g.b_scale = b_scale; g.b_shift = b_shift;
-    g.bias = bias; g.stats = col_stats; g.epi = epilogue; g.epi_batch_scalar = epi_batch_scalar;
+    g.bias = bias; g.bias_stride = bias_batch_stride; g.stats = col_stats; g.epi = epilogue; g.epi_batch_scalar = epi_batch_scalar;
     g.accumulate = accumulate; g.aux = epi_aux; g.ldaux = ld_aux; g.sAux = stride_aux;
     g.row_add = epi_row_add; g.a_rowsum = a_rowsum;
     if (a_rowsum && (layout == LAY_TN || splitk != 1)) return PRIFIT_EINVAL;

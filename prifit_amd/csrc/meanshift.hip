@@ -94,12 +94,14 @@ __global__ __launch_bounds__(256) void ms_update_bwd_kernel(const float *__restr
                                                             const float *__restrict__ nrm,
                                                             const float *__restrict__ O,
                                                             const float *__restrict__ rsum, int D,
-                                                            long long rows, float *__restrict__ gO,
+                                                            long long rows, int rows_per_batch,
+                                                            long long gO_batch_stride, float *__restrict__ gO,
                                                             float *__restrict__ grs)
 {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
+    float *gOr = gO + (row / rows_per_batch) * gO_batch_stride + (row % rows_per_batch) * D;
     const float *o = O + row * D;
     const float rinv = 1.0f / rsum[row];
     const float ninv = 1.0f / nrm[row];
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void ms_update_bwd_kernel(const float *__restr
         if (c < D) {
             const float gnew = (gg[j] - oo[j] * dot) * ninv;  // through the normalisation
             const float mv = o[c] * rinv;
-            gO[row * D + c] = gnew * rinv;                   // d/dO[c] of O[c]/r
+            gOr[c] = gnew * rinv;                            // d/dO[c] of O[c]/r
             gr -= gnew * mv;
         }
     }
@@ -328,13 +330,15 @@ int prifit_meanshift_update_fwd(const float *O, const float *rowsum, const float
 }
 
 int prifit_meanshift_update_bwd(const float *g, const float *out, const float *nrm, const float *O,
-                                const float *rowsum, int D, long long rows, float *gO, float *g_rowsum,
-                                void *stream)
+                                const float *rowsum, int D, int B, int N, float *gO, long long gO_batch_stride,
+                                float *g_rowsum, void *stream)
 {
-    if (!g || !out || !nrm || !O || !rowsum || !gO || !g_rowsum || rows <= 0 || D <= 0 || D > 256)
+    if (!g || !out || !nrm || !O || !rowsum || !gO || !g_rowsum || B <= 0 || N <= 0 || D <= 0 || D > 256 ||
+        gO_batch_stride < (long long)N * D)
         return PRIFIT_EINVAL;
+    const long long rows = (long long)B * N;
     hipLaunchKernelGGL(ms_update_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), g,
-                       out, nrm, O, rowsum, D, rows, gO, g_rowsum);
+                       out, nrm, O, rowsum, D, rows, N, gO_batch_stride, gO, g_rowsum);
     return prifit_check_launch();
 }
 

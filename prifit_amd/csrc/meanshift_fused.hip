@@ -1,0 +1,393 @@
+// Flash-style fused mean-shift iteration (src/mean_shift.py:61-82) for D = 128 on gfx950.
+//
+// One workgroup = 64 points ("queries") of one shape; it streams the whole dictionary X of that shape
+// through LDS in tiles of 64 rows ("keys") and never materialises the N x N score matrix in LDS or
+// registers beyond one 32 x 32 MFMA tile per wave:
+//     S^T tile = X_sub . Z_q^T          (v_mfma_f32_32x32x2_f32, keys on the accumulator rows,
+//                                        queries on the lanes)
+//     P        = exp(clamp((S - 1) / b^2, -13, 75))      in registers
+//     O_q     += P . X_sub              the accumulator registers of P are fed straight back as the
+//                                        A operand of the second MFMA (k index = key = register index)
+// Waves 0/1 own query rows 0-31 / 32-63 for the even 32-key sub-tiles, waves 2/3 the odd ones; the two
+// partial (O, rowsum) pairs are added through LDS at the end, followed by the normalisation epilogue
+// new = Z + (O/rowsum - Z); out = new / |new|.
+//
+// MODE 0 (forward) optionally streams P^T out (KT[key][query], coalesced: queries on lanes) for the
+// backward pass.  MODE 1 (backward, dZ): the same data flow with P replaced by
+//     gS^T = (X_sub . gO_q^T + g_rowsum_q) * K^T / b^2   where the clamp was inactive,
+// accumulating dZ_q += gS . X_sub, no normalisation.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int D = 128;        // embedding width (models/pointnet2_part_seg_msg.py:46: extra_conv_emb 128 -> 128)
+constexpr int QB = 64;        // queries per workgroup
+constexpr int KB = 64;        // keys per LDS tile
+constexpr int LDSW = D + 4;   // padded row: conflict-free ds_read_b128 fragments (132 * i mod 64 distinct)
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// global [rows x 128] tile -> registers (8 float4 per thread, 256 threads); rows beyond `nrows` read row 0 and are zeroed
+struct Tile64 {
+    float4 v[8];
+    __device__ __forceinline__ void load(const float *__restrict__ base, int row0, int nrows)
+    {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int id = threadIdx.x + 256 * p;  // 64 rows x 32 float4
+            const int r = id >> 5, c = (id & 31) * 4;
+            const bool ok = row0 + r < nrows;
+            float4 x = ld4(base + (size_t)(ok ? row0 + r : 0) * D + c);
+            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            v[p] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int id = threadIdx.x + 256 * p;
+            *reinterpret_cast<float4 *>(lds + (id >> 5) * LDSW + (id & 31) * 4) = v[p];
+        }
+    }
+};
+}  // namespace
+
+// Q: the query-side operand rows (Z for MODE 0, gO for MODE 1) [B,N,128]; X: dictionary [B,N,128].
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void ms_fused_kernel(
+    const float *__restrict__ Q, long long q_stride, const float *__restrict__ X, const float *__restrict__ bw,
+    int N, const float *__restrict__ row_add,   // q_stride: batch stride of Q; row_add (MODE 1): g_rowsum [B,N]
+    float *__restrict__ KT,              // MODE 0: out (may be NULL); MODE 1: in.  [B, N(keys), ldk] (queries contiguous)
+    long long ldk, long long sk,         // row / batch stride of KT and GST
+    float *__restrict__ GST,             // MODE 1: optional output gS^T, same layout as KT
+    const float *__restrict__ Zin,       // MODE 0: current points (== Q) for the epilogue
+    float *__restrict__ out,             // MODE 0: normalised new points; MODE 1: dZ   [B,N,128]
+    float *__restrict__ O_out, float *__restrict__ rsum_out, float *__restrict__ nrm_out)  // MODE 0 saves
+{
+    __shared__ __attribute__((aligned(16))) float s_q[QB * LDSW];
+    __shared__ __attribute__((aligned(16))) float s_x[KB * LDSW];
+    __shared__ float s_rs[2 * QB];
+
+    const int b = blockIdx.y, q0 = blockIdx.x * QB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qg = wave & 1, kh = wave >> 1;  // query group (32 rows), key half
+    const float *Qb = Q + (size_t)b * q_stride;
+    const float *Xb = X + (size_t)b * N * D;
+    const float bwv = bw[b];
+    const float rcp_b2 = 1.0f / (bwv * bwv);
+    const float kmin = __expf(-13.0f);
+
+    Tile64 t;
+    t.load(Qb, q0, N);
+    t.store(s_q);
+    t.load(Xb, 0, N);
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float rsum = 0.f;
+    const int qrow = qg * 32 + li;             // this lane's query row inside the tile
+    const int gq = q0 + qrow;                  // global query index
+    const bool q_ok = gq < N;
+    const float radd = (MODE == 1 && q_ok) ? row_add[(size_t)b * N + gq] : 0.f;
+    float *KTb = KT ? KT + (size_t)b * sk : nullptr;
+    float *GSb = (MODE == 1 && GST) ? GST + (size_t)b * sk : nullptr;
+
+    for (int k0 = 0; k0 < N; k0 += KB) {
+        __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
+        t.store(s_x);
+        __syncthreads();
+        if (k0 + KB < N) t.load(Xb, k0 + KB, N);
+
+        // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
+        const float *xa = s_x + (kh * 32 + li) * LDSW + lh * 4;
+        const float *qb = s_q + qrow * LDSW + lh * 4;
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4 *>(xa + g * 8);
+            const float4 bq = *reinterpret_cast<const float4 *>(qb + g * 8);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, sacc, 0, 0, 0);
+        }
+        // ---- elementwise transform; accumulator register r of lane (query li, half lh) is key (r&3)+8(r>>2)+4lh
+        const int key_base = k0 + kh * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key_base + (r & 3) + 8 * (r >> 2);
+            const bool ok = key < N && q_ok;
+            float p;
+            if (MODE == 0) {
+                // src/mean_shift.py:65-68 with src/guard.py:6-11
+                const float dist = 2.0f - 2.0f * sacc[r];
+                float e = (-dist * rcp_b2) * 0.5f;
+                e = fminf(fmaxf(e, -13.0f), 75.0f);
+                p = ok ? __expf(e) : 0.f;
+                rsum += p;
+                if (KTb && ok) KTb[(size_t)key * ldk + gq] = p;
+            } else {
+                const float kf = ok ? KTb[(size_t)key * ldk + gq] : 0.f;
+                p = kf > kmin ? (sacc[r] + radd) * kf * rcp_b2 : 0.f;
+                if (GSb && ok) GSb[(size_t)key * ldk + gq] = p;
+            }
+            sacc[r] = p;
+        }
+        // ---- O_q += P . X_sub : A = P from the accumulator registers (k = key), B = X_sub[key][d]
+        const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *row = xs + ((r & 3) + 8 * (r >> 2)) * LDSW;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], row[32 * d], oacc[d], 0, 0, 0);
+        }
+    }
+
+    // ---- combine the two key halves: waves 2,3 park their partials in LDS (the X tile is dead now)
+    __syncthreads();
+    // layout of a partial O tile: [d 0..127][33 query slots] so that lanes (d) are conflict-free
+    float *s_part = s_x;  // needs 2 * 32 * 128 floats = 32 KiB <= 33 KiB
+    if (MODE == 0) {
+        rsum += __shfl_xor(rsum, 32, 64);  // both key sub-rows of this wave
+        if (lh == 0) s_rs[kh * QB + qrow] = rsum;
+    }
+    if (kh == 1) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;  // O accumulator: row = query, col (lane) = d
+                s_part[(qg * 32 + qr) * D + 32 * d + li] = oacc[d][r];
+            }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            oacc[d][r] += s_part[(qg * 32 + qr) * D + 32 * d + li];
+        }
+
+    float *outb = out + (size_t)b * N * D;
+    if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = q0 + qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (gr >= N) continue;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) outb[(size_t)gr * D + 32 * d + li] = oacc[d][r];
+        }
+        return;
+    }
+    // ---- MODE 0 epilogue (src/mean_shift.py:70-82): Mv = O / rowsum; new = Z + (Mv - Z); out = new / |new|
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qr = qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gr = q0 + qr;
+        const float rs = s_rs[qr] + s_rs[QB + qr];
+        const float dinv = 1.0f / rs;
+        float nv[4];
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float z = s_q[qr * LDSW + 32 * d + li];
+            const float m = oacc[d][r] * dinv - z;
+            nv[d] = z + m;
+            ss += nv[d] * nv[d];
+        }
+        // sum over the 32 lanes of this half (d = 32 per tile x 4 tiles already added locally)
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float nrm = sqrtf(ss);
+        if (gr < N) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                outb[(size_t)gr * D + 32 * d + li] = nv[d] / nrm;
+                if (O_out) O_out[((size_t)b * N + gr) * D + 32 * d + li] = oacc[d][r];
+            }
+            if (li == 0) {
+                nrm_out[(size_t)b * N + gr] = nrm;
+                rsum_out[(size_t)b * N + gr] = rs;
+            }
+        }
+    }
+}
+
+// Backward w.r.t. the dictionary X (both of its uses in one iteration), key-major:
+//     dX_j += sum_q gS[q][j] Z_q + sum_q K[q][j] gO_q,   gS = (gO X^T + g_rowsum 1^T) * K / b^2 (clamp-masked)
+// One workgroup = 64 keys; it streams the query-side rows (gO and Z, 64 per tile) through LDS.  Waves 0/1
+// own keys 0-31 / 32-63 for query sub-tile 0, waves 2/3 for sub-tile 1 (combined through LDS at the end).
+//     T tile = gO_sub . X_j^T           (queries on the accumulator rows, keys on the lanes; X_j fragments
+//                                        stay in registers for the whole kernel)
+//     gS, K                             in registers (K^T is read as 4 float4 per lane along the query axis)
+//     dX_j  += gS^T . Z_sub + K^T . gO_sub   both A operands come straight from registers (k index = query)
+__global__ __launch_bounds__(256, 2) void ms_fused_dx_kernel(
+    const float *__restrict__ gO, const float *__restrict__ Zc, const float *__restrict__ X,
+    const float *__restrict__ bw, const float *__restrict__ row_add, const float *__restrict__ KT, long long ldk,
+    long long sk, int N, float *__restrict__ dX)
+{
+    __shared__ __attribute__((aligned(16))) float s_g[QB * LDSW];   // gO tile (64 queries)
+    __shared__ __attribute__((aligned(16))) float s_z[QB * LDSW];   // Z tile
+    __shared__ float s_ra[QB];
+
+    const int b = blockIdx.y, k0 = blockIdx.x * KB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kg = wave & 1, qh = wave >> 1;  // key group (32 keys), query half of every 64-query tile
+    const float *Gb = gO + (size_t)b * N * D;
+    const float *Zb = Zc + (size_t)b * N * D;
+    const float *Xb = X + (size_t)b * N * D;
+    const float *KTb = KT + (size_t)b * sk;
+    const float *RAb = row_add + (size_t)b * N;
+    const float bwv = bw[b];
+    const float rcp_b2 = 1.0f / (bwv * bwv);
+    const float kmin = __expf(-13.0f);
+
+    // this lane's key and its X row fragments (B operand of T = gO X^T): k = 8g + 4 lh + j
+    const int gkey = k0 + kg * 32 + li;
+    const bool key_ok = gkey < N;
+    float4 xf[D / 8];
+#pragma unroll
+    for (int g = 0; g < D / 8; ++g) {
+        xf[g] = ld4(Xb + (size_t)(key_ok ? gkey : 0) * D + g * 8 + lh * 4);
+        if (!key_ok) xf[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    Tile64 tg, tz;
+    tg.load(Gb, 0, N);
+    tz.load(Zb, 0, N);
+    for (int q0 = 0; q0 < N; q0 += QB) {
+        __syncthreads();
+        tg.store(s_g);
+        tz.store(s_z);
+        if (threadIdx.x < QB) s_ra[threadIdx.x] = (q0 + threadIdx.x) < N ? RAb[q0 + threadIdx.x] : 0.f;
+        __syncthreads();
+        if (q0 + QB < N) { tg.load(Gb, q0 + QB, N); tz.load(Zb, q0 + QB, N); }
+
+        // K values for (query register r, key lane): K^T[key][q0 + qh*32 + 8g + 4lh .. +3], 4 float4 per lane
+        const int qbase = q0 + qh * 32 + 4 * lh;
+        float4 kq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool ok = key_ok && (qbase + 8 * g + 3) < N;  // N % 4 == 0 is checked by the launcher
+            kq[g] = ld4(KTb + (size_t)(key_ok ? gkey : 0) * ldk + (ok ? qbase + 8 * g : 0));
+            if (!ok) kq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // T[q][key] : A = gO_sub rows (query = lane), B = X_j fragments
+        const float *ga = s_g + (qh * 32 + li) * LDSW + lh * 4;
+        f32x16 tacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tacc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4 *>(ga + g * 8);
+            tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xf[g].x, tacc, 0, 0, 0);
+            tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xf[g].y, tacc, 0, 0, 0);
+            tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xf[g].z, tacc, 0, 0, 0);
+            tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xf[g].w, tacc, 0, 0, 0);
+        }
+        // register r <-> query qh*32 + (r&3) + 8(r>>2) + 4lh ; kq[r>>2] component (r&3)
+        float kf[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { kf[4 * g] = kq[g].x; kf[4 * g + 1] = kq[g].y; kf[4 * g + 2] = kq[g].z; kf[4 * g + 3] = kq[g].w; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = qh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            tacc[r] = kf[r] > kmin ? (tacc[r] + s_ra[qr]) * kf[r] * rcp_b2 : 0.f;
+        }
+        // dX_j += gS^T . Z_sub + K^T . gO_sub   (A from registers: k = query; B rows of the LDS tiles)
+        const float *zs = s_z + (qh * 32 + 4 * lh) * LDSW + li;
+        const float *gs = s_g + (qh * 32 + 4 * lh) * LDSW + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = ((r & 3) + 8 * (r >> 2)) * LDSW;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(tacc[r], zs[ro + 32 * d], acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[r], gs[ro + 32 * d], acc[d], 0, 0, 0);
+            }
+        }
+    }
+    // combine the two query halves and accumulate into dX
+    __syncthreads();
+    float *s_part = s_g;
+    if (qh == 1) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s_part[(kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + 32 * d + li] = acc[d][r];
+    }
+    __syncthreads();
+    if (qh == 1) return;
+    float *dXb = dX + (size_t)b * N * D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kr = kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // accumulator row = key
+        if (k0 + kr >= N) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float *dst = dXb + (size_t)(k0 + kr) * D + 32 * d + li;
+            *dst += acc[d][r] + s_part[kr * D + 32 * d + li];
+        }
+    }
+}
+
+extern "C" {
+
+int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D_, float *KT,
+                               long long ld_kt, long long stride_kt, float *Znext, float *O, float *rowsum,
+                               float *nrm, void *stream)
+{
+    if (!Z || !X || !bw || !Znext || !rowsum || !nrm || B <= 0 || N <= 0 || D_ != D || B > 65535 ||
+        (KT && ld_kt < N))
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL((ms_fused_kernel<0>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), Z,
+                       (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                       Znext, O, rowsum, nrm);
+    return prifit_check_launch();
+}
+
+int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, const float *X, const float *bw,
+                                  const float *g_rowsum, const float *KT, long long ld_kt, long long stride_kt,
+                                  float *gST, int B, int N, int D_, float *dZ, void *stream)
+{
+    if (!gO || !X || !bw || !g_rowsum || !KT || !dZ || B <= 0 || N <= 0 || D_ != D || B > 65535 || ld_kt < N ||
+        gO_batch_stride < (long long)N * D)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL((ms_fused_kernel<1>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
+                       gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST, (const float *)nullptr, dZ,
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    return prifit_check_launch();
+}
+
+int prifit_meanshift_fused_bwd_dx(const float *gO, const float *Z, const float *X, const float *bw,
+                                  const float *g_rowsum, const float *KT, long long ld_kt, long long stride_kt,
+                                  int B, int N, int D_, float *dX, void *stream)
+{
+    if (!gO || !Z || !X || !bw || !g_rowsum || !KT || !dX || B <= 0 || N <= 0 || (N & 3) || (ld_kt & 3) ||
+        ld_kt < N || D_ != D || B > 65535)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(ms_fused_dx_kernel, dim3((N + KB - 1) / KB, B), dim3(256), 0, as_stream(stream), gO, Z, X, bw,
+                       g_rowsum, KT, ld_kt, stride_kt, N, dX);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

@@ -18,6 +18,7 @@ _LL = ctypes.c_longlong
 KM = 32          # cluster slots per shape (>= max_num_clusters = 25, src/ellipsoid_utils.py:6)
 NMS_CAP = 64     # centre ids kept by nms before the cluster-count check
 SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106)
+BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "gemm")  # mean-shift backward engine: "gemm" | "fused"
 
 
 def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
@@ -56,23 +57,30 @@ class MeanShiftFn(torch.autograd.Function):
         X = X.contiguous()
         Bt, N, D = X.shape
         dev = X.device
+        fused = D == 128  # flash-style kernel (csrc/meanshift_fused.hip); other widths take the GEMM chain
         Z = X.clone()
         saved = []
         for _ in range(iterations):
-            Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
-            _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
+            Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)  # fused: K^T [key][query]; else K
             O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
             rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
-            _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X and rowsum(K)
             Zn = torch.empty_like(Z)
             nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
-            call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
-                 cur_stream())
+            if fused:
+                with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
+                    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
+                         _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), cur_stream())
+            else:
+                _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
+                _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X, rowsum(K)
+                call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
+                     cur_stream())
             saved += [Z, Kmat, O, rsum, Zn, nrm]
             Z = Zn
         # save_for_backward (not a python attribute): the last Zn IS the output, and an attribute would close a
         # reference cycle output -> grad_fn -> ctx -> output that only the cyclic GC frees (4 GB of K per step)
         ctx.save_for_backward(X, bw, *saved)
+        ctx.fused = fused
         return Z
 
     @staticmethod
@@ -84,19 +92,39 @@ class MeanShiftFn(torch.autograd.Function):
         dev = X.device
         g = g.contiguous()
         gX = torch.zeros(Bt, N, D, dtype=torch.float32, device=dev)
-        gS = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
+        # Backward engine for the fused (K^T) layout.  "gemm" (default): MFMA GEMM chain, 4 N^2 D products per
+        # iteration.  "fused": flash-style kernels that re-form gS in registers (5 products, no gS in HBM); measured
+        # slower on MI355X at N=2048 (profiles/), kept selectable and parity-tested.
+        mode = BWD_MODE if (ctx.fused and N % 4 == 0) else "gemm"
+        gS = None if mode == "fused" else torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
         gO = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
         grs = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+        sM, sV = N * N, N * D
         for Z, Kmat, O, rsum, Zn, nrm in reversed(saved):
-            call("prifit_meanshift_update_bwd", ptr(g), ptr(Zn), ptr(nrm), ptr(O), ptr(rsum), D, _LL(Bt * N), ptr(gO),
-                 ptr(grs), cur_stream())
-            # dL/dS = (gO X^T + g_rowsum 1^T) * K / b^2 where the clamp is inactive
-            _bgemm(NT, N, N, D, gO, D, X, D, gS, N, Bt, N * D, N * D, N * N, epi=EPI_MSBWD, epi_scalar=bw,
-                   aux=Kmat, ld_aux=N, s_aux=N * N, row_add=grs)
+            call("prifit_meanshift_update_bwd", ptr(g), ptr(Zn), ptr(nrm), ptr(O), ptr(rsum), D, Bt, N, ptr(gO),
+                 _LL(sV), ptr(grs), cur_stream())
             gZ = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
-            _bgemm(NN, N, D, N, gS, N, X, D, gZ, D, Bt, N * N, N * D, N * D)                      # dZ = dS X
-            _bgemm(TN, N, D, N, gS, N, Z, D, gX, D, Bt, N * N, N * D, N * D, accumulate=True)     # dX += dS^T Z
-            _bgemm(TN, N, D, N, Kmat, N, gO, D, gX, D, Bt, N * N, N * D, N * D, accumulate=True)  # dX += K^T dO
+            if mode == "fused":
+                with profiler.span("ms_fused_bwd", 10.0 * Bt * N * N * D):
+                    call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
+                         _LL(N), _LL(sM), None, Bt, N, D, ptr(gZ), cur_stream())              # dZ  = gS X
+                    call("prifit_meanshift_fused_bwd_dx", ptr(gO), ptr(Z), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
+                         _LL(N), _LL(sM), Bt, N, D, ptr(gX), cur_stream())                    # dX += gS^T Z + K^T gO
+            elif ctx.fused:
+                # the transposed (key-major) orientation of the saved K^T:
+                # gS^T = (X gO^T + 1 g_rowsum^T) * K^T / b^2 where the clamp is inactive
+                _bgemm(NT, N, N, D, X, D, gO, D, gS, N, Bt, sV, sV, sM, epi=EPI_MSBWD, epi_scalar=bw, aux=Kmat,
+                       ld_aux=N, s_aux=sM, bias=grs, bias_stride=N)
+                _bgemm(TN, N, D, N, gS, N, X, D, gZ, D, Bt, sM, sV, sV)                       # dZ  = gS X
+                _bgemm(NN, N, D, N, gS, N, Z, D, gX, D, Bt, sM, sV, sV, accumulate=True)      # dX += gS^T Z
+                _bgemm(NN, N, D, N, Kmat, N, gO, D, gX, D, Bt, sM, sV, sV, accumulate=True)   # dX += K^T gO
+            else:
+                # dL/dS = (gO X^T + g_rowsum 1^T) * K / b^2 where the clamp is inactive
+                _bgemm(NT, N, N, D, gO, D, X, D, gS, N, Bt, sV, sV, sM, epi=EPI_MSBWD, epi_scalar=bw, aux=Kmat,
+                       ld_aux=N, s_aux=sM, row_add=grs)
+                _bgemm(NN, N, D, N, gS, N, X, D, gZ, D, Bt, sM, sV, sV)                       # dZ = dS X
+                _bgemm(TN, N, D, N, gS, N, Z, D, gX, D, Bt, sM, sV, sV, accumulate=True)      # dX += dS^T Z
+                _bgemm(TN, N, D, N, Kmat, N, gO, D, gX, D, Bt, sM, sV, sV, accumulate=True)   # dX += K^T dO
             g = gZ
         gX += g  # Z_0 = X.clone()
         return gX, None, None

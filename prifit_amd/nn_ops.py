@@ -26,7 +26,7 @@ def _rows_per_slab():
 
 
 def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
-         b_affine=None, bias=None, stats=None, epi=EPI_NONE, epi_scalar=None, aux=None, ld_aux=0, s_aux=0,
+         b_affine=None, bias=None, bias_stride=0, stats=None, epi=EPI_NONE, epi_scalar=None, aux=None, ld_aux=0, s_aux=0,
          row_add=None, a_rowsum=None, accumulate=None):
     if accumulate is None:
         accumulate = splitk > 1
@@ -37,7 +37,7 @@ def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, spl
              _LL(ldc), _LL(sC), batch, splitk,
              ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
              ptr(b_affine[0]) if b_affine else None, ptr(b_affine[1]) if b_affine else None,
-             ptr(bias), ptr(stats), epi, ptr(epi_scalar), ptr(aux), _LL(ld_aux), _LL(s_aux), ptr(row_add),
+             ptr(bias), _LL(bias_stride), ptr(stats), epi, ptr(epi_scalar), ptr(aux), _LL(ld_aux), _LL(s_aux), ptr(row_add),
              ptr(a_rowsum), int(accumulate), cur_stream())
 
 

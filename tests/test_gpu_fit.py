@@ -80,6 +80,24 @@ def test_mean_shift_iterations_fwd_bwd(F, golden):
     torch.testing.assert_close(Xg.grad[0].cpu(), Xo.grad, rtol=2e-3, atol=2e-4 * Xo.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("N,mode", [(200, "gemm"), (200, "fused"), (333, "gemm"), (2048, "fused")])
+def test_mean_shift_fused_ragged(F, N, mode, monkeypatch):
+    monkeypatch.setattr(F, "BWD_MODE", mode)
+    """D = 128 takes the flash-style fused kernels; N not a multiple of the 64-row tiles (and N % 4 != 0, which
+    falls back to the GEMM chain on K^T for the backward pass)."""
+    Xs = torch.nn.functional.normalize(_t(synth.features(2, N, 128, 15)), dim=-1)
+    bws = torch.stack([orc.compute_bandwidth(Xs[b], 0.1) for b in range(2)])
+    Gs = _t(synth.features(2, N, 128, 16))
+    Xo = Xs.clone().requires_grad_(True)
+    Zo = torch.stack([orc.mean_shift_iterations(Xo[b], bws[b], 3) for b in range(2)])
+    (Zo * Gs).sum().backward()
+    Xg = Xs.cuda().requires_grad_(True)
+    Zg = F.MeanShiftFn.apply(Xg, bws.cuda(), 3)
+    (Zg * Gs.cuda()).sum().backward()
+    torch.testing.assert_close(Zg.detach().cpu(), Zo.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(Xg.grad.cpu(), Xo.grad, rtol=2e-3, atol=2e-4 * Xo.grad.abs().max().item())
+
+
 def test_nms_and_membership(F, golden):
     g = golden("fit_meanshift")
     seed = int(g["seed"])

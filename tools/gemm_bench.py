@@ -47,6 +47,8 @@ def run(name, lay, M, N, K, batch=1, epi=0, affine=False, stats=False, splitk=1,
 CASES = [
     ("ms S=ZX^T NT 2048^2x128 b24 mskern", NT, 2048, 2048, 128, dict(batch=24, epi=2)),
     ("ms S plain NT 2048^2x128 b24", NT, 2048, 2048, 128, dict(batch=24)),
+    ("ms S NOSTORE NT 2048^2x128 b24", NT, 2048, 2048, 128, dict(batch=24, epi=100)),
+    ("big square NOSTORE NT 4096^3", NT, 4096, 4096, 4096, dict(epi=100)),
     ("ms O=KX NN 2048x128x2048 b24", NN, 2048, 128, 2048, dict(batch=24)),
     ("ms gS NT 2048^2x128 b24 msbwd", NT, 2048, 2048, 128, dict(batch=24, epi=3)),
     ("ms dX TN 2048x128x2048 b24", TN, 2048, 128, 2048, dict(batch=24)),
