@@ -1,0 +1,115 @@
+"""The training iteration of the hot path: what
+train_partseg_shapenet.py:252-259, :321-340, :372-399, :436-451, :467-475 does around the model, for one
+process per GPU.
+
+    tr = Trainer(model)                       # Adam(lr, betas .9/.999, eps 1e-8, weight_decay) as upstream :252-259
+    tr.set_epoch(epoch)                       # lr / BatchNorm-momentum schedule, upstream :325-334
+    loss, acc = tr.supervised_step(points, target)              # upstream :372-399
+    ss = tr.selfsup_step(chamfer_points, quantile=.05, ...)     # upstream :436-451
+    tr.save(path) / tr.load(path)             # checkpoint dict of upstream :467-475
+
+The augmentation (random per-shape scale in [0.8, 1.25] and shift in [-0.1, 0.1], provider.py:278-303) runs
+on the device.  Gradients are exchanged with `FlatGradBucket` when torch.distributed is initialised."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .ddp import FlatGradBucket
+
+LEARNING_RATE_CLIP = 1e-5      # upstream :285
+MOMENTUM_ORIGINAL = 0.1        # upstream :286
+MOMENTUM_DECAY = 0.5           # upstream :287
+
+
+def random_scale_shift(points, generator=None, scale_low=0.8, scale_high=1.25, shift_range=0.1):
+    """provider.py:278-303 on a [B,N,3+] device tensor (first three channels), one scale and shift per shape."""
+    B = points.shape[0]
+    dev = points.device
+    scales = torch.empty(B, 1, 1, device=dev).uniform_(scale_low, scale_high, generator=generator)
+    shifts = torch.empty(B, 1, 3, device=dev).uniform_(-shift_range, shift_range, generator=generator)
+    out = points.clone()
+    out[:, :, 0:3] = out[:, :, 0:3] * scales + shifts
+    return out
+
+
+class Trainer:
+    def __init__(self, model, num_part=50, learning_rate=0.001, decay_rate=1e-4, lr_decay=0.5, step_size=20, lmbda=1.0,
+                 fused_adam=True):
+        self.model = model
+        self.num_part = num_part
+        self.lr0, self.lr_decay, self.step_size, self.lmbda = learning_rate, lr_decay, step_size, lmbda
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, betas=(0.9, 0.999), eps=1e-08,
+                                          weight_decay=decay_rate,
+                                          fused=bool(fused_adam and next(model.parameters()).is_cuda))
+        self.bucket = FlatGradBucket(model)
+        self.epoch = 0
+        self.train_acc = 0.0
+
+    # ------------------------------------------------------------------ schedule (upstream :325-334)
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        lr = max(self.lr0 * (self.lr_decay ** (epoch // self.step_size)), LEARNING_RATE_CLIP)
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        momentum = max(MOMENTUM_ORIGINAL * (MOMENTUM_DECAY ** (epoch // self.step_size)), 0.01)
+        for m in self.model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.momentum = momentum
+        return lr, momentum
+
+    def _apply(self, loss):
+        loss.backward()
+        self.bucket.allreduce()
+        self.optimizer.step()
+
+    # ------------------------------------------------------------------ supervised step (upstream :372-399)
+    def supervised_step(self, points, target, category_label=None, augment=True, fps_start=None):
+        """points [B,N,3(+3)] channels-last, target [B,N] int64 part labels."""
+        B, N, _ = points.shape
+        if augment:
+            points = random_scale_shift(points)
+        xyz = points.transpose(2, 1).contiguous()
+        if category_label is None:
+            category_label = torch.zeros(B, 1, 16, device=points.device)
+        self.bucket.zero()
+        self.model.train()
+        out = self.model(xyz, category_label, include_convex_loss=False, fps_start=fps_start)
+        seg_pred = out[0].contiguous().view(-1, self.num_part)
+        tgt = target.view(-1)
+        loss = F.cross_entropy(seg_pred, tgt)      # get_loss: CE on log-probabilities (upstream msg:137-144)
+        self._apply(loss)
+        with torch.no_grad():
+            acc = (seg_pred.argmax(1) == tgt).float().mean()
+        return loss.detach(), acc
+
+    # ------------------------------------------------------------------ self-supervised step (upstream :436-451)
+    def selfsup_step(self, chamfer_points, npoint=2048, quantile=0.01, msc_iterations=20, max_num_clusters=25,
+                     augment=True, subset=None, **loss_kwargs):
+        """chamfer_points [B,M,3]: the model input is a random `npoint`-subset of them (upstream :441)."""
+        B, M, _ = chamfer_points.shape
+        if augment:
+            chamfer_points = random_scale_shift(chamfer_points)
+        cham = chamfer_points.transpose(2, 1).contiguous()
+        if subset is None:
+            subset = torch.from_numpy(np.random.choice(M, npoint, replace=False)).to(cham.device)
+        points = cham[:, :, subset].contiguous()
+        category_label = torch.zeros(B, 1, 16, device=cham.device)
+        self.bucket.zero()
+        self.model.train()
+        out = self.model(points, category_label, chamfer_points=cham, include_convex_loss=True, quantile=quantile,
+                         msc_iterations=msc_iterations, max_num_clusters=max_num_clusters, **loss_kwargs)
+        ss_loss = torch.mean(out[3]) * self.lmbda
+        self._apply(ss_loss)
+        return ss_loss.detach()
+
+    # ------------------------------------------------------------------ checkpoints (upstream :467-475, :263-274)
+    def save(self, path):
+        torch.save({"epoch": self.epoch, "train_acc": self.train_acc, "model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": self.optimizer.state_dict()}, path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location="cpu")
+        self.model.load_state_dict(ck["model_state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self.epoch = ck["epoch"]
+        return ck
