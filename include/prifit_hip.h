@@ -300,6 +300,16 @@ int prifit_ellipsoid_sdf_bwd(const float *targets, int B, int M, const float *r,
                              const float *c, const int32_t *arg, const float *gscale, int KM, float *g_r,
                              float *g_V, float *g_c, void *stream);
 
+/* Every live ellipsoid's SDF at every point (convex_loss.py:331-343 compute_sdf_ellipsoids_batch), for the
+ * optional intersection term (:374-413): sdf [B,M,KM], 0 in dead slots; and its autograd
+ * (g_{r,V,c} += d<g_sdf, sdf>/d{r,V,c}, outputs initialised by the caller). */
+int prifit_ellipsoid_sdf_matrix_fwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, int KM, float *sdf,
+                                    void *stream);
+int prifit_ellipsoid_sdf_matrix_bwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, const float *g_sdf, int KM,
+                                    float *g_r, float *g_V, float *g_c, void *stream);
+
 /* src/ellipsoid_utils.py:87-107: n [B,KM] surface samples per ellipsoid (round(10000*area/sum area),
  * <=0 -> 100), off [B,KM+1] exclusive prefix (off[KM] = total, clipped to cap). */
 int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n,

@@ -188,6 +188,18 @@ def run(save, eq, close):
          K=np.array([len(p) for p in prm_r]), labels=torch.stack(lab_r).to(torch.int16),
          dX_norm=Xr.grad.norm(), dX_head=Xr.grad[:, :, :32].contiguous())
 
+    # ---- optional entropy term (convex_loss.py:209-225) on a fixed quarter of the points
+    ent_idx = torch.from_numpy(np.random.default_rng(seed + 9).choice(N, N // 4, replace=False))
+    Xe = emb.clone().requires_grad_(True)
+    e_r = CL.entropy(torch.nn.functional.normalize(Xe, dim=2)[:, ent_idx])
+    e_r.backward()
+    Xo2 = emb.clone().requires_grad_(True)
+    e_o = orc.entropy(torch.nn.functional.normalize(Xo2, dim=2)[:, ent_idx])
+    e_o.backward()
+    close(e_o, e_r, "entropy", rtol=1e-6)
+    close(Xo2.grad, Xe.grad, "entropy dX", rtol=1e-4, atol=1e-9)
+    save("fit_entropy", seed=seed, idx=ent_idx, value=e_r.detach(), dX_head=Xe.grad[:, :64], dX_norm=Xe.grad.norm())
+
     # ---- known-answer test data: hard weights on analytic ellipsoid surfaces (fitting.py / ellipsoid_fitting_numpy.py:36-45)
     rng = np.random.default_rng(77)
     pts_k, W_k, abc_k, ctr_k = [], [], [], []

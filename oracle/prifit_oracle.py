@@ -686,18 +686,53 @@ def analytic_chamfer(params_batch, samples_batch, targets):
     return torch.stack(per).mean(), parts
 
 
+def entropy(X):
+    """convex_loss.py:209-225: relu(mean_b sum((1 + X_b X_b^T)^2) / n^2 - 1.8).  X [B,n,D] unit rows."""
+    n = X.shape[1]
+    l = [((1 + X[b] @ X[b].t()) ** 2).sum() / n ** 2 for b in range(X.shape[0])]
+    return torch.relu(torch.stack(l).mean() - 1.8)
+
+
+def intersection_loss_volume_3(params_batch, points):
+    """convex_loss.py:374-413.  Upstream calls torch_scatter.scatter_mean whose import is commented out
+    (convex_loss.py:17 -> NameError), so this term is PARITY-UNPINNED: it restates the documented
+    intent -- per point, the mean over the ellipsoids the point does NOT belong to of clamp_max(sdf, -1e-3),
+    squared, averaged over points and over the shapes with more than one ellipsoid."""
+    losses = []
+    for b, params in enumerate(params_batch):
+        if len(params) <= 1:
+            continue
+        sdf = torch.stack([sdf_ellipsoid(points[b], c, r, V) for r, V, c in params], 1)
+        sdf = torch.clamp_max(sdf, -1e-3)
+        own = sdf.min(1)[1]
+        mask = torch.ones_like(sdf)
+        mask[torch.arange(sdf.shape[0]), own] = 0.0
+        others = (sdf * mask).sum(1) / (sdf.shape[1] - 1)
+        losses.append((others ** 2).mean())
+    if not losses:
+        return torch.zeros(1, requires_grad=True)
+    return torch.stack(losses).mean()
+
+
 def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_clusters=25, rand_table=None,
-                canonical=False, return_info=False, **_unused):
+                canonical=False, return_info=False, include_entropy_loss=False, entropy_indices=None,
+                include_intersect_loss=False, intersect_jitter=None, alpha=1, beta=1, **_unused):
     """convex_loss.py:27-103 with the default flags of the benchmarked path (no entropy / intersection /
     pruning / cuboid).  points [B,3,N], chamfer_points [B,3,M], X [B,D,N]."""
     X = F.normalize(X.permute(0, 2, 1), dim=2, p=2)
     X = F.normalize(X, dim=2, p=2)
     pts = points.permute(0, 2, 1)
+    ent = torch.zeros(1)
+    if include_entropy_loss:  # convex_loss.py:59-62: a random quarter of the points (indices passed in explicitly)
+        ent = entropy(X[:, entropy_indices])
     Ws, labels, info = clustering(X, quantile, iterations, max_num_clusters)
     params = fit_ellipsoids_batch(pts, Ws, rand_table, canonical)
     samples = sample_from_params(params)
     loss, parts = analytic_chamfer(params, samples, chamfer_points.permute(0, 2, 1))
-    total = loss + 0.0
+    inter = torch.zeros(1)
+    if include_intersect_loss:  # convex_loss.py:96-99: targets jittered by U[0,0.2) (passed in explicitly)
+        inter = intersection_loss_volume_3(params, chamfer_points.permute(0, 2, 1) - intersect_jitter)
+    total = loss + (alpha * inter) + (beta * ent)
     if return_info:
         return total.view(1, 1), loss.view(1, 1), params, labels, {"W": Ws, "cluster": info, "parts": parts,
                                                                   "samples": samples}

@@ -10,12 +10,17 @@ Explicit inputs that replace hidden randomness / absent third-party code (SURVEY
                   drawn with torch.rand when omitted, like upstream;
   * `canonical`   pin the SVD column signs (largest component positive);
   * the surface sampler is the build's deterministic Fibonacci (U,V) table (trimesh is not used).
-Flags outside the benchmarked path (cuboids, intersection / entropy losses, pruning) raise.
+Optional terms (off in the README configuration): `include_entropy_loss` (upstream :59-62,209-225),
+`include_intersect_loss` (:96-99,374-413 -- upstream's scatter_mean import is commented out, so this term is
+parity-unpinned and restates the documented intent), `include_pruning` (:78-82: upstream computes the pruned
+set but never uses it in the loss, so it is a no-op here).  `if_cuboid` raises.
 """
 import torch
 import torch.nn.functional as F
 
 from . import fit_ops
+from .nn_ops import EPI_CHORD, NN, NT, gemm
+from ._lib import call, cur_stream, ptr
 
 
 class EllipseParams:
@@ -54,17 +59,88 @@ def analytic_chamfer_distance(r, V, c, valid, targets):
     return (per * has).sum() / has.sum().clamp(min=1.0), (d2_sum / total.clamp(min=1), sdf_sum / M)
 
 
+class EntropyFn(torch.autograd.Function):
+    """convex_loss.py:209-225: mean over shapes of sum((1 + X_b X_b^T)^2) / n^2 (before the margin/relu).
+    X [B,n,D] unit rows.  T = 1 + X X^T comes from the chord GEMM (2 - 2s -> T = 2 - chord/2)."""
+
+    @staticmethod
+    def forward(ctx, X):
+        X = X.contiguous()
+        B, n, D = X.shape
+        T = torch.empty(B, n, n, dtype=torch.float32, device=X.device)
+        gemm(NT, n, n, D, X, D, X, D, T, n, batch=B, sA=n * D, sB=n * D, sC=n * n, epi=EPI_CHORD)
+        T.mul_(-0.5).add_(2.0)
+        ctx.save_for_backward(X, T)
+        return (T * T).sum(dim=(1, 2)).mean() / (n * n)
+
+    @staticmethod
+    def backward(ctx, g):
+        X, T = ctx.saved_tensors
+        B, n, D = X.shape
+        dX = torch.empty_like(X)  # d/dX_b sum (1+s)^2 = 4 (1+S) X_b (S symmetric)
+        gemm(NN, n, D, n, T, n, X, D, dX, D, batch=B, sA=n * n, sB=n * D, sC=n * D)
+        return dX * (4.0 * g / (B * n * n))
+
+
+def entropy(X, margin=1.8):
+    return torch.relu(EntropyFn.apply(X) - margin)
+
+
+class SdfMatrixFn(torch.autograd.Function):
+    """sdf [B,M,KM] of every live ellipsoid at every point (convex_loss.py:331-343), 0 in dead slots."""
+
+    @staticmethod
+    def forward(ctx, points, r, V, c, valid):
+        points, r, V, c = points.contiguous(), r.contiguous(), V.contiguous(), c.contiguous()
+        B, M, _ = points.shape
+        K = r.shape[1]
+        out = torch.empty(B, M, K, dtype=torch.float32, device=points.device)
+        call("prifit_ellipsoid_sdf_matrix_fwd", ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(out),
+             cur_stream())
+        ctx.save_for_backward(points, r, V, c, valid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        points, r, V, c, valid = ctx.saved_tensors
+        B, M, _ = points.shape
+        K = r.shape[1]
+        g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
+        call("prifit_ellipsoid_sdf_matrix_bwd", ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid),
+             ptr(g.contiguous()), K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
+        return None, g_r, g_V, g_c, None
+
+
+def intersection_loss_volume_3(r, V, c, valid, points):
+    """convex_loss.py:374-413 (intent; see the module docstring): per point the mean, over the ellipsoids it does
+    not belong to, of clamp_max(sdf, -1e-3), squared; mean over points and over shapes with > 1 ellipsoid."""
+    sdf = torch.clamp_max(SdfMatrixFn.apply(points, r, V, c, valid), -1e-3)
+    live = (valid != 0).unsqueeze(1)                                     # [B,1,KM]
+    nlive = live.sum(dim=2).to(sdf.dtype)                                # [B,1]
+    own = sdf.masked_fill(~live, float("inf")).argmin(dim=2, keepdim=True)
+    mask = live & (torch.arange(sdf.shape[2], device=sdf.device).view(1, 1, -1) != own)
+    others = (sdf * mask).sum(dim=2) / (nlive - 1).clamp(min=1.0)
+    per = (others ** 2).mean(dim=1)
+    has = (nlive.squeeze(1) > 1).to(sdf.dtype)
+    return (per * has).sum() / has.sum().clamp(min=1.0)
+
+
 def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, quantile=0.01, iterations=5,
                 visualize=False, max_num_clusters=25, class_list=[], include_intersect_loss=False, alpha=1, beta=1,
                 if_cuboid=False, include_pruning=False, include_entropy_loss=False, evaluation=False,
-                rand_table=None, canonical=True, return_info=False):
+                rand_table=None, canonical=True, return_info=False, entropy_indices=None, intersect_jitter=None):
     """points [B,3,N], chamfer_points [B,3,M], X [B,D,N] (per-point embedding)."""
-    if if_cuboid or include_intersect_loss or include_entropy_loss or include_pruning:
-        raise NotImplementedError("cuboid / intersection / entropy / pruning terms are not part of the accelerated path yet")
+    if if_cuboid:
+        raise NotImplementedError("cuboid fitting (if_cuboid) is not part of the accelerated path yet")
     emb = X.permute(0, 2, 1)
     emb = F.normalize(emb, dim=2, p=2)
     emb = F.normalize(emb, dim=2, p=2).contiguous()      # normalised twice upstream (:41,57)
     pts = points.permute(0, 2, 1).contiguous()
+    entropy_loss = torch.zeros((), device=pts.device)
+    if include_entropy_loss:                              # :59-62: a random quarter of the points
+        if entropy_indices is None:
+            entropy_indices = torch.randperm(emb.shape[1], device=emb.device)[: emb.shape[1] // 4]
+        entropy_loss = entropy(emb[:, entropy_indices.to(emb.device)])
     cl = fit_ops.cluster(emb, quantile, iterations, max_num_clusters)   # clustering(): :68
     if rand_table is None:
         rand_table = torch.rand(pts.shape[0], fit_ops.KM, 3, 3, device=pts.device)
@@ -74,7 +150,12 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
         l, parts = analytic_chamfer_distance(r, V, c, valid, tgt)       # :73-89
     else:
         l, parts = torch.zeros((), device=pts.device, requires_grad=True), None
-    total = l + 0.0                                                      # + alpha*0 + beta*0 (:101)
+    intersection_loss = torch.zeros((), device=pts.device)
+    if include_intersect_loss and evaluation is False:                   # :96-99 (targets jittered by U[0, 0.2))
+        if intersect_jitter is None:
+            intersect_jitter = torch.rand_like(tgt) * 0.2
+        intersection_loss = intersection_loss_volume_3(r, V, c, valid, tgt - intersect_jitter.to(tgt.device))
+    total = l + (alpha * intersection_loss) + (beta * entropy_loss)      # :101
     params = EllipseParams(r, V, c, valid, cl["count"])
     labels = list(cl["labels"].unbind(0))
     if return_info:

@@ -470,6 +470,105 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// Full SDF matrix sdf[b][m][k] (0 for dead slots) and its autograd: used by the optional intersection term
+// (convex_loss.py:374-413), which needs every ellipsoid's value at every point, not only the closest one.
+__global__ __launch_bounds__(256) void sdf_matrix_fwd_kernel(const float *__restrict__ pts, int M,
+                                                             const float *__restrict__ r,
+                                                             const float *__restrict__ V,
+                                                             const float *__restrict__ c,
+                                                             const int32_t *__restrict__ valid, int KM,
+                                                             float *__restrict__ out)
+{
+    __shared__ EllParam s_e[KM_MAX];
+    __shared__ int s_ok[KM_MAX];
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < KM; k += 256) {
+        const size_t s = (size_t)b * KM + k;
+        s_ok[k] = valid[s];
+        for (int i = 0; i < 3; ++i) { s_e[k].r[i] = r[s * 3 + i]; s_e[k].c[i] = c[s * 3 + i]; }
+        for (int i = 0; i < 9; ++i) s_e[k].V[i] = V[s * 9 + i];
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float *p = pts + ((size_t)b * M + m) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    float *o = out + ((size_t)b * M + m) * KM;
+    for (int k = 0; k < KM; ++k) {
+        float q[3], k0, k1;
+        o[k] = s_ok[k] ? sdf_eval(s_e[k], px, py, pz, q, k0, k1) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sdf_matrix_bwd_kernel(const float *__restrict__ pts, int M,
+                                                             const float *__restrict__ r,
+                                                             const float *__restrict__ V,
+                                                             const float *__restrict__ c,
+                                                             const int32_t *__restrict__ valid,
+                                                             const float *__restrict__ g, int KM,
+                                                             float *__restrict__ g_r, float *__restrict__ g_V,
+                                                             float *__restrict__ g_c)
+{
+    __shared__ EllParam s_e[KM_MAX];
+    __shared__ int s_ok[KM_MAX];
+    __shared__ float s_acc[KM_MAX * 15];
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < KM; k += 256) {
+        const size_t s = (size_t)b * KM + k;
+        s_ok[k] = valid[s];
+        for (int i = 0; i < 3; ++i) { s_e[k].r[i] = r[s * 3 + i]; s_e[k].c[i] = c[s * 3 + i]; }
+        for (int i = 0; i < 9; ++i) s_e[k].V[i] = V[s * 9 + i];
+    }
+    for (int i = threadIdx.x; i < KM * 15; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < M) {
+        const float *p = pts + ((size_t)b * M + m) * 3;
+        for (int k = 0; k < KM; ++k) {
+            const float gf = g[((size_t)b * M + m) * KM + k];
+            if (!s_ok[k] || gf == 0.f) continue;
+            const EllParam &e = s_e[k];
+            float q[3], k0, k1;
+            sdf_eval(e, p[0], p[1], p[2], q, k0, k1);
+            const float den = k1 + 1e-6f;
+            const float df0 = (2.0f * k0 - 1.0f) / den, df1 = -k0 * (k0 - 1.0f) / (den * den);
+            float gq[3];
+            float *acc = s_acc + k * 15;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float ra = e.r[a] + 1e-6f, rb = e.r[a] * e.r[a] + 1e-6f;
+                const float u = q[a] / ra, v = q[a] / rb;
+                const float dk0dq = k0 > 0.f ? u / (k0 * ra) : 0.f, dk1dq = k1 > 0.f ? v / (k1 * rb) : 0.f;
+                const float dk0dr = k0 > 0.f ? -u * u / (k0 * ra) : 0.f;
+                const float dk1dr = k1 > 0.f ? -2.0f * e.r[a] * v * v / (k1 * rb) : 0.f;
+                gq[a] = gf * (df0 * dk0dq + df1 * dk1dq);
+                atomicAdd(acc + a, gf * (df0 * dk0dr + df1 * dk1dr));
+            }
+            const float d[3] = {p[0] - e.c[0], p[1] - e.c[1], p[2] - e.c[2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float gc = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    atomicAdd(acc + 3 + i * 3 + a, d[i] * gq[a]);
+                    gc -= e.V[i * 3 + a] * gq[a];
+                }
+                atomicAdd(acc + 12 + i, gc);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KM * 15; i += 256) {
+        const float v = s_acc[i];
+        if (v == 0.f) continue;
+        const int k = i / 15, j = i % 15;
+        const size_t s = (size_t)b * KM + k;
+        if (j < 3) unsafeAtomicAdd(g_r + s * 3 + j, v);
+        else if (j < 12) unsafeAtomicAdd(g_V + s * 9 + (j - 3), v);
+        else unsafeAtomicAdd(g_c + s * 3 + (j - 12), v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // surface sampling budget (src/ellipsoid_utils.py:87-107, :157-159)
 // ---------------------------------------------------------------------------------------------
@@ -674,6 +773,28 @@ int prifit_ellipsoid_sdf_bwd(const float *targets, int B, int M, const float *r,
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(sdf_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), targets, M, r, V,
                        c, arg, gscale, KM, g_r, g_V, g_c);
+    return prifit_check_launch();
+}
+
+int prifit_ellipsoid_sdf_matrix_fwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, int KM, float *sdf, void *stream)
+{
+    if (!points || !r || !V || !c || !valid || !sdf || B <= 0 || M <= 0 || KM <= 0 || KM > KM_MAX)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(sdf_matrix_fwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), points, M,
+                       r, V, c, valid, KM, sdf);
+    return prifit_check_launch();
+}
+
+int prifit_ellipsoid_sdf_matrix_bwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, const float *g_sdf, int KM, float *g_r,
+                                    float *g_V, float *g_c, void *stream)
+{
+    if (!points || !r || !V || !c || !valid || !g_sdf || !g_r || !g_V || !g_c || B <= 0 || M <= 0 || KM <= 0 ||
+        KM > KM_MAX)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(sdf_matrix_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), points, M,
+                       r, V, c, valid, g_sdf, KM, g_r, g_V, g_c);
     return prifit_check_launch();
 }
 

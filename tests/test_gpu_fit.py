@@ -270,3 +270,48 @@ def test_model_selfsup_step(hiplib):
         gr = dict(net.named_parameters())[name].grad
         assert gr is not None and torch.isfinite(gr).all(), name
     assert len(out[5]) == B and out[5][0].shape == (N,) and out[7].shape == (B, 128, N)
+
+
+def test_optional_terms_entropy_intersection_pruning(F, golden):
+    """include_entropy_loss (pinned vs the reference), include_intersect_loss (parity-unpinned upstream: vs the
+    oracle's restatement of the documented intent), include_pruning (a no-op upstream)."""
+    from prifit_amd import convex_loss as CLM
+    g = golden("fit_entropy")
+    seed = int(g["seed"])
+    pts, cham, emb = fit_inputs(2, 2048, 128, seed)
+    idx = _t(g["idx"])
+    # entropy: value vs reference golden; the pre-margin quantity and its gradient vs the oracle
+    Xn = torch.nn.functional.normalize(emb, dim=2)
+    val = CLM.entropy(Xn[:, idx].cuda())
+    torch.testing.assert_close(val.cpu(), _t(g["value"]), rtol=1e-5, atol=1e-6)
+    Xo = Xn[:, idx].clone().requires_grad_(True)
+    n = idx.shape[0]
+    raw_o = torch.stack([((1 + Xo[b] @ Xo[b].t()) ** 2).sum() / n ** 2 for b in range(2)]).mean()
+    raw_o.backward()
+    Xg = Xn[:, idx].cuda().requires_grad_(True)
+    raw = CLM.EntropyFn.apply(Xg)
+    raw.backward()
+    torch.testing.assert_close(raw.detach().cpu(), raw_o.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(Xg.grad.cpu(), Xo.grad, rtol=1e-4, atol=1e-7)
+    # full loss with all optional terms on, vs the oracle with the same explicit random inputs
+    jit = _t(synth.uniform01((2, 5000, 3), seed + 11)) * 0.2
+    R = _t(synth.uniform01((3, 3), seed))
+    kw = dict(quantile=0.05, iterations=10, max_num_clusters=25, include_entropy_loss=True, include_intersect_loss=True,
+              alpha=0.01, beta=0.5)
+    Xo = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    tot_o, ch_o, prm_o, _ = orc.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xo, rand_table=[[R] * 64] * 2,
+                                            canonical=True, entropy_indices=idx, intersect_jitter=jit, **kw)
+    tot_o.sum().backward()
+    Xg = emb.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    tot, ch, prm, _ = CLM.convex_loss(pts.permute(0, 2, 1).cuda(), cham.permute(0, 2, 1).cuda(), Xg, rand_table=R.cuda(),
+                                      canonical=True, entropy_indices=idx.cuda(), intersect_jitter=jit.cuda(),
+                                      include_pruning=True, **kw)
+    tot.sum().backward()
+    assert float(tot_o) > float(ch_o)  # the intersection term is active in this configuration
+    torch.testing.assert_close(tot.detach().cpu(), tot_o.detach(), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(ch.detach().cpu(), ch_o.detach(), rtol=1e-4, atol=1e-7)
+    ref = Xo.grad
+    assert abs(Xg.grad.norm().item() - ref.norm().item()) < 1e-2 * ref.norm().item()
+    torch.testing.assert_close(Xg.grad.cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        CLM.convex_loss(pts.permute(0, 2, 1).cuda(), cham.permute(0, 2, 1).cuda(), Xg, if_cuboid=True)
