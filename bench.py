@@ -192,8 +192,17 @@ def main():
         if detail:
             dom = next(iter(detail))
             d = detail[dom]
+            # HBM bytes per launch of that family from the committed PMC passes (rocprofv3 cannot run inside this
+            # process): profiles/r01_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE, see the file's "source"
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                    traffic = json.load(fh)["families"].get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": None, "avg_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
+                    "frac": d["frac"], "traffic": traffic, "avg_us": d["avg_us"],
+                    "launches_per_step": d["launches_per_step"]}
         grp = [detail[k] for k in detail if k in ("ball_query", "group_gather")]
         grouping = None
         if grp:
