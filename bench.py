@@ -157,7 +157,7 @@ def main():
     dominant = max(cal.items(), key=lambda kv: kv[1][1])[0] if cal else None
     profiler.disable()
     profiler.reset()
-    profiler.enable(*[n for n in (dominant, "ball_query", "group_gather") if n])
+    profiler.enable(*[n for n in (dominant, "ball_query", "group_gather", "gather_linear") if n])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -203,14 +203,15 @@ def main():
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                     "frac": d["frac"], "traffic": traffic, "avg_us": d["avg_us"],
                     "launches_per_step": d["launches_per_step"]}
-        grp = [detail[k] for k in detail if k in ("ball_query", "group_gather")]
+        grp = [detail[k] for k in detail if k in ("ball_query", "group_gather", "gather_linear")]
         grouping = None
         if grp:
             ms = sum(g["ms_per_step"] for g in grp)
             gb = sum(g["achieved"] * g["ms_per_step"] * 1e-3 for g in grp)
             grouping = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gb / (ms * 1e-3) / HBM_PEAK_GBS, "ms_per_step": ms,
-                        "note": "ball-query + grouping launches, algorithmic bytes of SURVEY.md 8(d)"}
+                        "note": "ball-query + grouping launches (group_gather, and gather_linear = grouping fused with the first "
+                                "MLP layer, whose grouped-out term is its C1-wide output), algorithmic bytes of SURVEY.md 8(d)"}
         line = {
             "metric": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG+ellipsoid fit",
             "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -176,6 +176,16 @@ int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const flo
                     int C, int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg,
                     void *stream);
 
+/* First layer of a set-abstraction MLP by linearity (models/pointnet_util.py:243-252 / :127-133,195-197):
+ * conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias with U [B,N,C] = [feat | xyz] W1^T per point and
+ * Vc [B,S,C] = c W1x^T per centre: Y [(b,s,k), C] = U[b, idx[b,s,k]] - Vc[b,s] + bias (bias may be NULL), plus
+ * per-512-row column (sum, sum of squares) slabs [ceil(P/512)][2][C] for the following BatchNorm. */
+int prifit_gather_linear_fwd(const float *U, const float *Vc, const float *bias, const int32_t *idx, int B,
+                             int N, int S, int K, int C, float *Y, float *slab, void *stream);
+/* autograd: dU [B,N,C] (initialised by the caller) += scatter of dY; dVc [B,S,C] = -sum_k dY. */
+int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, int S, int K, int C,
+                             float *dU, float *dVc, void *stream);
+
 /* Backward of relu(bn(Y)) given G = dL/d(relu output): partial slabs of m1 = sum(G*mask) and
  * m2 = sum(G*mask*yhat). */
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy,

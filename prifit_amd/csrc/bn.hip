@@ -153,6 +153,122 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// first layer of a set-abstraction MLP by linearity:  W1 [feat_j | xyz_j - c_g] = U_j - Vc_g with
+// U = [feat | xyz] W1^T per POINT and Vc = c W1x^T per CENTRE (two small GEMMs), so the per-sample work is
+// a gather of C1-wide rows instead of a (C+3)-wide gather plus a GEMM over all grouped samples.
+//   Y1[(b,s,k), :] = U[b, idx[b,s,k], :] - Vc[b,s,:] + bias        (+ per-block column sum / sum-of-squares
+//   slabs for the BatchNorm that follows, same layout as the GEMM epilogue's with 512-row slabs)
+// ---------------------------------------------------------------------------------------------
+constexpr int GL_UNR = 4;
+__global__ __launch_bounds__(256) void gather_linear_fwd_kernel(const float *__restrict__ U,
+                                                                const float *__restrict__ Vc,
+                                                                const float *__restrict__ bias,
+                                                                const int32_t *__restrict__ idx, int N, int S, int K,
+                                                                int P, int C, float *__restrict__ Y,
+                                                                float *__restrict__ slab)
+{
+    __shared__ float4 s_red[2][256];
+    __shared__ int s_src[RED_ROWS];   // row of U (b*N + n), or -1 for an out-of-range index
+    __shared__ int s_grp[RED_ROWS];   // row of Vc (b*S + s)
+    const int C4 = C >> 2;
+    const int r_begin = blockIdx.x * RED_ROWS, r_end = min(P, r_begin + RED_ROWS);
+    for (int i = threadIdx.x; i < r_end - r_begin; i += 256) {
+        const int r = r_begin + i, g = r / K, n = idx[r];
+        s_grp[i] = g;
+        s_src[i] = (n >= 0 && n < N) ? (g / S) * N + n : -1;
+    }
+    __syncthreads();
+    for (int cbase = 0; cbase < C4; cbase += 256) {
+        const int cols = min(256, C4 - cbase);
+        const int lanes = 256 / cols;
+        const int c4 = cbase + threadIdx.x % cols, rl = threadIdx.x / cols;
+        const int c = 4 * c4;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        const float4 bb = bias ? ld4g(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        auto emit = [&](int i, float4 u, float4 v, bool ok) {
+            float4 y = ok ? make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
+            st4g(Y + (size_t)(r_begin + i) * C + c, y);
+            a0.x += y.x; a0.y += y.y; a0.z += y.z; a0.w += y.w;
+            a1.x += y.x * y.x; a1.y += y.y * y.y; a1.z += y.z * y.z; a1.w += y.w * y.w;
+        };
+        if (rl < lanes) {
+            const int nrow = r_end - r_begin;
+            int i = rl;
+            for (; i + (GL_UNR - 1) * lanes < nrow; i += GL_UNR * lanes) {  // GL_UNR independent row loads in flight
+                float4 u[GL_UNR], v[GL_UNR];
+                bool ok[GL_UNR];
+#pragma unroll
+                for (int j = 0; j < GL_UNR; ++j) {
+                    const int src = s_src[i + j * lanes];
+                    ok[j] = src >= 0;
+                    u[j] = ld4g(U + (size_t)(ok[j] ? src : 0) * C + c);
+                    v[j] = ld4g(Vc + (size_t)s_grp[i + j * lanes] * C + c);
+                }
+#pragma unroll
+                for (int j = 0; j < GL_UNR; ++j) emit(i + j * lanes, u[j], v[j], ok[j]);
+            }
+            for (; i < nrow; i += lanes) {
+                const int src = s_src[i];
+                emit(i, ld4g(U + (size_t)(src >= 0 ? src : 0) * C + c), ld4g(Vc + (size_t)s_grp[i] * C + c), src >= 0);
+            }
+        }
+        s_red[0][threadIdx.x] = a0;
+        s_red[1][threadIdx.x] = a1;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            float4 t0 = s_red[0][threadIdx.x], t1 = s_red[1][threadIdx.x];
+            for (int l = 1; l < lanes; ++l) {
+                const float4 u0 = s_red[0][threadIdx.x + l * cols], u1 = s_red[1][threadIdx.x + l * cols];
+                t0.x += u0.x; t0.y += u0.y; t0.z += u0.z; t0.w += u0.w;
+                t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
+            }
+            st4g(slab + ((size_t)blockIdx.x * 2 + 0) * C + c, t0);
+            st4g(slab + ((size_t)blockIdx.x * 2 + 1) * C + c, t1);
+        }
+        __syncthreads();
+    }
+}
+
+// autograd: dU[b, idx, :] += dY (float atomics, one lane per float: 256 B contiguous per wave-instruction);
+// dVc[g, :] = -sum_k dY[(g,k), :]
+__global__ __launch_bounds__(256) void gather_linear_bwd_kernel(const float *__restrict__ dY,
+                                                                const int32_t *__restrict__ idx, int N, int S, int K,
+                                                                int C, long long total, float *__restrict__ dU,
+                                                                float *__restrict__ dVc)
+{
+    constexpr int UNR = 8;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long g = id / C;   // b*S + s
+        const int c = (int)(id - g * C);
+        const int b = (int)(g / S);
+        const float *src = dY + (size_t)g * K * C + c;
+        const int32_t *ix = idx + (size_t)g * K;
+        float *dst = dU + (size_t)b * N * C + c;
+        float acc = 0.f;
+        int k = 0;
+        for (; k + UNR <= K; k += UNR) {
+            float v[UNR];
+            int n[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) { v[j] = src[(size_t)(k + j) * C]; n[j] = ix[k + j]; }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                if (n[j] >= 0 && n[j] < N) unsafeAtomicAdd(dst + (size_t)n[j] * C, v[j]);
+                acc += v[j];
+            }
+        }
+        for (; k < K; ++k) {
+            const float v = src[(size_t)k * C];
+            const int n = ix[k];
+            if (n >= 0 && n < N) unsafeAtomicAdd(dst + (size_t)n * C, v);
+            acc += v;
+        }
+        dVc[id] = -acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
 // Partials of m1 = sum(G * mask), m2 = sum(G * mask * yhat) with mask = (scale*Y+shift > 0),
@@ -359,6 +475,29 @@ int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const flo
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((long long)G * (C / 4))), dim3(256), 0, as_stream(stream), Y,
                        ldy, scale, shift, G, K, C / 4, rows_per_sample, slope, out, ldo, arg);
+    return prifit_check_launch();
+}
+
+int prifit_gather_linear_fwd(const float *U, const float *Vc, const float *bias, const int32_t *idx, int B, int N,
+                             int S, int K, int C, float *Y, float *slab, void *stream)
+{
+    if (!U || !Vc || !idx || !Y || !slab || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || (C & 3) ||
+        ((uintptr_t)U & 15) || ((uintptr_t)Vc & 15) || ((uintptr_t)Y & 15))
+        return PRIFIT_EINVAL;
+    const long long P = (long long)B * S * K;
+    if (P > 2147483647LL) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(gather_linear_fwd_kernel, dim3((unsigned)((P + RED_ROWS - 1) / RED_ROWS)), dim3(256), 0,
+                       as_stream(stream), U, Vc, bias, idx, N, S, K, (int)P, C, Y, slab);
+    return prifit_check_launch();
+}
+
+int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, int S, int K, int C, float *dU,
+                             float *dVc, void *stream)
+{
+    if (!dY || !idx || !dU || !dVc || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0) return PRIFIT_EINVAL;
+    const long long total = (long long)B * S * C;
+    hipLaunchKernelGGL(gather_linear_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), dY, idx, N, S,
+                       K, C, total, dU, dVc);
     return prifit_check_launch();
 }
 

@@ -97,37 +97,68 @@ struct BallArgs {
 };
 
 constexpr int BQ_TILE = 2048;   // points staged in LDS per pass (32 KiB as float4)
-constexpr int BQ_QPW = 1;       // queries per wave (more, shorter waves: the per-query scan is a serial chain)
-constexpr int BQ_QPB = 4 * BQ_QPW;
+constexpr int BQ_QPB = 4;       // queries per block: one per wave
 
+// Two stages per wave.  Stage 1 scans the cloud 64 points at a time and only compacts the candidates of the LARGEST
+// ball (index, distance) into a 128-entry per-wave ring, in index order: one compare + one ballot per chunk, no
+// per-radius work, so successive chunks are independent.  Stage 2 runs whenever 64 candidates are pending (and once
+// at the end) and does the ordered per-radius compaction on those 64 only: a few % of the points on real clouds.
 template <int R, typename IdxT>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict__ xyz,
                                                          const float *__restrict__ new_xyz, int N,
                                                          int S, BallArgs args)
 {
     __shared__ float4 s_pts[BQ_TILE];
+    __shared__ float2 s_cand[4][128];
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float *P = xyz + (size_t)b * N * 3;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW], qq[BQ_QPW];
-    int cnt[BQ_QPW][R], first[BQ_QPW][R];
-    int qid[BQ_QPW];
+    const int qid = blockIdx.x * BQ_QPB + wave;
+    const bool valid = qid < S;   // wave-uniform
+    const float *Q = new_xyz + ((size_t)b * S + (valid ? qid : S - 1)) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    const float qq = norm2_3(qx, qy, qz);
+    int cnt[R], first[R];
 #pragma unroll
-    for (int q = 0; q < BQ_QPW; ++q) {
-        qid[q] = blockIdx.x * BQ_QPB + wave * BQ_QPW + q;
-        int s = qid[q] < S ? qid[q] : S - 1;
-        const float *Q = new_xyz + ((size_t)b * S + s) * 3;
-        qx[q] = Q[0]; qy[q] = Q[1]; qz[q] = Q[2];
-        qq[q] = norm2_3(qx[q], qy[q], qz[q]);
-#pragma unroll
-        for (int r = 0; r < R; ++r) { cnt[q][r] = 0; first[q][r] = N; }
-    }
-
+    for (int r = 0; r < R; ++r) { cnt[r] = 0; first[r] = N; }
     float r2max = args.r2[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) r2max = fmaxf(r2max, args.r2[r]);
+
+    int fill = 0, done = 0;       // candidates written / consumed (wave-uniform)
+    bool finished = !valid;       // every radius has its nsample indices
+    float2 *ring = s_cand[wave];
+
+    auto consume = [&](int nproc) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool act = lane < nproc;
+        const float2 e = ring[(done + lane) & 127];
+        const int gi = __float_as_int(e.x);
+        const float d = e.y;
+        bool all = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int K = args.nsample[r];
+            if (cnt[r] < K) {
+                const bool pred = act && !(d > args.r2[r]);
+                const unsigned long long m = __ballot(pred);
+                if (m != 0ull) {
+                    if (cnt[r] == 0) first[r] = __builtin_amdgcn_readlane(gi, __builtin_ctzll(m));
+                    const int pos = cnt[r] + __popcll(m & lt_mask);
+                    if (pred && pos < K)
+                        reinterpret_cast<IdxT *>(args.out[r])[((size_t)b * S + qid) * K + pos] = (IdxT)gi;
+                    cnt[r] += __popcll(m);
+                }
+            }
+            all = all && cnt[r] >= K;
+        }
+        done += nproc;
+        __builtin_amdgcn_wave_barrier();
+        return all;
+    };
 
     for (int base = 0; base < N; base += BQ_TILE) {
         const int tn = min(BQ_TILE, N - base);
@@ -138,47 +169,28 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float *__restrict
             s_pts[i] = make_float4(x, y, z, norm2_3(x, y, z));
         }
         __syncthreads();
-        // the wave's BQ_QPW queries share every LDS point read (4 independent dependency chains per chunk)
+        if (finished) continue;
         for (int c = 0; c < tn; c += 64) {
-            bool all_done = true;
-#pragma unroll
-            for (int q = 0; q < BQ_QPW; ++q)
-#pragma unroll
-                for (int r = 0; r < R; ++r) all_done = all_done && (qid[q] >= S || cnt[q][r] >= args.nsample[r]);
-            if (all_done) break;  // wave-uniform
             const int i = c + lane;
             const bool inb = i < tn;
             const float4 p = s_pts[inb ? i : 0];
-#pragma unroll
-            for (int q = 0; q < BQ_QPW; ++q) {
-                if (qid[q] >= S) continue;
-                const float d = sqdist_expanded(qx[q], qy[q], qz[q], qq[q], p.x, p.y, p.z, p.w);
-                // most 64-point chunks contain no point of even the largest ball: one ballot rejects them
-                if (__ballot(inb && !(d > r2max)) == 0ull) continue;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int K = args.nsample[r];
-                    const bool pred = inb && !(d > args.r2[r]);
-                    const unsigned long long m = __ballot(pred);
-                    if (m == 0ull || cnt[q][r] >= K) continue;
-                    if (cnt[q][r] == 0) first[q][r] = base + c + __builtin_ctzll(m);
-                    const int pos = cnt[q][r] + __popcll(m & lt_mask);
-                    if (pred && pos < K)
-                        reinterpret_cast<IdxT *>(args.out[r])[((size_t)b * S + qid[q]) * K + pos] =
-                            (IdxT)(base + i);
-                    cnt[q][r] += __popcll(m);
-                }
+            const float d = sqdist_expanded(qx, qy, qz, qq, p.x, p.y, p.z, p.w);
+            const bool pred = inb && !(d > r2max);
+            const unsigned long long m = __ballot(pred);
+            if (m != 0ull) {
+                if (pred) ring[(fill + __popcll(m & lt_mask)) & 127] = make_float2(__int_as_float(base + i), d);
+                fill += __popcll(m);
+                if (fill - done >= 64 && consume(64)) { finished = true; break; }
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < BQ_QPW; ++q) {
-        if (qid[q] >= S) continue;
+    if (valid) {
+        while (!finished && fill > done) finished = consume(min(64, fill - done));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int K = args.nsample[r];
-            IdxT *o = reinterpret_cast<IdxT *>(args.out[r]) + ((size_t)b * S + qid[q]) * K;
-            for (int k = cnt[q][r] + lane; k < K; k += 64) o[k] = (IdxT)first[q][r];
+            IdxT *o = reinterpret_cast<IdxT *>(args.out[r]) + ((size_t)b * S + qid) * K;
+            for (int k = min(cnt[r], K) + lane; k < K; k += 64) o[k] = (IdxT)first[r];
         }
     }
 }

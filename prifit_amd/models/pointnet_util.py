@@ -10,12 +10,14 @@ Differences that are deliberate and documented (SURVEY.md section 8a'):
   * internally activations are channels-last and input channels are zero-padded to multiples of 4
     (weights are re-packed on the fly; gradients flow back to the upstream-shaped parameters).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..nn_ops import GroupGatherFn, SharedMLPFn, ThreeInterpolateFn
+from ..nn_ops import GatherLinearFn, GroupGatherFn, LinearFn, SharedMLPFn, ThreeInterpolateFn
 
 
 # ------------------------------------------------------------------ functional surface (:19-107)
@@ -61,6 +63,45 @@ def _mlp_tensors(convs, bns, first_weight):
     for i, (conv, bn) in enumerate(zip(convs, bns)):
         w = first_weight if i == 0 else conv.weight.reshape(conv.weight.shape[0], -1)
         ts += [w, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    return ts
+
+
+# The first layer of a set-abstraction MLP is computed by linearity (no grouped tensor) when the grouped row would
+# be wider than the layer's output; PRIFIT_SA_LINEARITY=0 keeps the gather + GEMM form for A/B measurements.
+_SA_LINEARITY = os.environ.get("PRIFIT_SA_LINEARITY", "1") != "0"
+
+
+def _use_linearity(conv, kp):
+    return _SA_LINEARITY and kp > conv.weight.shape[0]
+
+
+def _first_layer_by_linearity(conv, bn_training, feats, xyz, new_xyz, idx, kp, feat_first):
+    """conv1 over the grouped [features | rel_xyz] rows without materialising them: project every POINT
+    once (U), every CENTRE once (Vc), then gather C1-wide rows (GatherLinearFn).  Used when the grouped row
+    would be wider than the layer's output."""
+    B, N, _ = xyz.shape
+    D = 0 if feats is None else feats.shape[-1]
+    S = new_xyz.shape[1]
+    w = conv.weight.reshape(conv.weight.shape[0], -1)
+    C1 = w.shape[0]
+    if feat_first:   # upstream MSG order [features, rel_xyz] (:247)
+        wf, wx = w[:, :D], w[:, D:D + 3]
+    else:            # upstream single-scale order [rel_xyz, features] (:131)
+        wf, wx = w[:, 3:3 + D], w[:, :3]
+    parts = ([feats] if feats is not None else []) + [xyz]
+    if kp > D + 3:
+        parts.append(xyz.new_zeros(B, N, kp - D - 3))
+    rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
+    w_pt = torch.cat([wf, wx] + ([w.new_zeros(C1, kp - D - 3)] if kp > D + 3 else []), dim=1)
+    U = LinearFn.apply(rows, w_pt, None).reshape(B, N, C1)
+    c4 = torch.cat([new_xyz, new_xyz.new_zeros(B, S, 1)], dim=-1).reshape(B * S, 4)
+    Vc = LinearFn.apply(c4, torch.cat([wx, w.new_zeros(C1, 1)], dim=1), None).reshape(B, S, C1)
+    return GatherLinearFn.apply(U, Vc, conv.bias, idx, bn_training)
+
+
+def _mlp_tensors_preact(convs, bns):
+    ts = _mlp_tensors(convs, bns, None)
+    ts[1] = None
     return ts
 
 
@@ -128,6 +169,13 @@ class PointNetSetAbstraction(nn.Module):
             _, new_xyz = ops.farthest_point_sample(xyz, S, fps_start, return_xyz=True)
             idx = ops.ball_query_multi([self.radius], [K], xyz, new_xyz)[0]
             # rows = [features, rel_xyz, pad]; upstream order is [rel_xyz, features] (:131)
+            if _use_linearity(self.mlp_convs[0], kp):
+                y1, slab = _first_layer_by_linearity(self.mlp_convs[0], self.training, feats, xyz, new_xyz, idx, kp,
+                                                     feat_first=False)
+                cfg = _mlp_cfg(self.mlp_bns, K, self.training)
+                cfg["preact_slab"] = slab
+                out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns))
+                return new_xyz, out.reshape(B, S, -1)
             rows = GroupGatherFn.apply(feats, xyz, new_xyz, idx, 0, kp)
             w0 = _pack_weight(self.mlp_convs[0], [(3, 3 + D), (0, 3)], kp)
         out = SharedMLPFn.apply(rows, _mlp_cfg(self.mlp_bns, K, self.training),
@@ -168,6 +216,13 @@ class PointNetSetAbstractionMsg(nn.Module):
         idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
         pooled = []
         for i, K in enumerate(self.nsample_list):
+            if _use_linearity(self.conv_blocks[i][0], kp):
+                y1, slab = _first_layer_by_linearity(self.conv_blocks[i][0], self.training, feats, xyz, new_xyz,
+                                                     idxs[i], kp, feat_first=True)
+                cfg = _mlp_cfg(self.bn_blocks[i], K, self.training)
+                cfg["preact_slab"] = slab
+                pooled.append(SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i])))
+                continue
             rows = GroupGatherFn.apply(feats, xyz, new_xyz, idxs[i], 0, kp)  # [features, rel_xyz] (:247)
             w0 = _pack_weight(self.conv_blocks[i][0], [(0, D + 3)], kp)
             pooled.append(SharedMLPFn.apply(rows, _mlp_cfg(self.bn_blocks[i], K, self.training),

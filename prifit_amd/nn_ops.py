@@ -63,7 +63,11 @@ class SharedMLPFn(torch.autograd.Function):
     """(conv1x1 + BatchNorm + ReLU) x L [+ max over the K samples of each group].
 
     apply(x, cfg, *tensors) with, per layer, tensors = (W [Cout, Kin], bias, gamma, beta,
-    running_mean, running_var); cfg = dict(pool_K, training, eps, momentum[list])."""
+    running_mean, running_var); cfg = dict(pool_K, training, eps, momentum[list]).
+
+    cfg["preact_slab"] (a [nslab, 2, C] column-statistics slab, or True in eval mode) marks x as the
+    already-computed pre-activation of layer 0 (GatherLinearFn): layer 0 then has no GEMM and its W/bias slots
+    are None; the gradient returned for x is the one w.r.t. that pre-activation."""
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
@@ -76,15 +80,30 @@ class SharedMLPFn(torch.autograd.Function):
         prev, prev_aff = x, None
         for l in range(L):
             W, b, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 6]
-            W = W.contiguous()
-            Cout, Kin = W.shape
-            assert Kin == prev.shape[1], (Kin, prev.shape)
-            Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            preact = l == 0 and cfg.get("preact_slab") is not None
+            if preact:
+                W, Cout, Kin, Y = None, x.shape[1], 0, x
+            else:
+                W = W.contiguous()
+                Cout, Kin = W.shape
+                assert Kin == prev.shape[1], (Kin, prev.shape)
+                Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
             scale = torch.empty(Cout, dtype=torch.float32, device=dev)
             shift = torch.empty_like(scale)
             mean = torch.empty_like(scale)
             invstd = torch.empty_like(scale)
-            if training:
+            if preact:
+                if training:
+                    slab = cfg["preact_slab"]
+                    call("prifit_bn_finalize", ptr(slab), slab.shape[0], Cout, _D(float(P)), ptr(gamma), ptr(beta),
+                         _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
+                         ptr(mean), ptr(invstd), cur_stream())
+                else:
+                    invstd = torch.rsqrt(rvar + cfg["eps"])
+                    mean = rmean.clone()
+                    scale = gamma * invstd
+                    shift = beta - mean * scale
+            elif training:
                 nslab = (P + tile_m - 1) // tile_m
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
@@ -115,7 +134,8 @@ class SharedMLPFn(torch.autograd.Function):
             out = torch.empty(P, CL, dtype=torch.float32, device=dev)
             call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, 0, _F(0.0),
                  ptr(out), _LL(CL), cur_stream())
-        ctx.cfg = cfg
+        ctx.cfg = {k: v for k, v in cfg.items() if k != "preact_slab"}
+        ctx.preact = cfg.get("preact_slab") is not None
         ctx.L = L
         ctx.saved = (x, Ys, Ws, affines, stats_saved, arg)
         return out
@@ -133,7 +153,7 @@ class SharedMLPFn(torch.autograd.Function):
         G_in = gout  # gradient w.r.t. the ReLU output of layer l (or pooled output for the last layer)
         for l in range(L - 1, -1, -1):
             Y, W = Ys[l], Ws[l]
-            Cout, Kin = W.shape
+            Cout, Kin = W.shape if W is not None else (Y.shape[1], 0)
             scale, shift = affines[l]
             mean, invstd = stats_saved[l]
             dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -162,6 +182,11 @@ class SharedMLPFn(torch.autograd.Function):
             else:
                 call("prifit_bn_relu_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
                      ptr(shift), ptr(ca), ptr(cb), ptr(cd), P, Cout, 0, _F(0.0), ptr(dY), _LL(Cout), cur_stream())
+            grads[6 * l + 2] = dgamma
+            grads[6 * l + 3] = dbeta
+            if l == 0 and ctx.preact:
+                G_in = dY
+                break
             A_in = x if l == 0 else Ys[l - 1]
             a_aff = None if l == 0 else affines[l - 1]
             if ctx.needs_input_grad[2 + 6 * l]:
@@ -179,6 +204,45 @@ class SharedMLPFn(torch.autograd.Function):
                 G_in = None
             del dY
         return (G_in, None) + tuple(grads)
+
+
+class GatherLinearFn(torch.autograd.Function):
+    """First layer of a set-abstraction MLP by linearity (upstream models/pointnet_util.py:243-252):
+    conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias with U = [feat | xyz] W1^T per point and
+    Vc = c W1x^T per centre.  apply(U [B,N,C], Vc [B,S,C], bias, idx [B,S,K], training)
+    -> (Y1 [B*S*K, C], column-statistics slab for the BatchNorm that follows)."""
+
+    @staticmethod
+    def forward(ctx, U, Vc, bias, idx, training):
+        U, Vc, idx = U.contiguous(), Vc.contiguous(), idx.contiguous()
+        B, N, C = U.shape
+        _, S, K = idx.shape
+        assert Vc.shape == (B, S, C) and idx.dtype == torch.int32, (Vc.shape, idx.dtype)
+        P = B * S * K
+        Y = torch.empty(P, C, dtype=torch.float32, device=U.device)
+        slab = torch.empty((P + 511) // 512, 2, C, dtype=torch.float32, device=U.device)
+        # algorithmic bytes: read U and Vc once, read idx, write the C-wide grouped pre-activations
+        with profiler.span("gather_linear", 4.0 * B * (N * C + S * C + S * K + S * K * C)):
+            call("prifit_gather_linear_fwd", ptr(U), ptr(Vc), ptr(bias), ptr(idx), B, N, S, K, C, ptr(Y), ptr(slab),
+                 cur_stream())
+        ctx.save_for_backward(idx)
+        ctx.meta = (B, N, S, K, C, training)
+        ctx.mark_non_differentiable(slab)
+        return Y, slab
+
+    @staticmethod
+    def backward(ctx, gY, _gslab):
+        (idx,) = ctx.saved_tensors
+        B, N, S, K, C, training = ctx.meta
+        gY = gY.contiguous()
+        dU = torch.zeros(B, N, C, dtype=torch.float32, device=gY.device)
+        dVc = torch.empty(B, S, C, dtype=torch.float32, device=gY.device)
+        call("prifit_gather_linear_bwd", ptr(gY), ptr(idx), B, N, S, K, C, ptr(dU), ptr(dVc), cur_stream())
+        db = None
+        if ctx.needs_input_grad[2]:
+            # a bias in front of a batch-statistics BatchNorm has zero gradient
+            db = torch.zeros(C, device=gY.device) if training else gY.sum(dim=0)
+        return dU, dVc, db, None, None
 
 
 class LinearFn(torch.autograd.Function):

@@ -27,3 +27,14 @@ for kind in ("cube", "surface"):
         timed(kind + " gather sa1 K=%d (C=3)" % K, lambda ii=ii: ops.group_gather(xyz, xyz, c1, ii, ld_out=8), B * (4 * 512 * K * 6))
     for K, ii in zip((64, 128), i2):
         timed(kind + " gather sa2 K=%d (C=320)" % K, lambda ii=ii: ops.group_gather(f1, c1, c2, ii, ld_out=324), B * (4 * 512 * 320 + 4 * 128 * K * 323))
+    # first SA2 layer by linearity: gather of C1-wide projected rows (GatherLinearFn)
+    from prifit_amd.nn_ops import GatherLinearFn
+    U = torch.randn(B, 512, 128, device="cuda", requires_grad=True)
+    for K, ii in zip((64, 128), i2):
+        Vc = torch.randn(B, 128, 128, device="cuda", requires_grad=True)
+        timed(kind + " gather_linear sa2 K=%d (C1=128)" % K, lambda ii=ii: GatherLinearFn.apply(U.detach(), Vc.detach(), None, ii, True),
+              4 * B * (512 * 128 + 128 * 128 + 128 * K + 128 * K * 128))
+        y, _ = GatherLinearFn.apply(U, Vc, None, ii, True)
+        g = torch.randn_like(y)
+        timed(kind + " gather_linear bwd K=%d" % K, lambda: torch.autograd.grad(y, (U, Vc), g, retain_graph=True),
+              4 * B * (512 * 128 + 128 * 128 + 128 * K + 128 * K * 128))
