@@ -6,6 +6,7 @@ validity masks instead of the reference's python lists / -1 sentinels), so one f
 the loss is a fixed sequence of launches with a single host read-back (the cluster-count check of
 src/ellipsoid_utils.py:19-27).  Reference sites are cited per function (paths relative to upstream).
 """
+import contextlib
 import ctypes
 
 import torch
@@ -282,13 +283,79 @@ class SampleNNLossFn(torch.autograd.Function):
         return g_r, g_V, g_c, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# Speculative clustering.  guard_mean_shift (src/mean_shift.py) reads the number of clusters on the host to
+# decide whether to retry with a doubled quantile; that read-back drains the GPU queue in the middle of a step.
+# Inside `with speculative() as spec:` cluster() assumes the first round is accepted (it is, except on
+# degenerate embeddings), copies the verdict to pinned host memory asynchronously and carries on; the caller
+# checks `spec.ok()` once everything is enqueued and, if the assumption was wrong, discards the step and re-runs
+# it outside the context (train_step.SpeculativeRunner does exactly that) - results are the reference's either way.
+# ------------------------------------------------------------------------------------------------
+class _Speculation:
+    def __init__(self):
+        self.checks = []
+
+    def ok(self):
+        good = True
+        for ev, flag in self.checks:
+            ev.synchronize()
+            good = good and int(flag[0]) == 0
+        self.checks.clear()
+        return good
+
+
+_spec = None
+_flag_pool, _flag_next = [], 0
+
+
+def _pinned_flag():
+    global _flag_next
+    if len(_flag_pool) < 16:
+        _flag_pool.append(torch.zeros(1, dtype=torch.int32).pin_memory())
+        return _flag_pool[-1]
+    _flag_next = (_flag_next + 1) % len(_flag_pool)
+    return _flag_pool[_flag_next]
+
+
+@contextlib.contextmanager
+def speculative():
+    global _spec
+    prev, _spec = _spec, _Speculation()
+    try:
+        yield _spec
+    finally:
+        _spec = prev
+
+
+def _cluster_speculative(X, quantile, iterations, max_num_clusters):
+    Bt, N, D = X.shape
+    with torch.no_grad():
+        bw = compute_bandwidth(X, quantile)
+    Z = MeanShiftFn.apply(X, bw, iterations)
+    with torch.no_grad():
+        ids, count, labels, used = nms(Z.detach(), bw)
+        nuniq = torch.where(count > NMS_CAP, count, used.sum(dim=1).to(torch.int32))
+        bad = ((nuniq > max_num_clusters) | (count > KM)).any().to(torch.int32).reshape(1)
+        flag = _pinned_flag()
+        flag.copy_(bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _spec.checks.append((ev, flag))
+    return {"bw": bw, "ids": ids[:, :KM].long(), "count": count, "labels": labels.long(),
+            "quantile": [quantile] * Bt, "Z": Z}
+
+
 def cluster(X, quantile, iterations, max_num_clusters):
     """src/ellipsoid_utils.py:9-73 batched: mean-shift + nms with the quantile-doubling retry
     (one host read-back per round).  X [B,N,D] unit rows.
     Returns dict(Z, bw, ids [B,KM], count [B], labels [B,N] int64, centres [B,KM,D], W [B,N,KM], quantile list)."""
     Bt, N, D = X.shape
     dev = X.device
-    Z_all = [None] * Bt
+    if _spec is not None:
+        res = _cluster_speculative(X, quantile, iterations, max_num_clusters)
+        res["centres"] = torch.gather(res["Z"], 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))
+        res["W"] = MembershipFn.apply(res["centres"], X, res["bw"], res["count"])
+        return res
     res = {"bw": torch.empty(Bt, device=dev), "ids": torch.zeros(Bt, KM, dtype=torch.int64, device=dev),
            "count": torch.zeros(Bt, dtype=torch.int32, device=dev),
            "labels": torch.zeros(Bt, N, dtype=torch.int64, device=dev), "quantile": [quantile] * Bt}

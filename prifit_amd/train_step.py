@@ -32,6 +32,32 @@ def random_scale_shift(points, generator=None, scale_low=0.8, scale_high=1.25, s
     return out
 
 
+class SpeculativeRunner:
+    """Run a forward+backward closure with fit_ops.speculative() (no mid-step host read-back); if the clustering
+    verdict, read once everything is enqueued, says a quantile-doubling retry was needed, put the BatchNorm
+    buffers back, clear the gradients and run the closure again the synchronous way."""
+
+    def __init__(self, model):
+        self.bufs = [b for b in model.buffers()]
+        self.snap = [torch.empty_like(b) for b in self.bufs]
+        self.fallbacks = 0
+
+    def run(self, fn, reset):
+        from . import fit_ops
+
+        if self.bufs:
+            torch._foreach_copy_(self.snap, self.bufs)
+        with fit_ops.speculative() as spec:
+            out = fn()
+        if spec.ok():
+            return out
+        self.fallbacks += 1
+        if self.bufs:
+            torch._foreach_copy_(self.bufs, self.snap)
+        reset()
+        return fn()
+
+
 class Trainer:
     def __init__(self, model, num_part=50, learning_rate=0.001, decay_rate=1e-4, lr_decay=0.5, step_size=20, lmbda=1.0,
                  fused_adam=True):
@@ -42,6 +68,7 @@ class Trainer:
                                           weight_decay=decay_rate,
                                           fused=bool(fused_adam and next(model.parameters()).is_cuda))
         self.bucket = FlatGradBucket(model)
+        self.speculative = SpeculativeRunner(model) if next(model.parameters()).is_cuda else None
         self.epoch = 0
         self.train_acc = 0.0
 
@@ -58,7 +85,8 @@ class Trainer:
         return lr, momentum
 
     def _apply(self, loss):
-        loss.backward()
+        if loss is not None:
+            loss.backward()
         self.bucket.allreduce()
         self.optimizer.step()
 
@@ -96,10 +124,19 @@ class Trainer:
         category_label = torch.zeros(B, 1, 16, device=cham.device)
         self.bucket.zero()
         self.model.train()
-        out = self.model(points, category_label, chamfer_points=cham, include_convex_loss=True, quantile=quantile,
-                         msc_iterations=msc_iterations, max_num_clusters=max_num_clusters, **loss_kwargs)
-        ss_loss = torch.mean(out[3]) * self.lmbda
-        self._apply(ss_loss)
+
+        def fwd_bwd():
+            out = self.model(points, category_label, chamfer_points=cham, include_convex_loss=True, quantile=quantile,
+                             msc_iterations=msc_iterations, max_num_clusters=max_num_clusters, **loss_kwargs)
+            ss_loss = torch.mean(out[3]) * self.lmbda
+            ss_loss.backward()
+            return ss_loss
+
+        if self.speculative is not None:
+            ss_loss = self.speculative.run(fwd_bwd, self.bucket.zero)
+        else:
+            ss_loss = fwd_bwd()
+        self._apply(None)
         return ss_loss.detach()
 
     # ------------------------------------------------------------------ checkpoints (upstream :467-475, :263-274)
