@@ -442,7 +442,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
         (epilogue != 100 && (epilogue < 0 || epilogue > 3)) || (epilogue >= EPI_MSKERNEL && !epi_batch_scalar) ||
         (epilogue == EPI_MSBWD && !epi_aux) || (splitk > 1 && !accumulate) ||
         ((a_scale == nullptr) != (a_shift == nullptr)) || ((b_scale == nullptr) != (b_shift == nullptr)) ||
-        (col_stats && (batch != 1 || splitk != 1)) || (epilogue != EPI_NONE && splitk != 1) || (long long)batch * splitk > 65535)
+        (col_stats && (batch != 1 || splitk != 1)) || (epilogue != EPI_NONE && epilogue != 100 && splitk != 1) || (long long)batch * splitk > 65535)
         return PRIFIT_EINVAL;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;

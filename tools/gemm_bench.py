@@ -21,7 +21,7 @@ def run(name, lay, M, N, K, batch=1, epi=0, affine=False, stats=False, splitk=1,
     bw = torch.full((batch,), 0.5, device=dev)
     aux = torch.rand(batch, M, N, device=dev) if epi == 3 else None
     slab = torch.empty((M + 127) // 128, 2, N, device=dev) if stats else None
-    kw = dict(batch=batch, sA=A.stride(0), sB=B.stride(0), sC=M * N, splitk=splitk, epi=epi,
+    kw = dict(batch=batch, sA=A.stride(0), sB=B.stride(0), sC=M * N, splitk=splitk, epi=epi, accumulate=splitk > 1,
               epi_scalar=bw if epi >= 2 else None, aux=aux, ld_aux=N, s_aux=M * N, stats=slab)
     if affine:
         kw["b_affine" if lay == TN else "a_affine"] = aff
@@ -50,6 +50,18 @@ CASES = [
     ("ms S NOSTORE NT 2048^2x128 b24", NT, 2048, 2048, 128, dict(batch=24, epi=100)),
     ("big square NOSTORE NT 4096^3", NT, 4096, 4096, 4096, dict(epi=100)),
     ("ms O=KX NN 2048x128x2048 b24", NN, 2048, 128, 2048, dict(batch=24)),
+    ("ms skinny NN sk1 NOSTORE", NN, 2048, 128, 2048, dict(batch=24, splitk=1, epi=100)),
+    ("ms skinny NN sk4 NOSTORE", NN, 2048, 128, 2048, dict(batch=24, splitk=4, epi=100)),
+    ("ms skinny NT sk1", NT, 2048, 128, 2048, dict(batch=24, splitk=1)),
+    ("ms skinny NT sk4", NT, 2048, 128, 2048, dict(batch=24, splitk=4)),
+    ("ms skinny NT sk4 NOSTORE", NT, 2048, 128, 2048, dict(batch=24, splitk=4, epi=100)),
+    ("ms skinny NN sk2", NN, 2048, 128, 2048, dict(batch=24, splitk=2)),
+    ("ms skinny NN sk4", NN, 2048, 128, 2048, dict(batch=24, splitk=4)),
+    ("ms skinny NN sk8", NN, 2048, 128, 2048, dict(batch=24, splitk=8)),
+    ("ms skinny TN sk1", TN, 2048, 128, 2048, dict(batch=24, splitk=1)),
+    ("ms skinny TN sk2", TN, 2048, 128, 2048, dict(batch=24, splitk=2)),
+    ("ms skinny TN sk4", TN, 2048, 128, 2048, dict(batch=24, splitk=4)),
+    ("ms skinny TN sk8", TN, 2048, 128, 2048, dict(batch=24, splitk=8)),
     ("ms gS NT 2048^2x128 b24 msbwd", NT, 2048, 2048, 128, dict(batch=24, epi=3)),
     ("ms dX TN 2048x128x2048 b24", TN, 2048, 128, 2048, dict(batch=24)),
     ("sa1.3 L3 fwd NT P=1.57M 96->128", NT, 1572864, 128, 96, dict(affine=True, stats=True)),
