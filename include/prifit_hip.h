@@ -335,6 +335,33 @@ int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const i
                          const int32_t *nn_idx, const float *gscale, float *g_r, float *g_V, float *g_c,
                          void *stream);
 
+/* The `--if_cuboid` variant of the same loss (convex_loss.py:72-76,89,99): the fitted (r, V, c) are read as
+ * boxes with half-sides r.  Same arguments and outputs as the ellipsoid entry points above.
+ *   sdf:    convex_loss.py:473-502  q = |V^T (p - c)| - r, sdf = ||relu(q)|| + min(max(q), 0)
+ *   budget: src/ellipsoid_utils.py:186-193  area = 8 (ab + bc + ca), round(10000 * area / sum), <= 0 -> 100
+ *   sample: src/sample_ellipsoid.py:65-96 on the build's deterministic box-surface parameters (face by
+ *           cumulative area, R2 sequence inside the face) in place of trimesh's random even sampling. */
+int prifit_cuboid_sdf_fwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                          const int32_t *valid, int KM, int32_t *arg, float *fval, float *sum_sq,
+                          void *stream);
+int prifit_cuboid_sdf_bwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                          const int32_t *arg, const float *gscale, int KM, float *g_r, float *g_V,
+                          float *g_c, void *stream);
+int prifit_cuboid_sdf_matrix_fwd(const float *points, int B, int M, const float *r, const float *V,
+                                 const float *c, const int32_t *valid, int KM, float *sdf, void *stream);
+int prifit_cuboid_sdf_matrix_bwd(const float *points, int B, int M, const float *r, const float *V,
+                                 const float *c, const int32_t *valid, const float *g_sdf, int KM,
+                                 float *g_r, float *g_V, float *g_c, void *stream);
+int prifit_cuboid_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n,
+                                int32_t *off, void *stream);
+int prifit_cuboid_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n,
+                                const int32_t *off, int B, int KM, const float *targets, int M, int cap,
+                                int32_t *nn_idx, float *sum_d2, void *stream);
+int prifit_cuboid_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n,
+                                const int32_t *off, int B, int KM, const float *targets, int M, int cap,
+                                const int32_t *nn_idx, const float *gscale, float *g_r, float *g_V,
+                                float *g_c, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* DGCNN graph ops (src/dgcnn.py, BASELINE.json configs[4])                                     */
 /* ------------------------------------------------------------------------------------------ */

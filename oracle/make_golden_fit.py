@@ -188,6 +188,46 @@ def run(save, eq, close):
          K=np.array([len(p) for p in prm_r]), labels=torch.stack(lab_r).to(torch.int16),
          dX_norm=Xr.grad.norm(), dX_head=Xr.grad[:, :, :32].contiguous())
 
+    # ---- cuboid variant (--if_cuboid, convex_loss.py:72-76,89): SDF, budget + sampler, chamfer, full loss.
+    # trimesh is absent: its box mesh and even surface sampler are replaced, on both sides, by the build's
+    # deterministic cuboid_surface(); the reference's own scaling code (src/sample_ellipsoid.py:78-95) runs as is.
+    import types
+
+    class _Box:
+        def __init__(self):
+            self.vertices = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+
+    def _sample_even(mesh, count):
+        return orc.cuboid_surface(int(count), *np.abs(mesh.vertices).max(0)), None
+
+    SE.trimesh.creation = types.SimpleNamespace(box=lambda extents: _Box())
+    SE.trimesh.sample = types.SimpleNamespace(sample_surface_even=_sample_even)
+    samples_rc = EU.sample_from_pred_params_cuboid(params_r, 500)
+    samples_oc = orc.sample_from_params(params_o, cuboid=True)
+    for b in range(B):
+        close(samples_oc[b], samples_rc[b], f"cuboid sampled points b={b}", rtol=1e-5, atol=1e-6)
+    lc_r = UT.analytic_chamfer_distance(params_r, samples_rc, cham, cuboid=True)
+    lc_o, parts_c = orc.analytic_chamfer(params_o, samples_oc, cham, cuboid=True)
+    close(lc_o, lc_r, "cuboid analytic chamfer", rtol=1e-5)
+    sdf_rc = CL.compute_sdf_cuboid_batch(cham, params_r)
+    Xrc = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    with patched(torch, "rand", lambda *a, **k: R.clone()), patched(EF, "customsvd", ref_customsvd_canonical), \
+            contextlib.redirect_stdout(open(os.devnull, "w")):
+        totc_r, chc_r, prmc_r, _ = CL.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xrc, quantile=q,
+                                                  iterations=iters, max_num_clusters=25, if_cuboid=True)
+    totc_r.sum().backward()
+    Xoc = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    totc_o, _, _, _ = orc.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xoc, quantile=q, iterations=iters,
+                                      max_num_clusters=25, rand_table=[[R] * 64] * B, canonical=True, if_cuboid=True)
+    totc_o.sum().backward()
+    close(totc_o, totc_r, "cuboid convex_loss total", rtol=1e-5)
+    close(Xoc.grad, Xrc.grad, "cuboid convex_loss dX", rtol=2e-3, atol=1e-3 * Xrc.grad.abs().max().item())
+    save("fit_cuboid", seed=seed, R=R, loss=lc_r.detach(), dist_st=torch.stack([p[0] for p in parts_c]),
+         sdf_ts=torch.stack([p[1] for p in parts_c]), nsamples=np.array([s_.shape[0] for s_ in samples_rc]),
+         sdf_head=torch.stack([torch.stack(s_, 1)[:256] for s_ in sdf_rc]).detach(), total=totc_r.detach(),
+         samples_head=torch.stack([s_[:64] for s_ in samples_rc]).detach(),
+         dX_norm=Xrc.grad.norm(), dX_head=Xrc.grad[:, :, :32].contiguous())
+
     # ---- optional entropy term (convex_loss.py:209-225) on a fixed quarter of the points
     ent_idx = torch.from_numpy(np.random.default_rng(seed + 9).choice(N, N // 4, replace=False))
     Xe = emb.clone().requires_grad_(True)

@@ -646,16 +646,70 @@ def sample_ellipsoid(a, b, c, center, V, n):
     return pts @ V.t() + center
 
 
-def sample_from_params(params_batch):
-    """src/ellipsoid_utils.py:76-130: list[B] of [~10000, 3] tensors, or -1 for a shape without ellipsoids."""
+def sample_from_params(params_batch, cuboid=False):
+    """src/ellipsoid_utils.py:76-130 (cuboid: :162-214): list[B] of [~10000, 3] tensors, or -1 for a shape
+    without primitives."""
     out = []
     for params in params_batch:
         if len(params) == 0:
             out.append(-1)
             continue
-        n = sample_budget(params)
-        out.append(torch.cat([sample_ellipsoid(r[0], r[1], r[2], c, V, n[i]) for i, (r, V, c) in enumerate(params)], 0))
+        n = cuboid_budget(params) if cuboid else sample_budget(params)
+        fn = sample_cuboid if cuboid else sample_ellipsoid
+        out.append(torch.cat([fn(r[0], r[1], r[2], c, V, n[i]) for i, (r, V, c) in enumerate(params)], 0))
     return out
+
+
+def sdf_cuboid(points, center, r, V):
+    """convex_loss.py:473-487 (box with half-sides r)."""
+    qv = (V.t() @ (points - center).t()).t()
+    q = torch.abs(qv) - r
+    return torch.norm(torch.relu(q), p=2, dim=1) + torch.clamp_max(torch.max(q, 1)[0], 0.0)
+
+
+def cuboid_budget(params):
+    """src/ellipsoid_utils.py:186-193: points per cuboid, proportional to 8 (ab + bc + ca) (fp32 .item())."""
+    areas = [(8 * (r[0] * r[1] + r[1] * r[2] + r[2] * r[0])).item() for r, _, _ in params]
+    w = areas / np.sum(areas)
+    n = np.round(10000 * w).astype(int)
+    n[n <= 0] = 100
+    return n
+
+
+def cuboid_surface(n, a, b, c):
+    """The build's deterministic stand-in for trimesh.sample.sample_surface_even on a box with half-sides
+    (a, b, c) (src/sample_ellipsoid.py:78-84): sample j of n lands on the face whose slice of the cumulative area
+    [+z, -z, +x, -x, +y, -y] contains (j + 0.5)/n; the two free coordinates follow the R2 sequence.
+    Returns float64 [n, 3] points ON the scaled box (what the mesh sampler returns)."""
+    a, b, c = float(a), float(b), float(c)
+    w = np.array([a * b, a * b, b * c, b * c, c * a, c * a], dtype=np.float64)
+    total = 0.0
+    for f in range(6):
+        total += w[f]
+    j = np.arange(n, dtype=np.float64)
+    t = (j + 0.5) / n
+    face = np.zeros(n, dtype=np.int64)
+    run = 0.0
+    for f in range(5):
+        run += w[f]
+        face[t >= run / total] = f + 1
+    s1 = 2.0 * np.modf(0.5 + j * 0.7548776662466927)[0] - 1.0
+    s2 = 2.0 * np.modf(0.5 + j * 0.5698402909980532)[0] - 1.0
+    sg = np.where(face % 2 == 1, -1.0, 1.0)
+    v = np.empty((n, 3), dtype=np.float64)
+    z, x, y = face < 2, (face >= 2) & (face < 4), face >= 4
+    v[z] = np.stack([s1[z], s2[z], sg[z]], 1)
+    v[x] = np.stack([sg[x], s1[x], s2[x]], 1)
+    v[y] = np.stack([s2[y], sg[y], s1[y]], 1)
+    return v * np.array([[a, b, c]])
+
+
+def sample_cuboid(a, b, c, center, V, n):
+    """src/sample_ellipsoid.py:65-96 with cuboid_surface() in place of the mesh sampler."""
+    sides_numpy = np.array([a.item(), b.item(), c.item()]).reshape((1, 3))
+    sides_torch = torch.stack([a, b, c]).view(1, 3)
+    pts = cuboid_surface(int(n), *sides_numpy[0]) / (sides_numpy + 1e-6)     # :88
+    return torch.from_numpy(pts.astype(np.float32)) * sides_torch @ V.t() + center
 
 
 def nearest_target(src, tgt, chunk=2048):
@@ -668,14 +722,15 @@ def nearest_target(src, tgt, chunk=2048):
     return torch.cat(idx)
 
 
-def analytic_chamfer(params_batch, samples_batch, targets):
+def analytic_chamfer(params_batch, samples_batch, targets, cuboid=False):
     """src/utils.py:384-426.  targets [B,M,3].  Returns (loss, per-shape (dist_st, sdf_ts) list)."""
+    sdf_fn = sdf_cuboid if cuboid else sdf_ellipsoid
     per, parts = [], []
     for b in range(targets.shape[0]):
         if not torch.is_tensor(samples_batch[b]):
             parts.append(None)
             continue
-        sdf = torch.stack([sdf_ellipsoid(targets[b], c, r, V) for r, V, c in params_batch[b]], 1).abs()
+        sdf = torch.stack([sdf_fn(targets[b], c, r, V) for r, V, c in params_batch[b]], 1).abs()
         sdf_ts = sdf.min(1)[0] ** 2
         nn_idx = nearest_target(samples_batch[b], targets[b])
         dist_st = ((samples_batch[b] - targets[b][nn_idx]) ** 2).sum(1)
@@ -693,7 +748,7 @@ def entropy(X):
     return torch.relu(torch.stack(l).mean() - 1.8)
 
 
-def intersection_loss_volume_3(params_batch, points):
+def intersection_loss_volume_3(params_batch, points, cuboid=False):
     """convex_loss.py:374-413.  Upstream calls torch_scatter.scatter_mean whose import is commented out
     (convex_loss.py:17 -> NameError), so this term is PARITY-UNPINNED: it restates the documented
     intent -- per point, the mean over the ellipsoids the point does NOT belong to of clamp_max(sdf, -1e-3),
@@ -702,7 +757,7 @@ def intersection_loss_volume_3(params_batch, points):
     for b, params in enumerate(params_batch):
         if len(params) <= 1:
             continue
-        sdf = torch.stack([sdf_ellipsoid(points[b], c, r, V) for r, V, c in params], 1)
+        sdf = torch.stack([(sdf_cuboid if cuboid else sdf_ellipsoid)(points[b], c, r, V) for r, V, c in params], 1)
         sdf = torch.clamp_max(sdf, -1e-3)
         own = sdf.min(1)[1]
         mask = torch.ones_like(sdf)
@@ -716,9 +771,9 @@ def intersection_loss_volume_3(params_batch, points):
 
 def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_clusters=25, rand_table=None,
                 canonical=False, return_info=False, include_entropy_loss=False, entropy_indices=None,
-                include_intersect_loss=False, intersect_jitter=None, alpha=1, beta=1, **_unused):
-    """convex_loss.py:27-103 with the default flags of the benchmarked path (no entropy / intersection /
-    pruning / cuboid).  points [B,3,N], chamfer_points [B,3,M], X [B,D,N]."""
+                include_intersect_loss=False, intersect_jitter=None, alpha=1, beta=1, if_cuboid=False, **_unused):
+    """convex_loss.py:27-103; the optional terms (entropy, intersection, cuboid primitives) behind their flags.
+    points [B,3,N], chamfer_points [B,3,M], X [B,D,N]."""
     X = F.normalize(X.permute(0, 2, 1), dim=2, p=2)
     X = F.normalize(X, dim=2, p=2)
     pts = points.permute(0, 2, 1)
@@ -727,11 +782,11 @@ def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_
         ent = entropy(X[:, entropy_indices])
     Ws, labels, info = clustering(X, quantile, iterations, max_num_clusters)
     params = fit_ellipsoids_batch(pts, Ws, rand_table, canonical)
-    samples = sample_from_params(params)
-    loss, parts = analytic_chamfer(params, samples, chamfer_points.permute(0, 2, 1))
+    samples = sample_from_params(params, cuboid=if_cuboid)
+    loss, parts = analytic_chamfer(params, samples, chamfer_points.permute(0, 2, 1), cuboid=if_cuboid)
     inter = torch.zeros(1)
     if include_intersect_loss:  # convex_loss.py:96-99: targets jittered by U[0,0.2) (passed in explicitly)
-        inter = intersection_loss_volume_3(params, chamfer_points.permute(0, 2, 1) - intersect_jitter)
+        inter = intersection_loss_volume_3(params, chamfer_points.permute(0, 2, 1) - intersect_jitter, cuboid=if_cuboid)
     total = loss + (alpha * inter) + (beta * ent)
     if return_info:
         return total.view(1, 1), loss.view(1, 1), params, labels, {"W": Ws, "cluster": info, "parts": parts,

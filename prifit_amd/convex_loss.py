@@ -13,7 +13,9 @@ Explicit inputs that replace hidden randomness / absent third-party code (SURVEY
 Optional terms (off in the README configuration): `include_entropy_loss` (upstream :59-62,209-225),
 `include_intersect_loss` (:96-99,374-413 -- upstream's scatter_mean import is commented out, so this term is
 parity-unpinned and restates the documented intent), `include_pruning` (:78-82: upstream computes the pruned
-set but never uses it in the loss, so it is a no-op here).  `if_cuboid` raises.
+set but never uses it in the loss, so it is a no-op here).  `if_cuboid` (:72-76) reads the fitted (r, V, c) as boxes
+with half-sides r: cuboid SDF (:473-502), area-proportional budget (src/ellipsoid_utils.py:186-193) and
+src/sample_ellipsoid.py:65-96 evaluated on the build's deterministic box-surface table (fit.hip cuboid_unit).
 """
 import torch
 import torch.nn.functional as F
@@ -48,12 +50,13 @@ class EllipseParams:
         return iter(self._materialise())
 
 
-def analytic_chamfer_distance(r, V, c, valid, targets):
+def analytic_chamfer_distance(r, V, c, valid, targets, cuboid=False):
     """src/utils.py:384-426: per shape (mean_s |s - NN_target(s)|^2 + mean_t (min_k |sdf_k(t)|)^2) / 2,
-    averaged over the shapes that have at least one ellipsoid; zeros(1) if none has."""
+    averaged over the shapes that have at least one ellipsoid; zeros(1) if none has.  cuboid=True: the
+    primitives are boxes with half-sides r (:396-397, convex_loss.py:473-502, src/sample_ellipsoid.py:65-96)."""
     M = targets.shape[1]
-    sdf_sum = fit_ops.SdfLossFn.apply(targets, r, V, c, valid)
-    d2_sum, total = fit_ops.SampleNNLossFn.apply(r, V, c, valid, targets)
+    sdf_sum = fit_ops.SdfLossFn.apply(targets, r, V, c, valid, cuboid)
+    d2_sum, total = fit_ops.SampleNNLossFn.apply(r, V, c, valid, targets, cuboid)
     has = (valid.sum(dim=1) > 0).to(r.dtype)
     per = (d2_sum / total.clamp(min=1).to(r.dtype) + sdf_sum / M) / 2.0
     return (per * has).sum() / has.sum().clamp(min=1.0), (d2_sum / total.clamp(min=1), sdf_sum / M)
@@ -90,12 +93,13 @@ class SdfMatrixFn(torch.autograd.Function):
     """sdf [B,M,KM] of every live ellipsoid at every point (convex_loss.py:331-343), 0 in dead slots."""
 
     @staticmethod
-    def forward(ctx, points, r, V, c, valid):
+    def forward(ctx, points, r, V, c, valid, cuboid=False):
         points, r, V, c = points.contiguous(), r.contiguous(), V.contiguous(), c.contiguous()
         B, M, _ = points.shape
         K = r.shape[1]
         out = torch.empty(B, M, K, dtype=torch.float32, device=points.device)
-        call("prifit_ellipsoid_sdf_matrix_fwd", ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(out),
+        ctx.prim = "cuboid" if cuboid else "ellipsoid"   # convex_loss.py:381-384
+        call("prifit_%s_sdf_matrix_fwd" % ctx.prim, ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(out),
              cur_stream())
         ctx.save_for_backward(points, r, V, c, valid)
         return out
@@ -106,15 +110,15 @@ class SdfMatrixFn(torch.autograd.Function):
         B, M, _ = points.shape
         K = r.shape[1]
         g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
-        call("prifit_ellipsoid_sdf_matrix_bwd", ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid),
+        call("prifit_%s_sdf_matrix_bwd" % ctx.prim, ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid),
              ptr(g.contiguous()), K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
-        return None, g_r, g_V, g_c, None
+        return None, g_r, g_V, g_c, None, None
 
 
-def intersection_loss_volume_3(r, V, c, valid, points):
+def intersection_loss_volume_3(r, V, c, valid, points, cuboid=False):
     """convex_loss.py:374-413 (intent; see the module docstring): per point the mean, over the ellipsoids it does
     not belong to, of clamp_max(sdf, -1e-3), squared; mean over points and over shapes with > 1 ellipsoid."""
-    sdf = torch.clamp_max(SdfMatrixFn.apply(points, r, V, c, valid), -1e-3)
+    sdf = torch.clamp_max(SdfMatrixFn.apply(points, r, V, c, valid, cuboid), -1e-3)
     live = (valid != 0).unsqueeze(1)                                     # [B,1,KM]
     nlive = live.sum(dim=2).to(sdf.dtype)                                # [B,1]
     own = sdf.masked_fill(~live, float("inf")).argmin(dim=2, keepdim=True)
@@ -130,8 +134,6 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
                 if_cuboid=False, include_pruning=False, include_entropy_loss=False, evaluation=False,
                 rand_table=None, canonical=True, return_info=False, entropy_indices=None, intersect_jitter=None):
     """points [B,3,N], chamfer_points [B,3,M], X [B,D,N] (per-point embedding)."""
-    if if_cuboid:
-        raise NotImplementedError("cuboid fitting (if_cuboid) is not part of the accelerated path yet")
     emb = X.permute(0, 2, 1)
     emb = F.normalize(emb, dim=2, p=2)
     emb = F.normalize(emb, dim=2, p=2).contiguous()      # normalised twice upstream (:41,57)
@@ -147,14 +149,15 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
     r, V, c, valid = fit_ops.EllipsoidFitFn.apply(pts, cl["W"], cl["count"], rand_table.to(pts.device), canonical)  # :70
     if evaluation is False:
         tgt = chamfer_points.permute(0, 2, 1).contiguous()
-        l, parts = analytic_chamfer_distance(r, V, c, valid, tgt)       # :73-89
+        l, parts = analytic_chamfer_distance(r, V, c, valid, tgt, cuboid=if_cuboid)   # :72-89
     else:
         l, parts = torch.zeros((), device=pts.device, requires_grad=True), None
     intersection_loss = torch.zeros((), device=pts.device)
     if include_intersect_loss and evaluation is False:                   # :96-99 (targets jittered by U[0, 0.2))
         if intersect_jitter is None:
             intersect_jitter = torch.rand_like(tgt) * 0.2
-        intersection_loss = intersection_loss_volume_3(r, V, c, valid, tgt - intersect_jitter.to(tgt.device))
+        intersection_loss = intersection_loss_volume_3(r, V, c, valid, tgt - intersect_jitter.to(tgt.device),
+                                                       cuboid=if_cuboid)
     total = l + (alpha * intersection_loss) + (beta * entropy_loss)      # :101
     params = EllipseParams(r, V, c, valid, cl["count"])
     labels = list(cl["labels"].unbind(0))

@@ -361,9 +361,74 @@ __device__ __forceinline__ float sdf_eval(const EllParam &e, float px, float py,
     return k0 * (k0 - 1.0f) / (k1 + 1e-6f);
 }
 
+// Cuboid with half-sides r in the same frame (convex_loss.py:473-487): q = |V^T (p - c)| - r,
+// sdf = ||relu(q)|| + min(max(q), 0).  `q` returns the shifted point as for the ellipsoid.
+__device__ __forceinline__ float sdf_eval_cuboid(const EllParam &e, float px, float py, float pz, float q[3])
+{
+    const float dx = px - e.c[0], dy = py - e.c[1], dz = pz - e.c[2];
+    float ss = 0.f, mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q[a] = e.V[a] * dx + e.V[3 + a] * dy + e.V[6 + a] * dz;
+        const float t = fabsf(q[a]) - e.r[a];
+        const float rl = fmaxf(t, 0.f);
+        ss += rl * rl;
+        mx = fmaxf(mx, t);
+    }
+    return sqrtf(ss) + fminf(mx, 0.f);
+}
+
+constexpr int KIND_ELLIPSOID = 0, KIND_CUBOID = 1;
+
+__device__ __forceinline__ float prim_eval(int kind, const EllParam &e, float px, float py, float pz, float q[3],
+                                           float &k0, float &k1)
+{
+    if (kind == KIND_CUBOID) { k0 = k1 = 0.f; return sdf_eval_cuboid(e, px, py, pz, q); }
+    return sdf_eval(e, px, py, pz, q, k0, k1);
+}
+
+// gf = dL/d(sdf)  ->  gq = dL/d(shifted point), gr = dL/d(r)
+__device__ __forceinline__ void prim_grad(int kind, const EllParam &e, const float q[3], float k0, float k1, float gf,
+                                          float gq[3], float gr[3])
+{
+    if (kind == KIND_CUBOID) {
+        float t[3], ss = 0.f, mx = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            t[a] = fabsf(q[a]) - e.r[a];
+            const float rl = fmaxf(t[a], 0.f);
+            ss += rl * rl;
+            if (t[a] > mx) { mx = t[a]; am = a; }   // first maximum, as torch.max
+        }
+        const float nrm = sqrtf(ss);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float d = (t[a] > 0.f && nrm > 0.f) ? t[a] / nrm : 0.f;
+            if (a == am && mx <= 0.f) d += 1.0f;     // clamp_max(max(q), 0) passes the gradient while max <= 0
+            const float sg = q[a] > 0.f ? 1.0f : (q[a] < 0.f ? -1.0f : 0.f);
+            gq[a] = gf * d * sg;
+            gr[a] = -gf * d;
+        }
+        return;
+    }
+    const float den = k1 + 1e-6f;
+    const float df0 = (2.0f * k0 - 1.0f) / den, df1 = -k0 * (k0 - 1.0f) / (den * den);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ra = e.r[a] + 1e-6f, rb = e.r[a] * e.r[a] + 1e-6f;
+        const float u = q[a] / ra, v = q[a] / rb;
+        const float dk0dq = k0 > 0.f ? u / (k0 * ra) : 0.f, dk1dq = k1 > 0.f ? v / (k1 * rb) : 0.f;
+        const float dk0dr = k0 > 0.f ? -u * u / (k0 * ra) : 0.f;
+        const float dk1dr = k1 > 0.f ? -2.0f * e.r[a] * v * v / (k1 * rb) : 0.f;
+        gq[a] = gf * (df0 * dk0dq + df1 * dk1dq);
+        gr[a] = gf * (df0 * dk0dr + df1 * dk1dr);
+    }
+}
+
 constexpr int KM_MAX = 64;
 
-__global__ __launch_bounds__(256) void sdf_fwd_kernel(const float *__restrict__ tgt, int M,
+__global__ __launch_bounds__(256) void sdf_fwd_kernel(int kind, const float *__restrict__ tgt, int M,
                                                       const float *__restrict__ r, const float *__restrict__ V,
                                                       const float *__restrict__ c,
                                                       const int32_t *__restrict__ valid, int KM,
@@ -390,7 +455,7 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float *__restrict__ 
         for (int k = 0; k < KM; ++k) {
             if (!s_ok[k]) continue;
             float q[3], k0, k1;
-            const float f = sdf_eval(s_e[k], px, py, pz, q, k0, k1);
+            const float f = prim_eval(kind, s_e[k], px, py, pz, q, k0, k1);
             if (fabsf(f) < best) { best = fabsf(f); bf = f; bk = k; }
         }
         arg[(size_t)b * M + m] = bk;
@@ -404,7 +469,7 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float *__restrict__ 
 }
 
 // d(sum f^2)/d(r, V, c), scaled per shape by gscale[b]
-__global__ __launch_bounds__(256) void sdf_bwd_kernel(const float *__restrict__ tgt, int M,
+__global__ __launch_bounds__(256) void sdf_bwd_kernel(int kind, const float *__restrict__ tgt, int M,
                                                       const float *__restrict__ r, const float *__restrict__ V,
                                                       const float *__restrict__ c,
                                                       const int32_t *__restrict__ arg,
@@ -429,22 +494,13 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(const float *__restrict__ 
             const EllParam &e = s_e[k];
             const float *p = tgt + ((size_t)b * M + m) * 3;
             float q[3], k0, k1;
-            const float f = sdf_eval(e, p[0], p[1], p[2], q, k0, k1);
+            const float f = prim_eval(kind, e, p[0], p[1], p[2], q, k0, k1);
             const float gf = gscale[b] * 2.0f * f;
-            const float den = k1 + 1e-6f;
-            const float df0 = (2.0f * k0 - 1.0f) / den, df1 = -k0 * (k0 - 1.0f) / (den * den);
-            float gq[3];
+            float gq[3], gr[3];
             float *acc = s_acc + k * 15;
+            prim_grad(kind, e, q, k0, k1, gf, gq, gr);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float ra = e.r[a] + 1e-6f, rb = e.r[a] * e.r[a] + 1e-6f;
-                const float u = q[a] / ra, v = q[a] / rb;
-                const float dk0dq = k0 > 0.f ? u / (k0 * ra) : 0.f, dk1dq = k1 > 0.f ? v / (k1 * rb) : 0.f;
-                const float dk0dr = k0 > 0.f ? -u * u / (k0 * ra) : 0.f;
-                const float dk1dr = k1 > 0.f ? -2.0f * e.r[a] * v * v / (k1 * rb) : 0.f;
-                gq[a] = gf * (df0 * dk0dq + df1 * dk1dq);
-                atomicAdd(acc + a, gf * (df0 * dk0dr + df1 * dk1dr));
-            }
+            for (int a = 0; a < 3; ++a) atomicAdd(acc + a, gr[a]);
             const float d[3] = {p[0] - e.c[0], p[1] - e.c[1], p[2] - e.c[2]};
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -472,7 +528,7 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(const float *__restrict__ 
 
 // Full SDF matrix sdf[b][m][k] (0 for dead slots) and its autograd: used by the optional intersection term
 // (convex_loss.py:374-413), which needs every ellipsoid's value at every point, not only the closest one.
-__global__ __launch_bounds__(256) void sdf_matrix_fwd_kernel(const float *__restrict__ pts, int M,
+__global__ __launch_bounds__(256) void sdf_matrix_fwd_kernel(int kind, const float *__restrict__ pts, int M,
                                                              const float *__restrict__ r,
                                                              const float *__restrict__ V,
                                                              const float *__restrict__ c,
@@ -496,11 +552,11 @@ __global__ __launch_bounds__(256) void sdf_matrix_fwd_kernel(const float *__rest
     float *o = out + ((size_t)b * M + m) * KM;
     for (int k = 0; k < KM; ++k) {
         float q[3], k0, k1;
-        o[k] = s_ok[k] ? sdf_eval(s_e[k], px, py, pz, q, k0, k1) : 0.f;
+        o[k] = s_ok[k] ? prim_eval(kind, s_e[k], px, py, pz, q, k0, k1) : 0.f;
     }
 }
 
-__global__ __launch_bounds__(256) void sdf_matrix_bwd_kernel(const float *__restrict__ pts, int M,
+__global__ __launch_bounds__(256) void sdf_matrix_bwd_kernel(int kind, const float *__restrict__ pts, int M,
                                                              const float *__restrict__ r,
                                                              const float *__restrict__ V,
                                                              const float *__restrict__ c,
@@ -529,21 +585,12 @@ __global__ __launch_bounds__(256) void sdf_matrix_bwd_kernel(const float *__rest
             if (!s_ok[k] || gf == 0.f) continue;
             const EllParam &e = s_e[k];
             float q[3], k0, k1;
-            sdf_eval(e, p[0], p[1], p[2], q, k0, k1);
-            const float den = k1 + 1e-6f;
-            const float df0 = (2.0f * k0 - 1.0f) / den, df1 = -k0 * (k0 - 1.0f) / (den * den);
-            float gq[3];
+            prim_eval(kind, e, p[0], p[1], p[2], q, k0, k1);
+            float gq[3], gr[3];
             float *acc = s_acc + k * 15;
+            prim_grad(kind, e, q, k0, k1, gf, gq, gr);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float ra = e.r[a] + 1e-6f, rb = e.r[a] * e.r[a] + 1e-6f;
-                const float u = q[a] / ra, v = q[a] / rb;
-                const float dk0dq = k0 > 0.f ? u / (k0 * ra) : 0.f, dk1dq = k1 > 0.f ? v / (k1 * rb) : 0.f;
-                const float dk0dr = k0 > 0.f ? -u * u / (k0 * ra) : 0.f;
-                const float dk1dr = k1 > 0.f ? -2.0f * e.r[a] * v * v / (k1 * rb) : 0.f;
-                gq[a] = gf * (df0 * dk0dq + df1 * dk1dq);
-                atomicAdd(acc + a, gf * (df0 * dk0dr + df1 * dk1dr));
-            }
+            for (int a = 0; a < 3; ++a) atomicAdd(acc + a, gr[a]);
             const float d[3] = {p[0] - e.c[0], p[1] - e.c[1], p[2] - e.c[2]};
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -572,7 +619,7 @@ __global__ __launch_bounds__(256) void sdf_matrix_bwd_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------
 // surface sampling budget (src/ellipsoid_utils.py:87-107, :157-159)
 // ---------------------------------------------------------------------------------------------
-__global__ void sample_budget_kernel(const float *__restrict__ r, const int32_t *__restrict__ valid, int KM,
+__global__ void sample_budget_kernel(int kind, const float *__restrict__ r, const int32_t *__restrict__ valid, int KM,
                                      int cap, int32_t *__restrict__ n_o, int32_t *__restrict__ off_o)
 {
     const int b = blockIdx.x;
@@ -584,9 +631,14 @@ __global__ void sample_budget_kernel(const float *__restrict__ r, const int32_t 
         if (!valid[(size_t)b * KM + k]) continue;
         const float a = r[((size_t)b * KM + k) * 3], bb = r[((size_t)b * KM + k) * 3 + 1],
                     cc = r[((size_t)b * KM + k) * 3 + 2];
-        const float p = 1.585f;
-        const float s = powf(a * bb, p) + powf(bb * cc, p) + powf(cc * a, p);
-        area[k] = (double)(4.0f * 3.142f * powf(s, 1.0f / p));
+        if (kind == KIND_CUBOID) {
+            // sides 2a, 2b, 2c: area = 8 (ab + bc + ca) in fp32 as upstream (src/ellipsoid_utils.py:186-188)
+            area[k] = (double)__fmul_rn(8.0f, __fadd_rn(__fadd_rn(__fmul_rn(a, bb), __fmul_rn(bb, cc)), __fmul_rn(cc, a)));
+        } else {
+            const float p = 1.585f;
+            const float s = powf(a * bb, p) + powf(bb * cc, p) + powf(cc * a, p);
+            area[k] = (double)(4.0f * 3.142f * powf(s, 1.0f / p));
+        }
         total += area[k];
     }
     int off = 0;
@@ -613,11 +665,52 @@ __device__ __forceinline__ void fib_dir(int j, int n, float &cu, float &su, floa
     cv = (float)z; sv = (float)sqrt(fmax(0.0, 1.0 - z * z));
 }
 
+// The build's deterministic surface parameters of a box with half-sides (a, b, c) (replaces
+// trimesh.sample.sample_surface_even of src/sample_ellipsoid.py:78-84): sample j of n goes to the face whose slice
+// of the cumulative area [+z, -z, +x, -x, +y, -y] contains (j + 0.5) / n; inside the face the two free coordinates
+// follow the R2 low-discrepancy sequence.  u is then scaled as upstream (:88): (u s) / (s + 1e-6), cast to fp32.
+__device__ __forceinline__ void cuboid_unit(int j, int n, const float r[3], float u[3])
+{
+    const double a = r[0], b = r[1], c = r[2];
+    const double w[6] = {a * b, a * b, b * c, b * c, c * a, c * a};
+    double total = 0.0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) total += w[f];
+    const double t = ((double)j + 0.5) / (double)n;
+    int face = 0;
+    double run = 0.0;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        run += w[f];
+        if (t >= run / total) face = f + 1;
+    }
+    double ip;
+    const double s1 = 2.0 * modf(0.5 + (double)j * 0.7548776662466927, &ip) - 1.0;
+    const double s2 = 2.0 * modf(0.5 + (double)j * 0.5698402909980532, &ip) - 1.0;
+    const double sg = (face & 1) ? -1.0 : 1.0;
+    double v[3];
+    if (face < 2) { v[0] = s1; v[1] = s2; v[2] = sg; }
+    else if (face < 4) { v[0] = sg; v[1] = s1; v[2] = s2; }
+    else { v[0] = s2; v[1] = sg; v[2] = s1; }
+    const double side[3] = {a, b, c};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[i] = (float)((v[i] * side[i]) / (side[i] + 1e-6));
+}
+
+// unit parameter of sample j of n on primitive `kind`: the point is V (r * u) + c for both kinds
+__device__ __forceinline__ void unit_param(int kind, int j, int n, const float r[3], float u[3])
+{
+    if (kind == KIND_CUBOID) { cuboid_unit(j, n, r, u); return; }
+    float cu, su, cv, sv;
+    fib_dir(j, n, cu, su, cv, sv);
+    u[0] = cu * sv; u[1] = su * sv; u[2] = cv;
+}
+
 constexpr int NN_TILE_T = 1024;
 
 // Sample s of shape b: point on ellipsoid k(s), nearest target, squared distance (src/utils.py:413-416).
 __global__ __launch_bounds__(256) void sample_nn_fwd_kernel(
-    const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
+    int kind, const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
     const int32_t *__restrict__ n_k, const int32_t *__restrict__ off_k, int KM, const float *__restrict__ tgt,
     int M, int cap, int32_t *__restrict__ nn_idx, float *__restrict__ sum_o)
 {
@@ -634,9 +727,17 @@ __global__ __launch_bounds__(256) void sample_nn_fwd_kernel(
         int k = 0;
         while (k + 1 < KM && s >= off[k + 1]) ++k;
         const size_t sl = (size_t)b * KM + k;
-        float cu, su, cv, sv;
-        fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
-        const float ex = r[sl * 3] * cu * sv, ey = r[sl * 3 + 1] * su * sv, ez = r[sl * 3 + 2] * cv;
+        const float rk[3] = {r[sl * 3], r[sl * 3 + 1], r[sl * 3 + 2]};
+        float ex, ey, ez;
+        if (kind == KIND_CUBOID) {
+            float u[3];
+            cuboid_unit(s - off[k], n_k[sl], rk, u);
+            ex = u[0] * rk[0]; ey = u[1] * rk[1]; ez = u[2] * rk[2];
+        } else {
+            float cu, su, cv, sv;
+            fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
+            ex = rk[0] * cu * sv; ey = rk[1] * su * sv; ez = rk[2] * cv;
+        }
         const float *Vk = V + sl * 9;
         px = Vk[0] * ex + Vk[1] * ey + Vk[2] * ez + c[sl * 3];
         py = Vk[3] * ex + Vk[4] * ey + Vk[5] * ez + c[sl * 3 + 1];
@@ -668,7 +769,7 @@ __global__ __launch_bounds__(256) void sample_nn_fwd_kernel(
 }
 
 __global__ __launch_bounds__(256) void sample_nn_bwd_kernel(
-    const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
+    int kind, const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
     const int32_t *__restrict__ n_k, const int32_t *__restrict__ off_k, int KM, const float *__restrict__ tgt,
     int M, int cap, const int32_t *__restrict__ nn_idx, const float *__restrict__ gscale,
     float *__restrict__ g_r, float *__restrict__ g_V, float *__restrict__ g_c)
@@ -685,10 +786,10 @@ __global__ __launch_bounds__(256) void sample_nn_bwd_kernel(
         int k = 0;
         while (k + 1 < KM && s >= off[k + 1]) ++k;
         const size_t sl = (size_t)b * KM + k;
-        float cu, su, cv, sv;
-        fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
-        const float dir[3] = {cu * sv, su * sv, cv};
-        const float e[3] = {r[sl * 3] * dir[0], r[sl * 3 + 1] * dir[1], r[sl * 3 + 2] * dir[2]};
+        const float rk[3] = {r[sl * 3], r[sl * 3 + 1], r[sl * 3 + 2]};
+        float dir[3];
+        unit_param(kind, s - off[k], n_k[sl], rk, dir);
+        const float e[3] = {rk[0] * dir[0], rk[1] * dir[1], rk[2] * dir[2]};
         const float *Vk = V + sl * 9;
         const float *t = tgt + ((size_t)b * M + nn_idx[(size_t)b * cap + s]) * 3;
         float gs[3];
@@ -751,7 +852,7 @@ int prifit_ellipsoid_fit_bwd(const float *points, const float *W, const int32_t 
     return prifit_check_launch();
 }
 
-int prifit_ellipsoid_sdf_fwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+static int impl_ellipsoid_sdf_fwd(int kind, const float *targets, int B, int M, const float *r, const float *V, const float *c,
                              const int32_t *valid, int KM, int32_t *arg, float *fval, float *sum_sq, void *stream)
 {
     if (!targets || !r || !V || !c || !valid || !arg || !fval || !sum_sq || B <= 0 || M <= 0 || KM <= 0 ||
@@ -759,54 +860,54 @@ int prifit_ellipsoid_sdf_fwd(const float *targets, int B, int M, const float *r,
         return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(sum_sq, 0, sizeof(float) * B, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    hipLaunchKernelGGL(sdf_fwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, targets, M, r, V, c, valid, KM,
+    hipLaunchKernelGGL(sdf_fwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, st, kind, targets, M, r, V, c, valid, KM,
                        arg, fval, sum_sq);
     return prifit_check_launch();
 }
 
-int prifit_ellipsoid_sdf_bwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+static int impl_ellipsoid_sdf_bwd(int kind, const float *targets, int B, int M, const float *r, const float *V, const float *c,
                              const int32_t *arg, const float *gscale, int KM, float *g_r, float *g_V, float *g_c,
                              void *stream)
 {
     if (!targets || !r || !V || !c || !arg || !gscale || !g_r || !g_V || !g_c || B <= 0 || M <= 0 || KM <= 0 ||
         KM > KM_MAX)
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(sdf_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), targets, M, r, V,
+    hipLaunchKernelGGL(sdf_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), kind, targets, M, r, V,
                        c, arg, gscale, KM, g_r, g_V, g_c);
     return prifit_check_launch();
 }
 
-int prifit_ellipsoid_sdf_matrix_fwd(const float *points, int B, int M, const float *r, const float *V,
+static int impl_ellipsoid_sdf_matrix_fwd(int kind, const float *points, int B, int M, const float *r, const float *V,
                                     const float *c, const int32_t *valid, int KM, float *sdf, void *stream)
 {
     if (!points || !r || !V || !c || !valid || !sdf || B <= 0 || M <= 0 || KM <= 0 || KM > KM_MAX)
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(sdf_matrix_fwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), points, M,
+    hipLaunchKernelGGL(sdf_matrix_fwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), kind, points, M,
                        r, V, c, valid, KM, sdf);
     return prifit_check_launch();
 }
 
-int prifit_ellipsoid_sdf_matrix_bwd(const float *points, int B, int M, const float *r, const float *V,
+static int impl_ellipsoid_sdf_matrix_bwd(int kind, const float *points, int B, int M, const float *r, const float *V,
                                     const float *c, const int32_t *valid, const float *g_sdf, int KM, float *g_r,
                                     float *g_V, float *g_c, void *stream)
 {
     if (!points || !r || !V || !c || !valid || !g_sdf || !g_r || !g_V || !g_c || B <= 0 || M <= 0 || KM <= 0 ||
         KM > KM_MAX)
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(sdf_matrix_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), points, M,
+    hipLaunchKernelGGL(sdf_matrix_bwd_kernel, dim3((M + 255) / 256, B), dim3(256), 0, as_stream(stream), kind, points, M,
                        r, V, c, valid, g_sdf, KM, g_r, g_V, g_c);
     return prifit_check_launch();
 }
 
-int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n, int32_t *off,
+static int impl_sample_budget(int kind, const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n, int32_t *off,
                          void *stream)
 {
     if (!r || !valid || !n || !off || B <= 0 || KM <= 0 || KM > KM_MAX || cap <= 0) return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(sample_budget_kernel, dim3(B), dim3(64), 0, as_stream(stream), r, valid, KM, cap, n, off);
+    hipLaunchKernelGGL(sample_budget_kernel, dim3(B), dim3(64), 0, as_stream(stream), kind, r, valid, KM, cap, n, off);
     return prifit_check_launch();
 }
 
-int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+static int impl_sample_nn_fwd(int kind, const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
                          int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
                          void *stream)
 {
@@ -815,21 +916,113 @@ int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const i
         return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(sum_d2, 0, sizeof(float) * B, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    hipLaunchKernelGGL(sample_nn_fwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, st, r, V, c, n, off, KM,
+    hipLaunchKernelGGL(sample_nn_fwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, st, kind, r, V, c, n, off, KM,
                        targets, M, cap, nn_idx, sum_d2);
     return prifit_check_launch();
 }
 
-int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+static int impl_sample_nn_bwd(int kind, const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
                          int B, int KM, const float *targets, int M, int cap, const int32_t *nn_idx,
                          const float *gscale, float *g_r, float *g_V, float *g_c, void *stream)
 {
     if (!r || !V || !c || !n || !off || !targets || !nn_idx || !gscale || !g_r || !g_V || !g_c || B <= 0 ||
         KM <= 0 || KM > KM_MAX || M <= 0 || cap <= 0)
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(sample_nn_bwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, as_stream(stream), r, V, c,
+    hipLaunchKernelGGL(sample_nn_bwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, as_stream(stream), kind, r, V, c,
                        n, off, KM, targets, M, cap, nn_idx, gscale, g_r, g_V, g_c);
     return prifit_check_launch();
+}
+
+int prifit_ellipsoid_sdf_fwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                             const int32_t *valid, int KM, int32_t *arg, float *fval, float *sum_sq, void *stream)
+{
+    return impl_ellipsoid_sdf_fwd(KIND_ELLIPSOID, targets, B, M, r, V, c, valid, KM, arg, fval, sum_sq, stream);
+}
+
+int prifit_cuboid_sdf_fwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                             const int32_t *valid, int KM, int32_t *arg, float *fval, float *sum_sq, void *stream)
+{
+    return impl_ellipsoid_sdf_fwd(KIND_CUBOID, targets, B, M, r, V, c, valid, KM, arg, fval, sum_sq, stream);
+}
+
+int prifit_ellipsoid_sdf_bwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                             const int32_t *arg, const float *gscale, int KM, float *g_r, float *g_V, float *g_c,
+                             void *stream)
+{
+    return impl_ellipsoid_sdf_bwd(KIND_ELLIPSOID, targets, B, M, r, V, c, arg, gscale, KM, g_r, g_V, g_c, stream);
+}
+
+int prifit_cuboid_sdf_bwd(const float *targets, int B, int M, const float *r, const float *V, const float *c,
+                             const int32_t *arg, const float *gscale, int KM, float *g_r, float *g_V, float *g_c,
+                             void *stream)
+{
+    return impl_ellipsoid_sdf_bwd(KIND_CUBOID, targets, B, M, r, V, c, arg, gscale, KM, g_r, g_V, g_c, stream);
+}
+
+int prifit_ellipsoid_sdf_matrix_fwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, int KM, float *sdf, void *stream)
+{
+    return impl_ellipsoid_sdf_matrix_fwd(KIND_ELLIPSOID, points, B, M, r, V, c, valid, KM, sdf, stream);
+}
+
+int prifit_cuboid_sdf_matrix_fwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, int KM, float *sdf, void *stream)
+{
+    return impl_ellipsoid_sdf_matrix_fwd(KIND_CUBOID, points, B, M, r, V, c, valid, KM, sdf, stream);
+}
+
+int prifit_ellipsoid_sdf_matrix_bwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, const float *g_sdf, int KM, float *g_r,
+                                    float *g_V, float *g_c, void *stream)
+{
+    return impl_ellipsoid_sdf_matrix_bwd(KIND_ELLIPSOID, points, B, M, r, V, c, valid, g_sdf, KM, g_r, g_V, g_c, stream);
+}
+
+int prifit_cuboid_sdf_matrix_bwd(const float *points, int B, int M, const float *r, const float *V,
+                                    const float *c, const int32_t *valid, const float *g_sdf, int KM, float *g_r,
+                                    float *g_V, float *g_c, void *stream)
+{
+    return impl_ellipsoid_sdf_matrix_bwd(KIND_CUBOID, points, B, M, r, V, c, valid, g_sdf, KM, g_r, g_V, g_c, stream);
+}
+
+int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n, int32_t *off,
+                         void *stream)
+{
+    return impl_sample_budget(KIND_ELLIPSOID, r, valid, B, KM, cap, n, off, stream);
+}
+
+int prifit_cuboid_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n, int32_t *off,
+                         void *stream)
+{
+    return impl_sample_budget(KIND_CUBOID, r, valid, B, KM, cap, n, off, stream);
+}
+
+int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+                         int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
+                         void *stream)
+{
+    return impl_sample_nn_fwd(KIND_ELLIPSOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, sum_d2, stream);
+}
+
+int prifit_cuboid_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+                         int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
+                         void *stream)
+{
+    return impl_sample_nn_fwd(KIND_CUBOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, sum_d2, stream);
+}
+
+int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+                         int B, int KM, const float *targets, int M, int cap, const int32_t *nn_idx,
+                         const float *gscale, float *g_r, float *g_V, float *g_c, void *stream)
+{
+    return impl_sample_nn_bwd(KIND_ELLIPSOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, gscale, g_r, g_V, g_c, stream);
+}
+
+int prifit_cuboid_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
+                         int B, int KM, const float *targets, int M, int cap, const int32_t *nn_idx,
+                         const float *gscale, float *g_r, float *g_V, float *g_c, void *stream)
+{
+    return impl_sample_nn_bwd(KIND_CUBOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, gscale, g_r, g_V, g_c, stream);
 }
 
 }  // extern "C"

@@ -236,7 +236,7 @@ class SdfLossFn(torch.autograd.Function):
     """sum over target points of (min_k |sdf_k|)^2 per shape (convex_loss.py:313-328, src/utils.py:410-411)."""
 
     @staticmethod
-    def forward(ctx, targets, r, V, c, valid):
+    def forward(ctx, targets, r, V, c, valid, cuboid=False):
         targets, r, V, c = targets.contiguous(), r.contiguous(), V.contiguous(), c.contiguous()
         Bt, M, _ = targets.shape
         K = r.shape[1]
@@ -244,7 +244,8 @@ class SdfLossFn(torch.autograd.Function):
         arg = torch.empty(Bt, M, dtype=torch.int32, device=dev)
         fval = torch.empty(Bt, M, dtype=torch.float32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
-        call("prifit_ellipsoid_sdf_fwd", ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(arg),
+        ctx.prim = "cuboid" if cuboid else "ellipsoid"   # convex_loss.py:473-502 vs :313-328
+        call("prifit_%s_sdf_fwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(arg),
              ptr(fval), ptr(s), cur_stream())
         ctx.save_for_backward(targets, r, V, c, arg)
         return s
@@ -255,9 +256,9 @@ class SdfLossFn(torch.autograd.Function):
         Bt, M, _ = targets.shape
         K = r.shape[1]
         g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
-        call("prifit_ellipsoid_sdf_bwd", ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(arg), ptr(gs.contiguous()),
+        call("prifit_%s_sdf_bwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(arg), ptr(gs.contiguous()),
              K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
-        return None, g_r, g_V, g_c, None
+        return None, g_r, g_V, g_c, None, None
 
 
 class SampleNNLossFn(torch.autograd.Function):
@@ -266,18 +267,20 @@ class SampleNNLossFn(torch.autograd.Function):
     src/utils.py:413-416).  Returns (sum_d2 [B], total [B] number of samples)."""
 
     @staticmethod
-    def forward(ctx, r, V, c, valid, targets):
+    def forward(ctx, r, V, c, valid, targets, cuboid=False):
         targets, r, V, c = targets.contiguous(), r.contiguous(), V.contiguous(), c.contiguous()
         Bt, M, _ = targets.shape
         K = r.shape[1]
         dev = targets.device
         n = torch.empty(Bt, K, dtype=torch.int32, device=dev)
         off = torch.empty(Bt, K + 1, dtype=torch.int32, device=dev)
-        call("prifit_sample_budget", ptr(r), ptr(valid), Bt, K, SAMPLE_CAP, ptr(n), ptr(off), cur_stream())
+        # cuboid: src/ellipsoid_utils.py:162-214 + src/sample_ellipsoid.py:65-96 on the build's box-surface table
+        ctx.pre = "prifit_cuboid_sample" if cuboid else "prifit_sample"
+        call(ctx.pre + "_budget", ptr(r), ptr(valid), Bt, K, SAMPLE_CAP, ptr(n), ptr(off), cur_stream())
         nn_idx = torch.empty(Bt, SAMPLE_CAP, dtype=torch.int32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
         with profiler.span("sample_nn", 0.0):
-            call("prifit_sample_nn_fwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M,
+            call(ctx.pre + "_nn_fwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M,
                  SAMPLE_CAP, ptr(nn_idx), ptr(s), cur_stream())
         total = off[:, K].clone()
         ctx.save_for_backward(r, V, c, n, off, targets, nn_idx)
@@ -290,9 +293,9 @@ class SampleNNLossFn(torch.autograd.Function):
         Bt, M, _ = targets.shape
         K = r.shape[1]
         g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
-        call("prifit_sample_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
+        call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
              ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
-        return g_r, g_V, g_c, None, None
+        return g_r, g_V, g_c, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

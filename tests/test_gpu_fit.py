@@ -205,6 +205,47 @@ def test_sdf_and_sample_chamfer(F, golden):
         torch.testing.assert_close(got.cpu(), ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
 
 
+def test_cuboid_variant(F, golden):
+    """--if_cuboid: cuboid SDF / budget / box-surface samples / chamfer vs the reference fixture, gradients vs the
+    oracle's autograd, and the full convex_loss(if_cuboid=True) with its embedding gradient."""
+    ge, gc = golden("fit_ellipsoid"), golden("fit_cuboid")
+    seed = int(ge["seed"])
+    pts, cham, emb = fit_inputs(2, 2048, 128, seed)
+    K = ge["r_0"].shape[0]
+    r = torch.zeros(2, F.KM, 3); V = torch.eye(3).repeat(2, F.KM, 1, 1); c = torch.zeros(2, F.KM, 3)
+    valid = torch.zeros(2, F.KM, dtype=torch.int32)
+    for b in range(2):
+        r[b, :K], V[b, :K], c[b, :K], valid[b, :K] = _t(ge[f"r_{b}"]), _t(ge[f"V_{b}"]), _t(ge[f"c_{b}"]), 1
+    rg, Vg, cg = (t.cuda().requires_grad_(True) for t in (r, V, c))
+    from prifit_amd.convex_loss import SdfMatrixFn, analytic_chamfer_distance, convex_loss
+    sdf = SdfMatrixFn.apply(cham.cuda(), rg, Vg, cg, valid.cuda(), True)
+    torch.testing.assert_close(sdf[:, :256, :K].detach().cpu(), _t(gc["sdf_head"]), rtol=1e-4, atol=1e-6)
+    loss, (dist_st, sdf_ts) = analytic_chamfer_distance(rg, Vg, cg, valid.cuda(), cham.cuda(), cuboid=True)
+    torch.testing.assert_close(sdf_ts.detach().cpu(), _t(gc["sdf_ts"]), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dist_st.detach().cpu(), _t(gc["dist_st"]), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(loss.detach().cpu(), _t(gc["loss"]), rtol=1e-4, atol=1e-8)
+    gm = _t(synth.features(2, 5000, F.KM, 41)) * 1e-3
+    (loss + (sdf * gm.cuda()).sum()).backward()
+    ro, Vo, co = r.clone().requires_grad_(True), V.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    params = [[(ro[b, k], Vo[b, k], co[b, k]) for k in range(K)] for b in range(2)]
+    lo, _ = orc.analytic_chamfer(params, orc.sample_from_params(params, cuboid=True), cham, cuboid=True)
+    for b in range(2):
+        so = torch.stack([orc.sdf_cuboid(cham[b], co[b, k], ro[b, k], Vo[b, k]) for k in range(K)], 1)
+        lo = lo + (so * gm[b, :, :K]).sum()
+    lo.backward()
+    for got, ref in ((rg.grad, ro.grad), (Vg.grad, Vo.grad), (cg.grad, co.grad)):
+        torch.testing.assert_close(got.cpu(), ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+    X = emb.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    total, l, _, _ = convex_loss(pts.permute(0, 2, 1).cuda(), cham.permute(0, 2, 1).cuda(), X, quantile=0.05,
+                                 iterations=10, max_num_clusters=25, rand_table=_t(gc["R"]).cuda(), canonical=True,
+                                 if_cuboid=True)
+    total.sum().backward()
+    torch.testing.assert_close(total.detach().cpu(), _t(gc["total"]), rtol=1e-4, atol=1e-7)
+    ref = _t(gc["dX_head"])
+    assert abs(X.grad.norm().item() - float(gc["dX_norm"])) < 1e-2 * float(gc["dX_norm"])
+    torch.testing.assert_close(X.grad[:, :, :32].cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
+
+
 def test_convex_loss_end_to_end(F, golden):
     g = golden("fit_convex_loss")
     seed = int(g["seed"])
@@ -353,5 +394,3 @@ def test_optional_terms_entropy_intersection_pruning(F, golden):
     ref = Xo.grad
     assert abs(Xg.grad.norm().item() - ref.norm().item()) < 1e-2 * ref.norm().item()
     torch.testing.assert_close(Xg.grad.cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
-    with pytest.raises(NotImplementedError):
-        CLM.convex_loss(pts.permute(0, 2, 1).cuda(), cham.permute(0, 2, 1).cuda(), Xg, if_cuboid=True)

@@ -68,6 +68,27 @@ def test_fit_and_chamfer(golden):
     torch.testing.assert_close(torch.stack([p[0] for p in parts]), _t(gc["dist_st"]), rtol=1e-5, atol=1e-9)
 
 
+def test_cuboid_variant(golden):
+    """--if_cuboid (convex_loss.py:72-76,89): cuboid SDF, area budget, box-surface samples, analytic chamfer."""
+    ge, gc = golden("fit_ellipsoid"), golden("fit_cuboid")
+    pts, cham, _ = fit_inputs(2, 2048, 128, int(ge["seed"]))
+    params = [[(_t(ge[f"r_{b}"])[k], _t(ge[f"V_{b}"])[k], _t(ge[f"c_{b}"])[k]) for k in range(ge[f"r_{b}"].shape[0])]
+              for b in range(2)]
+    samples = orc.sample_from_params(params, cuboid=True)
+    assert [s.shape[0] for s in samples] == list(gc["nsamples"])
+    for b in range(2):
+        torch.testing.assert_close(samples[b][:64], _t(gc["samples_head"])[b], rtol=1e-5, atol=1e-6)
+        sdf = torch.stack([orc.sdf_cuboid(cham[b][:256], c, r, V) for r, V, c in params[b]], 1)
+        torch.testing.assert_close(sdf, _t(gc["sdf_head"])[b], rtol=1e-5, atol=1e-6)
+    l, parts = orc.analytic_chamfer(params, samples, cham, cuboid=True)
+    torch.testing.assert_close(l, _t(gc["loss"]), rtol=1e-5, atol=1e-9)
+    # the box-surface table: on the faces, area-proportional, evenly spread
+    p = orc.cuboid_surface(6000, 1.0, 2.0, 3.0) / np.array([[1.0, 2.0, 3.0]])
+    assert np.allclose(np.abs(p).max(1), 1.0) and abs(p.mean(0)).max() < 2e-2
+    on_z = (np.abs(p[:, 2]) == 1.0).mean()
+    assert abs(on_z - 2.0 / 11.0) < 2e-3     # area share of the two z faces: ab / (ab + bc + ca) = 2 / 11
+
+
 def test_known_answer(golden):
     g = golden("fit_kat")
     prm = orc.fit_ellipsoids_batch(_t(g["points"]), [_t(g["W"])], [[_t(g["R"])] * 3])
