@@ -352,10 +352,23 @@ def golden_dgcnn():
          g_enc_conv1=rg["encoder.conv1.0.weight"], g_seg=rg["mlp_segmentation.weight"], g_emb=rg["mlp_seg_prob2.weight"])
 
 
+def golden_data():
+    """pc_normalize (data_utils/ShapeNetDataLoader.py:17-22): reference vs oracle on a small cloud."""
+    print("[data]")
+    DL = refshim.ref("data_utils.ShapeNetDataLoader")
+    pc = (synth.cloud("blobs", 1, 96, 5)[0] * 3.0 + np.array([[0.5, -1.0, 2.0]], dtype=np.float32)).astype(np.float32)
+    ref = DL.pc_normalize(pc.copy())
+    got = orc.pc_normalize_np(pc.copy())
+    eq(torch.from_numpy(got), torch.from_numpy(ref), "pc_normalize")
+    save("data_normalize", cloud=pc, normalized=ref)
+
+
 if __name__ == "__main__":
     assert refshim.available(), "needs the reference tree"
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["index", "modules", "model", "fit", "dgcnn"]
+    which = sys.argv[1:] or ["index", "modules", "model", "fit", "dgcnn", "data"]
+    if "data" in which:
+        golden_data()
     if "index" in which:
         golden_index_ops()
     if "modules" in which:

@@ -792,3 +792,60 @@ def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_
         return total.view(1, 1), loss.view(1, 1), params, labels, {"W": Ws, "cluster": info, "parts": parts,
                                                                   "samples": samples}
     return total.view(1, 1), loss.view(1, 1), params, labels
+
+
+# ----------------------------------------------------------------------------------------------
+# data path and evaluation
+# ----------------------------------------------------------------------------------------------
+def pc_normalize_np(pc):
+    """data_utils/ShapeNetDataLoader.py:17-22 (numpy, one cloud [n,3])."""
+    centroid = np.mean(pc, axis=0)
+    pc = pc - centroid
+    m = np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+    return pc / m
+
+
+EVAL_SEG_CLASSES = {'Airplane': [0, 1, 2, 3], 'Bag': [4, 5], 'Cap': [6, 7], 'Car': [8, 9, 10, 11],
+                    'Chair': [12, 13, 14, 15], 'Earphone': [16, 17, 18], 'Guitar': [19, 20, 21], 'Knife': [22, 23],
+                    'Lamp': [24, 25, 26, 27], 'Laptop': [28, 29], 'Motorbike': [30, 31, 32, 33, 34, 35],
+                    'Mug': [36, 37], 'Pistol': [38, 39, 40], 'Rocket': [41, 42, 43], 'Skateboard': [44, 45, 46],
+                    'Table': [47, 48, 49]}   # testing.py:30-33
+
+
+def eval_metrics_loops(batches, num_part=50):
+    """The metric loops of testing.py:138-240 (the function itself needs the dataset on disk and a checkpoint, so
+    it cannot be called: PARITY of this restatement is pinned by hand-computed cases in tests/, not by a run of the
+    reference).  batches: list of (logits [B,N,num_part], target [B,N]) numpy arrays."""
+    seg_label_to_cat = {l: c for c, ls in EVAL_SEG_CLASSES.items() for l in ls}
+    total_correct = total_seen = 0
+    seen_class = [0] * num_part
+    correct_class = [0] * num_part
+    shape_ious = {c: [] for c in EVAL_SEG_CLASSES}
+    for logits, target in batches:
+        B, N, _ = logits.shape
+        pred = np.zeros((B, N), dtype=np.int32)
+        for i in range(B):
+            cat = seg_label_to_cat[target[i, 0]]
+            pred[i] = np.argmax(logits[i][:, EVAL_SEG_CLASSES[cat]], 1) + EVAL_SEG_CLASSES[cat][0]
+        total_correct += np.sum(pred == target)
+        total_seen += B * N
+        for l in range(num_part):
+            seen_class[l] += np.sum(target == l)
+            correct_class[l] += np.sum((pred == l) & (target == l))
+        for i in range(B):
+            segp, segl = pred[i], target[i]
+            cat = seg_label_to_cat[segl[0]]
+            ious = []
+            for l in EVAL_SEG_CLASSES[cat]:
+                if np.sum(segl == l) == 0 and np.sum(segp == l) == 0:
+                    ious.append(1.0)
+                else:
+                    ious.append(np.sum((segl == l) & (segp == l)) / float(np.sum((segl == l) | (segp == l))))
+            shape_ious[cat].append(np.mean(ious))
+    all_ious = [v for c in shape_ious for v in shape_ious[c]]
+    per_cat = {c: (np.mean(v) if v else float('nan')) for c, v in shape_ious.items()}
+    with np.errstate(invalid='ignore', divide='ignore'):
+        class_acc = np.mean(np.array(correct_class) / np.array(seen_class, dtype=np.float64))
+    return {'accuracy': total_correct / float(total_seen), 'class_avg_accuracy': class_acc,
+            'class_avg_iou': np.mean([v for v in per_cat.values() if not np.isnan(v)]),
+            'instance_avg_iou': np.mean(all_ious), 'category_iou': per_cat}
