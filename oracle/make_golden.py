@@ -8,6 +8,7 @@ A fixture is data only: seeds / small inputs and the reference's outputs.  Input
 are regenerated from a seed by `oracle/synth.py` (the build's own generator) on both sides.
 """
 import contextlib
+import importlib
 import os
 import sys
 
@@ -305,6 +306,55 @@ def golden_model():
     save("model_ssg", seed=9, s1=t1, s2=t2, seg_sum=sseg.detach().sum(dim=1), l3=sl3.detach())
 
 
+def golden_variants():
+    """cls MSG / cls SSG / sem-seg variants (models/pointnet2_cls_msg.py, pointnet2_cls_ssg.py, pointnet2_sem_seg.py)
+    on 2 x 1024 points: oracle vs reference forward with identical seeded init and FPS starts."""
+    print("[variants]")
+    sys.path.insert(0, os.path.join(refshim.REF_ROOT, "models"))   # the cls files import pointnet_util bare
+    xyz = torch.from_numpy(synth.cloud("surface", 2, 1024, 12)).transpose(1, 2).contiguous()
+    starts = [torch.from_numpy(synth.fps_start(2, n, 200 + i)) for i, n in enumerate((1024, 512, 256, 64))]
+    out = {"seed": 12}
+    for name, modname, kw, okw in (("cls_msg", "pointnet2_cls_msg", dict(normal_channel=False), dict(msg=True)),
+                                   ("cls_ssg", "pointnet2_cls_ssg", dict(normal_channel=False), dict(msg=False))):
+        R = importlib.import_module(modname)
+        torch.manual_seed(5)
+        ref = R.get_model(40, **kw)
+        ref.train(); ref.drop1.eval(); ref.drop2.eval()
+        with fixed_randint(starts[:2]):
+            lp, l3 = ref(xyz)
+        torch.manual_seed(5)
+        mine = orc.OracleCls(40, normal_channel=False, **okw)
+        for (ka, va), (kb, vb) in zip(ref.named_parameters(), mine.named_parameters()):
+            assert ka == kb and torch.equal(va, vb), ka
+        mine.train(); mine.drop1.eval(); mine.drop2.eval()
+        olp, ol3 = mine(xyz, fps_start=(starts[0], starts[1]))
+        close(olp, lp, name + " log-probs", rtol=1e-4, atol=1e-5)
+        close(ol3, l3, name + " l3", rtol=1e-4, atol=1e-5)
+        out[name + "_logp"] = lp.detach()
+        out[name + "_l3_sum"] = l3.detach().sum(dim=1)
+    SS = refshim.ref("models.pointnet2_sem_seg")
+    feats = torch.from_numpy(synth.features(2, 1024, 3, 13)).transpose(1, 2)   # with_rgb: input is xyz + rgb
+    x9 = torch.cat([xyz, feats], 1).contiguous()
+    torch.manual_seed(6)
+    ref = SS.get_model(13, with_rgb=True)
+    ref.train(); ref.drop1.eval()
+    with fixed_randint(starts):
+        lp, l4 = ref(x9)
+    torch.manual_seed(6)
+    mine = orc.OracleSemSeg(13, with_rgb=True)
+    for (ka, va), (kb, vb) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert ka == kb and torch.equal(va, vb), ka
+    mine.train(); mine.drop1.eval()
+    olp, ol4 = mine(x9, fps_start=tuple(starts))
+    close(olp, lp, "sem_seg log-probs", rtol=1e-4, atol=1e-5)
+    close(ol4, l4, "sem_seg l4", rtol=1e-4, atol=1e-5)
+    out["sem_logp_sum"] = lp.detach().sum(dim=1)
+    out["sem_l4"] = l4.detach()
+    for i, t in enumerate(starts):
+        out["s%d" % i] = t
+    save("model_variants", **out)
+
+
 def golden_dgcnn():
     """config 5: src/dgcnn.DGCNGn (k=20) on B=2 x 1024 points: outputs + gradients."""
     print("[dgcnn]")
@@ -366,9 +416,11 @@ def golden_data():
 if __name__ == "__main__":
     assert refshim.available(), "needs the reference tree"
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["index", "modules", "model", "fit", "dgcnn", "data"]
+    which = sys.argv[1:] or ["index", "modules", "model", "fit", "dgcnn", "data", "variants"]
     if "data" in which:
         golden_data()
+    if "variants" in which:
+        golden_variants()
     if "index" in which:
         golden_index_ops()
     if "modules" in which:

@@ -375,6 +375,79 @@ class OracleSSGPartSeg(nn.Module):
         return F.log_softmax(logits, dim=1).transpose(1, 2), l3_points
 
 
+class OracleCls(nn.Module):
+    """models/pointnet2_cls_msg.py:7-41 (msg=True) / models/pointnet2_cls_ssg.py:7-40 (msg=False)."""
+
+    def __init__(self, num_class, normal_channel=True, msg=True):
+        super().__init__()
+        self.normal_channel = normal_channel
+        if msg:
+            c = 3 if normal_channel else 0
+            self.sa1 = OracleSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], c,
+                                               [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+            self.sa2 = OracleSetAbstractionMsg(128, [0.2, 0.4, 0.8], [32, 64, 128], 320,
+                                               [[64, 64, 128], [128, 128, 256], [128, 128, 256]])
+            self.sa3 = OracleSetAbstraction(None, None, None, 640 + 3, [256, 512, 1024], True)
+            p2 = 0.5
+        else:
+            self.sa1 = OracleSetAbstraction(512, 0.2, 32, 6 if normal_channel else 3, [64, 64, 128], False)
+            self.sa2 = OracleSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False)
+            self.sa3 = OracleSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True)
+            p2 = 0.4
+        self.fc1, self.bn1, self.drop1 = nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.Dropout(0.4)
+        self.fc2, self.bn2, self.drop2 = nn.Linear(512, 256), nn.BatchNorm1d(256), nn.Dropout(p2)
+        self.fc3 = nn.Linear(256, num_class)
+
+    def forward(self, xyz, fps_start=None):
+        B = xyz.shape[0]
+        norm = xyz[:, 3:, :] if self.normal_channel else None
+        xyz = xyz[:, :3, :]
+        s1, s2 = (fps_start if fps_start is not None else (None, None))
+        l1_xyz, l1_points = self.sa1(xyz, norm, s1)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s2)
+        _, l3_points = self.sa3(l2_xyz, l2_points)
+        x = l3_points.reshape(B, 1024)
+        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
+        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
+        return F.log_softmax(self.fc3(x), -1), l3_points
+
+
+class OracleSemSeg(nn.Module):
+    """models/pointnet2_sem_seg.py:6-48."""
+
+    def __init__(self, num_classes, with_rgb=True):
+        super().__init__()
+        self.with_rgb = with_rgb
+        extra = 3 if with_rgb else 0
+        self.sa1 = OracleSetAbstraction(1024, 0.1, 32, 6 + extra, [32, 32, 64], False)
+        self.sa2 = OracleSetAbstraction(256, 0.2, 32, 64 + 3, [64, 64, 128], False)
+        self.sa3 = OracleSetAbstraction(64, 0.4, 32, 128 + 3, [128, 128, 256], False)
+        self.sa4 = OracleSetAbstraction(16, 0.8, 32, 256 + 3, [256, 256, 512], False)
+        self.fp4 = OracleFeaturePropagation(768, [256, 256])
+        self.fp3 = OracleFeaturePropagation(384, [256, 256])
+        self.fp2 = OracleFeaturePropagation(320, [256, 128])
+        self.fp1 = OracleFeaturePropagation(128, [128, 128, 128])
+        self.conv1, self.bn1 = nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128)
+        self.drop1 = nn.Dropout(0.5)
+        self.conv2 = nn.Conv1d(128, num_classes, 1)
+
+    def forward(self, xyz, fps_start=None):
+        l0_points = xyz
+        l0_xyz = xyz[:, :3, :] if self.with_rgb else xyz
+        s = fps_start if fps_start is not None else (None,) * 4
+        l1_xyz, l1_points = self.sa1(l0_xyz, l0_points, s[0])
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1])
+        l3_xyz, l3_points = self.sa3(l2_xyz, l2_points, s[2])
+        l4_xyz, l4_points = self.sa4(l3_xyz, l3_points, s[3])
+        l3_points = self.fp4(l3_xyz, l4_xyz, l3_points, l4_points)
+        l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)
+        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points)
+        l0_points = self.fp1(l0_xyz, l1_xyz, None, l1_points)
+        x = self.drop1(F.relu(self.bn1(self.conv1(l0_points))))
+        x = F.log_softmax(self.conv2(x), dim=1)
+        return x.permute(0, 2, 1), l4_points
+
+
 def seg_loss(pred, target):
     """models/pointnet2_part_seg_msg.py:137-144: cross_entropy applied to log-probabilities."""
     return F.cross_entropy(pred, target)

@@ -17,7 +17,12 @@ _ALIASES = {
     "models.pointnet2_part_seg_msg": "prifit_amd.models.pointnet2_part_seg_msg",
     "models.pretrain_pointnet2_part_seg_msg": "prifit_amd.models.pretrain_pointnet2_part_seg_msg",
     "models.pointnet2_part_seg_ssg": "prifit_amd.models.pointnet2_part_seg_ssg",
+    "models.pointnet2_cls_msg": "prifit_amd.models.pointnet2_cls_msg",
+    "models.pointnet2_cls_ssg": "prifit_amd.models.pointnet2_cls_ssg",
+    "models.pointnet2_sem_seg": "prifit_amd.models.pointnet2_sem_seg",
     "convex_loss": "prifit_amd.convex_loss",
+    "testing": "prifit_amd.testing",
+    "data_utils.ShapeNetDataLoader": "prifit_amd.data",
     "src.mean_shift": "prifit_amd.src.mean_shift",
     "src.ellipsoid_fitting": "prifit_amd.src.ellipsoid_fitting",
     "src.ellipsoid_utils": "prifit_amd.src.ellipsoid_utils",
@@ -26,7 +31,7 @@ _ALIASES = {
 
 
 def install():
-    for pkg in ("models", "src"):
+    for pkg in ("models", "src", "data_utils"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = []  # namespace-like package

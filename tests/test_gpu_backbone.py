@@ -245,3 +245,56 @@ def test_ssg_model_config1(hiplib, golden):
     torch.testing.assert_close(seg.detach().sum(dim=1).cpu(), _t(g["seg_sum"]), rtol=1e-3, atol=5e-2)
     S.get_loss()(seg.reshape(-1, 50), torch.zeros(4096, dtype=torch.long, device="cuda")).backward()
     assert torch.isfinite(net.sa1.mlp_convs[0].weight.grad).all()
+
+
+def test_model_variants(hiplib, golden):
+    """cls MSG / cls SSG / sem-seg vs the reference's outputs (same seeded init) and, for
+    the gradients, vs the oracle's autograd on the same parameters."""
+    from prifit_amd.models import pointnet2_cls_msg, pointnet2_cls_ssg, pointnet2_sem_seg
+    g = golden("model_variants")
+    xyz = _t(synth.cloud("surface", 2, 1024, int(g["seed"]))).transpose(1, 2).contiguous()
+    starts = [_t(g["s%d" % i]) for i in range(4)]
+    for name, mod, msg in (("cls_msg", pointnet2_cls_msg, True), ("cls_ssg", pointnet2_cls_ssg, False)):
+        torch.manual_seed(5)
+        net = mod.get_model(40, normal_channel=False)
+        o = orc.OracleCls(40, normal_channel=False, msg=msg)
+        o.load_state_dict(net.state_dict())
+        for m in (net, o):
+            m.train(); m.drop1.eval(); m.drop2.eval()
+        net.cuda()
+        lp, l3 = net(xyz.cuda(), fps_start=(starts[0].cuda(), starts[1].cuda()))
+        assert lp.shape == (2, 40) and l3.shape == (2, 1024, 1)
+        torch.testing.assert_close(l3.detach().sum(dim=1).cpu(), _t(g[name + "_l3_sum"]), rtol=1e-3, atol=5e-2)
+        # the head's BatchNorm runs on a batch of 2, which amplifies rounding: loose on the log-probs
+        torch.testing.assert_close(lp.detach().cpu(), _t(g[name + "_logp"]), rtol=2e-2, atol=2e-2)
+        olp, _ = o(xyz, fps_start=(starts[0], starts[1]))
+        tgt = torch.tensor([3, 17])
+        mod.get_loss()(lp, tgt.cuda()).backward()
+        torch.nn.functional.nll_loss(olp, tgt).backward()
+        for (n_, p), (_, q) in zip(net.named_parameters(), o.named_parameters()):
+            # (a bias in front of a batch-statistics BatchNorm has zero gradient: rounding noise in the oracle)
+            if n_.startswith("fc3") or ("sa3" in n_ and n_.endswith("weight")):
+                ref = q.grad
+                assert (p.grad.cpu() - ref).norm() <= 5e-2 * ref.norm() + 1e-6, n_
+    feats = _t(synth.features(2, 1024, 3, 13)).transpose(1, 2)
+    x6 = torch.cat([xyz, feats], 1).contiguous()
+    torch.manual_seed(6)
+    net = pointnet2_sem_seg.get_model(13, with_rgb=True)
+    o = orc.OracleSemSeg(13, with_rgb=True)
+    o.load_state_dict(net.state_dict())
+    for m in (net, o):
+        m.train(); m.drop1.eval()
+    net.cuda()
+    lp, l4 = net(x6.cuda(), fps_start=tuple(s.cuda() for s in starts))
+    assert lp.shape == (2, 1024, 13) and l4.shape == (2, 512, 16)
+    torch.testing.assert_close(l4.detach().cpu(), _t(g["sem_l4"]), rtol=1e-3, atol=2e-4)
+    torch.testing.assert_close(lp.detach().sum(dim=1).cpu(), _t(g["sem_logp_sum"]), rtol=1e-3, atol=5e-2)
+    olp, _ = o(x6, fps_start=tuple(starts))
+    tgt = torch.from_numpy(synth.labels(2, 1024, 13, 14)) if hasattr(synth, "labels") else torch.zeros(2, 1024, dtype=torch.long)
+    w = torch.linspace(0.5, 1.5, 13)
+    pointnet2_sem_seg.get_loss()(lp.reshape(-1, 13), tgt.reshape(-1).cuda(), None, w.cuda()).backward()
+    torch.nn.functional.nll_loss(olp.reshape(-1, 13), tgt.reshape(-1), weight=w).backward()
+    for (n_, p), (_, q) in zip(net.named_parameters(), o.named_parameters()):
+        if n_ in ("conv2.weight", "fp1.mlp_convs.0.weight", "sa4.mlp_convs.2.weight", "sa1.mlp_convs.0.weight"):
+            ref = q.grad
+            assert (p.grad.cpu() - ref).norm() <= 5e-2 * ref.norm() + 1e-6, n_
