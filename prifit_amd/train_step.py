@@ -38,22 +38,27 @@ class SpeculativeRunner:
     buffers back, clear the gradients and run the closure again the synchronous way."""
 
     def __init__(self, model):
-        self.bufs = [b for b in model.buffers()]
-        self.snap = [torch.empty_like(b) for b in self.bufs]
+        # one list per dtype: _foreach_copy_ then runs as a single multi-tensor kernel per list instead of one
+        # copy per buffer (BatchNorm statistics are fp32, the batch counters int64)
+        groups = {}
+        for b in model.buffers():
+            groups.setdefault(b.dtype, []).append(b)
+        self.bufs = list(groups.values())
+        self.snap = [[torch.empty_like(b) for b in g] for g in self.bufs]
         self.fallbacks = 0
 
     def run(self, fn, reset):
         from . import fit_ops
 
-        if self.bufs:
-            torch._foreach_copy_(self.snap, self.bufs)
+        for dst, src in zip(self.snap, self.bufs):
+            torch._foreach_copy_(dst, src)
         with fit_ops.speculative() as spec:
             out = fn()
         if spec.ok():
             return out
         self.fallbacks += 1
-        if self.bufs:
-            torch._foreach_copy_(self.bufs, self.snap)
+        for dst, src in zip(self.bufs, self.snap):
+            torch._foreach_copy_(dst, src)
         reset()
         return fn()
 
