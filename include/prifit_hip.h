@@ -148,6 +148,8 @@ int prifit_gemm_tile_m(int N);
 
 /* Rows reduced into one partial slab by the *_reduce / col_stats kernels below. */
 int prifit_reduce_rows_per_slab(void);
+/* groups (rows of the pooled gradient) per slab of prifit_pool_bwd_reduce: its slab is [ceil(G/this)][2][C] */
+int prifit_pool_reduce_groups_per_slab(void);
 
 /* slab [ceil(P/rows_per_slab)][2][C] = per-block column (sum, sum of squares) of Y. */
 int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream);

@@ -12,12 +12,14 @@ __device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<flo
 
 // Column-slab reduction skeleton: threads are laid out as (C/4 float4 columns) x (row lanes).
 // f(row, c4, acc0, acc1) accumulates two float4 partials per thread.
-template <typename F>
+constexpr int POOL_RED_ROWS = 16;  // groups per workgroup in the pooled-layer reduction (only G = P/K rows: keep the grid wide)
+
+template <int ROWS = RED_ROWS, typename F>
 __device__ __forceinline__ void column_reduce(int P, int C, float *__restrict__ slab, F f)
 {
     __shared__ float4 s_red[2][256];
     const int C4 = C >> 2;
-    const int r_begin = blockIdx.x * RED_ROWS, r_end = min(P, r_begin + RED_ROWS);
+    const int r_begin = blockIdx.x * ROWS, r_end = min(P, r_begin + ROWS);
     for (int cbase = 0; cbase < C4; cbase += 256) {
         const int cols = min(256, C4 - cbase);
         const int lanes = 256 / cols;  // row lanes
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                                                               int C, int rps, float slope,
                                                               float *__restrict__ slab)
 {
-    column_reduce(G, C, slab, [&](int gi, int c4, float4 &a0, float4 &a1) {
+    column_reduce<POOL_RED_ROWS>(G, C, slab, [&](int gi, int c4, float4 &a0, float4 &a1) {
         const int c = 4 * c4;
         const long long to = tab_off((long long)gi * K, rps, C) + c;
         const float4 g = ld4g(gp + (size_t)gi * ldgp + c);
@@ -436,6 +438,7 @@ static inline bool bad_mat(const void *p, long long ld, int C)
 extern "C" {
 
 int prifit_reduce_rows_per_slab(void) { return RED_ROWS; }
+int prifit_pool_reduce_groups_per_slab(void) { return POOL_RED_ROWS; }
 
 int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream)
 {
@@ -519,9 +522,9 @@ int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long
                            int K, int C, int rows_per_sample, float slope, float *slab, void *stream)
 {
     if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || !arg || !scale || !shift || !mean || !invstd || !slab ||
-        G <= 0 || K <= 0 || rows_per_sample < 0 || (rows_per_sample % (K * RED_ROWS)) != 0)
+        G <= 0 || K <= 0 || rows_per_sample < 0 || (rows_per_sample % (K * POOL_RED_ROWS)) != 0)
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((G + RED_ROWS - 1) / RED_ROWS), dim3(256), 0,
+    hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((G + POOL_RED_ROWS - 1) / POOL_RED_ROWS), dim3(256), 0,
                        as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, mean, invstd, G, K, C, rows_per_sample,
                        slope, slab);
     return prifit_check_launch();

@@ -164,7 +164,8 @@ class SharedMLPFn(torch.autograd.Function):
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
-                nslab = (G + rps - 1) // rps
+                prs = dll().prifit_pool_reduce_groups_per_slab()
+                nslab = (G + prs - 1) // prs
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
                      ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, 0, _F(0.0), ptr(slab), cur_stream())

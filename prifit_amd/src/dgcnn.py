@@ -143,6 +143,7 @@ class ConvGNActFn(torch.autograd.Function):
         rows = dll().prifit_reduce_rows_per_slab()
         if pool_K:
             Gp = P // pool_K
+            rows = dll().prifit_pool_reduce_groups_per_slab()
             nslab = (Gp + rows - 1) // rows
             slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
             call("prifit_pool_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
