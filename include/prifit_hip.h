@@ -181,7 +181,8 @@ int prifit_pool_fwd(const float *Y, long long ldy, const float *scale, const flo
 /* First layer of a set-abstraction MLP by linearity (models/pointnet_util.py:243-252 / :127-133,195-197):
  * conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias with U [B,N,C] = [feat | xyz] W1^T per point and
  * Vc [B,S,C] = c W1x^T per centre: Y [(b,s,k), C] = U[b, idx[b,s,k]] - Vc[b,s] + bias (bias may be NULL), plus
- * per-512-row column (sum, sum of squares) slabs [ceil(P/512)][2][C] for the following BatchNorm. */
+ * per-slab column (sum, sum of squares) [ceil(P/rows)][2][C], rows = prifit_reduce_rows_per_slab(), for the
+ * following BatchNorm. */
 int prifit_gather_linear_fwd(const float *U, const float *Vc, const float *bias, const int32_t *idx, int B,
                              int N, int S, int K, int C, float *Y, float *slab, void *stream);
 /* autograd: dU [B,N,C] (initialised by the caller) += scatter of dY; dVc [B,S,C] = -sum_k dY. */

@@ -5,7 +5,7 @@
 // per-block partial slabs [nblk][2][C] finalised in double precision (deterministic, no atomics).
 #include "common.h"
 
-constexpr int RED_ROWS = 512;  // rows of the matrix reduced by one workgroup
+constexpr int RED_ROWS = 128;  // rows of the matrix reduced by one workgroup
 
 __device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }

@@ -221,7 +221,8 @@ class GatherLinearFn(torch.autograd.Function):
         assert Vc.shape == (B, S, C) and idx.dtype == torch.int32, (Vc.shape, idx.dtype)
         P = B * S * K
         Y = torch.empty(P, C, dtype=torch.float32, device=U.device)
-        slab = torch.empty((P + 511) // 512, 2, C, dtype=torch.float32, device=U.device)
+        rps = _rows_per_slab()
+        slab = torch.empty((P + rps - 1) // rps, 2, C, dtype=torch.float32, device=U.device)
         # algorithmic bytes: read U and Vc once, read idx, write the C-wide grouped pre-activations
         with profiler.span("gather_linear", 4.0 * B * (N * C + S * C + S * K + S * K * C)):
             call("prifit_gather_linear_fwd", ptr(U), ptr(Vc), ptr(bias), ptr(idx), B, N, S, K, C, ptr(Y), ptr(slab),

@@ -272,8 +272,9 @@ def test_model_variants(hiplib, golden):
         mod.get_loss()(lp, tgt.cuda()).backward()
         torch.nn.functional.nll_loss(olp, tgt).backward()
         for (n_, p), (_, q) in zip(net.named_parameters(), o.named_parameters()):
-            # (a bias in front of a batch-statistics BatchNorm has zero gradient: rounding noise in the oracle)
-            if n_.startswith("fc3") or ("sa3" in n_ and n_.endswith("weight")):
+            # only the classifier layer: the head's BatchNorm1d sees a batch of TWO rows, where (x - mean) / std is
+            # +-1 whatever x is, so every gradient upstream of it is rounding noise amplified (norms ~1e3)
+            if n_.startswith("fc3"):
                 ref = q.grad
                 assert (p.grad.cpu() - ref).norm() <= 5e-2 * ref.norm() + 1e-6, n_
     feats = _t(synth.features(2, 1024, 3, 13)).transpose(1, 2)
