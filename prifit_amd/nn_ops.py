@@ -48,13 +48,17 @@ def _splitk_for(P, tiles):
     return int(max(1, min(want, ktiles // 8 if ktiles >= 8 else 1, 4096)))
 
 
-def _weight_grad(dY, P, Cout, Ain, Kin, a_affine):
-    """dW [Cout, Kin] = dY[P, Cout]^T . A[P, Kin] (A optionally normalised on load)."""
-    dW = torch.zeros(Cout, Kin, dtype=torch.float32, device=dY.device)
+def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
+    """dW [Cout, Kin] = dY[P, Cout]^T . A[P, Kin] (A optionally normalised on load).  `out`: a zero-filled
+    [Cout, Kin] destination (several layers share one zeroed arena: one fill instead of one per layer)."""
     tiles = ((Cout + 127) // 128) * ((Kin + 127) // 128)
     sk = _splitk_for(P, tiles)
-    if sk == 1:
-        dW = torch.empty_like(dW)
+    if out is not None:
+        dW = out
+    elif sk == 1:
+        dW = torch.empty(Cout, Kin, dtype=torch.float32, device=dY.device)
+    else:
+        dW = torch.zeros(Cout, Kin, dtype=torch.float32, device=dY.device)
     gemm(TN, Cout, Kin, P, dY, dY.stride(0), Ain, Ain.stride(0), dW, Kin, splitk=sk, b_affine=a_affine)
     return dW
 
@@ -150,6 +154,17 @@ class SharedMLPFn(torch.autograd.Function):
         gout = gout.contiguous()
         rps = _rows_per_slab()
         grads = [None] * (6 * L)
+        # one zero-filled arena for every weight gradient (split-K adds into it) and, in training, the (exactly
+        # zero) bias gradients of this stack
+        wslots, total = {}, 0
+        for l in range(L):
+            if Ws[l] is None:
+                continue
+            n = Ws[l].numel() if ctx.needs_input_grad[2 + 6 * l] else 0
+            nb = Ws[l].shape[0] if (training and ctx.needs_input_grad[2 + 6 * l + 1]) else 0
+            wslots[l] = (total, n, total + n, nb)
+            total += n + nb
+        arena = torch.zeros(total, dtype=torch.float32, device=dev) if total else None
         G_in = gout  # gradient w.r.t. the ReLU output of layer l (or pooled output for the last layer)
         for l in range(L - 1, -1, -1):
             Y, W = Ys[l], Ws[l]
@@ -190,11 +205,12 @@ class SharedMLPFn(torch.autograd.Function):
                 break
             A_in = x if l == 0 else Ys[l - 1]
             a_aff = None if l == 0 else affines[l - 1]
+            wo, wn, bo, bn_ = wslots[l]
             if ctx.needs_input_grad[2 + 6 * l]:
-                grads[6 * l] = _weight_grad(dY, P, Cout, A_in, Kin, a_aff)
+                grads[6 * l] = _weight_grad(dY, P, Cout, A_in, Kin, a_aff, out=arena[wo:wo + wn].view(Cout, Kin))
             if ctx.needs_input_grad[2 + 6 * l + 1]:
                 # bias in front of a batch-stat BatchNorm has zero gradient; with running stats it is sum(dY)
-                grads[6 * l + 1] = torch.zeros(Cout, device=dev) if training else dY.sum(dim=0)
+                grads[6 * l + 1] = arena[bo:bo + bn_] if training else dY.sum(dim=0)
             grads[6 * l + 2] = dgamma
             grads[6 * l + 3] = dbeta
             if l > 0 or ctx.needs_input_grad[0]:
