@@ -220,8 +220,18 @@ def main():
         if grp:
             ms = sum(g["ms_per_step"] for g in grp)
             gb = sum(g["achieved"] * g["ms_per_step"] * 1e-3 for g in grp)
+            # compulsory traffic of ball query + MATERIALISED grouping of the MSG backbone per shape
+            # (the work the reference does); the launches above do the same grouping job with fewer bytes
+            sa1 = 12 * (2048 + 512) + sum(4 * 512 * k + 4 * 512 * k * 6 for k in (32, 64, 128))
+            sa2 = 12 * (512 + 128) + 4 * 512 * 320 + sum(4 * 128 * k + 4 * 128 * k * 323 for k in (64, 128))
+            survey_gb = B_PER_GPU * (sa1 + sa2) / 1e9
             grouping = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gb / (ms * 1e-3) / HBM_PEAK_GBS, "ms_per_step": ms,
+                        "survey_formula": {"gbytes_per_step": survey_gb, "equivalent_gbs": survey_gb / (ms * 1e-3),
+                                           "frac": survey_gb / (ms * 1e-3) / HBM_PEAK_GBS,
+                                           "note": "bytes of the reference's materialised grouping (SURVEY.md 8d) / time "
+                                                   "of the launches that now do that job; with PRIFIT_SA_LINEARITY=0 the "
+                                                   "launches move exactly these bytes"},
                         "note": "ball-query + grouping launches (group_gather, and gather_linear = grouping fused with the first "
                                 "MLP layer, whose grouped-out term is its C1-wide output), algorithmic bytes of SURVEY.md 8(d)"}
         line = {
