@@ -35,15 +35,28 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
     }
     unsigned prefix = 0;
     int kk = k;  // 1-based rank among the remaining candidates
+    int rem = VPT * 64;  // candidates whose decided high bits equal `prefix`
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned hi_mask = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+        if (rem == 1) {
+            // a single candidate is left: it is the answer, whatever its remaining bits (typically after ~12 of
+            // the 32 steps for a row of distinct distances)
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) m = max(m, (key[j] & hi_mask) == prefix ? key[j] : 0u);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+            prefix = m;
+            break;
+        }
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < VPT; ++j)
             cnt += ((key[j] & hi_mask) == prefix && !((key[j] >> bit) & 1u)) ? 1 : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (kk > cnt) { kk -= cnt; prefix |= (1u << bit); }
+        if (kk > cnt) { kk -= cnt; rem -= cnt; prefix |= (1u << bit); }
+        else rem = cnt;
     }
     if (lane == 0) out[row] = key2f(prefix);
 }
