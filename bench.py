@@ -30,6 +30,9 @@ NPTS = 2048
 NUM_PARTS = 50
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured by a float4 copy)
+# launches of the ball-query + grouping stage: sa_group_linear = ball query + grouping + first MLP layer of a
+# set-abstraction level in one launch (default); the others run with PRIFIT_SA_FUSED=0 / PRIFIT_SA_LINEARITY=0
+GROUPING_FAMILIES = ("sa_group_linear", "ball_query", "group_gather", "gather_linear")
 
 
 def make_inputs(workload, rank, device):
@@ -115,8 +118,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is taken even with one rank, so that a 1-GPU box
+    # rehearses exactly the code the N>1 runs execute (pack, all-reduce, broadcast, barrier)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from prifit_amd import _lib, profiler
@@ -169,20 +176,20 @@ def main():
     dominant = max(cal.items(), key=lambda kv: kv[1][1])[0] if cal else None
     profiler.disable()
     profiler.reset()
-    profiler.enable(*[n for n in (dominant, "ball_query", "group_gather", "gather_linear") if n])
-    if world > 1:
+    profiler.enable(*[n for n in (dominant,) + GROUPING_FAMILIES if n])
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     profiler.disable()
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = el.item()
     fams = profiler.collect()
@@ -215,7 +222,7 @@ def main():
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
                     "frac": d["frac"], "traffic": traffic, "avg_us": d["avg_us"],
                     "launches_per_step": d["launches_per_step"]}
-        grp = [detail[k] for k in detail if k in ("ball_query", "group_gather", "gather_linear")]
+        grp = [detail[k] for k in detail if k in GROUPING_FAMILIES]
         grouping = None
         if grp:
             ms = sum(g["ms_per_step"] for g in grp)
@@ -232,8 +239,9 @@ def main():
                                            "note": "bytes of the reference's materialised grouping (SURVEY.md 8d) / time "
                                                    "of the launches that now do that job; with PRIFIT_SA_LINEARITY=0 the "
                                                    "launches move exactly these bytes"},
-                        "note": "ball-query + grouping launches (group_gather, and gather_linear = grouping fused with the first "
-                                "MLP layer, whose grouped-out term is its C1-wide output), algorithmic bytes of SURVEY.md 8(d)"}
+                        "note": "ball-query + grouping launches (sa_group_linear = ball query + grouping + first MLP layer of a "
+                                "set-abstraction level in one launch; its grouped-out term is the C1-wide first-layer "
+                                "output it writes), algorithmic bytes of SURVEY.md 8(d)"}
         line = {
             "metric": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG+ellipsoid fit",
             "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -251,7 +259,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

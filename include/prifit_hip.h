@@ -189,6 +189,31 @@ int prifit_gather_linear_fwd(const float *U, const float *Vc, const float *bias,
 int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, int S, int K, int C,
                              float *dU, float *dVc, void *stream);
 
+/* Set-abstraction front end in ONE launch per layer: multi-radius ball query (models/pointnet_util.py:87-107 with
+ * :19-40 fused, bit-exact like prifit_ball_query) + grouping (:43-60, :127-133 / :243-249) + the first 1x1 conv of
+ * every per-radius MLP (:195-197 / :250-252), one wave per query centre, the shape's cloud in LDS.  N <= 2048,
+ * R <= 4, sum(nsample) <= 320, width[r] a power of two in 16..128.  Host arrays of length R: radius2 (fp32 of
+ * radius^2 like prifit_ball_query), nsample, width (C1 of the first layer), bias (device [C1] or NULL entries),
+ * Y (device [B*S*K_r, C1_r] pre-activations), slab (device [B*ceil(S/q)][2][C1_r] column sum / sum of squares
+ * for the BatchNorm that follows, q = prifit_sa_group_queries_per_slab(B,S); NULL entries skip them),
+ * idx (device int32 [B,S,K_r], written).
+ *   mode 0 "direct": y = W_r [feat_j | xyz_j - c] + bias from the upstream weight W_r [C1, D+3] (device pointers
+ *     in the host array W), column order [feat, rel] when feat_first else [rel, feat]; feat [B,N,D], D in {0,3,6};
+ *   mode 1 "gather": y = U_r[b, j] - Vc_r[b, s] + bias (the layer by linearity, see prifit_gather_linear_fwd);
+ *     U / Vc host arrays of device pointers [B,N,C1_r] / [B,S,C1_r]. */
+int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, int N, int S, int R,
+                               const float *radius2, const int *nsample, const int *width, int mode,
+                               const float *feat, int D, int feat_first, const float *const *W,
+                               const float *const *U, const float *const *Vc, const float *const *bias,
+                               float *const *Y, float *const *slab, int32_t *const *idx, void *stream);
+/* Queries per statistics slab of the call above (the workgroup size it will pick for B shapes x S centres). */
+int prifit_sa_group_queries_per_slab(int B, int S);
+/* autograd of mode 0 w.r.t. the weight: partial [nblocks][C][D+3] (upstream column order) with
+ * sum_blocks partial = dY^T [feat_j | xyz_j - c] over all grouped samples; dY [B*S*K, C]. */
+int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz,
+                             const float *feat, int B, int N, int S, int K, int C, int D, int feat_first,
+                             int nblocks, float *partial, void *stream);
+
 /* Backward of relu(bn(Y)) given G = dL/d(relu output): partial slabs of m1 = sum(G*mask) and
  * m2 = sum(G*mask*yhat). */
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy,

@@ -21,6 +21,7 @@ ARCH = "gfx950"
 # source -> extra flags
 SOURCES = {
     "pointops.hip": ["-ffp-contract=off"],
+    "sa_group.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "bn.hip": [],
     "meanshift.hip": [],

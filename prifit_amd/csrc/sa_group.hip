@@ -1,0 +1,450 @@
+// Set-abstraction front end in ONE launch per layer (models/pointnet_util.py:87-107 query_ball_point with
+// :19-40 square_distance, :43-60 index_points, :127-133 / :243-249 grouping, and the first 1x1 conv of the
+// per-group MLP :195-197 / :250-252) for gfx950.
+//
+// One wave = one query centre.  The workgroup keeps the shape's cloud in LDS (float4: x, y, z, |p|^2).
+//   phase 1  ball query for all radii of the layer in one scan (same two-stage ordered compaction and the same
+//            bit-exact expanded-form distances as ball_query_kernel in pointops.hip); the index lists stay in
+//            LDS and are copied to HBM with coalesced stores (the backward pass needs them);
+//   phase 2  emission: for every (radius, sample) the pre-activation row of the FIRST MLP layer is written
+//            straight from the wave, together with the column sums / sums of squares the BatchNorm needs:
+//              MODE 0 "direct"  y = W [rel_xyz | feat_j] + b computed from the LDS cloud with the weights in
+//                               registers (narrow inputs: SA1, 3..9 input channels) -- no grouped tensor, no GEMM;
+//              MODE 1 "gather"  y = U_j - Vc_g + b, the layer by linearity (U = [feat | xyz] W^T per point,
+//                               Vc = c Wx^T per centre): rows of U are gathered from L2.
+// A row of C floats is written by C/4 lanes as float4, 64/(C/4) rows per wave instruction: every store
+// instruction covers 1 KiB of contiguous output.  HBM traffic = the compulsory bytes: clouds + index lists +
+// the C-wide rows once (+ U/Vc reads in gather mode); this is the bandwidth-bound kernel of the grouping stage.
+#include "common.h"
+#include "distance.h"
+
+namespace {
+
+constexpr int SG_TILE = 2048;   // cloud size limit (LDS copy)
+constexpr int SG_LIST = 320;    // sum of nsample over the radii of one launch
+constexpr int SG_CMAX = 128;    // widest first layer
+constexpr int SG_UNR = 4;       // independent row chains in flight per lane
+
+struct SAGroupArgs {
+    const float *xyz, *new_xyz, *feat;
+    int B, N, S, feat_first;
+    float r2[4];
+    int K[4], C[4];
+    const float *W[4];     // MODE 0: upstream conv weight [C][D+3]
+    const float *U[4];     // MODE 1: [B,N,C]
+    const float *Vc[4];    // MODE 1: [B,S,C]
+    const float *bias[4];  // [C] or NULL
+    float *Y[4];           // [B*S*K, C]
+    float *slab[4];        // [B*ceil(S/NW)][2][C] or NULL
+    int32_t *idx[4];       // [B,S,K]
+};
+
+__device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// R radii, MODE (0 direct / 1 gather), D feature channels of the direct mode (0, 3 or 6), NW waves per workgroup
+template <int R, int MODE, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
+{
+    constexpr int KP = D + 3;
+    __shared__ float4 s_pts[SG_TILE];
+    __shared__ float2 s_cand[NW][128];
+    __shared__ int s_list[NW][SG_LIST];
+    __shared__ __attribute__((aligned(16))) float s_red[NW][2][SG_CMAX];
+
+    // XCD-aware placement: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so XCD x works on the
+    // shapes x, x+8, ...: the gathered U rows of a shape stay in ONE L2.
+    const int N = a.N, S = a.S;
+    const int nb = (S + NW - 1) / NW;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int b = (jj / nb) * 8 + xcd, tile = jj % nb;
+    if (b >= a.B) return;  // whole workgroup
+    const int slab_id = b * nb + tile;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float *P = a.xyz + (size_t)b * N * 3;
+    for (int i = threadIdx.x; i < N; i += NW * 64) {
+        const float x = P[(size_t)i * 3 + 0], y = P[(size_t)i * 3 + 1], z = P[(size_t)i * 3 + 2];
+        s_pts[i] = make_float4(x, y, z, norm2_3(x, y, z));
+    }
+    __syncthreads();
+
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int qid = tile * NW + wave;
+    const bool valid = qid < S;  // wave-uniform
+    const float *Q = a.new_xyz + ((size_t)b * S + (valid ? qid : S - 1)) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    const float qq = norm2_3(qx, qy, qz);
+    int *lst = s_list[wave];
+    int off[R];
+    off[0] = 0;
+#pragma unroll
+    for (int r = 1; r < R; ++r) off[r] = off[r - 1] + a.K[r - 1];
+
+    // ---------------------------------------------------------------- phase 1: ball query
+    if (valid) {
+        int cnt[R], first[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { cnt[r] = 0; first[r] = N; }
+        float r2max = a.r2[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) r2max = fmaxf(r2max, a.r2[r]);
+        int fill = 0, done = 0;  // candidates written / consumed (wave-uniform)
+        bool finished = false;
+        float2 *ring = s_cand[wave];
+
+        auto consume = [&](int nproc) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool act = lane < nproc;
+            const float2 e = ring[(done + lane) & 127];
+            const int gi = __float_as_int(e.x);
+            const float d = e.y;
+            bool all = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int K = a.K[r];
+                if (cnt[r] < K) {
+                    const bool pred = act && !(d > a.r2[r]);
+                    const unsigned long long m = __ballot(pred);
+                    if (m != 0ull) {
+                        if (cnt[r] == 0) first[r] = __builtin_amdgcn_readlane(gi, __builtin_ctzll(m));
+                        const int pos = cnt[r] + __popcll(m & lt_mask);
+                        if (pred && pos < K) lst[off[r] + pos] = gi;
+                        cnt[r] += __popcll(m);
+                    }
+                }
+                all = all && cnt[r] >= K;
+            }
+            done += nproc;
+            __builtin_amdgcn_wave_barrier();
+            return all;
+        };
+
+        for (int c = 0; c < N; c += 64) {
+            const int i = c + lane;
+            const bool inb = i < N;
+            const float4 p = s_pts[inb ? i : 0];
+            const float d = sqdist_expanded(qx, qy, qz, qq, p.x, p.y, p.z, p.w);
+            const bool pred = inb && !(d > r2max);
+            const unsigned long long m = __ballot(pred);
+            if (m != 0ull) {
+                if (pred) ring[(fill + __popcll(m & lt_mask)) & 127] = make_float2(__int_as_float(i), d);
+                fill += __popcll(m);
+                if (fill - done >= 64 && consume(64)) { finished = true; break; }
+            }
+        }
+        while (!finished && fill > done) finished = consume(min(64, fill - done));
+        // pointnet_util.py:104-106: slots beyond the in-ball count repeat the first in-ball index
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int K = a.K[r];
+            for (int k = min(cnt[r], K) + lane; k < K; k += 64) lst[off[r] + k] = first[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int K = a.K[r];
+            int32_t *o = a.idx[r] + ((size_t)b * S + qid) * K;
+            for (int k = lane; k < K; k += 64) o[k] = lst[off[r] + k];
+        }
+    }
+
+    // ---------------------------------------------------------------- phase 2: first-layer rows + column statistics
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int K = a.K[r], C = a.C[r];
+        const int L = C >> 2, sh = __builtin_ctz(L);  // C is a power of two, 16..128
+        const int rpi = 64 >> sh;                     // rows per wave instruction
+        const int c4 = lane & (L - 1), rsel = lane >> sh;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (valid) {
+            const float4 bb = a.bias[r] ? ld4g(a.bias[r] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float *Yq = a.Y[r] + ((size_t)b * S + qid) * K * C + 4 * c4;
+            const int *l = lst + off[r];
+            float w[4][KP];
+            float4 vc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *Ub = nullptr;
+            if (MODE == 0) {
+                // x = [rel(3), feat(D)]; upstream column of x[k]: MSG order [feat, rel] (:247), SSG [rel, feat] (:131)
+                const float *Wr = a.W[r] + (size_t)(4 * c4) * KP;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const int col = k < 3 ? (a.feat_first ? D + k : k) : (a.feat_first ? k - 3 : k);
+                        w[j][k] = Wr[j * KP + col];
+                    }
+            } else {
+                vc = ld4g(a.Vc[r] + ((size_t)b * S + qid) * C + 4 * c4);
+                Ub = a.U[r] + (size_t)b * N * C + 4 * c4;
+            }
+            const float *Fb = (MODE == 0 && D > 0) ? a.feat + (size_t)b * N * D : nullptr;
+            for (int k0 = 0; k0 < K; k0 += rpi * SG_UNR) {
+                bool okk[SG_UNR], inb[SG_UNR];
+                int n[SG_UNR];
+                float4 p[SG_UNR];
+                float f[SG_UNR][D > 0 ? D : 1];
+#pragma unroll
+                for (int u = 0; u < SG_UNR; ++u) {
+                    const int k = k0 + u * rpi + rsel;
+                    okk[u] = k < K;
+                    const int nn = l[okk[u] ? k : K - 1];
+                    inb[u] = nn >= 0 && nn < N;
+                    n[u] = inb[u] ? nn : 0;
+                    if (MODE == 0) {
+                        p[u] = s_pts[n[u]];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) f[u][i] = Fb[(size_t)n[u] * D + i];
+                    } else {
+                        p[u] = ld4g(Ub + (size_t)n[u] * C);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SG_UNR; ++u) {
+                    float4 y;
+                    if (MODE == 0) {
+                        float x[KP];
+                        x[0] = inb[u] ? p[u].x - qx : 0.f;
+                        x[1] = inb[u] ? p[u].y - qy : 0.f;
+                        x[2] = inb[u] ? p[u].z - qz : 0.f;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) x[3 + i] = inb[u] ? f[u][i] : 0.f;
+                        float yy[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float acc = w[j][0] * x[0];
+#pragma unroll
+                            for (int k = 1; k < KP; ++k) acc = fmaf(w[j][k], x[k], acc);
+                            yy[j] = acc;
+                        }
+                        y = make_float4(yy[0] + bb.x, yy[1] + bb.y, yy[2] + bb.z, yy[3] + bb.w);
+                    } else {
+                        y = inb[u] ? make_float4(p[u].x - vc.x, p[u].y - vc.y, p[u].z - vc.z, p[u].w - vc.w)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                        y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
+                    }
+                    if (okk[u]) {
+                        st4g(Yq + (size_t)(k0 + u * rpi + rsel) * C, y);
+                        s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
+                        s1.x += y.x * y.x; s1.y += y.y * y.y; s1.z += y.z * y.z; s1.w += y.w * y.w;
+                    }
+                }
+            }
+        }
+        if (a.slab[r]) {  // block-uniform
+            for (int o = L; o < 64; o <<= 1) {
+                s0.x += __shfl_xor(s0.x, o, 64); s0.y += __shfl_xor(s0.y, o, 64);
+                s0.z += __shfl_xor(s0.z, o, 64); s0.w += __shfl_xor(s0.w, o, 64);
+                s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
+                s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+            }
+            if (rsel == 0) {
+                *reinterpret_cast<float4 *>(&s_red[wave][0][4 * c4]) = s0;
+                *reinterpret_cast<float4 *>(&s_red[wave][1][4 * c4]) = s1;
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < 2 * C; t += NW * 64) {
+                const int which = t >= C ? 1 : 0, c = t - which * C;
+                float s = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) s += s_red[wv][which][c];
+                a.slab[r][((size_t)slab_id * 2 + which) * C + c] = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// dW of the direct-mode first layer: dW[c][col] = sum over grouped samples of dY[row][c] * x_row[col] with
+// x_row = [rel_xyz | feat_j] re-formed from the index lists (the grouped tensor is never materialised).
+// Every workgroup reduces a contiguous range of rows and writes one [C][D+3] partial (upstream column order).
+template <int D>
+__global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
+    const float *__restrict__ dY, const int32_t *__restrict__ idx, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ feat, int N, int S, int K, int C, int feat_first,
+    long long P, long long rows_per_block, float *__restrict__ partial)
+{
+    constexpr int KP = D + 3;
+    __shared__ float s_x[256][KP];
+    __shared__ float s_acc[4][SG_CMAX * KP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int L = C >> 2, sh = __builtin_ctz(L), rpi = 64 >> sh;
+    const int c4 = lane & (L - 1), rsel = lane >> sh;
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    const long long r_end = r_begin + rows_per_block < P ? r_begin + rows_per_block : P;
+    float acc[4][KP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[j][k] = 0.f;
+
+    for (long long base = r_begin; base < r_end; base += 256) {
+        {   // x rows of this chunk: one thread per row
+            const long long row = base + threadIdx.x;
+            float x[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) x[k] = 0.f;
+            if (row < r_end) {
+                const long long g = row / K;  // b*S + s
+                const int bb = (int)(g / S);
+                const int n = idx[row];
+                if (n >= 0 && n < N) {
+                    const float *p = xyz + ((size_t)bb * N + n) * 3;
+                    const float *c = new_xyz + (size_t)g * 3;
+                    x[0] = p[0] - c[0]; x[1] = p[1] - c[1]; x[2] = p[2] - c[2];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) x[3 + i] = feat[((size_t)bb * N + n) * D + i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) s_x[threadIdx.x][k] = x[k];
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < 64; i0 += rpi * SG_UNR) {
+            float4 gy[SG_UNR];
+            int lr[SG_UNR];
+#pragma unroll
+            for (int u = 0; u < SG_UNR; ++u) {
+                lr[u] = wave * 64 + i0 + u * rpi + rsel;
+                const long long row = base + lr[u];
+                const bool ok = (i0 + u * rpi + rsel) < 64 && row < r_end;
+                gy[u] = ld4g(dY + (size_t)(ok ? row : r_begin) * C + 4 * c4);
+                if (!ok) gy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                lr[u] = ok ? lr[u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < SG_UNR; ++u) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const float xv = s_x[lr[u]][k];
+                    acc[0][k] = fmaf(gy[u].x, xv, acc[0][k]);
+                    acc[1][k] = fmaf(gy[u].y, xv, acc[1][k]);
+                    acc[2][k] = fmaf(gy[u].z, xv, acc[2][k]);
+                    acc[3][k] = fmaf(gy[u].w, xv, acc[3][k]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = L; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc[j][k] += __shfl_xor(acc[j][k], o, 64);
+    }
+    if (rsel == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) s_acc[wave][(4 * c4 + j) * KP + k] = acc[j][k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < C * KP; t += 256) {
+        const int c = t / KP, k = t - c * KP;
+        const int col = k < 3 ? (feat_first ? D + k : k) : (feat_first ? k - 3 : k);
+        partial[(size_t)blockIdx.x * C * KP + c * KP + col] = s_acc[0][t] + s_acc[1][t] + s_acc[2][t] + s_acc[3][t];
+    }
+}
+
+template <int R, int MODE, int D>
+int launch_nw(const SAGroupArgs &a, hipStream_t st)
+{
+    // 8 queries per workgroup share one LDS copy of the cloud; 4 when the layer has few queries (fuller last wave of
+    // workgroups on 256 CUs)
+    const int B8 = (a.B + 7) / 8 * 8;
+    if ((long long)a.B * ((a.S + 7) / 8) >= 1024) {
+        hipLaunchKernelGGL((sa_group_kernel<R, MODE, D, 8>), dim3(B8 * ((a.S + 7) / 8)), dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((sa_group_kernel<R, MODE, D, 4>), dim3(B8 * ((a.S + 3) / 4)), dim3(256), 0, st, a);
+    }
+    return prifit_check_launch();
+}
+
+template <int MODE, int D>
+int launch_r(const SAGroupArgs &a, int R, hipStream_t st)
+{
+    switch (R) {
+        case 1: return launch_nw<1, MODE, D>(a, st);
+        case 2: return launch_nw<2, MODE, D>(a, st);
+        case 3: return launch_nw<3, MODE, D>(a, st);
+        default: return launch_nw<4, MODE, D>(a, st);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int prifit_sa_group_queries_per_slab(int B, int S)
+{
+    return ((long long)B * ((S + 7) / 8) >= 1024) ? 8 : 4;
+}
+
+int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, int N, int S, int R,
+                               const float *radius2, const int *nsample, const int *width, int mode,
+                               const float *feat, int D, int feat_first, const float *const *W,
+                               const float *const *U, const float *const *Vc, const float *const *bias,
+                               float *const *Y, float *const *slab, int32_t *const *idx, void *stream)
+{
+    if (!xyz || !new_xyz || !radius2 || !nsample || !width || !bias || !Y || !slab || !idx || B <= 0 || N <= 0 ||
+        N > SG_TILE || S <= 0 || R < 1 || R > 4 || (mode != 0 && mode != 1))
+        return PRIFIT_EINVAL;
+    if (mode == 0 && (!W || (D != 0 && D != 3 && D != 6) || (D > 0 && !feat))) return PRIFIT_EINVAL;
+    if (mode == 1 && (!U || !Vc)) return PRIFIT_EINVAL;
+    SAGroupArgs a;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.B = B; a.N = N; a.S = S; a.feat_first = feat_first;
+    int ksum = 0;
+    for (int r = 0; r < 4; ++r) {
+        const bool in = r < R;
+        a.r2[r] = in ? radius2[r] : 0.f;
+        a.K[r] = in ? nsample[r] : 0;
+        a.C[r] = in ? width[r] : 0;
+        a.W[r] = (in && mode == 0) ? W[r] : nullptr;
+        a.U[r] = (in && mode == 1) ? U[r] : nullptr;
+        a.Vc[r] = (in && mode == 1) ? Vc[r] : nullptr;
+        a.bias[r] = in ? bias[r] : nullptr;
+        a.Y[r] = in ? Y[r] : nullptr;
+        a.slab[r] = in ? slab[r] : nullptr;
+        a.idx[r] = in ? idx[r] : nullptr;
+        if (!in) continue;
+        const int C = width[r];
+        if (nsample[r] < 1 || C < 16 || C > SG_CMAX || (C & (C - 1)) || !Y[r] || !idx[r] ||
+            (mode == 0 ? !W[r] : (!U[r] || !Vc[r])) || ((uintptr_t)Y[r] & 15) ||
+            (mode == 1 && (((uintptr_t)U[r] | (uintptr_t)Vc[r]) & 15)) || (bias[r] && ((uintptr_t)bias[r] & 15)))
+            return PRIFIT_EINVAL;
+        ksum += nsample[r];
+    }
+    if (ksum > SG_LIST) return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (mode == 1) return launch_r<1, 0>(a, R, st);
+    if (D == 0) return launch_r<0, 0>(a, R, st);
+    if (D == 3) return launch_r<0, 3>(a, R, st);
+    return launch_r<0, 6>(a, R, st);
+}
+
+int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz,
+                             const float *feat, int B, int N, int S, int K, int C, int D, int feat_first,
+                             int nblocks, float *partial, void *stream)
+{
+    if (!dY || !idx || !xyz || !new_xyz || !partial || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C < 16 ||
+        C > SG_CMAX || (C & (C - 1)) || (D != 0 && D != 3 && D != 6) || (D > 0 && !feat) || nblocks < 1 ||
+        ((uintptr_t)dY & 15))
+        return PRIFIT_EINVAL;
+    const long long P = (long long)B * S * K;
+    long long per = (P + nblocks - 1) / nblocks;
+    per = (per + 255) / 256 * 256;
+    if ((long long)nblocks * per < P) return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+#define DW_LAUNCH(DD)                                                                                              \
+    hipLaunchKernelGGL((sa_first_layer_dw_kernel<DD>), dim3(nblocks), dim3(256), 0, st, dY, idx, xyz, new_xyz, feat, \
+                       N, S, K, C, feat_first, P, per, partial)
+    if (D == 0) DW_LAUNCH(0);
+    else if (D == 3) DW_LAUNCH(3);
+    else DW_LAUNCH(6);
+#undef DW_LAUNCH
+    return prifit_check_launch();
+}
+
+}  // extern "C"

@@ -18,7 +18,7 @@ class FlatGradBucket:
     Gradients are produced by autograd as ordinary per-parameter tensors (zero() only drops the old
     ones, so backward *writes* instead of accumulating); `allreduce()` packs them into the flat fp32
     bucket with one multi-tensor copy, runs ONE all-reduce, scales by 1/world and points every
-    `p.grad` at its slice of the bucket.  With a single rank nothing is copied or exchanged."""
+    `p.grad` at its slice of the bucket.  Without an initialised process group nothing is copied or exchanged."""
 
     def __init__(self, module, process_group=None):
         self.module = module
@@ -32,7 +32,8 @@ class FlatGradBucket:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.dist = dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.dist else 1
 
     def zero(self):
         for p in self.params:
@@ -50,18 +51,18 @@ class FlatGradBucket:
 
     def allreduce(self):
         """Average gradients over ranks: one sum all-reduce of the flat bucket, then scale by 1/world."""
-        if self.world == 1:
+        if not self.dist:
             return
         self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.dist:
             for t in list(self.module.parameters()) + list(self.module.buffers()):
                 dist.broadcast(t.data, src=src, group=self.group)
 
     def sync_buffers(self, src=0):
-        if self.world > 1:
+        if self.dist:
             for b in self.module.buffers():
                 dist.broadcast(b.data, src=src, group=self.group)

@@ -17,7 +17,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..nn_ops import GatherLinearFn, GroupGatherFn, LinearFn, SharedMLPFn, ThreeInterpolateFn
+from ..nn_ops import (GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
+                      ThreeInterpolateFn, sa_group_supported)
 
 
 # ------------------------------------------------------------------ functional surface (:19-107)
@@ -75,10 +76,9 @@ def _use_linearity(conv, kp):
     return _SA_LINEARITY and kp > conv.weight.shape[0]
 
 
-def _first_layer_by_linearity(conv, bn_training, feats, xyz, new_xyz, idx, kp, feat_first):
-    """conv1 over the grouped [features | rel_xyz] rows without materialising them: project every POINT
-    once (U), every CENTRE once (Vc), then gather C1-wide rows (GatherLinearFn).  Used when the grouped row
-    would be wider than the layer's output."""
+def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first):
+    """U [B,N,C1] = [feat | xyz] W1^T per POINT and Vc [B,S,C1] = c W1x^T per CENTRE (two small GEMMs):
+    conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias."""
     B, N, _ = xyz.shape
     D = 0 if feats is None else feats.shape[-1]
     S = new_xyz.shape[1]
@@ -96,7 +96,48 @@ def _first_layer_by_linearity(conv, bn_training, feats, xyz, new_xyz, idx, kp, f
     U = LinearFn.apply(rows, w_pt, None).reshape(B, N, C1)
     c4 = torch.cat([new_xyz, new_xyz.new_zeros(B, S, 1)], dim=-1).reshape(B * S, 4)
     Vc = LinearFn.apply(c4, torch.cat([wx, w.new_zeros(C1, 1)], dim=1), None).reshape(B, S, C1)
+    return U, Vc
+
+
+def _first_layer_by_linearity(conv, bn_training, feats, xyz, new_xyz, idx, kp, feat_first):
+    """conv1 over the grouped [features | rel_xyz] rows without materialising them: project every POINT
+    once (U), every CENTRE once (Vc), then gather C1-wide rows (GatherLinearFn).  Used when the grouped row
+    would be wider than the layer's output."""
+    U, Vc = _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first)
     return GatherLinearFn.apply(U, Vc, conv.bias, idx, bn_training)
+
+
+# Ball query + grouping + the first conv of every per-radius MLP in ONE launch (csrc/sa_group.hip);
+# PRIFIT_SA_FUSED=0 keeps the separate ball-query / gather / GEMM launches for A/B measurements.
+_SA_FUSED = os.environ.get("PRIFIT_SA_FUSED", "1") != "0"
+
+
+def _fused_mode(first_convs, feats, N, nsamples, kp):
+    """None (separate launches), "direct" (narrow data inputs: weights in registers) or "gather" (by linearity)."""
+    if not (_SA_FUSED and _SA_LINEARITY) or not sa_group_supported(N, nsamples, [c.weight.shape[0] for c in first_convs]):
+        return None
+    D = 0 if feats is None else feats.shape[-1]
+    if D in (0, 3, 6) and (feats is None or not feats.requires_grad):
+        return "direct"
+    if all(_use_linearity(c, kp) for c in first_convs):
+        return "gather"
+    return None
+
+
+def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii, nsamples, kp, feat_first):
+    """-> per radius (Y1 [B*S*K, C1], column-statistics slab)."""
+    if mode == "direct":
+        ts = []
+        for c in first_convs:
+            ts += [c.weight.reshape(c.weight.shape[0], -1), c.bias]
+        out = SAGroupDirectFn.apply(xyz, new_xyz, feats, (list(radii), list(nsamples), feat_first, training), *ts)
+    else:
+        ts = []
+        for c in first_convs:
+            U, Vc = _linearity_operands(c, feats, xyz, new_xyz, kp, feat_first)
+            ts += [U, Vc, c.bias]
+        out = SAGroupGatherFn.apply(xyz, new_xyz, (list(radii), list(nsamples), training), *ts)
+    return [(out[2 * i], out[2 * i + 1]) for i in range(len(first_convs))]
 
 
 def _mlp_tensors_preact(convs, bns):
@@ -167,6 +208,14 @@ class PointNetSetAbstraction(nn.Module):
         else:
             S, K = self.npoint, self.nsample
             _, new_xyz = ops.farthest_point_sample(xyz, S, fps_start, return_xyz=True)
+            mode = _fused_mode([self.mlp_convs[0]], feats, N, [K], kp)
+            if mode is not None:
+                (y1, slab), = _fused_first_layers(mode, [self.mlp_convs[0]], self.training, feats, xyz, new_xyz,
+                                                  [self.radius], [K], kp, feat_first=False)
+                cfg = _mlp_cfg(self.mlp_bns, K, self.training)
+                cfg["preact_slab"] = slab
+                out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns))
+                return new_xyz, out.reshape(B, S, -1)
             idx = ops.ball_query_multi([self.radius], [K], xyz, new_xyz)[0]
             # rows = [features, rel_xyz, pad]; upstream order is [rel_xyz, features] (:131)
             if _use_linearity(self.mlp_convs[0], kp):
@@ -213,8 +262,18 @@ class PointNetSetAbstractionMsg(nn.Module):
         D = 0 if feats is None else feats.shape[-1]
         kp = _pad4(D + 3)
         _, new_xyz = ops.farthest_point_sample(xyz, S, fps_start, return_xyz=True)
-        idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
         pooled = []
+        firsts = [blk[0] for blk in self.conv_blocks]
+        mode = _fused_mode(firsts, feats, N, self.nsample_list, kp) if len(firsts) <= 4 else None
+        if mode is not None:
+            ys = _fused_first_layers(mode, firsts, self.training, feats, xyz, new_xyz, self.radius_list,
+                                     self.nsample_list, kp, feat_first=True)
+            for i, K in enumerate(self.nsample_list):
+                cfg = _mlp_cfg(self.bn_blocks[i], K, self.training)
+                cfg["preact_slab"] = ys[i][1]
+                pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i])))
+            return new_xyz, torch.cat(pooled, dim=-1).reshape(B, S, -1)
+        idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
         for i, K in enumerate(self.nsample_list):
             if _use_linearity(self.conv_blocks[i][0], kp):
                 y1, slab = _first_layer_by_linearity(self.conv_blocks[i][0], self.training, feats, xyz, new_xyz,

@@ -263,6 +263,137 @@ class GatherLinearFn(torch.autograd.Function):
         return dU, dVc, db, None, None
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def sa_group_supported(N, nsamples, widths):
+    """Limits of prifit_sa_group_linear_fwd (include/prifit_hip.h)."""
+    return (N <= 2048 and 1 <= len(nsamples) <= 4 and sum(nsamples) <= 320 and
+            all(16 <= c <= 128 and (c & (c - 1)) == 0 for c in widths))
+
+
+def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, Us, Vcs, biases):
+    """One launch: ball query for every radius + the first-layer pre-activations Y_r [B*S*K_r, C_r], their
+    BatchNorm column-statistics slabs and the int32 index lists."""
+    import numpy as np
+
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    R = len(radii)
+    dev = xyz.device
+    q = dll().prifit_sa_group_queries_per_slab(B, S)
+    nslab = B * ((S + q - 1) // q)
+    Ys = [torch.empty(B * S * k, c, dtype=torch.float32, device=dev) for k, c in zip(nsamples, widths)]
+    slabs = [torch.empty(nslab, 2, c, dtype=torch.float32, device=dev) for c in widths]
+    idxs = [torch.empty(B, S, k, dtype=torch.int32, device=dev) for k in nsamples]
+    r2 = (ctypes.c_float * R)(*[float(np.float32(r ** 2)) for r in radii])  # fp32(radius^2), like ops.ball_query_multi
+    ns = (ctypes.c_int * R)(*[int(k) for k in nsamples])
+    wd = (ctypes.c_int * R)(*[int(c) for c in widths])
+    D = 0 if feat is None else feat.shape[-1]
+    # algorithmic bytes (SURVEY.md 8d with the grouped-out term = the C1-wide first-layer rows this launch writes):
+    # clouds and centres once, index lists once, rows once, plus the per-point / per-centre projections (gather mode)
+    # or the feature table (direct mode)
+    work = B * (12.0 * (N + S) + sum(4.0 * S * k * (1 + c) for k, c in zip(nsamples, widths)) +
+                (sum(4.0 * (N + S) * c for c in widths) if mode == 1 else 4.0 * N * D))
+    with profiler.span("sa_group_linear", work):
+        call("prifit_sa_group_linear_fwd", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, wd, mode, ptr(feat), D,
+             int(feat_first), _ptr_array(Ws) if Ws else None, _ptr_array(Us) if Us else None,
+             _ptr_array(Vcs) if Vcs else None, _ptr_array(biases), _ptr_array(Ys), _ptr_array(slabs), _ptr_array(idxs),
+             cur_stream())
+    return Ys, slabs, idxs
+
+
+class SAGroupDirectFn(torch.autograd.Function):
+    """Ball query + grouping + first conv of every per-radius MLP in one launch, narrow inputs (upstream
+    models/pointnet_util.py:87-107, :127-133 / :243-249, :195-197 / :250-252): y = W_r [feat_j | xyz_j - c] + b_r
+    computed from the LDS copy of the cloud, no grouped tensor.  apply(xyz [B,N,3], new_xyz [B,S,3], feat [B,N,D] or
+    None (D in 0/3/6, data: no gradient), meta = (radii, nsamples, feat_first, training), W_0, b_0, W_1, b_1, ...)
+    with W_r [C_r, D+3] in upstream column order -> (Y_0, slab_0, Y_1, slab_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feat, meta, *tensors):
+        radii, nsamples, feat_first, training = meta
+        Ws = [w.contiguous() for w in tensors[0::2]]
+        bs = [None if b is None else b.contiguous() for b in tensors[1::2]]
+        widths = [w.shape[0] for w in Ws]
+        Ys, slabs, idxs = _sa_group_launch(0, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, None, None, bs)
+        ctx.save_for_backward(xyz, new_xyz, feat, *idxs)
+        ctx.meta = (nsamples, widths, feat_first, training, [b is not None for b in bs])
+        out = []
+        for y, sl in zip(Ys, slabs):
+            out += [y, sl]
+        ctx.mark_non_differentiable(*slabs)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        xyz, new_xyz, feat = ctx.saved_tensors[:3]
+        idxs = ctx.saved_tensors[3:]
+        nsamples, widths, feat_first, training, has_bias = ctx.meta
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        D = 0 if feat is None else feat.shape[-1]
+        grads = []
+        for r, (K, C) in enumerate(zip(nsamples, widths)):
+            gY = gouts[2 * r]
+            dW = db = None
+            if gY is not None:
+                gY = gY.contiguous()
+                P = B * S * K
+                nblk = int(max(1, min(1024, (P + 1023) // 1024)))
+                part = torch.empty(nblk, C, D + 3, dtype=torch.float32, device=gY.device)
+                with profiler.span("sa_first_layer_dw", 4.0 * P * (C + 1)):
+                    call("prifit_sa_first_layer_dw", ptr(gY), ptr(idxs[r]), ptr(xyz), ptr(new_xyz), ptr(feat), B, N, S,
+                         K, C, D, int(feat_first), nblk, ptr(part), cur_stream())
+                dW = part.sum(dim=0)
+                if has_bias[r]:
+                    # a bias in front of a batch-statistics BatchNorm has zero gradient
+                    db = torch.zeros(C, device=gY.device) if training else gY.sum(dim=0)
+            grads += [dW, db]
+        return (None, None, None, None) + tuple(grads)
+
+
+class SAGroupGatherFn(torch.autograd.Function):
+    """Same launch for wide inputs, the first layer by linearity: y = U_r[b, j] - Vc_r[b, s] + b_r with
+    U = [feat | xyz] W1^T per point and Vc = c W1x^T per centre (see GatherLinearFn).  apply(xyz, new_xyz,
+    meta = (radii, nsamples, training), U_0, Vc_0, b_0, U_1, ...) -> (Y_0, slab_0, Y_1, slab_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, meta, *tensors):
+        radii, nsamples, training = meta
+        Us = [u.contiguous() for u in tensors[0::3]]
+        Vcs = [v.contiguous() for v in tensors[1::3]]
+        bs = [None if b is None else b.contiguous() for b in tensors[2::3]]
+        widths = [u.shape[-1] for u in Us]
+        Ys, slabs, idxs = _sa_group_launch(1, xyz, new_xyz, None, True, radii, nsamples, widths, None, Us, Vcs, bs)
+        ctx.save_for_backward(*idxs)
+        ctx.meta = (xyz.shape[0], xyz.shape[1], new_xyz.shape[1], nsamples, widths, training, [b is not None for b in bs])
+        out = []
+        for y, sl in zip(Ys, slabs):
+            out += [y, sl]
+        ctx.mark_non_differentiable(*slabs)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        idxs = ctx.saved_tensors
+        B, N, S, nsamples, widths, training, has_bias = ctx.meta
+        grads = []
+        for r, (K, C) in enumerate(zip(nsamples, widths)):
+            gY = gouts[2 * r]
+            dU = dVc = db = None
+            if gY is not None:
+                gY = gY.contiguous()
+                dU = torch.zeros(B, N, C, dtype=torch.float32, device=gY.device)
+                dVc = torch.empty(B, S, C, dtype=torch.float32, device=gY.device)
+                call("prifit_gather_linear_bwd", ptr(gY), ptr(idxs[r]), B, N, S, K, C, ptr(dU), ptr(dVc), cur_stream())
+                if has_bias[r]:
+                    db = torch.zeros(C, device=gY.device) if training else gY.sum(dim=0)
+            grads += [dU, dVc, db]
+        return (None, None, None) + tuple(grads)
+
+
 class LinearFn(torch.autograd.Function):
     """Y = X W^T + b on [P, C] rows (a conv1x1 without BatchNorm: conv2 / extra_conv_emb,
     models/pointnet2_part_seg_msg.py:109,128)."""

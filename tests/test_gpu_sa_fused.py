@@ -1,0 +1,163 @@
+"""GPU parity of the one-launch set-abstraction front end (csrc/sa_group.hip) through the C ABI.
+
+* index lists: bit-exact against the CPU oracle (and therefore against prifit_ball_query) on cube, surface and
+  blob clouds, ragged sizes, duplicated points, empty balls (centres outside the cloud);
+* first-layer rows: against a float64 evaluation of conv1([feat | rel]) on the gathered rows, 1e-5;
+* BatchNorm column-statistics slabs: against sums of the rows the kernel wrote, 1e-4 relative;
+* autograd (weight gradient kernel, gather-mode scatter) and whole modules: against the separate-launch path
+  (ball query + gather + GEMM), 2e-4 relative norm."""
+import numpy as np
+import pytest
+import torch
+
+import prifit_oracle as orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def mods(hiplib):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from prifit_amd import nn_ops, ops
+    from prifit_amd.models import pointnet_util as pu
+    return ops, nn_ops, pu
+
+
+def _rows64(xyz, ctr, feat, idx, feat_first):
+    """float64 grouped rows [B,S,K,D+3] in upstream column order from int64 idx (entries >= N -> zero row)."""
+    B, N, _ = xyz.shape
+    ok = (idx < N).unsqueeze(-1)
+    ii = idx.clamp(max=N - 1)
+    bidx = torch.arange(B).view(B, 1, 1)
+    rel = xyz.double()[bidx, ii] - ctr.double().unsqueeze(2)
+    parts = [rel]
+    if feat is not None:
+        f = feat.double()[bidx, ii]
+        parts = [f, rel] if feat_first else [rel, f]
+    return torch.cat(parts, dim=-1) * ok
+
+
+@pytest.mark.parametrize("kind,B,N,S,D,feat_first,radii,ks,widths", [
+    ("surface", 4, 2048, 512, 3, True, [0.1, 0.2, 0.4], [32, 64, 128], [32, 64, 64]),
+    ("cube", 3, 1000, 37, 3, True, [0.1, 0.2, 0.4, 0.3], [32, 64, 128, 16], [32, 64, 64, 16]),
+    ("blobs", 9, 2048, 131, 6, True, [0.2, 0.4], [32, 64], [64, 128]),
+    ("surface", 2, 777, 64, 0, False, [0.3], [48], [64]),
+    ("cube", 2, 63, 5, 3, False, [0.5, 2.0], [16, 64], [16, 32]),
+])
+def test_direct_mode_indices_rows_slabs(mods, kind, B, N, S, D, feat_first, radii, ks, widths):
+    ops, nn_ops, pu = mods
+    xyz_c = _t(synth.cloud(kind, B, N, 5))
+    xyz_c[:, 7] = xyz_c[:, 3]                                    # duplicated points
+    start = torch.zeros(B, dtype=torch.long)
+    fps = orc.c_farthest_point_sample(xyz_c, S, start)
+    ctr_c = orc.gather_rows(xyz_c, fps)
+    ctr_c[0, 0] = torch.tensor([9.0, 9.0, 9.0])                  # empty ball: every slot = N -> zero rows
+    g = torch.Generator().manual_seed(1)
+    feat_c = None if D == 0 else (xyz_c if D == 3 else torch.cat([xyz_c, torch.randn(B, N, 3, generator=g)], -1))
+    Ws = [torch.randn(c, D + 3, generator=g) * 0.5 for c in widths]
+    bs = [torch.randn(c, generator=g) if i % 2 == 0 else None for i, c in enumerate(widths)]
+    dev = "cuda"
+    feat = None if feat_c is None else feat_c.to(dev).contiguous()
+    Ys, slabs, idxs = nn_ops._sa_group_launch(0, xyz_c.to(dev), ctr_c.to(dev), feat, feat_first, radii, ks, widths,
+                                              [w.to(dev) for w in Ws], None, None,
+                                              [None if b is None else b.to(dev) for b in bs])
+    torch.cuda.synchronize()
+    for r, k, c, W, b, Y, slab, idx in zip(radii, ks, widths, Ws, bs, Ys, slabs, idxs):
+        want = orc.c_query_ball_point(r, k, xyz_c, ctr_c)
+        assert torch.equal(idx.cpu().long(), want), (kind, r)
+        ref = _rows64(xyz_c, ctr_c, feat_c, want, feat_first) @ W.double().t()
+        if b is not None:
+            ref = ref + b.double()
+        torch.testing.assert_close(Y.cpu().double().view(B, S, k, c), ref, rtol=1e-5, atol=1e-5)
+        Yd = Y.double()
+        torch.testing.assert_close(slab[:, 0].double().sum(0), Yd.sum(0), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(slab[:, 1].double().sum(0), (Yd * Yd).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,N,S,radii,ks,C", [(24, 512, 128, [0.4, 0.8], [64, 128], 128), (3, 300, 50, [0.3], [32], 64)])
+def test_gather_mode_vs_gather_linear(mods, B, N, S, radii, ks, C):
+    ops, nn_ops, pu = mods
+    xyz_c = _t(synth.cloud("surface", B, N, 2))
+    xyz = xyz_c.cuda()
+    _, ctr = ops.farthest_point_sample(xyz, S, torch.zeros(B, dtype=torch.long, device="cuda"), return_xyz=True)
+    R = len(radii)
+    Us = [torch.randn(B, N, C, device="cuda", requires_grad=True) for _ in range(R)]
+    Vcs = [torch.randn(B, S, C, device="cuda", requires_grad=True) for _ in range(R)]
+    bias = [torch.randn(C, device="cuda") for _ in range(R)]
+    ts = []
+    for u, v, b in zip(Us, Vcs, bias):
+        ts += [u, v, b]
+    out = nn_ops.SAGroupGatherFn.apply(xyz, ctr, (radii, ks, True), *ts)
+    idx_ref = ops.ball_query_multi(radii, ks, xyz, ctr)
+    for r in range(R):
+        Y, slab = out[2 * r], out[2 * r + 1]
+        Yr, slab_r = nn_ops.GatherLinearFn.apply(Us[r], Vcs[r], bias[r], idx_ref[r], True)
+        torch.testing.assert_close(Y, Yr, rtol=0, atol=0)
+        torch.testing.assert_close(slab.double().sum(0), slab_r.double().sum(0), rtol=1e-5, atol=1e-3)
+        g = torch.randn_like(Y)
+        gu, gv = torch.autograd.grad(Y, (Us[r], Vcs[r]), g, retain_graph=True)
+        gur, gvr = torch.autograd.grad(Yr, (Us[r], Vcs[r]), g)
+        assert (gu - gur).norm() <= 1e-5 * gur.norm()
+        assert (gv - gvr).norm() <= 1e-5 * gvr.norm()
+
+
+def _run_module(pu, fused, make, args, seed, feat_grad):
+    old = pu._SA_FUSED
+    pu._SA_FUSED = fused
+    try:
+        torch.manual_seed(seed)
+        m = make().cuda().train()
+        ins = [None if a is None else a.clone() for a in args]
+        if feat_grad:
+            ins[1].requires_grad_(True)
+        nx, out = m.forward_cl(*ins[:2], fps_start=ins[2])
+        g = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        (out * g).sum().backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+        gin = None if ins[1] is None or ins[1].grad is None else ins[1].grad.clone()
+        stats = {n: b.clone() for n, b in m.named_buffers()}
+        return out.detach(), grads, gin, stats
+    finally:
+        pu._SA_FUSED = old
+
+
+def _close(a, b, tol):
+    assert (a - b).norm() <= tol * max(b.norm().item(), 1e-6), ((a - b).norm().item(), b.norm().item())
+
+
+@pytest.mark.parametrize("case", ["msg_sa1", "msg_sa2", "ssg_sa1", "ssg_nofeat"])
+def test_modules_fused_vs_separate_launches(mods, case):
+    ops, nn_ops, pu = mods
+    B = 4
+    if case == "msg_sa1":   # models/pointnet2_part_seg_msg.py:26: narrow data input -> direct mode
+        xyz = _t(synth.cloud("surface", B, 2048, 1)).cuda()
+        make = lambda: pu.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], 3, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        args = (xyz, xyz, torch.zeros(B, dtype=torch.long, device="cuda"))
+    elif case == "msg_sa2":  # :27: 320 feature channels with gradient -> gather mode
+        xyz = _t(synth.cloud("surface", B, 512, 2)).cuda()
+        make = lambda: pu.PointNetSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 320, [[128, 128, 256], [128, 196, 256]])
+        args = (xyz, torch.randn(B, 512, 320, device="cuda"), torch.zeros(B, dtype=torch.long, device="cuda"))
+    elif case == "ssg_sa1":  # models/pointnet2_part_seg_ssg.py: [rel, feat] column order
+        xyz = _t(synth.cloud("cube", B, 1024, 3)).cuda()
+        make = lambda: pu.PointNetSetAbstraction(256, 0.2, 32, 6 + 3, [64, 64, 128], False)
+        args = (xyz, torch.cat([xyz, torch.randn(B, 1024, 3, device="cuda")], -1), torch.zeros(B, dtype=torch.long, device="cuda"))
+    else:
+        xyz = _t(synth.cloud("surface", B, 1024, 4)).cuda()
+        make = lambda: pu.PointNetSetAbstraction(128, 0.4, 64, 3, [64, 64, 128], False)
+        args = (xyz, None, torch.zeros(B, dtype=torch.long, device="cuda"))
+    feat_grad = case == "msg_sa2"
+    out_f, gr_f, gin_f, st_f = _run_module(pu, True, make, args, 7, feat_grad)
+    out_s, gr_s, gin_s, st_s = _run_module(pu, False, make, args, 7, feat_grad)
+    _close(out_f, out_s, 2e-4)
+    for n in gr_s:
+        _close(gr_f[n], gr_s[n], 2e-3 if n.endswith("bias") else 5e-4)
+    if gin_s is not None:
+        _close(gin_f, gin_s, 5e-4)
+    for n in st_s:
+        if st_s[n].dtype.is_floating_point:
+            _close(st_f[n], st_s[n], 1e-4)

@@ -38,3 +38,16 @@ for kind in ("cube", "surface"):
         g = torch.randn_like(y)
         timed(kind + " gather_linear bwd K=%d" % K, lambda: torch.autograd.grad(y, (U, Vc), g, retain_graph=True),
               4 * B * (512 * 128 + 128 * 128 + 128 * K + 128 * K * 128))
+    # one launch per set-abstraction level: ball query + grouping + first MLP layer (csrc/sa_group.hip)
+    from prifit_amd import nn_ops
+    Ws = [torch.randn(c, 6, device="cuda") for c in (32, 64, 64)]
+    w1 = B * (12 * 2560 + sum(4 * 512 * k * (1 + c) for k, c in zip((32, 64, 128), (32, 64, 64))) + 4 * 2048 * 3)
+    timed(kind + " sa_group_linear sa1 direct (3 radii)", lambda: nn_ops._sa_group_launch(0, xyz, c1, xyz, True, [.1, .2, .4], [32, 64, 128], [32, 64, 64], Ws, None, None, [None] * 3), w1)
+    Us = [torch.randn(B, 512, 128, device="cuda") for _ in range(2)]
+    Vs = [torch.randn(B, 128, 128, device="cuda") for _ in range(2)]
+    w2 = B * (12 * 640 + sum(4 * 128 * k * 129 for k in (64, 128)) + 2 * 4 * 640 * 128)
+    timed(kind + " sa_group_linear sa2 gather (2 radii)", lambda: nn_ops._sa_group_launch(1, c1, c2, None, True, [.4, .8], [64, 128], [128, 128], None, Us, Vs, [None] * 2), w2)
+    Y, _, ii = nn_ops._sa_group_launch(0, xyz, c1, xyz, True, [.4], [128], [64], Ws[2:], None, None, [None])
+    gy = torch.randn_like(Y[0])
+    part = torch.empty(1024, 64, 6, device="cuda")
+    timed(kind + " sa_first_layer_dw K=128 C=64", lambda: nn_ops.call("prifit_sa_first_layer_dw", nn_ops.ptr(gy), nn_ops.ptr(ii[0]), nn_ops.ptr(xyz), nn_ops.ptr(c1), nn_ops.ptr(xyz), B, 2048, 512, 128, 64, 3, 1, 1024, nn_ops.ptr(part), nn_ops.cur_stream()), 4 * B * 512 * 128 * 65)
