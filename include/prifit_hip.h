@@ -199,11 +199,13 @@ int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, 
  * idx (device int32 [B,S,K_r], written).
  *   mode 0 "direct": y = W_r [feat_j | xyz_j - c] + bias from the upstream weight W_r [C1, D+3] (device pointers
  *     in the host array W), column order [feat, rel] when feat_first else [rel, feat]; feat [B,N,D], D in {0,3,6};
+ *     feat_xyz != 0 promises that feature channels 0..2 are the coordinates (models/pointnet2_part_seg_msg.py:69-75:
+ *     l0_points = xyz), which are then taken from the LDS copy of the cloud instead of being gathered;
  *   mode 1 "gather": y = U_r[b, j] - Vc_r[b, s] + bias (the layer by linearity, see prifit_gather_linear_fwd);
  *     U / Vc host arrays of device pointers [B,N,C1_r] / [B,S,C1_r]. */
 int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, int N, int S, int R,
                                const float *radius2, const int *nsample, const int *width, int mode,
-                               const float *feat, int D, int feat_first, const float *const *W,
+                               const float *feat, int D, int feat_first, int feat_xyz, const float *const *W,
                                const float *const *U, const float *const *Vc, const float *const *bias,
                                float *const *Y, float *const *slab, int32_t *const *idx, void *stream);
 /* Queries per statistics slab of the call above (the workgroup size it will pick for B shapes x S centres). */

@@ -28,6 +28,7 @@ constexpr int SG_UNR = 4;       // independent row chains in flight per lane
 struct SAGroupArgs {
     const float *xyz, *new_xyz, *feat;
     int B, N, S, feat_first;
+    int feat_xyz;          // MODE 0: the first 3 feature channels ARE the coordinates (taken from the LDS cloud)
     float r2[4];
     int K[4], C[4];
     const float *W[4];     // MODE 0: upstream conv weight [C][D+3]
@@ -42,8 +43,9 @@ struct SAGroupArgs {
 __device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
-// R radii, MODE (0 direct / 1 gather), D feature channels of the direct mode (0, 3 or 6), NW waves per workgroup
-template <int R, int MODE, int D, int NW>
+// R radii, MODE (0 direct / 1 gather), D feature channels of the direct mode (0, 3 or 6), FX: features 0..2 are the
+// coordinates (no global loads for them), NW waves per workgroup
+template <int R, int MODE, int D, bool FX, int NW>
 __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
 {
     constexpr int KP = D + 3;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                 bool okk[SG_UNR], inb[SG_UNR];
                 int n[SG_UNR];
                 float4 p[SG_UNR];
+                constexpr int F0 = FX ? 3 : 0;  // first feature channel that is read from HBM / L2
                 float f[SG_UNR][D > 0 ? D : 1];
 #pragma unroll
                 for (int u = 0; u < SG_UNR; ++u) {
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                     if (MODE == 0) {
                         p[u] = s_pts[n[u]];
 #pragma unroll
-                        for (int i = 0; i < D; ++i) f[u][i] = Fb[(size_t)n[u] * D + i];
+                        for (int i = F0; i < D; ++i) f[u][i] = Fb[(size_t)n[u] * D + i];
+                        if (FX) { f[u][0] = p[u].x; f[u][1] = p[u].y; f[u][2] = p[u].z; }
                     } else {
                         p[u] = ld4g(Ub + (size_t)n[u] * C);
                     }
@@ -348,28 +352,28 @@ __global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
     }
 }
 
-template <int R, int MODE, int D>
+template <int R, int MODE, int D, bool FX>
 int launch_nw(const SAGroupArgs &a, hipStream_t st)
 {
     // 8 queries per workgroup share one LDS copy of the cloud; 4 when the layer has few queries (fuller last wave of
     // workgroups on 256 CUs)
     const int B8 = (a.B + 7) / 8 * 8;
     if ((long long)a.B * ((a.S + 7) / 8) >= 1024) {
-        hipLaunchKernelGGL((sa_group_kernel<R, MODE, D, 8>), dim3(B8 * ((a.S + 7) / 8)), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((sa_group_kernel<R, MODE, D, FX, 8>), dim3(B8 * ((a.S + 7) / 8)), dim3(512), 0, st, a);
     } else {
-        hipLaunchKernelGGL((sa_group_kernel<R, MODE, D, 4>), dim3(B8 * ((a.S + 3) / 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((sa_group_kernel<R, MODE, D, FX, 4>), dim3(B8 * ((a.S + 3) / 4)), dim3(256), 0, st, a);
     }
     return prifit_check_launch();
 }
 
-template <int MODE, int D>
+template <int MODE, int D, bool FX>
 int launch_r(const SAGroupArgs &a, int R, hipStream_t st)
 {
     switch (R) {
-        case 1: return launch_nw<1, MODE, D>(a, st);
-        case 2: return launch_nw<2, MODE, D>(a, st);
-        case 3: return launch_nw<3, MODE, D>(a, st);
-        default: return launch_nw<4, MODE, D>(a, st);
+        case 1: return launch_nw<1, MODE, D, FX>(a, st);
+        case 2: return launch_nw<2, MODE, D, FX>(a, st);
+        case 3: return launch_nw<3, MODE, D, FX>(a, st);
+        default: return launch_nw<4, MODE, D, FX>(a, st);
     }
 }
 
@@ -384,17 +388,19 @@ int prifit_sa_group_queries_per_slab(int B, int S)
 
 int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, int N, int S, int R,
                                const float *radius2, const int *nsample, const int *width, int mode,
-                               const float *feat, int D, int feat_first, const float *const *W,
+                               const float *feat, int D, int feat_first, int feat_xyz, const float *const *W,
                                const float *const *U, const float *const *Vc, const float *const *bias,
                                float *const *Y, float *const *slab, int32_t *const *idx, void *stream)
 {
     if (!xyz || !new_xyz || !radius2 || !nsample || !width || !bias || !Y || !slab || !idx || B <= 0 || N <= 0 ||
         N > SG_TILE || S <= 0 || R < 1 || R > 4 || (mode != 0 && mode != 1))
         return PRIFIT_EINVAL;
-    if (mode == 0 && (!W || (D != 0 && D != 3 && D != 6) || (D > 0 && !feat))) return PRIFIT_EINVAL;
+    if (mode == 0 && (!W || (D != 0 && D != 3 && D != 6) || (D > 0 && !feat) || (feat_xyz && D < 3)))
+        return PRIFIT_EINVAL;
     if (mode == 1 && (!U || !Vc)) return PRIFIT_EINVAL;
     SAGroupArgs a;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.B = B; a.N = N; a.S = S; a.feat_first = feat_first;
+    a.feat_xyz = feat_xyz;
     int ksum = 0;
     for (int r = 0; r < 4; ++r) {
         const bool in = r < R;
@@ -418,10 +424,10 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
     }
     if (ksum > SG_LIST) return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (mode == 1) return launch_r<1, 0>(a, R, st);
-    if (D == 0) return launch_r<0, 0>(a, R, st);
-    if (D == 3) return launch_r<0, 3>(a, R, st);
-    return launch_r<0, 6>(a, R, st);
+    if (mode == 1) return launch_r<1, 0, false>(a, R, st);
+    if (D == 0) return launch_r<0, 0, false>(a, R, st);
+    if (D == 3) return feat_xyz ? launch_r<0, 3, true>(a, R, st) : launch_r<0, 3, false>(a, R, st);
+    return feat_xyz ? launch_r<0, 6, true>(a, R, st) : launch_r<0, 6, false>(a, R, st);
 }
 
 int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz,

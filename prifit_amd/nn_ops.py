@@ -273,7 +273,8 @@ def sa_group_supported(N, nsamples, widths):
             all(16 <= c <= 128 and (c & (c - 1)) == 0 for c in widths))
 
 
-def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, Us, Vcs, biases):
+def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, Us, Vcs, biases,
+                     feat_xyz=False):
     """One launch: ball query for every radius + the first-layer pre-activations Y_r [B*S*K_r, C_r], their
     BatchNorm column-statistics slabs and the int32 index lists."""
     import numpy as np
@@ -298,7 +299,7 @@ def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widt
                 (sum(4.0 * (N + S) * c for c in widths) if mode == 1 else 4.0 * N * D))
     with profiler.span("sa_group_linear", work):
         call("prifit_sa_group_linear_fwd", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, wd, mode, ptr(feat), D,
-             int(feat_first), _ptr_array(Ws) if Ws else None, _ptr_array(Us) if Us else None,
+             int(feat_first), int(feat_xyz), _ptr_array(Ws) if Ws else None, _ptr_array(Us) if Us else None,
              _ptr_array(Vcs) if Vcs else None, _ptr_array(biases), _ptr_array(Ys), _ptr_array(slabs), _ptr_array(idxs),
              cur_stream())
     return Ys, slabs, idxs
@@ -317,7 +318,10 @@ class SAGroupDirectFn(torch.autograd.Function):
         Ws = [w.contiguous() for w in tensors[0::2]]
         bs = [None if b is None else b.contiguous() for b in tensors[1::2]]
         widths = [w.shape[0] for w in Ws]
-        Ys, slabs, idxs = _sa_group_launch(0, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, None, None, bs)
+        # upstream feeds the coordinates themselves as point features (models/pointnet2_part_seg_msg.py:69-75)
+        feat_xyz = feat is not None and feat.shape[-1] == 3 and feat.data_ptr() == xyz.data_ptr()
+        Ys, slabs, idxs = _sa_group_launch(0, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, None, None, bs,
+                                           feat_xyz=feat_xyz)
         ctx.save_for_backward(xyz, new_xyz, feat, *idxs)
         ctx.meta = (nsamples, widths, feat_first, training, [b is not None for b in bs])
         out = []

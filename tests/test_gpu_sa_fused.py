@@ -5,7 +5,8 @@
 * first-layer rows: against a float64 evaluation of conv1([feat | rel]) on the gathered rows, 1e-5;
 * BatchNorm column-statistics slabs: against sums of the rows the kernel wrote, 1e-4 relative;
 * autograd (weight gradient kernel, gather-mode scatter) and whole modules: against the separate-launch path
-  (ball query + gather + GEMM), 2e-4 relative norm."""
+  (ball query + gather + GEMM): outputs 2e-4, gradients 1e-2 relative norm
+  (winner flips, see below); the weight-gradient kernel itself against float64, 1e-5."""
 import numpy as np
 import pytest
 import torch
@@ -63,10 +64,17 @@ def test_direct_mode_indices_rows_slabs(mods, kind, B, N, S, D, feat_first, radi
     bs = [torch.randn(c, generator=g) if i % 2 == 0 else None for i, c in enumerate(widths)]
     dev = "cuda"
     feat = None if feat_c is None else feat_c.to(dev).contiguous()
-    Ys, slabs, idxs = nn_ops._sa_group_launch(0, xyz_c.to(dev), ctr_c.to(dev), feat, feat_first, radii, ks, widths,
+    xyz_d, ctr_d = xyz_c.to(dev), ctr_c.to(dev)
+    Ys, slabs, idxs = nn_ops._sa_group_launch(0, xyz_d, ctr_d, feat, feat_first, radii, ks, widths,
                                               [w.to(dev) for w in Ws], None, None,
                                               [None if b is None else b.to(dev) for b in bs])
     torch.cuda.synchronize()
+    if D >= 3:  # features 0..2 are the coordinates: the variant that takes them from the LDS cloud gives the same rows
+        Ys2, _, idxs2 = nn_ops._sa_group_launch(0, xyz_d, ctr_d, feat, feat_first, radii, ks, widths,
+                                                [w.to(dev) for w in Ws], None, None,
+                                                [None if b is None else b.to(dev) for b in bs], feat_xyz=True)
+        for y, y2, i1, i2 in zip(Ys, Ys2, idxs, idxs2):
+            assert torch.equal(y, y2) and torch.equal(i1, i2)
     for r, k, c, W, b, Y, slab, idx in zip(radii, ks, widths, Ws, bs, Ys, slabs, idxs):
         want = orc.c_query_ball_point(r, k, xyz_c, ctr_c)
         assert torch.equal(idx.cpu().long(), want), (kind, r)
@@ -77,6 +85,16 @@ def test_direct_mode_indices_rows_slabs(mods, kind, B, N, S, D, feat_first, radi
         Yd = Y.double()
         torch.testing.assert_close(slab[:, 0].double().sum(0), Yd.sum(0), rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(slab[:, 1].double().sum(0), (Yd * Yd).sum(0), rtol=1e-4, atol=1e-3)
+        # weight-gradient kernel: dW = dY^T [feat | rel] over all grouped samples, against float64
+        gY = torch.randn(Y.shape, generator=g).to(dev)
+        for nblk in (1, 7, 1024):
+            part = torch.empty(nblk, c, D + 3, device=dev)
+            nn_ops.call("prifit_sa_first_layer_dw", nn_ops.ptr(gY), nn_ops.ptr(idx), nn_ops.ptr(xyz_d),
+                        nn_ops.ptr(ctr_d), nn_ops.ptr(feat), B, N, S, k, c, D, int(feat_first), nblk,
+                        nn_ops.ptr(part), nn_ops.cur_stream())
+            dW_ref = gY.cpu().double().t() @ _rows64(xyz_c, ctr_c, feat_c, want, feat_first).reshape(-1, D + 3)
+            got = part.double().sum(0).cpu()
+            assert (got - dW_ref).norm() <= 1e-5 * dW_ref.norm(), (nblk, (got - dW_ref).norm(), dW_ref.norm())
 
 
 @pytest.mark.parametrize("B,N,S,radii,ks,C", [(24, 512, 128, [0.4, 0.8], [64, 128], 128), (3, 300, 50, [0.3], [32], 64)])
@@ -154,10 +172,13 @@ def test_modules_fused_vs_separate_launches(mods, case):
     out_f, gr_f, gin_f, st_f = _run_module(pu, True, make, args, 7, feat_grad)
     out_s, gr_s, gin_s, st_s = _run_module(pu, False, make, args, 7, feat_grad)
     _close(out_f, out_s, 2e-4)
+    # the two paths sum the BatchNorm statistics in a different order; behind 2-3 BatchNorm + ReLU + max-pool stages a
+    # rounding-level change flips a few ReLU / pool winners, which is what bounds the gradient agreement (the
+    # reference itself reproduces these gradients to ~2.5e-3 against a float64 run, oracle/make_golden.py)
     for n in gr_s:
-        _close(gr_f[n], gr_s[n], 2e-3 if n.endswith("bias") else 5e-4)
+        _close(gr_f[n], gr_s[n], 1e-2)
     if gin_s is not None:
-        _close(gin_f, gin_s, 5e-4)
+        _close(gin_f, gin_s, 1e-2)
     for n in st_s:
         if st_s[n].dtype.is_floating_point:
             _close(st_f[n], st_s[n], 1e-4)

@@ -43,6 +43,7 @@ for kind in ("cube", "surface"):
     Ws = [torch.randn(c, 6, device="cuda") for c in (32, 64, 64)]
     w1 = B * (12 * 2560 + sum(4 * 512 * k * (1 + c) for k, c in zip((32, 64, 128), (32, 64, 64))) + 4 * 2048 * 3)
     timed(kind + " sa_group_linear sa1 direct (3 radii)", lambda: nn_ops._sa_group_launch(0, xyz, c1, xyz, True, [.1, .2, .4], [32, 64, 128], [32, 64, 64], Ws, None, None, [None] * 3), w1)
+    timed(kind + " sa_group_linear sa1 direct, feat = xyz from LDS", lambda: nn_ops._sa_group_launch(0, xyz, c1, xyz, True, [.1, .2, .4], [32, 64, 128], [32, 64, 64], Ws, None, None, [None] * 3, feat_xyz=True), w1)
     Us = [torch.randn(B, 512, 128, device="cuda") for _ in range(2)]
     Vs = [torch.randn(B, 128, 128, device="cuda") for _ in range(2)]
     w2 = B * (12 * 640 + sum(4 * 128 * k * 129 for k in (64, 128)) + 2 * 4 * 640 * 128)
