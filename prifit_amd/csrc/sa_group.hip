@@ -15,6 +15,8 @@
 // A row of C floats is written by C/4 lanes as float4, 64/(C/4) rows per wave instruction: every store
 // instruction covers 1 KiB of contiguous output.  HBM traffic = the compulsory bytes: clouds + index lists +
 // the C-wide rows once (+ U/Vc reads in gather mode); this is the bandwidth-bound kernel of the grouping stage.
+#include <stdlib.h>
+
 #include "common.h"
 #include "distance.h"
 
@@ -28,6 +30,7 @@ constexpr int SG_UNR = 4;       // independent row chains in flight per lane
 struct SAGroupArgs {
     const float *xyz, *new_xyz, *feat;
     int B, N, S, feat_first;
+    int nt;                // non-temporal row stores (default; PRIFIT_SA_NT=0 for A/B): the rows do not evict U from L2
     int feat_xyz;          // MODE 0: the first 3 feature channels ARE the coordinates (taken from the LDS cloud)
     float r2[4];
     int K[4], C[4];
@@ -42,6 +45,13 @@ struct SAGroupArgs {
 
 __device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// streaming store: the rows are consumed by a later launch, hundreds of MB of traffic away
+__device__ __forceinline__ void st4nt(float *p, float4 v)
+{
+    f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p));
+}
 
 // R radii, MODE (0 direct / 1 gather), D feature channels of the direct mode (0, 3 or 6), FX: features 0..2 are the
 // coordinates (no global loads for them), NW waves per workgroup
@@ -50,9 +60,11 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
 {
     constexpr int KP = D + 3;
     __shared__ float4 s_pts[SG_TILE];
-    __shared__ float2 s_cand[NW][128];
+    __shared__ __attribute__((aligned(16))) float2 s_cand[NW][128];
     __shared__ int s_list[NW][SG_LIST];
-    __shared__ __attribute__((aligned(16))) float s_red[NW][2][SG_CMAX];
+    // the statistics staging area reuses the candidate rings: a wave's ring is dead once its phase 1 is over
+    static_assert(sizeof(float2) * 128 == sizeof(float) * 2 * SG_CMAX, "ring and staging row have the same size");
+    float (*s_red)[2][SG_CMAX] = reinterpret_cast<float (*)[2][SG_CMAX]>(&s_cand[0][0]);
 
     // XCD-aware placement: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so XCD x works on the
     // shapes x, x+8, ...: the gathered U rows of a shape stay in ONE L2.
@@ -230,7 +242,8 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                         y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
                     }
                     if (okk[u]) {
-                        st4g(Yq + (size_t)(k0 + u * rpi + rsel) * C, y);
+                        if (a.nt) st4nt(Yq + (size_t)(k0 + u * rpi + rsel) * C, y);
+                        else st4g(Yq + (size_t)(k0 + u * rpi + rsel) * C, y);
                         s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
                         s1.x += y.x * y.x; s1.y += y.y * y.y; s1.z += y.z * y.z; s1.w += y.w * y.w;
                     }
@@ -401,6 +414,7 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
     SAGroupArgs a;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.B = B; a.N = N; a.S = S; a.feat_first = feat_first;
     a.feat_xyz = feat_xyz;
+    { const char *e = getenv("PRIFIT_SA_NT"); a.nt = e ? atoi(e) : 1; }
     int ksum = 0;
     for (int r = 0; r < 4; ++r) {
         const bool in = r < R;
