@@ -138,6 +138,17 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
                     void *stream);
 
+/* Weights-stationary streaming variant for the tall-and-skinny (HBM-bound) layers of the shared MLPs: layout
+ * PRIFIT_GEMM_NT (C = A B^T, B [N,K]) or PRIFIT_GEMM_NN (C = A B, B [K,N]) with M >= 32768, N in {64,96,128},
+ * K in {64,96,128}; A [M,K] with lda % 4 == 0.  Persistent workgroups keep B in registers and stream 64-row tiles
+ * of A; same prologue (a_scale/a_shift [K]) and bias [N] semantics as prifit_gemm_f32; col_stats
+ * [prifit_gemm_stream_slabs(M,K)][2][N] or NULL receives one column (sum, sum of squares) slab per workgroup. */
+int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long long lda, const float *B,
+                           long long ldb, float *C, long long ldc, const float *a_scale, const float *a_shift,
+                           const float *bias, float *col_stats, void *stream);
+int prifit_gemm_stream_supported(int layout, int M, int N, int K);  /* 1 / 0 */
+int prifit_gemm_stream_slabs(int M, int K);                         /* workgroups = statistics slabs */
+
 /* Rows of C covered by one col_stats slab of prifit_gemm_f32 (its M tile). */
 int prifit_gemm_tile_m(int N);
 

@@ -23,6 +23,7 @@ SOURCES = {
     "pointops.hip": ["-ffp-contract=off"],
     "sa_group.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
+    "gemm_stream.hip": [],
     "bn.hip": [],
     "meanshift.hip": [],
     "meanshift_fused.hip": [],

@@ -8,6 +8,7 @@ layer's BatchNorm+ReLU while loading ("normalise on load") and whose epilogue em
 sums for its own BatchNorm, so no normalised activation is ever written to HBM.
 """
 import ctypes
+import os
 
 import torch
 
@@ -25,11 +26,38 @@ def _rows_per_slab():
     return dll().prifit_reduce_rows_per_slab()
 
 
+_STREAM = os.environ.get("PRIFIT_GEMM_STREAM", "1") != "0"   # 0: every product takes the tiled kernel (A/B runs)
+
+
+def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, a_rowsum=None, accumulate=False,
+               aux=None, row_add=None, bias_stride=0):
+    """The tall-and-skinny products of the shared MLPs (forward NT, dA NN) take the weights-stationary streaming
+    kernel (csrc/gemm_stream.hip); everything else the tiled kernel (csrc/gemm.hip)."""
+    return (_STREAM and batch == 1 and splitk == 1 and epi == EPI_NONE and b_affine is None and a_rowsum is None and
+            not accumulate and aux is None and row_add is None and
+            bool(dll().prifit_gemm_stream_supported(layout, M, N, K)))
+
+
+def gemm_stats_slabs(M, N, K):
+    """Number of column-statistics slabs a forward (NT) product of this shape writes."""
+    if _stream_ok(NT, M, N, K):
+        return dll().prifit_gemm_stream_slabs(M, K)
+    return (M + 127) // 128
+
+
 def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
          b_affine=None, bias=None, bias_stride=0, stats=None, epi=EPI_NONE, epi_scalar=None, aux=None, ld_aux=0, s_aux=0,
          row_add=None, a_rowsum=None, accumulate=None):
     if accumulate is None:
         accumulate = splitk > 1
+    if (_stream_ok(layout, M, N, K, batch, splitk, epi, b_affine, a_rowsum, accumulate, aux, row_add) and lda % 4 == 0 and
+            A.data_ptr() % 16 == 0 and (layout == NN or (ldb % 4 == 0 and B.data_ptr() % 16 == 0))):
+        # HBM-bound: the span's work is the algorithmic bytes (A read once, C written once, B once)
+        with profiler.span("gemm_stream_%s" % ("nt", "nn")[layout], 4.0 * (M * K + M * N + N * K)):
+            call("prifit_gemm_stream_f32", layout, M, N, K, ptr(A), _LL(lda), ptr(B), _LL(ldb), ptr(C), _LL(ldc),
+                 ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None, ptr(bias), ptr(stats),
+                 cur_stream())
+        return
     # span name = the kernel instantiation (layout, BN tile) so that it lines up with rocprofv3's per-kernel rows
     with profiler.span("gemm_%s_bn%d" % (("nt", "nn", "tn")[layout], 32 if N <= 32 else (64 if N <= 64 else (96 if N <= 96 else 128))),
                        2.0 * M * N * K * batch):
@@ -108,7 +136,8 @@ class SharedMLPFn(torch.autograd.Function):
                     scale = gamma * invstd
                     shift = beta - mean * scale
             elif training:
-                nslab = (P + tile_m - 1) // tile_m
+                aligned = prev.stride(0) % 4 == 0 and prev.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
+                nslab = gemm_stats_slabs(P, Cout, Kin) if aligned else (P + tile_m - 1) // tile_m
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
                 call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),

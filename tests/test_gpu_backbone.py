@@ -77,6 +77,44 @@ def test_gemm_prologue_bias_stats_splitk_batched(nn_ops):
     torch.testing.assert_close(out.cpu(), refk, rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("lay,M,N,K,aff", [(0, 40000, 96, 64, True), (0, 65536, 128, 96, True), (0, 33001, 64, 64, False),
+                                           (0, 32768, 128, 128, True), (0, 50000, 64, 128, True),
+                                           (1, 40000, 96, 128, False), (1, 33333, 64, 96, False), (1, 70000, 128, 64, False)])
+def test_gemm_stream_tall_skinny(nn_ops, lay, M, N, K, aff):
+    """Weights-stationary streaming kernel (csrc/gemm_stream.hip) on the shared-MLP shapes: forward (NT, BatchNorm+ReLU
+    prologue, bias, column statistics) and dA (NN) against float64, ragged M; and against the tiled kernel."""
+    assert nn_ops._stream_ok(lay, M, N, K)
+    A, W = _rand((M, K), 11), _rand((N, K), 12)
+    sc, sh, bias = _rand((K,), 13), _rand((K,), 14), _rand((N,), 15)
+    An = torch.relu(A * sc + sh) if aff else A
+    ref = (An.double() @ W.double().T).float() + (bias if lay == 0 else 0)
+    Ad = A.cuda()
+    Wd = (W if lay == 0 else W.T.contiguous()).cuda()
+    C = torch.empty(M, N, device="cuda")
+    nslab = nn_ops.gemm_stats_slabs(M, N, K) if lay == 0 else 1
+    slab = torch.full((nslab, 2, N), float("nan"), device="cuda") if lay == 0 else None
+    kw = dict(a_affine=(sc.cuda(), sh.cuda())) if aff else {}
+    if lay == 0:
+        kw.update(bias=bias.cuda(), stats=slab)
+    nn_ops.gemm(lay, M, N, K, Ad, K, Wd, Wd.stride(0), C, N, **kw)
+    tol = 2e-5 * (An.norm(dim=1, keepdim=True) * W.norm(dim=1).unsqueeze(0))
+    assert ((C.cpu() - ref).abs() <= tol + 1e-5).all()
+    if lay == 0:
+        torch.testing.assert_close(slab[:, 0].double().sum(0).cpu(), ref.double().sum(0), rtol=1e-4, atol=5e-2)
+        torch.testing.assert_close(slab[:, 1].double().sum(0).cpu(), (ref.double() ** 2).sum(0), rtol=1e-4, atol=5e-2)
+    old = nn_ops._STREAM
+    nn_ops._STREAM = False
+    try:
+        C2 = torch.empty(M, N, device="cuda")
+        kw2 = dict(kw)
+        if lay == 0:
+            kw2["stats"] = torch.empty((M + 127) // 128, 2, N, device="cuda")
+        nn_ops.gemm(lay, M, N, K, Ad, K, Wd, Wd.stride(0), C2, N, **kw2)
+    finally:
+        nn_ops._STREAM = old
+    assert torch.equal(C, C2)  # same k-ordered fp32 MFMA chain -> bit-identical products
+
+
 def _run_pair(my, orc_mod, args_gpu, args_cpu, gout, n_out=1, pick=lambda o: o):
     """Run the HIP module and the oracle module with identical parameters; return outputs+grads."""
     my.load_state_dict(orc_mod.state_dict())

@@ -20,7 +20,7 @@ def run(name, lay, M, N, K, batch=1, epi=0, affine=False, stats=False, splitk=1,
     aff = (torch.rand(4096, device=dev), torch.rand(4096, device=dev)) if affine else None
     bw = torch.full((batch,), 0.5, device=dev)
     aux = torch.rand(batch, M, N, device=dev) if epi == 3 else None
-    slab = torch.empty((M + 127) // 128, 2, N, device=dev) if stats else None
+    slab = torch.empty(max((M + 127) // 128, 4096), 2, N, device=dev) if stats else None
     kw = dict(batch=batch, sA=A.stride(0), sB=B.stride(0), sC=M * N, splitk=splitk, epi=epi, accumulate=splitk > 1,
               epi_scalar=bw if epi >= 2 else None, aux=aux, ld_aux=N, s_aux=M * N, stats=slab)
     if affine:
@@ -68,6 +68,11 @@ CASES = [
     ("sa1.3 L2 fwd NT P=1.57M 64->96", NT, 1572864, 96, 64, dict(affine=True, stats=True)),
     ("sa1.3 L1 fwd NT P=1.57M 8->64", NT, 1572864, 64, 8, dict(stats=True)),
     ("sa1.3 L3 dA NN P=1.57M 128->96", NN, 1572864, 96, 128, {}),
+    ("sa1.3 L2 dA NN P=1.57M 96->64", NN, 1572864, 64, 96, {}),
+    ("sa1.2 L2 fwd NT P=786K 64->64", NT, 786432, 64, 64, dict(affine=True, stats=True)),
+    ("sa1.2 L3 fwd NT P=786K 64->128", NT, 786432, 128, 64, dict(affine=True, stats=True)),
+    ("sa1.2 L3 dA NN P=786K 128->64", NN, 786432, 64, 128, {}),
+    ("sa2.1 L2 fwd NT P=196K 128->128", NT, 196608, 128, 128, dict(affine=True, stats=True)),
     ("sa1.3 L3 dW TN 128x96 P=1.57M", TN, 128, 96, 1572864, dict(affine=True, splitk=512)),
     ("sa2.2 L1 fwd NT P=393K 324->128", NT, 393216, 128, 324, dict(stats=True)),
     ("sa2.2 L3 fwd NT P=393K 196->256", NT, 393216, 256, 196, dict(affine=True, stats=True)),
