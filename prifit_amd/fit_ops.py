@@ -189,8 +189,11 @@ class MembershipFn(torch.autograd.Function):
         gd = torch.empty_like(dots)
         call("prifit_membership_bwd", ptr(gW), ptr(W), ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(gd),
              cur_stream())
-        gc = torch.empty_like(centres)
-        _bgemm(TN, K, D, N, gd, K, X, D, gc, D, Bt, N * K, N * D, K * D)     # dcentres = gd^T X
+        # dcentres = gd^T X: one 32 x 128 output tile per shape over N = 2048 rows -- split the reduction so that
+        # more than 24 workgroups run (242 us -> tens of us at B = 24)
+        sk = _skinny_splitk(K, D, N, Bt)
+        gc = (torch.zeros_like if sk > 1 else torch.empty_like)(centres)
+        _bgemm(TN, K, D, N, gd, K, X, D, gc, D, Bt, N * K, N * D, K * D, splitk=sk)
         gX = torch.empty_like(X)
         _bgemm(NN, N, D, K, gd, K, centres, D, gX, D, Bt, N * K, K * D, N * D)  # dX = gd centres
         return gc, gX, None, None

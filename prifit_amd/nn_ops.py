@@ -47,10 +47,12 @@ def gemm_stats_slabs(M, N, K):
 
 def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
          b_affine=None, bias=None, bias_stride=0, stats=None, epi=EPI_NONE, epi_scalar=None, aux=None, ld_aux=0, s_aux=0,
-         row_add=None, a_rowsum=None, accumulate=None):
+         row_add=None, a_rowsum=None, accumulate=None, tiled_stats=False):
+    """tiled_stats=True: the caller reads `stats` as one slab per 128 rows of C (per-sample statistics, src/dgcnn.py);
+    otherwise the slab count is gemm_stats_slabs(M, N, K)."""
     if accumulate is None:
         accumulate = splitk > 1
-    if (_stream_ok(layout, M, N, K, batch, splitk, epi, b_affine, a_rowsum, accumulate, aux, row_add) and lda % 4 == 0 and
+    if (not (tiled_stats and stats is not None) and _stream_ok(layout, M, N, K, batch, splitk, epi, b_affine, a_rowsum, accumulate, aux, row_add) and lda % 4 == 0 and
             A.data_ptr() % 16 == 0 and (layout == NN or (ldb % 4 == 0 and B.data_ptr() % 16 == 0))):
         # HBM-bound: the span's work is the algorithmic bytes (A read once, C written once, B once)
         with profiler.span("gemm_stream_%s" % ("nt", "nn")[layout], 4.0 * (M * K + M * N + N * K)):

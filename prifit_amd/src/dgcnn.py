@@ -102,7 +102,7 @@ class ConvGNActFn(torch.autograd.Function):
         Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
         nslab = (P + 127) // 128
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
-        gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab)
+        gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
         sums = slab.view(Bs, rps // 128, 2, Cout).double().sum(dim=1)            # [Bs, 2, C] per-sample column sums
         m = float(rps * (Cout // G))
         s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
