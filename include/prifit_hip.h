@@ -149,6 +149,18 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
 int prifit_gemm_stream_supported(int layout, int M, int N, int K);  /* 1 / 0 */
 int prifit_gemm_stream_slabs(int M, int K);                         /* workgroups = statistics slabs */
 
+/* dW = dY^T relu(bn(A)) of the same layers (PRIFIT_GEMM_TN with the reduction over P >= 32768 grouped samples,
+ * P % 8 == 0, and an output of Mo x No, both multiples of 32 in 32..128): out [Mo, ldo] += sum_rows G[row,0:Mo]^T
+ * A[row,0:No] with A read as max(a*b_scale[n]+b_shift[n], 0) when the prologue is given.  `out` is initialised by
+ * the caller (zeros, or a gradient to accumulate into).  Every wave streams its own rows as MFMA fragments (no
+ * LDS staging); per-workgroup partial slabs go to `workspace` (prifit_gemm_stream_tn_workspace(Mo,No,P) floats,
+ * caller-owned scratch) and a second small launch adds them to `out`. */
+int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long long ldg, const float *A,
+                              long long lda, float *out, long long ldo, const float *b_scale,
+                              const float *b_shift, float *workspace, void *stream);
+long long prifit_gemm_stream_tn_workspace(int Mo, int No, long long P);  /* floats */
+int prifit_gemm_stream_tn_supported(int Mo, int No, long long P);  /* 1 / 0 */
+
 /* Rows of C covered by one col_stats slab of prifit_gemm_f32 (its M tile). */
 int prifit_gemm_tile_m(int N);
 

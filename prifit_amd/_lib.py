@@ -23,10 +23,14 @@ _dll = None
 
 
 def declared_symbols(header_path=HEADER_PATH):
-    """Names of every `int prifit_*(...)` entry point declared in the public header."""
+    """Names of every `int prifit_*(...)` / `long long prifit_*(...)` entry point declared in the public header."""
+    return sorted(_declared(header_path))
+
+
+def _declared(header_path=HEADER_PATH):
     with open(header_path) as f:
         text = f.read()
-    return sorted(set(re.findall(r"^\s*int\s+(prifit_\w+)\s*\(", text, flags=re.M)))
+    return {name: ret for ret, name in re.findall(r"^\s*(int|long long)\s+(prifit_\w+)\s*\(", text, flags=re.M)}
 
 
 def dll():
@@ -37,9 +41,9 @@ def dll():
                 "libprifit_hip.so is not built (%s). Run `python -m prifit_amd.build` "
                 "(needs hipcc); there is no CPU fallback." % LIB_PATH)
         _dll = ctypes.CDLL(LIB_PATH)
-        for name in declared_symbols():
+        for name, ret in _declared().items():
             fn = getattr(_dll, name)  # AttributeError if the library lacks a declared symbol
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_int if ret == "int" else ctypes.c_longlong
     return _dll
 
 

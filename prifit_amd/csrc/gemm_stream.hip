@@ -162,6 +162,149 @@ __global__ __launch_bounds__(256, (KG <= 8 ? 4 : (KG <= 12 ? 3 : 2))) void gemm_
     }
 }
 
+// dW = G^T . relu(bn(A)) over the grouped samples: out[Mo, No] += sum_rows G[row, 0:Mo]^T A[row, 0:No]  (TN, the
+// reduction runs over 10^5..10^6 rows, the output is at most 128 x 128).  Both operands stream; there is nothing to
+// share between tiles, so there is no LDS and no barrier at all: every WAVE walks its own rows, loads the MFMA
+// fragments straight from global memory (lane = output row / column, 2 x 128 contiguous bytes per load instruction),
+// keeps one 8-row group in flight while the previous one is multiplied, and accumulates an output sub-block of at
+// most 64 x 64 in registers.  The four waves of a workgroup cover (sub-blocks) x (interleaved row groups), so the
+// second reader of a row finds it in L1 / L2.  The row-group streams of a workgroup are combined through LDS, every
+// workgroup stores one partial [Mo, No] slab into the caller's workspace (plain stores: 768 workgroups hammering the
+// same few KB with atomics cost more than the streaming itself), and a second tiny launch adds the slabs to `out`.
+struct StreamTNArgs {
+    const float *G, *A;
+    float *ws;   // [gridDim.x][Mo * No] partial slabs
+    int Mo, No;
+    long long P, ldg, lda, rows_per_wg;
+    const float *b_scale, *b_shift;  // prologue on A (channel = output column) or NULL
+};
+
+template <bool AFF>
+__global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNArgs g)
+{
+    __shared__ float s_part[3][64 * 64];  // partial sub-blocks of the row-group streams ks = 1..3
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int mt_total = g.Mo >> 5, nt_total = g.No >> 5;
+    const int mb = (mt_total + 1) >> 1, nb = (nt_total + 1) >> 1;
+    const int SB = mb * nb, KS = 4 / SB;          // sub-blocks (1, 2 or 4) x interleaved row-group streams
+    const int sb = wave % SB, ks = wave / SB;
+    const int mblk = sb / nb, nblk = sb - mblk * nb;
+    const int m0 = 64 * mblk, n0 = 64 * nblk;
+    const bool m2 = mt_total - 2 * mblk >= 2, n2 = nt_total - 2 * nblk >= 2;  // wave-uniform
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+    if (AFF) {
+        sc[0] = g.b_scale[n0 + li]; sh[0] = g.b_shift[n0 + li];
+        if (n2) { sc[1] = g.b_scale[n0 + 32 + li]; sh[1] = g.b_shift[n0 + 32 + li]; }
+    }
+    const long long r0 = (long long)blockIdx.x * g.rows_per_wg;
+    const long long r1 = r0 + g.rows_per_wg < g.P ? r0 + g.rows_per_wg : g.P;
+    const float *Gp = g.G + m0 + li + (long long)(4 * lh) * g.ldg;
+    const float *Ap = g.A + n0 + li + (long long)(4 * lh) * g.lda;
+    const long long stride = 8 * KS;
+
+    float cg[2][4], ca[2][4], ng[2][4], na[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cg[1][j] = 0.f; ca[1][j] = 0.f; ng[1][j] = 0.f; na[1][j] = 0.f; }
+    auto load = [&](long long row, float (&fg)[2][4], float (&fa)[2][4]) {
+        const float *gp = Gp + row * g.ldg;
+        const float *ap = Ap + row * g.lda;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fg[0][j] = gp[(long long)j * g.ldg];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[0][j] = ap[(long long)j * g.lda];
+        if (m2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fg[1][j] = gp[(long long)j * g.ldg + 32];
+        }
+        if (n2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[1][j] = ap[(long long)j * g.lda + 32];
+        }
+    };
+    long long row = r0 + 8 * ks;
+    if (row < r1) load(row, cg, ca);
+    for (; row < r1; row += stride) {
+        if (row + stride < r1) load(row + stride, ng, na);
+        if (AFF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ca[0][j] = fmaxf(fmaf(ca[0][j], sc[0], sh[0]), 0.f);
+                ca[1][j] = fmaxf(fmaf(ca[1][j], sc[1], sh[1]), 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[0][j], ca[0][j], acc[0][0], 0, 0, 0);
+            if (n2) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[0][j], ca[1][j], acc[0][1], 0, 0, 0);
+            if (m2) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[1][j], ca[0][j], acc[1][0], 0, 0, 0);
+            if (m2 && n2) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[1][j], ca[1][j], acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cg[0][j] = ng[0][j]; cg[1][j] = ng[1][j]; ca[0][j] = na[0][j]; ca[1][j] = na[1][j]; }
+    }
+    // combine the KS row-group streams of every sub-block through LDS (stream 0 of each sub-block collects)
+    if (KS > 1) {
+        if (ks > 0) {
+            float *dst = s_part[wave - SB];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+        for (int k = 1; k < KS; ++k) {
+            const float *src = s_part[k * SB + sb - SB];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * 2 + b) * 16 + r) * 64 + lane];
+        }
+    }
+    // C/D layout: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
+    float *slab = g.ws + (long long)blockIdx.x * g.Mo * g.No;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a == 1 && !m2) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b == 1 && !n2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[m * g.No + n0 + 32 * b + li] = acc[a][b][r];
+            }
+        }
+    }
+}
+
+// out[m, n] += sum over slabs of ws[slab][m * No + n]; gridDim.y slices of the slab range, 8 adders per address
+__global__ __launch_bounds__(256) void stream_tn_reduce_kernel(const float *__restrict__ ws, int nslab, int Mo, int No,
+                                                               long long ldo, float *__restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Mo * No) return;
+    const int per = (nslab + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(nslab, s0 + per);
+    float acc = 0.f;
+    for (int sl = s0; sl < s1; ++sl) acc += ws[(long long)sl * Mo * No + e];
+    const int m = e / No, n = e - m * No;
+    unsafeAtomicAdd(out + (long long)m * ldo + n, acc);
+}
+
 int stream_grid(int M, int K)
 {
     const int tiles = (M + SBM - 1) / SBM;
@@ -215,6 +358,46 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
     hipStream_t st = as_stream(stream);
     if (N == 64) return layout == 0 ? launch_k<2, true>(g, grid, st) : launch_k<2, false>(g, grid, st);
     return layout == 0 ? launch_k<4, true>(g, grid, st) : launch_k<4, false>(g, grid, st);
+}
+
+int prifit_gemm_stream_tn_supported(int Mo, int No, long long P)
+{
+    return Mo >= 32 && Mo <= 128 && (Mo & 31) == 0 && No >= 32 && No <= 128 && (No & 31) == 0 && P >= 32768 &&
+           (P & 7) == 0;
+}
+
+static long long stream_tn_split(long long P, long long *per_out)
+{
+    long long nwg = 768;                        // 3 resident workgroups per CU (about 140 VGPRs per wave)
+    long long per = (P + nwg - 1) / nwg;
+    per = (per + 31) / 32 * 32;                 // whole 8-row groups for every interleaved stream
+    *per_out = per;
+    return (P + per - 1) / per;
+}
+
+long long prifit_gemm_stream_tn_workspace(int Mo, int No, long long P)
+{
+    long long per;
+    return stream_tn_split(P, &per) * Mo * No;
+}
+
+int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long long ldg, const float *A,
+                              long long lda, float *out, long long ldo, const float *b_scale,
+                              const float *b_shift, float *workspace, void *stream)
+{
+    if (!G || !A || !out || !workspace || !prifit_gemm_stream_tn_supported(Mo, No, P) || ldg < Mo || lda < No ||
+        ldo < No || ((b_scale == nullptr) != (b_shift == nullptr)))
+        return PRIFIT_EINVAL;
+    StreamTNArgs g;
+    g.G = G; g.A = A; g.ws = workspace; g.Mo = Mo; g.No = No; g.P = P; g.ldg = ldg; g.lda = lda;
+    g.b_scale = b_scale; g.b_shift = b_shift;
+    const long long nwg = stream_tn_split(P, &g.rows_per_wg);
+    hipStream_t st = as_stream(stream);
+    if (b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_stream_tn_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((Mo * No + 255) / 256, 8), dim3(256), 0, st, workspace, (int)nwg,
+                       Mo, No, ldo, out);
+    return prifit_check_launch();
 }
 
 }  // extern "C"

@@ -81,6 +81,15 @@ def _splitk_for(P, tiles):
 def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
     """dW [Cout, Kin] = dY[P, Cout]^T . A[P, Kin] (A optionally normalised on load).  `out`: a zero-filled
     [Cout, Kin] destination (several layers share one zeroed arena: one fill instead of one per layer)."""
+    if _STREAM and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)):
+        # tall reduction, small output: the LDS-free streaming kernel (csrc/gemm_stream.hip), HBM-bound
+        dW = out if out is not None else torch.zeros(Cout, Kin, dtype=torch.float32, device=dY.device)
+        ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dY.device)
+        with profiler.span("gemm_stream_tn", 4.0 * P * (Cout + Kin)):
+            call("prifit_gemm_stream_tn_f32", Cout, Kin, _LL(P), ptr(dY), _LL(dY.stride(0)), ptr(Ain), _LL(Ain.stride(0)),
+                 ptr(dW), _LL(Kin), ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
+                 ptr(ws), cur_stream())
+        return dW
     tiles = ((Cout + 127) // 128) * ((Kin + 127) // 128)
     sk = _splitk_for(P, tiles)
     if out is not None:

@@ -115,6 +115,31 @@ def test_gemm_stream_tall_skinny(nn_ops, lay, M, N, K, aff):
     assert torch.equal(C, C2)  # same k-ordered fp32 MFMA chain -> bit-identical products
 
 
+@pytest.mark.parametrize("Mo,No,P,aff", [(128, 96, 40008, True), (96, 64, 65536, True), (64, 64, 33000, False),
+                                         (128, 64, 100000, True), (64, 32, 32768, True), (32, 32, 50000, False),
+                                         (128, 128, 40000, True), (96, 96, 36000, False)])
+def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
+    """LDS-free streaming dW kernel: dW = dY^T relu(bn(A)) over P rows against float64; accumulates into `out`."""
+    assert nn_ops.dll().prifit_gemm_stream_tn_supported(Mo, No, nn_ops._LL(P))
+    dY, A = _rand((P, Mo), 21), _rand((P, No), 22)
+    sc, sh = _rand((No,), 23), _rand((No,), 24)
+    An = torch.relu(A * sc + sh) if aff else A
+    ref = dY.double().T @ An.double()
+    init = _rand((Mo, No), 25)
+    out = init.clone().cuda()
+    got = nn_ops._weight_grad(dY.cuda(), P, Mo, A.cuda(), No, (sc.cuda(), sh.cuda()) if aff else None, out=out)
+    assert got is out
+    err = (out.cpu().double() - init.double() - ref).norm() / ref.norm()
+    assert err < 2e-6, err
+    old = nn_ops._STREAM
+    nn_ops._STREAM = False
+    try:
+        tiled = nn_ops._weight_grad(dY.cuda(), P, Mo, A.cuda(), No, (sc.cuda(), sh.cuda()) if aff else None)
+    finally:
+        nn_ops._STREAM = old
+    assert ((tiled.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+
+
 def _run_pair(my, orc_mod, args_gpu, args_cpu, gout, n_out=1, pick=lambda o: o):
     """Run the HIP module and the oracle module with identical parameters; return outputs+grads."""
     my.load_state_dict(orc_mod.state_dict())

@@ -82,8 +82,35 @@ CASES = [
     ("big square NT 4096^3", NT, 4096, 4096, 4096, {}),
 ]
 
+def run_dw(name, Mo, No, P, iters=20):
+    dev = "cuda"
+    dY, A = torch.randn(P, Mo, device=dev), torch.randn(P, No, device=dev)
+    aff = (torch.rand(No, device=dev), torch.rand(No, device=dev))
+    out = torch.zeros(Mo, No, device=dev)
+    go = lambda: nn_ops._weight_grad(dY, P, Mo, A, No, aff, out=out)
+    for _ in range(3):
+        go()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        go()
+    e.record()
+    torch.cuda.synchronize()
+    us = 1e3 * s.elapsed_time(e) / iters
+    print("%-34s %9.1f us  %6.1f TF/s  %6.0f GB/s(alg)" % (name, us, 2.0 * Mo * No * P / us / 1e6, 4.0 * P * (Mo + No) / us / 1e3), flush=True)
+
+
+DW_CASES = [("sa1.3 dW 128x96 P=1.57M", 128, 96, 1572864), ("sa1.3 dW 96x64 P=1.57M", 96, 64, 1572864),
+            ("sa1.2 dW 128x64 P=786K", 128, 64, 786432), ("sa1.2 dW 64x64 P=786K", 64, 64, 786432),
+            ("sa1.1 dW 64x32 P=393K", 64, 32, 393216), ("sa1.1 dW 32x32 P=393K", 32, 32, 393216),
+            ("sa2.1 dW 128x128 P=196K", 128, 128, 196608)]
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     for name, lay, M, N, K, kw in CASES:
         if flt in name:
             run(name, lay, M, N, K, **kw)
+    for name, Mo, No, P in DW_CASES:
+        if flt in name:
+            run_dw(name, Mo, No, P)
