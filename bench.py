@@ -105,8 +105,10 @@ def cpu_baseline(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 10 warm-up steps bring the clocks and the caching allocator to steady state (with 3 the first timed
+    # steps still run ~10 % slow); 50 timed steps = ~2 s
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("PRIFIT_WORKLOAD", "c3"), choices=["c2", "c3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -176,7 +178,8 @@ def main():
     dominant = max(cal.items(), key=lambda kv: kv[1][1])[0] if cal else None
     profiler.disable()
     profiler.reset()
-    profiler.enable(*[n for n in (dominant,) + GROUPING_FAMILIES if n])
+    if os.environ.get("PRIFIT_BENCH_EVENTS", "1") != "0":  # 0: diagnosis only (no roofline objects in the line)
+        profiler.enable(*[n for n in (dominant,) + GROUPING_FAMILIES if n])
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
