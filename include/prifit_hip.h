@@ -163,6 +163,9 @@ int prifit_gemm_stream_tn_supported(int Mo, int No, long long P);  /* 1 / 0 */
 
 /* Rows of C covered by one col_stats slab of prifit_gemm_f32 (its M tile). */
 int prifit_gemm_tile_m(int N);
+/* Rows per col_stats slab for a batch == 1, splitk == 1 product of M x N: 128, or 64 when the product has so few
+ * output tiles that prifit_gemm_f32 switches to 64 x 64 tiles. */
+int prifit_gemm_stats_tile_m(int M, int N);
 
 /* ------------------------------------------------------------------------------------------ */
 /* train-mode BatchNorm + ReLU + group max-pool around the GEMMs                                */

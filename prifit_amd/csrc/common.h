@@ -29,6 +29,22 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// 32-bit unsigned max across the wave on the DPP network (no LDS crossbar): quad swaps, row rotates, then the two
+// row broadcasts of the GFX9 family; the result is read from lane 63 and returned wave-uniform.
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v)
+{
+#define PRIFIT_DPP_MAX(ctrl, rmask)                                                                          \
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false))
+    PRIFIT_DPP_MAX(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    PRIFIT_DPP_MAX(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    PRIFIT_DPP_MAX(0x124, 0xf);  // row_ror:4
+    PRIFIT_DPP_MAX(0x128, 0xf);  // row_ror:8  -> every lane holds the max of its row of 16
+    PRIFIT_DPP_MAX(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    PRIFIT_DPP_MAX(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
+#undef PRIFIT_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v)
 {
 #pragma unroll

@@ -430,6 +430,19 @@ int prifit_gemm_tile_m(int N)
     return 128;
 }
 
+// Few output tiles (the group-all / feature-propagation layers: M = B x 128 rows): 64 x 64 tiles put four times as
+// many workgroups on the 256 CUs (M = 3072, N = 256: 48 -> 192).
+static inline bool small_tiles(int M, int N, int batch, int splitk)
+{
+    const long long wgs = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
+    return wgs < 160 && M > 64 && N > 32;
+}
+
+int prifit_gemm_stats_tile_m(int M, int N)
+{
+    return small_tiles(M, N, 1, 1) ? 64 : 128;
+}
+
 int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long lda, long long strideA,
                     const float *B, long long ldb, long long strideB, float *C, long long ldc,
                     long long strideC, int batch, int splitk, const float *a_scale, const float *a_shift,
@@ -459,6 +472,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0) && (extB % 4 == 0);
     hipStream_t st = as_stream(stream);
     // N tile: 128 (2x2 waves of 64x64), 96 / 64 / 32 (4 waves stacked along M, each 32 x BN)
+    if (small_tiles(M, N, batch, splitk)) return launch_cfg<64, 64, 32, 32>(g, layout, st);
     if (N <= 32) return launch_cfg<128, 32, 32, 32>(g, layout, st);
     if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
     if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);

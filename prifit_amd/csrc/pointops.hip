@@ -57,9 +57,13 @@ __global__ __launch_bounds__(256) void fps_kernel(const float *__restrict__ xyz,
             key = n < N ? key : 0ull;
             best = key > best ? key : best;
         }
-        best = wave_max_u64(best);
+        // wave arg-max of the packed key in two 32-bit DPP reductions: the largest distance, then the largest ~index
+        // (= lowest index) among the lanes that hold it
+        const unsigned bhi = (unsigned)(best >> 32), blo = (unsigned)(best & 0xffffffffu);
+        const unsigned mhi = wave_max_u32_dpp(bhi);
+        const unsigned mlo = wave_max_u32_dpp(bhi == mhi ? blo : 0u);
         unsigned long long *sl = slots + (it & 1) * 4;
-        if ((tid & 63) == 0) sl[tid >> 6] = best;
+        if ((tid & 63) == 0) sl[tid >> 6] = ((unsigned long long)mhi << 32) | mlo;
         __syncthreads();
         unsigned long long a = sl[0], c = sl[1], e = sl[2], g = sl[3];
         a = a > c ? a : c;

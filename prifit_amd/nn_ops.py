@@ -42,7 +42,8 @@ def gemm_stats_slabs(M, N, K):
     """Number of column-statistics slabs a forward (NT) product of this shape writes."""
     if _stream_ok(NT, M, N, K):
         return dll().prifit_gemm_stream_slabs(M, K)
-    return (M + 127) // 128
+    t = dll().prifit_gemm_stats_tile_m(M, N)
+    return (M + t - 1) // t
 
 
 def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
@@ -148,6 +149,7 @@ class SharedMLPFn(torch.autograd.Function):
                     shift = beta - mean * scale
             elif training:
                 aligned = prev.stride(0) % 4 == 0 and prev.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
+                tile_m = dll().prifit_gemm_stats_tile_m(P, Cout)
                 nslab = gemm_stats_slabs(P, Cout, Kin) if aligned else (P + tile_m - 1) // tile_m
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)

@@ -100,10 +100,11 @@ class ConvGNActFn(torch.autograd.Function):
         Bs = P // rps
         dev = x.device
         Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
-        nslab = (P + 127) // 128
+        tile = dll().prifit_gemm_stats_tile_m(P, Cout)   # rows per statistics slab (divides rps: 64 or 128)
+        nslab = (P + tile - 1) // tile
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
-        sums = slab.view(Bs, rps // 128, 2, Cout).double().sum(dim=1)            # [Bs, 2, C] per-sample column sums
+        sums = slab.view(Bs, rps // tile, 2, Cout).double().sum(dim=1)           # [Bs, 2, C] per-sample column sums
         m = float(rps * (Cout // G))
         s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
         s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m

@@ -52,7 +52,7 @@ def test_gemm_prologue_bias_stats_splitk_batched(nn_ops):
     ref = (An.double() @ W.double().T).float() + bias
     Ad, Wd = A.cuda(), W.cuda()
     C = torch.empty(M, N, device="cuda")
-    nslab = (M + 127) // 128
+    nslab = nn_ops.gemm_stats_slabs(M, N, K)
     slab = torch.zeros(nslab, 2, N, device="cuda")
     nn_ops.gemm(0, M, N, K, Ad, K, Wd, K, C, N, a_affine=(sc.cuda(), sh.cuda()), bias=bias.cuda(), stats=slab)
     torch.testing.assert_close(C.cpu(), ref, rtol=1e-4, atol=1e-4)
@@ -108,7 +108,7 @@ def test_gemm_stream_tall_skinny(nn_ops, lay, M, N, K, aff):
         C2 = torch.empty(M, N, device="cuda")
         kw2 = dict(kw)
         if lay == 0:
-            kw2["stats"] = torch.empty((M + 127) // 128, 2, N, device="cuda")
+            kw2["stats"] = torch.empty(nn_ops.gemm_stats_slabs(M, N, K), 2, N, device="cuda")
         nn_ops.gemm(lay, M, N, K, Ad, K, Wd, Wd.stride(0), C2, N, **kw2)
     finally:
         nn_ops._STREAM = old
