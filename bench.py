@@ -205,7 +205,7 @@ def main():
         detail = {}
         for name, (n, ms, work) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
             per = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps, "avg_us": 1e3 * ms / max(n, 1)}
-            if name.startswith("gemm"):
+            if name.startswith("gemm") and not name.startswith("gemm_stream"):
                 per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s")
             else:
                 per.update(bound="hbm", achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")

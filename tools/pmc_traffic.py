@@ -13,11 +13,19 @@ def load(d, counter):
     for r in csv.DictReader(open(f[0])):
         if r.get("Counter_Name") != counter:
             continue
-        m = re.match(r"void gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", r["Kernel_Name"])
-        if not m:
-            fam = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
-        else:
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        m = re.match(r"void gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
+        ms = re.match(r"void gemm_stream_kernel<(\d+), (\d+), (true|false)", name)
+        if m:
             fam = "gemm_%s_bn%s" % (("nt", "nn", "tn")[int(m.group(5))], m.group(2))
+        elif ms:       # profiler span names of prifit_amd/nn_ops.gemm: gemm_stream_nt / gemm_stream_nn
+            fam = "gemm_stream_%s" % ("nt" if ms.group(3) == "true" else "nn")
+        elif "gemm_stream_tn_kernel" in name:
+            fam = "gemm_stream_tn"
+        elif "sa_group_kernel" in name:
+            fam = "sa_group_linear"
+        else:
+            fam = name.split("(")[0].replace("void ", "")[:60]
         a = per.setdefault(fam, [0.0, 0])
         a[0] += float(r["Counter_Value"]); a[1] += 1
     return per
