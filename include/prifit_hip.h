@@ -149,6 +149,16 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
 int prifit_gemm_stream_supported(int layout, int M, int N, int K);  /* 1 / 0 */
 int prifit_gemm_stream_slabs(int M, int K);                         /* workgroups = statistics slabs */
 
+/* dA of a shared-MLP layer with the BatchNorm-backward reduction of the layer below fused into the epilogue:
+ * G [M,N] = dY [M,K] . W [K,N] (PRIFIT_GEMM_NN, streaming shapes), and red_slab [prifit_gemm_stream_slabs(M,K)][2][N]
+ * receives per-workgroup partials of m1 = sum_rows(G * mask), m2 = sum_rows(G * mask * yhat) with
+ * mask = (Yprev * scale + shift > 0), yhat = (Yprev - mean) * invstd -- the inputs of prifit_bn_bwd_finalize that
+ * prifit_bn_relu_bwd_reduce would otherwise compute by re-reading G (autograd of models/pointnet_util.py:195-199). */
+int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
+                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
+                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
+                                 void *stream);
+
 /* dW = dY^T relu(bn(A)) of the same layers (PRIFIT_GEMM_TN with the reduction over P >= 32768 grouped samples,
  * P % 8 == 0, and an output of Mo x No, both multiples of 32 in 32..128): out [Mo, ldo] += sum_rows G[row,0:Mo]^T
  * A[row,0:No] with A read as max(a*b_scale[n]+b_shift[n], 0) when the prologue is given.  `out` is initialised by

@@ -30,14 +30,21 @@ struct StreamArgs {
     const float *a_scale, *a_shift;  // [K] or NULL
     const float *bias;               // [N] or NULL
     float *stats;                    // [gridDim.x][2][N] or NULL
+    // RED (dA products): C is the gradient G w.r.t. relu(bn(Yp)) of the previous layer; the epilogue also emits the
+    // partial column sums of that layer's BatchNorm backward, m1 = sum(G * mask), m2 = sum(G * mask * yhat) with
+    // mask = (Yp * scale + shift > 0), yhat = (Yp - mean) * invstd  (what bn_relu_bwd_reduce would re-read G for)
+    const float *red_Y;              // [M, ldry]
+    long long ldry;
+    const float *red_scale, *red_shift, *red_mean, *red_invstd;  // [N]
+    float *red_slab;                 // [gridDim.x][2][N]
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // WN: waves along N (2 or 4; 256 threads = 4 waves, WM = 4 / WN waves along M); KG = K / 8;
 // BKC: B is [N][K] (NT) else [K][N] (NN); AFF: prologue on A
-template <int WN, int KG, bool BKC, bool AFF>
-__global__ __launch_bounds__(256, (KG <= 8 ? 4 : (KG <= 12 ? 3 : 2))) void gemm_stream_kernel(const StreamArgs g)
+template <int WN, int KG, bool BKC, bool AFF, bool RED>
+__global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
 {
     constexpr int K = KG * 8;
     constexpr int WM = 4 / WN;
@@ -70,6 +77,8 @@ __global__ __launch_bounds__(256, (KG <= 8 ? 4 : (KG <= 12 ? 3 : 2))) void gemm_
     }
     const float bias = (g.bias && col_ok) ? g.bias[col] : 0.f;
     float csum = 0.f, csq = 0.f;
+    float r_s = 0.f, r_t = 0.f, r_mu = 0.f, r_is = 0.f, m1 = 0.f, m2 = 0.f;
+    if (RED && col_ok) { r_s = g.red_scale[col]; r_t = g.red_shift[col]; r_mu = g.red_mean[col]; r_is = g.red_invstd[col]; }
 
     const int tiles = (g.M + SBM - 1) / SBM;
     float4 st[NV];
@@ -116,6 +125,18 @@ __global__ __launch_bounds__(256, (KG <= 8 ? 4 : (KG <= 12 ? 3 : 2))) void gemm_
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        // RED: the previous layer's pre-activations under this wave's output elements, in flight during the MFMAs
+        float yp[TM][16];
+        if (RED && col_ok) {
+            const int mr = tile * SBM + wm * 32 * TM + 4 * lh;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mr + 32 * a + (r & 3) + 8 * (r >> 2);
+                    yp[a][r] = g.red_Y[(long long)(row < g.M ? row : g.M - 1) * g.ldry + col];
+                }
+        }
         const float *ap = As + (wm * 32 * TM + li) * LD + 4 * lh;
 #pragma unroll
         for (int q = 0; q < KG; ++q) {
@@ -144,10 +165,18 @@ __global__ __launch_bounds__(256, (KG <= 8 ? 4 : (KG <= 12 ? 3 : 2))) void gemm_
                     csum += v;
                     csq += v * v;
                     g.C[(long long)row * g.ldc + col] = v;
+                    if (RED) {
+                        const float y = yp[a][r];
+                        const float gm = fmaf(y, r_s, r_t) > 0.f ? v : 0.f;
+                        m1 += gm;
+                        m2 += gm * ((y - r_mu) * r_is);
+                    }
                 }
         }
     }
-    if (g.stats) {
+    if (RED) { csum = m1; csq = m2; }
+    float *slab_out = RED ? g.red_slab : g.stats;
+    if (slab_out) {
         csum += __shfl_xor(csum, 32, 64);
         csq += __shfl_xor(csq, 32, 64);
         if (lh == 0) { s_red[wm][0][32 * wn + li] = csum; s_red[wm][1][32 * wn + li] = csq; }
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(256, (KG <= 8 ? 4 : (KG <= 12 ? 3 : 2))) void gemm_
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += s_red[w][which][c];
-            g.stats[((long long)blockIdx.x * 2 + which) * g.N + c] = s;
+            slab_out[((long long)blockIdx.x * 2 + which) * g.N + c] = s;
         }
     }
 }
@@ -315,8 +344,9 @@ int stream_grid(int M, int K)
 template <int WN, int KG, bool BKC>
 void launch_aff(const StreamArgs &g, int grid, hipStream_t st)
 {
-    if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false>), dim3(grid), dim3(256), 0, st, g);
+    if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false, false>), dim3(grid), dim3(256), 0, st, g);
 }
 
 template <int WN, bool BKC>
@@ -343,6 +373,31 @@ int prifit_gemm_stream_supported(int layout, int M, int N, int K)
 
 int prifit_gemm_stream_slabs(int M, int K) { return stream_grid(M, K); }
 
+static int stream_launch(StreamArgs &g, int layout, void *stream)
+{
+    const int grid = stream_grid(g.M, g.K);
+    hipStream_t st = as_stream(stream);
+    if (g.N == 64) return layout == 0 ? launch_k<2, true>(g, grid, st) : launch_k<2, false>(g, grid, st);
+    return layout == 0 ? launch_k<4, true>(g, grid, st) : launch_k<4, false>(g, grid, st);
+}
+
+int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
+                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
+                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
+                                 void *stream)
+{
+    if (!dY || !W || !G || !Yprev || !scale || !shift || !mean || !invstd || !red_slab ||
+        !prifit_gemm_stream_supported(1, M, N, K) || lda < K || ldc < N || ldb < N || ldy < N || (lda & 3) ||
+        ((uintptr_t)dY & 15))
+        return PRIFIT_EINVAL;
+    StreamArgs g;
+    g.A = dY; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
+    g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
+    g.red_slab = red_slab;
+    return stream_launch(g, 1, stream);
+}
+
 int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long long lda, const float *B,
                            long long ldb, float *C, long long ldc, const float *a_scale, const float *a_shift,
                            const float *bias, float *col_stats, void *stream)
@@ -354,10 +409,8 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
     StreamArgs g;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
-    const int grid = stream_grid(M, K);
-    hipStream_t st = as_stream(stream);
-    if (N == 64) return layout == 0 ? launch_k<2, true>(g, grid, st) : launch_k<2, false>(g, grid, st);
-    return layout == 0 ? launch_k<4, true>(g, grid, st) : launch_k<4, false>(g, grid, st);
+    g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
+    return stream_launch(g, layout, stream);
 }
 
 int prifit_gemm_stream_tn_supported(int Mo, int No, long long P)
