@@ -27,6 +27,7 @@ def _rows_per_slab():
 
 
 _STREAM = os.environ.get("PRIFIT_GEMM_STREAM", "1") != "0"   # 0: every product takes the tiled kernel (A/B runs)
+_FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate bn_relu_bwd_reduce launches (A/B runs)
 
 
 def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, a_rowsum=None, accumulate=False,
@@ -208,6 +209,7 @@ class SharedMLPFn(torch.autograd.Function):
             total += n + nb
         arena = torch.zeros(total, dtype=torch.float32, device=dev) if total else None
         G_in = gout  # gradient w.r.t. the ReLU output of layer l (or pooled output for the last layer)
+        fused_red = None
         for l in range(L - 1, -1, -1):
             Y, W = Ys[l], Ws[l]
             Cout, Kin = W.shape if W is not None else (Y.shape[1], 0)
@@ -226,11 +228,14 @@ class SharedMLPFn(torch.autograd.Function):
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
                      ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, 0, _F(0.0), ptr(slab), cur_stream())
+            elif fused_red is not None:
+                slab, nslab = fused_red   # emitted by the dA product of the layer above (prifit_gemm_stream_dgrad_f32)
             else:
                 nslab = (P + rps - 1) // rps
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_bn_relu_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
                      ptr(shift), ptr(mean), ptr(invstd), P, Cout, 0, _F(0.0), ptr(slab), cur_stream())
+            fused_red = None
             call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
                  ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
             if pooled:
@@ -257,7 +262,18 @@ class SharedMLPFn(torch.autograd.Function):
             grads[6 * l + 3] = dbeta
             if l > 0 or ctx.needs_input_grad[0]:
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
-                gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, G_prev, Kin)
+                if l > 0 and _FUSE_RED and _stream_ok(NN, P, Kin, Cout):
+                    # streaming dA product with the BatchNorm-backward column sums of layer l-1 in its epilogue
+                    ns = dll().prifit_gemm_stream_slabs(P, Cout)
+                    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                    (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
+                    with profiler.span("gemm_stream_nn", 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
+                        call("prifit_gemm_stream_dgrad_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
+                             _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
+                             ptr(rslab), cur_stream())
+                    fused_red = (rslab, ns)
+                else:
+                    gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, G_prev, Kin)
                 G_in = G_prev
             else:
                 G_in = None
