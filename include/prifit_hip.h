@@ -149,6 +149,12 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
 int prifit_gemm_stream_supported(int layout, int M, int N, int K);  /* 1 / 0 */
 int prifit_gemm_stream_slabs(int M, int K);                         /* workgroups = statistics slabs */
 
+/* The same fusion on the tiled kernel (any M, N, K; every dA product that is not a streaming shape): G = dY . W with
+ * red_slab [ceil(M / prifit_gemm_stats_tile_m(M, N))][2][N] receiving the (m1, m2) partials described below. */
+int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
+                                float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
+                                const float *shift, const float *mean, const float *invstd, float *red_slab,
+                                void *stream);
 /* dA of a shared-MLP layer with the BatchNorm-backward reduction of the layer below fused into the epilogue:
  * G [M,N] = dY [M,K] . W [K,N] (PRIFIT_GEMM_NN, streaming shapes), and red_slab [prifit_gemm_stream_slabs(M,K)][2][N]
  * receives per-workgroup partials of m1 = sum_rows(G * mask), m2 = sum_rows(G * mask * yhat) with

@@ -18,7 +18,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { LAY_NT = 0, LAY_NN = 1, LAY_TN = 2 };
-enum { EPI_NONE = 0, EPI_CHORD = 1, EPI_MSKERNEL = 2, EPI_MSBWD = 3 };
+enum { EPI_NONE = 0, EPI_CHORD = 1, EPI_MSKERNEL = 2, EPI_MSBWD = 3, EPI_BNRED = 4 };
 
 struct GemmArgs {
     const float *A, *B;
@@ -38,6 +38,10 @@ struct GemmArgs {
     const float *row_add;            // EPI_MSBWD: per-row additive term [batch][M] (may be NULL)
     float *a_rowsum;                 // NN/NT only: sum over k of the staged A rows -> [batch][M] (may be NULL)
     long long ldaux, sAux;
+    // EPI_BNRED (dA products): aux = the previous layer's pre-activations Yp (indexed like C); C is stored unchanged
+    // and `stats` receives, instead of (sum, sum of squares) of C, the BatchNorm-backward partials
+    // m1 = sum(C * mask), m2 = sum(C * mask * yhat), mask = (Yp*red_scale+red_shift > 0), yhat = (Yp-red_mean)*red_invstd
+    const float *red_scale, *red_shift, *red_mean, *red_invstd;
     int accumulate;                  // 1: C += result (atomics when split-K); 0: store
     int vecA, vecB;                  // 16-byte loads legal for the operand
 };
@@ -314,11 +318,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     };
     const float *AUX = g.epi == EPI_MSBWD ? g.aux + (long long)z * g.sAux : nullptr;
     const float *RADD = (g.epi == EPI_MSBWD && g.row_add) ? g.row_add + (long long)z * g.M : nullptr;
+    const float *YP = g.epi == EPI_BNRED ? g.aux : nullptr;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = n0 + wn0 + 32 * b + li;
         const bool cok = col < g.N;
         const float bias = (g.bias && cok && ks == 0) ? g.bias[(long long)z * g.bias_stride + col] : 0.f;
+        float rs = 0.f, rt = 0.f, rmu = 0.f, ris = 0.f;
+        if (g.epi == EPI_BNRED && cok) { rs = g.red_scale[col]; rt = g.red_shift[col]; rmu = g.red_mean[col]; ris = g.red_invstd[col]; }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int rbase = m0 + wm0 + 32 * a + 4 * lh;
@@ -331,14 +338,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
                         kf[r] = AUX[(long long)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldaux + col];
                         ra[r] = RADD ? RADD[rbase + (r & 3) + 8 * (r >> 2)] : 0.f;
                     }
+                } else if (g.epi == EPI_BNRED) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) kf[r] = YP[(long long)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldaux + col];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
                     const float v = transform(acc[a][b][r] + bias + (g.epi == EPI_MSBWD ? ra[r] : 0.f),
                                               g.epi == EPI_MSBWD ? kf[r] : 0.f);
-                    csum[b] += v;
-                    csq[b] += v * v;
+                    if (g.epi == EPI_BNRED) {
+                        const float gm = fmaf(kf[r], rs, rt) > 0.f ? v : 0.f;
+                        csum[b] += gm;
+                        csq[b] += gm * ((kf[r] - rmu) * ris);
+                    } else {
+                        csum[b] += v;
+                        csq[b] += v * v;
+                    }
                     float *dst = C + (long long)row * g.ldc + col;
                     if (g.accumulate) {
                         if (g.splitk > 1) unsafeAtomicAdd(dst, v);
@@ -350,10 +366,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
                     if (!(cok && row < g.M)) continue;
-                    const float kf = g.epi == EPI_MSBWD ? AUX[(long long)row * g.ldaux + col] : 0.f;
+                    const float kf = g.epi == EPI_MSBWD ? AUX[(long long)row * g.ldaux + col]
+                                                        : (g.epi == EPI_BNRED ? YP[(long long)row * g.ldaux + col] : 0.f);
                     const float v = transform(acc[a][b][r] + bias + (RADD ? RADD[row] : 0.f), kf);
-                    csum[b] += v;
-                    csq[b] += v * v;
+                    if (g.epi == EPI_BNRED) {
+                        const float gm = fmaf(kf, rs, rt) > 0.f ? v : 0.f;
+                        csum[b] += gm;
+                        csq[b] += gm * ((kf - rmu) * ris);
+                    } else {
+                        csum[b] += v;
+                        csq[b] += v * v;
+                    }
                     float *dst = C + (long long)row * g.ldc + col;
                     if (g.accumulate) {
                         if (g.splitk > 1) unsafeAtomicAdd(dst, v);
@@ -422,20 +445,36 @@ static int launch_cfg(const GemmArgs &g, int lay, hipStream_t st)
 
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-extern "C" {
-
-int prifit_gemm_tile_m(int N)
-{
-    (void)N;
-    return 128;
-}
-
 // Few output tiles (the group-all / feature-propagation layers: M = B x 128 rows): 64 x 64 tiles put four times as
 // many workgroups on the 256 CUs (M = 3072, N = 256: 48 -> 192).
 static inline bool small_tiles(int M, int N, int batch, int splitk)
 {
     const long long wgs = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
     return wgs < 160 && M > 64 && N > 32;
+}
+
+static int dispatch(GemmArgs &g, int layout, void *stream)
+{
+    const int M = g.M, N = g.N, K = g.K;
+    // contiguous extents: A is k-contiguous unless TN (then m-contiguous); B is k-contiguous for NT else n-contiguous
+    const int extA = layout == LAY_TN ? M : K, extB = layout == LAY_NT ? K : N;
+    g.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (g.sA % 4 == 0) && (extA % 4 == 0);
+    g.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (g.sB % 4 == 0) && (extB % 4 == 0);
+    hipStream_t st = as_stream(stream);
+    // N tile: 128 (2x2 waves of 64x64), 96 / 64 / 32 (4 waves stacked along M, each 32 x BN)
+    if (small_tiles(M, N, g.batch, g.splitk)) return launch_cfg<64, 64, 32, 32>(g, layout, st);
+    if (N <= 32) return launch_cfg<128, 32, 32, 32>(g, layout, st);
+    if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
+    if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);
+    return launch_cfg<128, 128, 32, 64>(g, layout, st);  // 8 waves of 32x64: more waves per SIMD hide the staging waits
+}
+
+extern "C" {
+
+int prifit_gemm_tile_m(int N)
+{
+    (void)N;
+    return 128;
 }
 
 int prifit_gemm_stats_tile_m(int M, int N)
@@ -465,18 +504,28 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.bias = bias; g.bias_stride = bias_batch_stride; g.stats = col_stats; g.epi = epilogue; g.epi_batch_scalar = epi_batch_scalar;
     g.accumulate = accumulate; g.aux = epi_aux; g.ldaux = ld_aux; g.sAux = stride_aux;
     g.row_add = epi_row_add; g.a_rowsum = a_rowsum;
+    g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr;
     if (a_rowsum && (layout == LAY_TN || splitk != 1)) return PRIFIT_EINVAL;
-    // contiguous extents: A is k-contiguous unless TN (then m-contiguous); B is k-contiguous for NT else n-contiguous
-    const int extA = layout == LAY_TN ? M : K, extB = layout == LAY_NT ? K : N;
-    g.vecA = aligned16(A) && (lda % 4 == 0) && (strideA % 4 == 0) && (extA % 4 == 0);
-    g.vecB = aligned16(B) && (ldb % 4 == 0) && (strideB % 4 == 0) && (extB % 4 == 0);
-    hipStream_t st = as_stream(stream);
-    // N tile: 128 (2x2 waves of 64x64), 96 / 64 / 32 (4 waves stacked along M, each 32 x BN)
-    if (small_tiles(M, N, batch, splitk)) return launch_cfg<64, 64, 32, 32>(g, layout, st);
-    if (N <= 32) return launch_cfg<128, 32, 32, 32>(g, layout, st);
-    if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
-    if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);
-    return launch_cfg<128, 128, 32, 64>(g, layout, st);  // 8 waves of 32x64: more waves per SIMD hide the staging waits
+    return dispatch(g, layout, stream);
+}
+
+int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
+                                float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
+                                const float *shift, const float *mean, const float *invstd, float *red_slab,
+                                void *stream)
+{
+    if (!dY || !W || !G || !Yprev || !scale || !shift || !mean || !invstd || !red_slab || M <= 0 || N <= 0 || K <= 0 ||
+        lda < K || ldb < N || ldc < N || ldy < N)
+        return PRIFIT_EINVAL;
+    GemmArgs g;
+    g.A = dY; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = g.sB = g.sC = 0;
+    g.batch = 1; g.splitk = 1;
+    g.a_scale = g.a_shift = g.b_scale = g.b_shift = nullptr;
+    g.bias = nullptr; g.bias_stride = 0; g.stats = red_slab; g.epi = EPI_BNRED; g.epi_batch_scalar = nullptr;
+    g.accumulate = 0; g.aux = Yprev; g.ldaux = ldy; g.sAux = 0; g.row_add = nullptr; g.a_rowsum = nullptr;
+    g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
+    return dispatch(g, LAY_NN, stream);
 }
 
 }  // extern "C"

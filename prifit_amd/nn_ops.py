@@ -272,6 +272,18 @@ class SharedMLPFn(torch.autograd.Function):
                              _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
                              ptr(rslab), cur_stream())
                     fused_red = (rslab, ns)
+                elif l > 0 and _FUSE_RED:
+                    # tiled kernel, same epilogue
+                    t = dll().prifit_gemm_stats_tile_m(P, Kin)
+                    ns = (P + t - 1) // t
+                    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                    (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
+                    with profiler.span("gemm_nn_bn%d" % (32 if Kin <= 32 else (64 if Kin <= 64 else (96 if Kin <= 96 else 128))),
+                                       2.0 * P * Kin * Cout):
+                        call("prifit_gemm_dgrad_bnred_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
+                             _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
+                             ptr(rslab), cur_stream())
+                    fused_red = (rslab, ns)
                 else:
                     gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, G_prev, Kin)
                 G_in = G_prev

@@ -140,25 +140,28 @@ def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
     assert ((tiled.cpu().double() - ref).norm() / ref.norm()) < 2e-6
 
 
-def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops):
-    """The BatchNorm-backward column sums emitted by the streaming dA epilogue (prifit_gemm_stream_dgrad_f32) against
-    the separate bn_relu_bwd_reduce launches: same gradients up to summation order."""
-    P, K = 65536, 64
-    x = _rand((P, 64), 31).cuda()
+@pytest.mark.parametrize("P,K,dims", [(65536, 64, ((64, 64), (64, 96), (96, 128))),     # streaming dA products
+                                      (6144, 32, ((64, 196), (196, 256))),                 # tiled kernel, 128-row tiles
+                                      (3072, 0, ((516, 256), (256, 512), (512, 1024)))])   # tiled kernel, 64-row tiles
+def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims):
+    """The BatchNorm-backward column sums emitted by the dA epilogues (prifit_gemm_stream_dgrad_f32 /
+    prifit_gemm_dgrad_bnred_f32) against the separate bn_relu_bwd_reduce launches: same gradients up to summation order."""
+    x = _rand((P, dims[0][0]), 31).cuda()
     g = torch.Generator().manual_seed(32)
     tens = []
-    for cin, cout in ((64, 64), (64, 96), (96, 128)):
-        tens += [(torch.randn(cout, cin, generator=g) * 0.2).cuda().requires_grad_(True), torch.zeros(cout, device="cuda", requires_grad=True),
+    for cin, cout in dims:
+        tens += [(torch.randn(cout, cin, generator=g) * (2.0 / cin ** 0.5)).cuda().requires_grad_(True),
+                 torch.zeros(cout, device="cuda", requires_grad=True),
                  (torch.rand(cout, generator=g) + 0.5).cuda().requires_grad_(True), (torch.randn(cout, generator=g) * 0.1).cuda().requires_grad_(True),
                  torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")]
-    gout = _rand((P // K, 128), 33).cuda()
+    gout = _rand((P // K if K else P, dims[-1][1]), 33).cuda()
     res = {}
     for fuse in (True, False):
         old = nn_ops._FUSE_RED
         nn_ops._FUSE_RED = fuse
         try:
             xi = x.clone().requires_grad_(True)
-            cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * 3}
+            cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
             out = nn_ops.SharedMLPFn.apply(xi, cfg, *[t.clone() if not t.requires_grad else t for t in tens])
             grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
             res[fuse] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
@@ -168,7 +171,7 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops):
         if b is None:
             assert a is None
             continue
-        assert (a - b).norm() <= 2e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
+        assert (a - b).norm() <= 5e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
 
 
 def _run_pair(my, orc_mod, args_gpu, args_cpu, gout, n_out=1, pick=lambda o: o):
