@@ -149,6 +149,14 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
 int prifit_gemm_stream_supported(int layout, int M, int N, int K);  /* 1 / 0 */
 int prifit_gemm_stream_slabs(int M, int K);                         /* workgroups = statistics slabs */
 
+/* C (+)= A1 B1 + A2 B2 as ONE batched PRIFIT_GEMM_NN product over K1 + K2 (K1 % 32 == 0; both pairs share lda / ldb
+ * and the batch strides; A1/A2 and B1/B2 equally aligned): the two dX terms of a mean-shift backward iteration,
+ * dX += gS^T Z + K^T gO (autograd of src/mean_shift.py:65-73), with one epilogue instead of two. */
+int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const float *A2, long long lda,
+                            long long strideA, const float *B1, const float *B2, long long ldb, long long strideB,
+                            float *C, long long ldc, long long strideC, int batch, int splitk, int accumulate,
+                            void *stream);
+
 /* The same fusion on the tiled kernel (any M, N, K; every dA product that is not a streaming shape): G = dY . W with
  * red_slab [ceil(M / prifit_gemm_stats_tile_m(M, N))][2][N] receiving the (m1, m2) partials described below. */
 int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,

@@ -42,6 +42,11 @@ struct GemmArgs {
     // and `stats` receives, instead of (sum, sum of squares) of C, the BatchNorm-backward partials
     // m1 = sum(C * mask), m2 = sum(C * mask * yhat), mask = (Yp*red_scale+red_shift > 0), yhat = (Yp-red_mean)*red_invstd
     const float *red_scale, *red_shift, *red_mean, *red_invstd;
+    // Dual source: k-tiles >= kswitch read A + dA2 / B + dB2 (element offsets that already absorb the k shift), so that
+    // C = A1 B1 + A2 B2 runs as ONE product over K = K1 + K2 when the two pairs share their leading dimensions
+    // (mean-shift backward: dX += gS^T Z + K^T gO, one epilogue instead of two).  kswitch = 0: off.
+    long long dA2, dB2;
+    int kswitch;
     int accumulate;                  // 1: C += result (atomics when split-K); 0: store
     int vecA, vecB;                  // 16-byte loads legal for the operand
 };
@@ -136,6 +141,12 @@ struct TileLoader {
         }
     }
 
+    __device__ __forceinline__ void shift(long long delta)
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) ptr[p] += delta;
+    }
+
     __device__ __forceinline__ void store(float *__restrict__ lds) const
     {
 #pragma unroll
@@ -222,6 +233,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     // Software pipeline: tile kt is computed from LDS stage s while tile kt+1 travels global -> registers;
     // it is written to stage s^1 after the MFMAs (nobody reads s^1 any more: the barrier that ended the
     // previous iteration) and one barrier per k-tile publishes it.
+    const int kswitch = g.kswitch ? g.kswitch : 0x7fffffff;  // first k-tile of the second source
+    if (kt0 >= kswitch) { la.shift(g.dA2); lb.shift(g.dB2); }
     if (kt0 < kt1) {
         la.load(kt0 * BK, g.a_scale, g.a_shift);
         lb.load(kt0 * BK, g.b_scale, g.b_shift);
@@ -238,6 +251,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         const float *As = lds + stage * (SZA + SZB), *Bs = As + SZA;
         const bool more = kt + 1 < kt1;
         if (more) {
+            if (kt + 1 == kswitch) { la.shift(g.dA2); lb.shift(g.dB2); }
             la.load((kt + 1) * BK, g.a_scale, g.a_shift);
             lb.load((kt + 1) * BK, g.b_scale, g.b_shift);
         }
@@ -505,8 +519,36 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.accumulate = accumulate; g.aux = epi_aux; g.ldaux = ld_aux; g.sAux = stride_aux;
     g.row_add = epi_row_add; g.a_rowsum = a_rowsum;
     g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr;
+    g.dA2 = g.dB2 = 0; g.kswitch = 0;
     if (a_rowsum && (layout == LAY_TN || splitk != 1)) return PRIFIT_EINVAL;
     return dispatch(g, layout, stream);
+}
+
+int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const float *A2, long long lda,
+                            long long strideA, const float *B1, const float *B2, long long ldb, long long strideB,
+                            float *C, long long ldc, long long strideC, int batch, int splitk, int accumulate,
+                            void *stream)
+{
+    if (!A1 || !A2 || !B1 || !B2 || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 <= 0 || (K1 % BK) || batch <= 0 ||
+        splitk <= 0 || (splitk > 1 && !accumulate) || (long long)batch * splitk > 65535 || lda < K1 || lda < K2 ||
+        ldb < N || ldc < N)
+        return PRIFIT_EINVAL;
+    // the vector path needs both sources equally aligned
+    if ((((uintptr_t)A1 ^ (uintptr_t)A2) | ((uintptr_t)B1 ^ (uintptr_t)B2)) & 15) return PRIFIT_EINVAL;
+    GemmArgs g;
+    g.A = A1; g.B = B1; g.C = C; g.M = M; g.N = N; g.K = K1 + K2;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.batch = batch; g.splitk = splitk;
+    g.a_scale = g.a_shift = g.b_scale = g.b_shift = nullptr;
+    g.bias = nullptr; g.bias_stride = 0; g.stats = nullptr; g.epi = EPI_NONE; g.epi_batch_scalar = nullptr;
+    g.accumulate = accumulate; g.aux = nullptr; g.ldaux = 0; g.sAux = 0; g.row_add = nullptr; g.a_rowsum = nullptr;
+    g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr;
+    // A is [M][k] (k contiguous): element (m, k >= K1) of the virtual operand lives at A2 + m*lda + (k - K1);
+    // B is [k][N]: row k >= K1 lives at B2 + (k - K1)*ldb
+    g.dA2 = (A2 - A1) - (long long)K1;
+    g.dB2 = (B2 - B1) - (long long)K1 * ldb;
+    g.kswitch = K1 / BK;
+    return dispatch(g, LAY_NN, stream);
 }
 
 int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
@@ -525,6 +567,7 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
     g.bias = nullptr; g.bias_stride = 0; g.stats = red_slab; g.epi = EPI_BNRED; g.epi_batch_scalar = nullptr;
     g.accumulate = 0; g.aux = Yprev; g.ldaux = ldy; g.sAux = 0; g.row_add = nullptr; g.a_rowsum = nullptr;
     g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
+    g.dA2 = g.dB2 = 0; g.kswitch = 0;
     return dispatch(g, LAY_NN, stream);
 }
 

@@ -20,6 +20,7 @@ KM = 32          # cluster slots per shape (>= max_num_clusters = 25, src/ellips
 NMS_CAP = 64     # centre ids kept by nms before the cluster-count check
 SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106)
 BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "gemm")  # mean-shift backward engine: "gemm" | "fused"
+DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
 
 
 def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
@@ -116,6 +117,7 @@ class MeanShiftFn(torch.autograd.Function):
             call("prifit_meanshift_update_bwd", ptr(g), ptr(Zn), ptr(nrm), ptr(O), ptr(rsum), D, Bt, N, ptr(gO),
                  _LL(sV), ptr(grs), cur_stream())
             sk = _skinny_splitk(N, D, N, Bt)
+            sk2 = _skinny_splitk(N, D, 2 * N, Bt)
             gZ = (torch.zeros if sk > 1 and mode != "fused" else torch.empty)(Bt, N, D, dtype=torch.float32, device=dev)
             if mode == "fused":
                 with profiler.span("ms_fused_bwd", 10.0 * Bt * N * N * D):
@@ -129,8 +131,14 @@ class MeanShiftFn(torch.autograd.Function):
                 _bgemm(NT, N, N, D, X, D, gO, D, gS, N, Bt, sV, sV, sM, epi=EPI_MSBWD, epi_scalar=bw, aux=Kmat,
                        ld_aux=N, s_aux=sM, bias=grs, bias_stride=N)
                 _bgemm(TN, N, D, N, gS, N, X, D, gZ, D, Bt, sM, sV, sV, splitk=sk)                       # dZ  = gS X
-                _bgemm(NN, N, D, N, gS, N, Z, D, gX, D, Bt, sM, sV, sV, accumulate=True, splitk=sk)      # dX += gS^T Z
-                _bgemm(NN, N, D, N, Kmat, N, gO, D, gX, D, Bt, sM, sV, sV, accumulate=True, splitk=sk)   # dX += K^T gO
+                if DUAL_DX:
+                    # dX += gS^T Z + K^T gO as one product over 2N (one epilogue of float atomics instead of two)
+                    with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
+                        call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),
+                             _LL(D), _LL(sV), ptr(gX), _LL(D), _LL(sV), Bt, sk2, 1, cur_stream())
+                else:
+                    _bgemm(NN, N, D, N, gS, N, Z, D, gX, D, Bt, sM, sV, sV, accumulate=True, splitk=sk)      # dX += gS^T Z
+                    _bgemm(NN, N, D, N, Kmat, N, gO, D, gX, D, Bt, sM, sV, sV, accumulate=True, splitk=sk)   # dX += K^T gO
             else:
                 # dL/dS = (gO X^T + g_rowsum 1^T) * K / b^2 where the clamp is inactive
                 _bgemm(NT, N, N, D, gO, D, X, D, gS, N, Bt, sV, sV, sM, epi=EPI_MSBWD, epi_scalar=bw, aux=Kmat,
