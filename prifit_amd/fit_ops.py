@@ -131,7 +131,7 @@ class MeanShiftFn(torch.autograd.Function):
                 _bgemm(NT, N, N, D, X, D, gO, D, gS, N, Bt, sV, sV, sM, epi=EPI_MSBWD, epi_scalar=bw, aux=Kmat,
                        ld_aux=N, s_aux=sM, bias=grs, bias_stride=N)
                 _bgemm(TN, N, D, N, gS, N, X, D, gZ, D, Bt, sM, sV, sV, splitk=sk)                       # dZ  = gS X
-                if DUAL_DX:
+                if DUAL_DX and N % 32 == 0:
                     # dX += gS^T Z + K^T gO as one product over 2N (one epilogue of float atomics instead of two)
                     with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
                         call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),
