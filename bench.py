@@ -12,6 +12,7 @@ clouds per GPU: zero_grad, forward, loss, backward, gradient all-reduce (N>1, RC
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -184,6 +185,10 @@ def main():
     profiler.reset()
     if os.environ.get("PRIFIT_BENCH_EVENTS", "1") != "0":  # 0: diagnosis only (no roofline objects in the line)
         profiler.enable(*[n for n in (dominant,) + GROUPING_FAMILIES if n])
+    # no cyclic-GC pauses inside the timed region (a generation-2 pass over the autograd graphs stalls the launch
+    # thread for tens of ms; nothing on the step relies on the cycle collector, see MeanShiftFn.forward)
+    gc.collect()
+    gc.disable()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -194,6 +199,7 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     profiler.disable()
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
