@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNAr
     }
 }
 
-// out[m, n] += sum over slabs of ws[slab][m * No + n]; gridDim.y slices of the slab range, 8 adders per address
+// out[m, n] += sum over slabs of ws[slab][m * No + n]; gridDim.y slices of the slab range (32 adders per address), four
+// independent partial sums per thread so that the slab loads of a slice are in flight together
 __global__ __launch_bounds__(256) void stream_tn_reduce_kernel(const float *__restrict__ ws, int nslab, int Mo, int No,
                                                                long long ldo, float *__restrict__ out)
 {
@@ -328,10 +329,16 @@ __global__ __launch_bounds__(256) void stream_tn_reduce_kernel(const float *__re
     if (e >= Mo * No) return;
     const int per = (nslab + gridDim.y - 1) / gridDim.y;
     const int s0 = blockIdx.y * per, s1 = min(nslab, s0 + per);
-    float acc = 0.f;
-    for (int sl = s0; sl < s1; ++sl) acc += ws[(long long)sl * Mo * No + e];
+    const long long stride = (long long)Mo * No;
+    const float *p = ws + (long long)s0 * stride + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sl = s0;
+    for (; sl + 4 <= s1; sl += 4, p += 4 * stride) {
+        a0 += p[0]; a1 += p[stride]; a2 += p[2 * stride]; a3 += p[3 * stride];
+    }
+    for (; sl < s1; ++sl, p += stride) a0 += p[0];
     const int m = e / No, n = e - m * No;
-    unsafeAtomicAdd(out + (long long)m * ldo + n, acc);
+    if (s1 > s0) unsafeAtomicAdd(out + (long long)m * ldo + n, (a0 + a1) + (a2 + a3));
 }
 
 int stream_grid(int M, int K)
@@ -448,7 +455,7 @@ int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long 
     hipStream_t st = as_stream(stream);
     if (b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_stream_tn_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, st, g);
-    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((Mo * No + 255) / 256, 8), dim3(256), 0, st, workspace, (int)nwg,
+    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((Mo * No + 255) / 256, 32), dim3(256), 0, st, workspace, (int)nwg,
                        Mo, No, ldo, out);
     return prifit_check_launch();
 }
