@@ -173,6 +173,28 @@ int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long
                                  const float *shift, const float *mean, const float *invstd, float *red_slab,
                                  void *stream);
 
+/* The max-pooled LAST layer of a per-group MLP (models/pointnet_util.py:199,256), autograd without materialising
+ * its dY: with (a, b, d) = prifit_bn_bwd_finalize's coefficients, dY[g,k,c] = T[g,c]*[k == arg[g,c]] + b[c]*Y[g,k,c] + d[c]
+ * where T[g,c] = a[c] * relu'(.) * gp[g,c] (prifit_pool_bwd_table: gp [G,C] the gradient of the pooled output, arg the
+ * winners saved by prifit_pool_fwd).  The two consumers form dY while staging their operand from Y itself:
+ *   prifit_gemm_stream_dgrad_pool_f32: G = dY . W for the layer below (bias_dW = d^T W [N] supplied by the caller;
+ *     pool_K a multiple of 64 dividing M; red_slab / Yprev / ... as in prifit_gemm_stream_dgrad_f32, or all NULL),
+ *   prifit_gemm_stream_tn_pool_f32: out += dY^T relu(bn(A)) (pool_K a multiple of 8 dividing P).
+ * prifit_pool_bwd_apply (which writes dY) stays for the shapes outside the streaming kernels. */
+int prifit_pool_bwd_table(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
+                          const float *scale, const float *shift, const float *coef_a, int G, int K, int C, float slope,
+                          float *T, void *stream);
+int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long long lda, const float *W, long long ldb,
+                                      float *G, long long ldc, const float *bias_dW, const int32_t *pool_arg,
+                                      const float *pool_T, const float *coef_b, int pool_K, const float *Yprev,
+                                      long long ldy, const float *scale, const float *shift, const float *mean,
+                                      const float *invstd, float *red_slab, void *stream);
+int prifit_gemm_stream_tn_pool_f32(int Mo, int No, long long P, const float *Y, long long ldy, const float *A,
+                                   long long lda, float *out, long long ldo, const float *b_scale,
+                                   const float *b_shift, const int32_t *pool_arg, const float *pool_T,
+                                   const float *coef_b, const float *coef_d, int pool_K, float *workspace,
+                                   void *stream);
+
 /* dW = dY^T relu(bn(A)) of the same layers (PRIFIT_GEMM_TN with the reduction over P >= 32768 grouped samples,
  * P % 8 == 0, and an output of Mo x No, both multiples of 32 in 32..128): out [Mo, ldo] += sum_rows G[row,0:Mo]^T
  * A[row,0:No] with A read as max(a*b_scale[n]+b_shift[n], 0) when the prologue is given.  `out` is initialised by

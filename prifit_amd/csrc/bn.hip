@@ -424,6 +424,27 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float *__rest
     }
 }
 
+// T[g,c] = a[c] * (relu'(y at the winning sample) * gp[g,c]): the sparse term of the pooled layer's dY
+// (dY[g,k,c] = T[g,c] * [k == arg[g,c]] + b[c] * Y + d[c]) for consumers that form dY in their operand staging.
+__global__ __launch_bounds__(256) void pool_bwd_table_kernel(const float *__restrict__ gp, long long ldgp,
+                                                             const float *__restrict__ Y, long long ldy,
+                                                             const int32_t *__restrict__ arg,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift,
+                                                             const float *__restrict__ ca, int G, int K, int C,
+                                                             float slope, float *__restrict__ T)
+{
+    const long long total = (long long)G * C;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long g = id / C;
+        const int c = (int)(id - g * C);
+        const int w = arg[id];
+        const float y = Y[(g * K + w) * ldy + c];
+        const float gv = gp[g * ldgp + c];
+        T[id] = ca[c] * (fmaf(y, scale[c], shift[c]) > 0.f ? gv : gv * slope);
+    }
+}
+
 static inline int ew_grid(long long total)
 {
     long long g = (total + 255) / 256;
@@ -566,6 +587,17 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
     hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((long long)G * K * (C / 4))), dim3(256), 0,
                        as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C / 4,
                        rows_per_sample, slope, dY, ldd);
+    return prifit_check_launch();
+}
+
+int prifit_pool_bwd_table(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
+                          const float *scale, const float *shift, const float *coef_a, int G, int K, int C, float slope,
+                          float *T, void *stream)
+{
+    if (!gp || !Y || !arg || !scale || !shift || !coef_a || !T || G <= 0 || K <= 0 || C <= 0 || ldgp < C || ldy < C)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(pool_bwd_table_kernel, dim3(ew_grid((long long)G * C)), dim3(256), 0, as_stream(stream), gp, ldgp,
+                       Y, ldy, arg, scale, shift, coef_a, G, K, C, slope, T);
     return prifit_check_launch();
 }
 

@@ -37,13 +37,20 @@ struct StreamArgs {
     long long ldry;
     const float *red_scale, *red_shift, *red_mean, *red_invstd;  // [N]
     float *red_slab;                 // [gridDim.x][2][N]
+    // POOL (dA of the max-pooled last layer): A is the layer's pre-activation Y; the operand dY = b*Y + d + one-hot*T
+    // is formed when the fragments are read: b per channel here, d folded into `bias` (d^T W) by the caller, and per
+    // pooling group g (pool_K consecutive rows, a multiple of 64) arg[g][c] = winning sample, T[g][c] its gradient
+    const int32_t *pool_arg;         // [M / pool_K][K]
+    const float *pool_T;             // [M / pool_K][K]
+    const float *pool_b;             // [K]
+    int pool_K;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // WN: waves along N (2 or 4; 256 threads = 4 waves, WM = 4 / WN waves along M); KG = K / 8;
 // BKC: B is [N][K] (NT) else [K][N] (NN); AFF: prologue on A
-template <int WN, int KG, bool BKC, bool AFF, bool RED>
+template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL>
 __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
 {
     constexpr int K = KG * 8;
@@ -53,7 +60,8 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
     constexpr int NV = SBM * K / 4 / 256;     // float4 staged per thread
     static_assert(NV * 256 * 4 == SBM * K, "tile divides evenly");
     __shared__ __attribute__((aligned(16))) float s_a[2][SBM * LD];
-    __shared__ __attribute__((aligned(16))) float s_aff[2][K];
+    __shared__ __attribute__((aligned(16))) float s_aff[2][K];   // POOL: [0] = b
+    __shared__ __attribute__((aligned(16))) float s_pool[2][2][POOL ? K : 4];  // [stage][arg | T][channel]
     __shared__ float s_red[WM][2][32 * WN];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -64,6 +72,9 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 
     if (AFF) {
         for (int t = threadIdx.x; t < K; t += 256) { s_aff[0][t] = g.a_scale[t]; s_aff[1][t] = g.a_shift[t]; }
+    }
+    if (POOL) {
+        for (int t = threadIdx.x; t < K; t += 256) s_aff[0][t] = g.pool_b[t];
     }
     // this wave's slice of B as fragments: lane (li, lh) of k-group q holds B[col][8q + 4lh + 0..3]
     float4 bf[KG];
@@ -82,8 +93,14 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 
     const int tiles = (g.M + SBM - 1) / SBM;
     float4 st[NV];
+    float4 st_pool = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tile = [&](int tile) {
         const int m0 = tile * SBM;
+        if (POOL && threadIdx.x < 2 * (K / 4)) {  // the (arg, T) rows of this tile's pooling group: 2 x K values
+            const int which = threadIdx.x / (K / 4), c4 = threadIdx.x - which * (K / 4);
+            const float *src = which ? g.pool_T : reinterpret_cast<const float *>(g.pool_arg);
+            st_pool = ld4(src + (long long)(m0 / g.pool_K) * K + 4 * c4);
+        }
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int id = threadIdx.x + 256 * p;
@@ -92,8 +109,12 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
             st[p] = ld4(g.A + (long long)(gr < g.M ? gr : g.M - 1) * g.lda + 4 * c4);
         }
     };
-    auto store_tile = [&](int tile, float *dst) {
+    auto store_tile = [&](int tile, float *dst, int stage) {
         const int m0 = tile * SBM;
+        if (POOL && threadIdx.x < 2 * (K / 4)) {
+            const int which = threadIdx.x / (K / 4), c4 = threadIdx.x - which * (K / 4);
+            *reinterpret_cast<float4 *>(&s_pool[stage][which][4 * c4]) = st_pool;
+        }
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int id = threadIdx.x + 256 * p;
@@ -112,10 +133,10 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 
     int tile = blockIdx.x;
     if (tile < tiles) load_tile(tile);
-    if (AFF) __syncthreads();  // s_aff visible before the first staging
+    if (AFF || POOL) __syncthreads();  // s_aff visible before the first staging
     for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
         float *As = s_a[it & 1];
-        store_tile(tile, As);
+        store_tile(tile, As, it & 1);
         __syncthreads();
         const int next = tile + gridDim.x;
         if (next < tiles) load_tile(next);
@@ -143,6 +164,20 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
             float4 fa[TM];
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LD + 8 * q);
+            if (POOL) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(&s_aff[0][8 * q + 4 * lh]);
+                const int4 w4 = *reinterpret_cast<const int4 *>(&s_pool[it & 1][0][8 * q + 4 * lh]);
+                const float4 t4 = *reinterpret_cast<const float4 *>(&s_pool[it & 1][1][8 * q + 4 * lh]);
+                const int kr0 = (tile * SBM) % g.pool_K + wm * 32 * TM + li;  // sample index of this lane's row in its group
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int kr = kr0 + 32 * a;
+                    fa[a].x = fmaf(b4.x, fa[a].x, w4.x == kr ? t4.x : 0.f);
+                    fa[a].y = fmaf(b4.y, fa[a].y, w4.y == kr ? t4.y : 0.f);
+                    fa[a].z = fmaf(b4.z, fa[a].z, w4.z == kr ? t4.z : 0.f);
+                    fa[a].w = fmaf(b4.w, fa[a].w, w4.w == kr ? t4.w : 0.f);
+                }
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
@@ -206,9 +241,15 @@ struct StreamTNArgs {
     int Mo, No;
     long long P, ldg, lda, rows_per_wg;
     const float *b_scale, *b_shift;  // prologue on A (channel = output column) or NULL
+    // POOL: G is the pooled layer's pre-activation Y and the operand dY = b*Y + d + one-hot*T is formed on load
+    // (lane = channel: b, d are per-lane constants; arg / T rows of the pooling group once per 8-row group)
+    const int32_t *pool_arg;         // [P / pool_K][Mo]
+    const float *pool_T;             // [P / pool_K][Mo]
+    const float *pool_b, *pool_d;    // [Mo]
+    int pool_K;                      // multiple of 8
 };
 
-template <bool AFF>
+template <bool AFF, bool POOL>
 __global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNArgs g)
 {
     __shared__ float s_part[3][64 * 64];  // partial sub-blocks of the row-group streams ks = 1..3
@@ -234,6 +275,11 @@ __global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNAr
         sc[0] = g.b_scale[n0 + li]; sh[0] = g.b_shift[n0 + li];
         if (n2) { sc[1] = g.b_scale[n0 + 32 + li]; sh[1] = g.b_shift[n0 + 32 + li]; }
     }
+    float pb[2] = {0.f, 0.f}, pd[2] = {0.f, 0.f};
+    if (POOL) {
+        pb[0] = g.pool_b[m0 + li]; pd[0] = g.pool_d[m0 + li];
+        if (m2) { pb[1] = g.pool_b[m0 + 32 + li]; pd[1] = g.pool_d[m0 + 32 + li]; }
+    }
     const long long r0 = (long long)blockIdx.x * g.rows_per_wg;
     const long long r1 = r0 + g.rows_per_wg < g.P ? r0 + g.rows_per_wg : g.P;
     const float *Gp = g.G + m0 + li + (long long)(4 * lh) * g.ldg;
@@ -241,11 +287,18 @@ __global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNAr
     const long long stride = 8 * KS;
 
     float cg[2][4], ca[2][4], ng[2][4], na[2][4];
+    int cw[2] = {0, 0}, nw[2] = {0, 0};          // POOL: winning sample of this lane's channel in the row group's pool
+    float ct[2] = {0.f, 0.f}, nt[2] = {0.f, 0.f};  //       and its gradient
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cg[1][j] = 0.f; ca[1][j] = 0.f; ng[1][j] = 0.f; na[1][j] = 0.f; }
-    auto load = [&](long long row, float (&fg)[2][4], float (&fa)[2][4]) {
+    auto load = [&](long long row, float (&fg)[2][4], float (&fa)[2][4], int (&fw)[2], float (&ft)[2]) {
         const float *gp = Gp + row * g.ldg;
         const float *ap = Ap + row * g.lda;
+        if (POOL) {
+            const long long o = (row / g.pool_K) * g.Mo + m0 + li;
+            fw[0] = g.pool_arg[o]; ft[0] = g.pool_T[o];
+            if (m2) { fw[1] = g.pool_arg[o + 32]; ft[1] = g.pool_T[o + 32]; }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) fg[0][j] = gp[(long long)j * g.ldg];
 #pragma unroll
@@ -260,9 +313,17 @@ __global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNAr
         }
     };
     long long row = r0 + 8 * ks;
-    if (row < r1) load(row, cg, ca);
+    if (row < r1) load(row, cg, ca, cw, ct);
     for (; row < r1; row += stride) {
-        if (row + stride < r1) load(row + stride, ng, na);
+        if (row + stride < r1) load(row + stride, ng, na, nw, nt);
+        if (POOL) {
+            const int kb = (int)(row % g.pool_K) + 4 * lh;  // sample index of this lane's first row in its pooling group
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cg[0][j] = fmaf(pb[0], cg[0][j], pd[0]) + (cw[0] == kb + j ? ct[0] : 0.f);
+                cg[1][j] = fmaf(pb[1], cg[1][j], pd[1]) + (cw[1] == kb + j ? ct[1] : 0.f);
+            }
+        }
         if (AFF) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -279,6 +340,7 @@ __global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNAr
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { cg[0][j] = ng[0][j]; cg[1][j] = ng[1][j]; ca[0][j] = na[0][j]; ca[1][j] = na[1][j]; }
+        if (POOL) { cw[0] = nw[0]; cw[1] = nw[1]; ct[0] = nt[0]; ct[1] = nt[1]; }
     }
     // combine the KS row-group streams of every sub-block through LDS (stream 0 of each sub-block collects)
     if (KS > 1) {
@@ -351,9 +413,11 @@ int stream_grid(int M, int K)
 template <int WN, int KG, bool BKC>
 void launch_aff(const StreamArgs &g, int grid, hipStream_t st)
 {
-    if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true>), dim3(grid), dim3(256), 0, st, g);
-    else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false, false>), dim3(grid), dim3(256), 0, st, g);
+    if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && g.pool_arg) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false, false>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false, false, false>), dim3(grid), dim3(256), 0, st, g);
 }
 
 template <int WN, bool BKC>
@@ -402,6 +466,27 @@ int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0;
+    return stream_launch(g, 1, stream);
+}
+
+int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long long lda, const float *W, long long ldb,
+                                      float *G, long long ldc, const float *bias_dW, const int32_t *pool_arg,
+                                      const float *pool_T, const float *coef_b, int pool_K, const float *Yprev,
+                                      long long ldy, const float *scale, const float *shift, const float *mean,
+                                      const float *invstd, float *red_slab, void *stream)
+{
+    if (!Y || !W || !G || !pool_arg || !pool_T || !coef_b || !prifit_gemm_stream_supported(1, M, N, K) || lda < K ||
+        ldc < N || ldb < N || (lda & 3) || ((uintptr_t)Y & 15) || pool_K < 64 || (pool_K & 63) || (M % pool_K) ||
+        (((uintptr_t)pool_arg | (uintptr_t)pool_T) & 15))
+        return PRIFIT_EINVAL;
+    if (red_slab && (!Yprev || !scale || !shift || !mean || !invstd || ldy < N)) return PRIFIT_EINVAL;
+    StreamArgs g;
+    g.A = Y; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_scale = nullptr; g.a_shift = nullptr; g.bias = bias_dW; g.stats = nullptr;
+    g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
+    g.red_slab = red_slab;
+    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_K = pool_K;
     return stream_launch(g, 1, stream);
 }
 
@@ -417,6 +502,7 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0;
     return stream_launch(g, layout, stream);
 }
 
@@ -441,6 +527,23 @@ long long prifit_gemm_stream_tn_workspace(int Mo, int No, long long P)
     return stream_tn_split(P, &per) * Mo * No;
 }
 
+static int stream_tn_launch(StreamTNArgs &g, float *out, long long ldo, void *stream)
+{
+    const long long nwg = stream_tn_split(g.P, &g.rows_per_wg);
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)nwg), block(256);
+    if (g.pool_arg) {
+        if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_stream_tn_kernel<false, true>), grid, block, 0, st, g);
+    } else {
+        if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_stream_tn_kernel<false, false>), grid, block, 0, st, g);
+    }
+    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((g.Mo * g.No + 255) / 256, 32), dim3(256), 0, st, g.ws, (int)nwg,
+                       g.Mo, g.No, ldo, out);
+    return prifit_check_launch();
+}
+
 int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long long ldg, const float *A,
                               long long lda, float *out, long long ldo, const float *b_scale,
                               const float *b_shift, float *workspace, void *stream)
@@ -451,13 +554,25 @@ int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long 
     StreamTNArgs g;
     g.G = G; g.A = A; g.ws = workspace; g.Mo = Mo; g.No = No; g.P = P; g.ldg = ldg; g.lda = lda;
     g.b_scale = b_scale; g.b_shift = b_shift;
-    const long long nwg = stream_tn_split(P, &g.rows_per_wg);
-    hipStream_t st = as_stream(stream);
-    if (b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_stream_tn_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, st, g);
-    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((Mo * No + 255) / 256, 32), dim3(256), 0, st, workspace, (int)nwg,
-                       Mo, No, ldo, out);
-    return prifit_check_launch();
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = g.pool_d = nullptr; g.pool_K = 0;
+    return stream_tn_launch(g, out, ldo, stream);
+}
+
+int prifit_gemm_stream_tn_pool_f32(int Mo, int No, long long P, const float *Y, long long ldy, const float *A,
+                                   long long lda, float *out, long long ldo, const float *b_scale,
+                                   const float *b_shift, const int32_t *pool_arg, const float *pool_T,
+                                   const float *coef_b, const float *coef_d, int pool_K, float *workspace,
+                                   void *stream)
+{
+    if (!Y || !A || !out || !workspace || !pool_arg || !pool_T || !coef_b || !coef_d ||
+        !prifit_gemm_stream_tn_supported(Mo, No, P) || ldy < Mo || lda < No || ldo < No ||
+        ((b_scale == nullptr) != (b_shift == nullptr)) || pool_K < 8 || (pool_K & 7) || (P % pool_K))
+        return PRIFIT_EINVAL;
+    StreamTNArgs g;
+    g.G = Y; g.A = A; g.ws = workspace; g.Mo = Mo; g.No = No; g.P = P; g.ldg = ldy; g.lda = lda;
+    g.b_scale = b_scale; g.b_shift = b_shift;
+    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_d = coef_d; g.pool_K = pool_K;
+    return stream_tn_launch(g, out, ldo, stream);
 }
 
 }  // extern "C"

@@ -28,6 +28,7 @@ def _rows_per_slab():
 
 _STREAM = os.environ.get("PRIFIT_GEMM_STREAM", "1") != "0"   # 0: every product takes the tiled kernel (A/B runs)
 _FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate bn_relu_bwd_reduce launches (A/B runs)
+_FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
 
 
 def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, a_rowsum=None, accumulate=False,
@@ -218,8 +219,13 @@ class SharedMLPFn(torch.autograd.Function):
             dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
             dbeta = torch.empty_like(dgamma)
             ca, cb, cd = torch.empty_like(dgamma), torch.empty_like(dgamma), torch.empty_like(dgamma)
-            dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
             pooled = (l == L - 1) and cfg["pool_K"]
+            # the pooled last layer: dY = T*[k == arg] + b*Y + d is formed inside the streaming dA / dW kernels from Y
+            # itself (no pool_bwd_apply pass writing dY, no reads of it) when both consumers are streaming shapes
+            fuse_pool = bool(pooled and _FUSE_POOL and training and l > 0 and W is not None and cfg["pool_K"] % 64 == 0 and
+                             ctx.needs_input_grad[2 + 6 * l] and _stream_ok(NN, P, Kin, Cout) and
+                             dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
+            dY = None if fuse_pool else torch.empty(P, Cout, dtype=torch.float32, device=dev)
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
@@ -238,6 +244,37 @@ class SharedMLPFn(torch.autograd.Function):
             fused_red = None
             call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
                  ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
+            if fuse_pool:
+                Ttab = torch.empty(G, Cout, dtype=torch.float32, device=dev)
+                call("prifit_pool_bwd_table", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+                     ptr(shift), ptr(ca), G, K, Cout, _F(0.0), ptr(Ttab), cur_stream())
+                wo, wn, bo, bn_ = wslots[l]
+                dW = arena[wo:wo + wn].view(Cout, Kin)
+                ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
+                a_aff = affines[l - 1]
+                with profiler.span("gemm_stream_tn", 4.0 * P * (Cout + Kin)):
+                    call("prifit_gemm_stream_tn_pool_f32", Cout, Kin, _LL(P), ptr(Y), _LL(Cout), ptr(Ys[l - 1]),
+                         _LL(Ys[l - 1].stride(0)), ptr(dW), _LL(Kin), ptr(a_aff[0]), ptr(a_aff[1]), ptr(arg), ptr(Ttab),
+                         ptr(cb), ptr(cd), K, ptr(ws), cur_stream())
+                grads[6 * l] = dW
+                if ctx.needs_input_grad[2 + 6 * l + 1]:
+                    grads[6 * l + 1] = arena[bo:bo + bn_]
+                grads[6 * l + 2] = dgamma
+                grads[6 * l + 3] = dbeta
+                G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+                bias_dw = torch.mv(W.t(), cd)   # the constant d^T W of every row of dY . W
+                rslab, ns = None, 0
+                if _FUSE_RED:
+                    ns = dll().prifit_gemm_stream_slabs(P, Cout)
+                    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
+                with profiler.span("gemm_stream_nn", 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
+                    call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
+                         _LL(Kin), ptr(bias_dw), ptr(arg), ptr(Ttab), ptr(cb), K, ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)),
+                         ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), cur_stream())
+                fused_red = (rslab, ns) if rslab is not None else None
+                G_in = G_prev
+                continue
             if pooled:
                 call("prifit_pool_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
                      ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), G, K, Cout, 0, _F(0.0), ptr(dY), _LL(Cout),

@@ -140,12 +140,16 @@ def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
     assert ((tiled.cpu().double() - ref).norm() / ref.norm()) < 2e-6
 
 
-@pytest.mark.parametrize("P,K,dims", [(65536, 64, ((64, 64), (64, 96), (96, 128))),     # streaming dA products
+@pytest.mark.parametrize("P,K,dims", [(65536, 64, ((64, 64), (64, 96), (96, 128))),     # streaming dA products, pooled fusion
+                                      (131072, 128, ((64, 64), (64, 128))),                # pooled fusion, 128-sample groups, N = 64
+                                      (65536, 32, ((64, 96), (96, 128))),                  # K = 32: pool_bwd_apply stays
                                       (6144, 32, ((64, 196), (196, 256))),                 # tiled kernel, 128-row tiles
                                       (3072, 0, ((516, 256), (256, 512), (512, 1024)))])   # tiled kernel, 64-row tiles
 def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims):
     """The BatchNorm-backward column sums emitted by the dA epilogues (prifit_gemm_stream_dgrad_f32 /
-    prifit_gemm_dgrad_bnred_f32) against the separate bn_relu_bwd_reduce launches: same gradients up to summation order."""
+    prifit_gemm_dgrad_bnred_f32) against the separate bn_relu_bwd_reduce launches, and the pooled last layer's dY formed
+    in the streaming consumers (prifit_gemm_stream_dgrad_pool_f32 / _tn_pool_f32) against pool_bwd_apply: same gradients
+    up to summation order."""
     x = _rand((P, dims[0][0]), 31).cuda()
     g = torch.Generator().manual_seed(32)
     tens = []
@@ -157,8 +161,8 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
     gout = _rand((P // K if K else P, dims[-1][1]), 33).cuda()
     res = {}
     for fuse in (True, False):
-        old = nn_ops._FUSE_RED
-        nn_ops._FUSE_RED = fuse
+        old = nn_ops._FUSE_RED, nn_ops._FUSE_POOL
+        nn_ops._FUSE_RED = nn_ops._FUSE_POOL = fuse
         try:
             xi = x.clone().requires_grad_(True)
             cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
@@ -166,7 +170,7 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
             grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
             res[fuse] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
         finally:
-            nn_ops._FUSE_RED = old
+            nn_ops._FUSE_RED, nn_ops._FUSE_POOL = old
     for a, b in zip(res[True], res[False]):
         if b is None:
             assert a is None
