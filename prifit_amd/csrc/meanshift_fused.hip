@@ -104,6 +104,17 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
         __syncthreads();
         if (k0 + KB < N) t.load(Xb, k0 + KB, N);
 
+        // MODE 1: the saved kernel values under this wave's sub-tile, requested before the S MFMAs so that their
+        // latency hides behind the 64 matrix instructions (they were the exposed part of this mode)
+        float kfv[16];
+        if (MODE == 1) {
+            const int kb0 = k0 + kh * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb0 + (r & 3) + 8 * (r >> 2);
+                kfv[r] = (key < N && q_ok) ? KTb[(size_t)key * ldk + gq] : 0.f;
+            }
+        }
         // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
         const float *xa = s_x + (kh * 32 + li) * LDSW + lh * 4;
         const float *qb = s_q + qrow * LDSW + lh * 4;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
                 rsum += p;
                 if (KTb && ok) KTb[(size_t)key * ldk + gq] = p;
             } else {
-                const float kf = ok ? KTb[(size_t)key * ldk + gq] : 0.f;
+                const float kf = kfv[r];
                 p = kf > kmin ? (sacc[r] + radd) * kf * rcp_b2 : 0.f;
                 if (GSb && ok) GSb[(size_t)key * ldk + gq] = p;
             }

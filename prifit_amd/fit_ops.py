@@ -19,7 +19,8 @@ _LL = ctypes.c_longlong
 KM = 32          # cluster slots per shape (>= max_num_clusters = 25, src/ellipsoid_utils.py:6)
 NMS_CAP = 64     # centre ids kept by nms before the cluster-count check
 SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106)
-BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "gemm")  # mean-shift backward engine: "gemm" | "fused"
+# mean-shift backward engine: "hybrid" (default) | "gemm" | "fused", see MeanShiftFn.backward
+BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "hybrid")
 DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
 
 
@@ -105,10 +106,14 @@ class MeanShiftFn(torch.autograd.Function):
         dev = X.device
         g = g.contiguous()
         gX = torch.zeros(Bt, N, D, dtype=torch.float32, device=dev)
-        # Backward engine for the fused (K^T) layout.  "gemm" (default): MFMA GEMM chain, 4 N^2 D products per
-        # iteration.  "fused": flash-style kernels that re-form gS in registers (5 products, no gS in HBM); measured
-        # slower on MI355X at N=2048 (profiles/), kept selectable and parity-tested.
+        # Backward engine for the fused (K^T) layout, 4 N^2 D products per iteration in every case but "fused":
+        #   "hybrid" (default): flash-style dZ kernel (gS = (gO X^T + g_rowsum) * K / b^2 in registers, dZ = gS X, gS^T
+        #             streamed out once) + ONE dual-source MFMA GEMM for dX += gS^T Z + K^T gO;
+        #   "gemm":   MFMA GEMM chain (gS^T by a GEMM epilogue, dZ by a TN GEMM, the same dual-source GEMM): +0.6 ms / step;
+        #   "fused":  flash-style kernels that re-form gS in registers for dX too (5 products, no gS in HBM): +4.5 ms.
         mode = BWD_MODE if (ctx.fused and N % 4 == 0) else "gemm"
+        if mode == "hybrid" and N % 32:
+            mode = "gemm"
         gS = None if mode == "fused" else torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
         gO = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
         grs = torch.empty(Bt, N, dtype=torch.float32, device=dev)
@@ -118,8 +123,16 @@ class MeanShiftFn(torch.autograd.Function):
                  _LL(sV), ptr(grs), cur_stream())
             sk = _skinny_splitk(N, D, N, Bt)
             sk2 = _skinny_splitk(N, D, 2 * N, Bt)
-            gZ = (torch.zeros if sk > 1 and mode != "fused" else torch.empty)(Bt, N, D, dtype=torch.float32, device=dev)
-            if mode == "fused":
+            gZ = (torch.zeros if sk > 1 and mode == "gemm" else torch.empty)(Bt, N, D, dtype=torch.float32, device=dev)
+            if mode == "hybrid":
+                # flash-style dZ kernel (products 1 + 2, streams gS^T out) + both dX terms as one dual-source product
+                with profiler.span("ms_fused_bwd", 4.0 * Bt * N * N * D):
+                    call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
+                         _LL(N), _LL(sM), ptr(gS), Bt, N, D, ptr(gZ), cur_stream())
+                with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
+                    call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),
+                         _LL(D), _LL(sV), ptr(gX), _LL(D), _LL(sV), Bt, sk2, 1, cur_stream())
+            elif mode == "fused":
                 with profiler.span("ms_fused_bwd", 10.0 * Bt * N * N * D):
                     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
                          _LL(N), _LL(sM), None, Bt, N, D, ptr(gZ), cur_stream())              # dZ  = gS X

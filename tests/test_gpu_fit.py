@@ -80,7 +80,7 @@ def test_mean_shift_iterations_fwd_bwd(F, golden):
     torch.testing.assert_close(Xg.grad[0].cpu(), Xo.grad, rtol=2e-3, atol=2e-4 * Xo.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("N,mode", [(200, "gemm"), (200, "fused"), (333, "gemm"), (2048, "fused")])
+@pytest.mark.parametrize("N,mode", [(200, "gemm"), (200, "fused"), (333, "gemm"), (2048, "fused"), (2048, "hybrid"), (200, "hybrid")])
 def test_mean_shift_fused_ragged(F, N, mode, monkeypatch):
     monkeypatch.setattr(F, "BWD_MODE", mode)
     """D = 128 takes the flash-style fused kernels; N not a multiple of the 64-row tiles (and N % 4 != 0, which
