@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from ..nn_ops import LinearFn, SharedMLPFn
 from .pointnet_util import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
-                            _mlp_cfg, _mlp_tensors)
+                            _mlp_cfg, _mlp_tensors, batched_bn_counters)
 
 
 class get_model(nn.Module):
@@ -51,6 +51,10 @@ class get_model(nn.Module):
     def embed_features(self, xyz, cls_label, fps_start=None):
         """Backbone up to `feat` (upstream :64-88), channels-last internally.
         Returns (l1 [B,512,320], l2 [B,128,256], l3 [B,1,1024], feat [B*N,128]) channels-last."""
+        with batched_bn_counters():
+            return self._embed_features(xyz, cls_label, fps_start)
+
+    def _embed_features(self, xyz, cls_label, fps_start=None):
         B, C, N = xyz.shape
         pts = xyz.permute(0, 2, 1).contiguous()           # l0_points (= xyz, also without normals: :69-75)
         l0_xyz = pts[:, :, :3].contiguous() if self.normal_channel else pts

@@ -146,10 +146,33 @@ def _mlp_tensors_preact(convs, bns):
     return ts
 
 
+_pending_counters = None   # list while a model forward batches the BatchNorm step counters, else None
+
+
+class batched_bn_counters:
+    """`num_batches_tracked += 1` of every BatchNorm touched inside the block as ONE multi-tensor add at exit
+    (25 single-element kernels per forward otherwise)."""
+
+    def __enter__(self):
+        global _pending_counters
+        self.prev, _pending_counters = _pending_counters, []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_counters
+        todo, _pending_counters = _pending_counters, self.prev
+        if todo and exc[0] is None:
+            torch._foreach_add_(todo, 1)
+        return False
+
+
 def _mlp_cfg(bns, pool_K, training):
     for bn in bns:
         if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            if _pending_counters is not None:
+                _pending_counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked += 1
     return {"pool_K": pool_K, "training": training, "eps": bns[0].eps,
             "momentum": [0.1 if bn.momentum is None else bn.momentum for bn in bns]}
 
