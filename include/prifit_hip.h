@@ -322,6 +322,11 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
 /* mean-shift clustering on the unit hypersphere (src/mean_shift.py)                            */
 /* ------------------------------------------------------------------------------------------ */
 
+/* Y = normalize(normalize(X)) over rows of D <= 256 floats, F.normalize semantics (x / max(|x|, eps)) applied twice
+ * as convex_loss.py:41,57 does with the per-point embedding; _bwd: its autograd (GX from X and the gradient G of Y). */
+int prifit_row_normalize2_fwd(const float *X, int D, long long rows, float eps, float *Y, void *stream);
+int prifit_row_normalize2_bwd(const float *X, const float *G, int D, long long rows, float eps, float *GX, void *stream);
+
 /* out[row] = k-th smallest entry (1-based) of row `row` of M [rows, C], C <= 4096: the
  * torch.topk(dist, k, largest=False)[0][:, -1] of compute_bandwidth, src/mean_shift.py:156-158. */
 int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float *out, void *stream);

@@ -135,8 +135,11 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
                 rand_table=None, canonical=True, return_info=False, entropy_indices=None, intersect_jitter=None):
     """points [B,3,N], chamfer_points [B,3,M], X [B,D,N] (per-point embedding)."""
     emb = X.permute(0, 2, 1)
-    emb = F.normalize(emb, dim=2, p=2)
-    emb = F.normalize(emb, dim=2, p=2).contiguous()      # normalised twice upstream (:41,57)
+    if emb.shape[2] <= 256 and emb.dtype == torch.float32:
+        emb = fit_ops.Normalize2Fn.apply(emb)                # normalised twice upstream (:41,57), one kernel here
+    else:
+        emb = F.normalize(emb, dim=2, p=2)
+        emb = F.normalize(emb, dim=2, p=2).contiguous()
     pts = points.permute(0, 2, 1).contiguous()
     entropy_loss = torch.zeros((), device=pts.device)
     if include_entropy_loss:                              # :59-62: a random quarter of the points

@@ -319,7 +319,89 @@ __global__ __launch_bounds__(256) void membership_bwd_kernel(const float *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// y = normalize(normalize(x)) row-wise (convex_loss.py:41,57 normalises the embedding twice with
+// F.normalize: x / max(|x|, 1e-12)) and its autograd, one wave per row, D <= 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_normalize2_fwd_kernel(const float *__restrict__ X, int D, long long rows,
+                                                                 float eps, float *__restrict__ Y)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < D ? X[row * D + c] : 0.f;
+        ss += v[j] * v[j];
+    }
+    const float n1 = fmaxf(sqrtf(wave_sum_f32(ss)), eps);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = v[j] / n1; s2 += v[j] * v[j]; }
+    const float n2 = fmaxf(sqrtf(wave_sum_f32(s2)), eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        if (c < D) Y[row * D + c] = v[j] / n2;
+    }
+}
+
+// gx = J1^T J2^T g with J(y = x/n): g -> (g - y (g.y)) / n (zero Jacobian of the clamp when the norm is below eps)
+__global__ __launch_bounds__(256) void row_normalize2_bwd_kernel(const float *__restrict__ X, const float *__restrict__ G,
+                                                                 int D, long long rows, float eps, float *__restrict__ GX)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float x[4], y1[4], y2[4], g[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        x[j] = c < D ? X[row * D + c] : 0.f;
+        g[j] = c < D ? G[row * D + c] : 0.f;
+        ss += x[j] * x[j];
+    }
+    const float r1 = sqrtf(wave_sum_f32(ss)), n1 = fmaxf(r1, eps);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { y1[j] = x[j] / n1; s2 += y1[j] * y1[j]; }
+    const float r2 = sqrtf(wave_sum_f32(s2)), n2 = fmaxf(r2, eps);
+    float d2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { y2[j] = y1[j] / n2; d2 += g[j] * y2[j]; }
+    d2 = r2 > eps ? wave_sum_f32(d2) : 0.f;
+    float d1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { g[j] = (g[j] - y2[j] * d2) / n2; d1 += g[j] * y1[j]; }
+    d1 = r1 > eps ? wave_sum_f32(d1) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        if (c < D) GX[row * D + c] = (g[j] - y1[j] * d1) / n1;
+    }
+}
+
 extern "C" {
+
+int prifit_row_normalize2_fwd(const float *X, int D, long long rows, float eps, float *Y, void *stream)
+{
+    if (!X || !Y || D <= 0 || D > 256 || rows <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(row_normalize2_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), X, D,
+                       rows, eps, Y);
+    return prifit_check_launch();
+}
+
+int prifit_row_normalize2_bwd(const float *X, const float *G, int D, long long rows, float eps, float *GX, void *stream)
+{
+    if (!X || !G || !GX || D <= 0 || D > 256 || rows <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(row_normalize2_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), X, G,
+                       D, rows, eps, GX);
+    return prifit_check_launch();
+}
 
 int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float *out, void *stream)
 {

@@ -58,6 +58,28 @@ def compute_bandwidth(X, quantile):
     return torch.sqrt(torch.clamp(kth, min=1e-6)).view(Bt, N).mean(dim=1)
 
 
+class Normalize2Fn(torch.autograd.Function):
+    """F.normalize(F.normalize(x, dim=-1), dim=-1) on [..., D <= 256] rows in one kernel (convex_loss.py:41,57)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        D = x.shape[-1]
+        y = torch.empty_like(x)
+        call("prifit_row_normalize2_fwd", ptr(x), D, _LL(x.numel() // D), ctypes.c_float(1e-12), ptr(y), cur_stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        D = x.shape[-1]
+        gx = torch.empty_like(x)
+        call("prifit_row_normalize2_bwd", ptr(x), ptr(g.contiguous()), D, _LL(x.numel() // D), ctypes.c_float(1e-12), ptr(gx),
+             cur_stream())
+        return gx
+
+
 class MeanShiftFn(torch.autograd.Function):
     """src/mean_shift.py:50-84 (gaussian kernel, delta = 1), all shapes at once.
 

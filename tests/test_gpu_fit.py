@@ -394,3 +394,21 @@ def test_optional_terms_entropy_intersection_pruning(F, golden):
     ref = Xo.grad
     assert abs(Xg.grad.norm().item() - ref.norm().item()) < 1e-2 * ref.norm().item()
     torch.testing.assert_close(Xg.grad.cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
+
+
+def test_normalize_twice_kernel_vs_torch(F):
+    """convex_loss.py:41,57: the embedding is F.normalize'd twice; one kernel, forward and autograd, incl. a zero row."""
+    torch.manual_seed(5)
+    x = torch.randn(3, 257, 128)
+    x[1, 7] = 0.0
+    x[2, 9] *= 1e-14
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.normalize(torch.nn.functional.normalize(xr, dim=2), dim=2)
+    g = torch.randn(3, 257, 128)
+    (yr * g).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    yd = F.Normalize2Fn.apply(xd)
+    (yd * g.cuda()).sum().backward()
+    torch.testing.assert_close(yd.detach().cpu(), yr.detach(), rtol=1e-6, atol=1e-7)
+    ok = x.norm(dim=2) > 1e-10   # rows at the eps clamp: torch differentiates the clamp as constant, same here, but 0/0 noise
+    torch.testing.assert_close(xd.grad.cpu()[ok], xr.grad[ok], rtol=1e-4, atol=1e-5)
