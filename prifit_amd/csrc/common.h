@@ -45,6 +45,20 @@ __device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// 32-bit integer sum across the wave on the DPP network, wave-uniform result (same sequence as wave_max_u32_dpp)
+__device__ __forceinline__ int wave_sum_i32_dpp(int v)
+{
+#define PRIFIT_DPP_ADD(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+    PRIFIT_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    PRIFIT_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    PRIFIT_DPP_ADD(0x124, 0xf);  // row_ror:4
+    PRIFIT_DPP_ADD(0x128, 0xf);  // row_ror:8  -> every lane holds the sum of its row of 16
+    PRIFIT_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3 (other rows add the `old` value 0)
+    PRIFIT_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef PRIFIT_DPP_ADD
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v)
 {
 #pragma unroll

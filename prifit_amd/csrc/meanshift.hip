@@ -44,17 +44,14 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
             unsigned m = 0;
 #pragma unroll
             for (int j = 0; j < VPT; ++j) m = max(m, (key[j] & hi_mask) == prefix ? key[j] : 0u);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-            prefix = m;
+            prefix = wave_max_u32_dpp(m);
             break;
         }
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < VPT; ++j)
             cnt += ((key[j] & hi_mask) == prefix && !((key[j] >> bit) & 1u)) ? 1 : 0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        cnt = wave_sum_i32_dpp(cnt);
         if (kk > cnt) { kk -= cnt; rem -= cnt; prefix |= (1u << bit); }
         else rem = cnt;
     }
