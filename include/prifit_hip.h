@@ -288,6 +288,15 @@ int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *x
                              const float *feat, int B, int N, int S, int K, int C, int D, int feat_first,
                              int nblocks, float *partial, void *stream);
 
+/* The same weight gradient with the BatchNorm + ReLU backward of that first layer fused in: G [B*S*K, C] is the
+ * gradient w.r.t. relu(bn(Y1)), Y1 the pre-activations prifit_sa_group_linear_fwd wrote, (scale, shift) the forward
+ * affine and (a, b, d) prifit_bn_bwd_finalize's coefficients: dy = a*(Y1*scale+shift > 0 ? g : 0) + b*Y1 + d is formed
+ * on load, so no prifit_bn_relu_bwd_apply pass writes dY for this layer. */
+int prifit_sa_first_layer_dw_bn(const float *G, const float *Y1, const float *scale, const float *shift,
+                                const float *coef_a, const float *coef_b, const float *coef_d, const int32_t *idx,
+                                const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int K,
+                                int C, int D, int feat_first, int nblocks, float *partial, void *stream);
+
 /* Backward of relu(bn(Y)) given G = dL/d(relu output): partial slabs of m1 = sum(G*mask) and
  * m2 = sum(G*mask*yhat). */
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy,

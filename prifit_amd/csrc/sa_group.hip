@@ -277,11 +277,18 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
 // dW of the direct-mode first layer: dW[c][col] = sum over grouped samples of dY[row][c] * x_row[col] with
 // x_row = [rel_xyz | feat_j] re-formed from the index lists (the grouped tensor is never materialised).
 // Every workgroup reduces a contiguous range of rows and writes one [C][D+3] partial (upstream column order).
-template <int D>
+// BNB (fused BatchNorm backward): dY is not materialised; `dY` then holds G = the gradient w.r.t. relu(bn(Y1)) and
+// dy = ca * (Y1*scale+shift > 0 ? g : 0) + cb * y + cd is formed on load from (G, Y1) -- the bn_relu_bwd_apply pass
+// that would write dY and the read of it here are gone.
+struct DwBn {
+    const float *Y1, *scale, *shift, *ca, *cb, *cd;
+};
+
+template <int D, bool BNB>
 __global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
     const float *__restrict__ dY, const int32_t *__restrict__ idx, const float *__restrict__ xyz,
     const float *__restrict__ new_xyz, const float *__restrict__ feat, int N, int S, int K, int C, int feat_first,
-    long long P, long long rows_per_block, float *__restrict__ partial)
+    long long P, long long rows_per_block, float *__restrict__ partial, const DwBn bn)
 {
     constexpr int KP = D + 3;
     __shared__ float s_x[256][KP];
@@ -296,6 +303,12 @@ __global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < KP; ++k) acc[j][k] = 0.f;
+    float4 b_s, b_t, b_a, b_b, b_d;
+    b_s = b_t = b_a = b_b = b_d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BNB) {
+        b_s = ld4g(bn.scale + 4 * c4); b_t = ld4g(bn.shift + 4 * c4);
+        b_a = ld4g(bn.ca + 4 * c4); b_b = ld4g(bn.cb + 4 * c4); b_d = ld4g(bn.cd + 4 * c4);
+    }
 
     for (long long base = r_begin; base < r_end; base += 256) {
         {   // x rows of this chunk: one thread per row
@@ -328,6 +341,13 @@ __global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
                 const long long row = base + lr[u];
                 const bool ok = (i0 + u * rpi + rsel) < 64 && row < r_end;
                 gy[u] = ld4g(dY + (size_t)(ok ? row : r_begin) * C + 4 * c4);
+                if (BNB) {
+                    const float4 y = ld4g(bn.Y1 + (size_t)(ok ? row : r_begin) * C + 4 * c4);
+                    gy[u].x = fmaf(b_a.x, fmaf(y.x, b_s.x, b_t.x) > 0.f ? gy[u].x : 0.f, fmaf(b_b.x, y.x, b_d.x));
+                    gy[u].y = fmaf(b_a.y, fmaf(y.y, b_s.y, b_t.y) > 0.f ? gy[u].y : 0.f, fmaf(b_b.y, y.y, b_d.y));
+                    gy[u].z = fmaf(b_a.z, fmaf(y.z, b_s.z, b_t.z) > 0.f ? gy[u].z : 0.f, fmaf(b_b.z, y.z, b_d.z));
+                    gy[u].w = fmaf(b_a.w, fmaf(y.w, b_s.w, b_t.w) > 0.f ? gy[u].w : 0.f, fmaf(b_b.w, y.w, b_d.w));
+                }
                 if (!ok) gy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 lr[u] = ok ? lr[u] : 0;
             }
@@ -444,9 +464,9 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
     return feat_xyz ? launch_r<0, 6, true>(a, R, st) : launch_r<0, 6, false>(a, R, st);
 }
 
-int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz,
-                             const float *feat, int B, int N, int S, int K, int C, int D, int feat_first,
-                             int nblocks, float *partial, void *stream)
+static int dw_launch(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz, const float *feat,
+                     int B, int N, int S, int K, int C, int D, int feat_first, int nblocks, float *partial,
+                     const DwBn *bn, void *stream)
 {
     if (!dY || !idx || !xyz || !new_xyz || !partial || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C < 16 ||
         C > SG_CMAX || (C & (C - 1)) || (D != 0 && D != 3 && D != 6) || (D > 0 && !feat) || nblocks < 1 ||
@@ -457,14 +477,34 @@ int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *x
     per = (per + 255) / 256 * 256;
     if ((long long)nblocks * per < P) return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
-#define DW_LAUNCH(DD)                                                                                              \
-    hipLaunchKernelGGL((sa_first_layer_dw_kernel<DD>), dim3(nblocks), dim3(256), 0, st, dY, idx, xyz, new_xyz, feat, \
-                       N, S, K, C, feat_first, P, per, partial)
-    if (D == 0) DW_LAUNCH(0);
-    else if (D == 3) DW_LAUNCH(3);
-    else DW_LAUNCH(6);
+    DwBn none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#define DW_LAUNCH(DD)                                                                                                \
+    if (bn) hipLaunchKernelGGL((sa_first_layer_dw_kernel<DD, true>), dim3(nblocks), dim3(256), 0, st, dY, idx, xyz,     \
+                               new_xyz, feat, N, S, K, C, feat_first, P, per, partial, *bn);                          \
+    else hipLaunchKernelGGL((sa_first_layer_dw_kernel<DD, false>), dim3(nblocks), dim3(256), 0, st, dY, idx, xyz,      \
+                            new_xyz, feat, N, S, K, C, feat_first, P, per, partial, none)
+    if (D == 0) { DW_LAUNCH(0); }
+    else if (D == 3) { DW_LAUNCH(3); }
+    else { DW_LAUNCH(6); }
 #undef DW_LAUNCH
     return prifit_check_launch();
+}
+
+int prifit_sa_first_layer_dw(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz,
+                             const float *feat, int B, int N, int S, int K, int C, int D, int feat_first,
+                             int nblocks, float *partial, void *stream)
+{
+    return dw_launch(dY, idx, xyz, new_xyz, feat, B, N, S, K, C, D, feat_first, nblocks, partial, nullptr, stream);
+}
+
+int prifit_sa_first_layer_dw_bn(const float *G, const float *Y1, const float *scale, const float *shift,
+                                const float *coef_a, const float *coef_b, const float *coef_d, const int32_t *idx,
+                                const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int K,
+                                int C, int D, int feat_first, int nblocks, float *partial, void *stream)
+{
+    if (!Y1 || !scale || !shift || !coef_a || !coef_b || !coef_d || ((uintptr_t)Y1 & 15)) return PRIFIT_EINVAL;
+    const DwBn bn = {Y1, scale, shift, coef_a, coef_b, coef_d};
+    return dw_launch(G, idx, xyz, new_xyz, feat, B, N, S, K, C, D, feat_first, nblocks, partial, &bn, stream);
 }
 
 }  // extern "C"

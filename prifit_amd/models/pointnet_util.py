@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..nn_ops import (GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
-                      ThreeInterpolateFn, sa_group_supported)
+                      ThreeInterpolateFn, _sa_group_launch, sa_group_supported)
 
 
 # ------------------------------------------------------------------ functional surface (:19-107)
@@ -110,6 +110,9 @@ def _first_layer_by_linearity(conv, bn_training, feats, xyz, new_xyz, idx, kp, f
 # Ball query + grouping + the first conv of every per-radius MLP in ONE launch (csrc/sa_group.hip);
 # PRIFIT_SA_FUSED=0 keeps the separate ball-query / gather / GEMM launches for A/B measurements.
 _SA_FUSED = os.environ.get("PRIFIT_SA_FUSED", "1") != "0"
+# direct mode in training: the first layer's BatchNorm backward is fused into its weight-gradient kernel (0: separate
+# bn_relu_bwd_apply pass + SAGroupDirectFn autograd, A/B)
+_DIRECT_FUSED_BWD = os.environ.get("PRIFIT_SA_DIRECT_FUSED_BWD", "1") != "0"
 
 
 def _fused_mode(first_convs, feats, N, nsamples, kp):
@@ -125,7 +128,19 @@ def _fused_mode(first_convs, feats, N, nsamples, kp):
 
 
 def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii, nsamples, kp, feat_first):
-    """-> per radius (Y1 [B*S*K, C1], column-statistics slab)."""
+    """-> per radius (Y1 [B*S*K, C1], column-statistics slab, info): `info` is None, or -- direct mode in training --
+    the dict SharedMLPFn needs to take over the first conv's weight gradient (cfg["preact_direct"]): Y1 is then plain
+    data for autograd and the BatchNorm backward of that layer is fused into the weight-gradient kernel."""
+    if mode == "direct" and training and _DIRECT_FUSED_BWD:
+        D = 0 if feats is None else feats.shape[-1]
+        with torch.no_grad():
+            Ws = [c.weight.reshape(c.weight.shape[0], -1).contiguous() for c in first_convs]
+            bs = [None if c.bias is None else c.bias.contiguous() for c in first_convs]
+            fx = feats is not None and D == 3 and feats.data_ptr() == xyz.data_ptr()
+            Ys, slabs, idxs = _sa_group_launch(0, xyz, new_xyz, feats, feat_first, list(radii), list(nsamples),
+                                               [w.shape[0] for w in Ws], Ws, None, None, bs, feat_xyz=fx)
+        return [(Ys[i], slabs[i], {"idx": idxs[i], "xyz": xyz, "new_xyz": new_xyz, "feat": feats, "feat_first": feat_first,
+                                   "K": nsamples[i], "D": D}) for i in range(len(first_convs))]
     if mode == "direct":
         ts = []
         for c in first_convs:
@@ -137,10 +152,13 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
             U, Vc = _linearity_operands(c, feats, xyz, new_xyz, kp, feat_first)
             ts += [U, Vc, c.bias]
         out = SAGroupGatherFn.apply(xyz, new_xyz, (list(radii), list(nsamples), training), *ts)
-    return [(out[2 * i], out[2 * i + 1]) for i in range(len(first_convs))]
+    return [(out[2 * i], out[2 * i + 1], None) for i in range(len(first_convs))]
 
 
-def _mlp_tensors_preact(convs, bns):
+def _mlp_tensors_preact(convs, bns, direct=False):
+    """Layer 0 is already computed: its W / bias slots are None -- unless SharedMLPFn owns their gradient (direct mode)."""
+    if direct:
+        return _mlp_tensors(convs, bns, convs[0].weight.reshape(convs[0].weight.shape[0], -1))
     ts = _mlp_tensors(convs, bns, None)
     ts[1] = None
     return ts
@@ -233,11 +251,12 @@ class PointNetSetAbstraction(nn.Module):
             _, new_xyz = ops.farthest_point_sample(xyz, S, fps_start, return_xyz=True)
             mode = _fused_mode([self.mlp_convs[0]], feats, N, [K], kp)
             if mode is not None:
-                (y1, slab), = _fused_first_layers(mode, [self.mlp_convs[0]], self.training, feats, xyz, new_xyz,
-                                                  [self.radius], [K], kp, feat_first=False)
+                (y1, slab, info), = _fused_first_layers(mode, [self.mlp_convs[0]], self.training, feats, xyz, new_xyz,
+                                                        [self.radius], [K], kp, feat_first=False)
                 cfg = _mlp_cfg(self.mlp_bns, K, self.training)
                 cfg["preact_slab"] = slab
-                out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns))
+                cfg["preact_direct"] = info
+                out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns, info is not None))
                 return new_xyz, out.reshape(B, S, -1)
             idx = ops.ball_query_multi([self.radius], [K], xyz, new_xyz)[0]
             # rows = [features, rel_xyz, pad]; upstream order is [rel_xyz, features] (:131)
@@ -294,7 +313,9 @@ class PointNetSetAbstractionMsg(nn.Module):
             for i, K in enumerate(self.nsample_list):
                 cfg = _mlp_cfg(self.bn_blocks[i], K, self.training)
                 cfg["preact_slab"] = ys[i][1]
-                pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i])))
+                cfg["preact_direct"] = ys[i][2]
+                pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i],
+                                                                                    ys[i][2] is not None)))
             return new_xyz, torch.cat(pooled, dim=-1).reshape(B, S, -1)
         idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
         for i, K in enumerate(self.nsample_list):

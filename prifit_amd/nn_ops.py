@@ -182,8 +182,11 @@ class SharedMLPFn(torch.autograd.Function):
             out = torch.empty(P, CL, dtype=torch.float32, device=dev)
             call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, 0, _F(0.0),
                  ptr(out), _LL(CL), cur_stream())
-        ctx.cfg = {k: v for k, v in cfg.items() if k != "preact_slab"}
+        ctx.cfg = {k: v for k, v in cfg.items() if k not in ("preact_slab", "preact_direct")}
         ctx.preact = cfg.get("preact_slab") is not None
+        # direct-mode set-abstraction front end: this function owns the gradient of the first conv's weight (tensors[0],
+        # upstream layout [C1, D+3]) and computes it with the BatchNorm backward fused in (prifit_sa_first_layer_dw_bn)
+        ctx.preact_direct = cfg.get("preact_direct") if ctx.preact else None
         ctx.L = L
         ctx.saved = (x, Ys, Ws, affines, stats_saved, arg)
         return out
@@ -225,7 +228,8 @@ class SharedMLPFn(torch.autograd.Function):
             fuse_pool = bool(pooled and _FUSE_POOL and training and l > 0 and W is not None and cfg["pool_K"] % 64 == 0 and
                              ctx.needs_input_grad[2 + 6 * l] and _stream_ok(NN, P, Kin, Cout) and
                              dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
-            dY = None if fuse_pool else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            direct0 = l == 0 and ctx.preact_direct is not None
+            dY = None if (fuse_pool or direct0) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
@@ -275,6 +279,25 @@ class SharedMLPFn(torch.autograd.Function):
                 fused_red = (rslab, ns) if rslab is not None else None
                 G_in = G_prev
                 continue
+            if direct0:
+                # first layer of a direct-mode set-abstraction scale: dW1 = dY^T [feat | rel] with dY formed on load
+                info = ctx.preact_direct
+                grads[2] = dgamma
+                grads[3] = dbeta
+                if ctx.needs_input_grad[2]:
+                    Bq, Nq, _ = info["xyz"].shape
+                    Sq, Kq, Dq = info["new_xyz"].shape[1], info["K"], info["D"]
+                    nblk = int(max(1, min(1024, (P + 1023) // 1024)))
+                    part = torch.empty(nblk, Cout, Dq + 3, dtype=torch.float32, device=dev)
+                    with profiler.span("sa_first_layer_dw", 4.0 * P * (2 * Cout + 1)):
+                        call("prifit_sa_first_layer_dw_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
+                             ptr(info["idx"]), ptr(info["xyz"]), ptr(info["new_xyz"]), ptr(info["feat"]), Bq, Nq, Sq, Kq, Cout,
+                             Dq, int(info["feat_first"]), nblk, ptr(part), cur_stream())
+                    grads[0] = part.sum(dim=0)
+                if ctx.needs_input_grad[3]:
+                    grads[1] = torch.zeros(Cout, dtype=torch.float32, device=dev)  # bias in front of a batch-stat BatchNorm
+                G_in = None
+                break
             if pooled:
                 call("prifit_pool_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
                      ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), G, K, Cout, 0, _F(0.0), ptr(dY), _LL(Cout),
