@@ -163,6 +163,17 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
                                 void *stream);
+/* Forward of a max-pooled last layer without re-reading it for the pool (models/pointnet_util.py:199,256):
+ * prifit_gemm_stream_f32 (NT, prologue required, M % 32 == 0) that also emits, per 32-row block and column, the largest
+ * and smallest stored C and the row of their first occurrence, cand [M/32][4][N]; once the BatchNorm affine (scale,
+ * shift) of this layer is final, prifit_pool_from_candidates gives out [G, ldo] = max_k relu(bn(Y)) and arg [G, C] (the
+ * winning sample, first maximum) for groups of K rows, K % 32 == 0 -- what prifit_pool_fwd computes from Y itself. */
+int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
+                                float *C, long long ldc, const float *a_scale, const float *a_shift, const float *bias,
+                                float *col_stats, float *cand, void *stream);
+int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
+                                float slope, float *out, long long ldo, int32_t *arg, void *stream);
+
 /* dA of a shared-MLP layer with the BatchNorm-backward reduction of the layer below fused into the epilogue:
  * G [M,N] = dY [M,K] . W [K,N] (PRIFIT_GEMM_NN, streaming shapes), and red_slab [prifit_gemm_stream_slabs(M,K)][2][N]
  * receives per-workgroup partials of m1 = sum_rows(G * mask), m2 = sum_rows(G * mask * yhat) with

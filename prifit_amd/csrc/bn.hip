@@ -445,6 +445,45 @@ __global__ __launch_bounds__(256) void pool_bwd_table_kernel(const float *__rest
     }
 }
 
+// Group max-pool from the per-32-row candidates of prifit_gemm_stream_pool_f32 (max, argmax, min, argmin of the raw
+// pre-activations): max_k relu(s*y+t) = relu(s*y*+t) with y* the block maximum for s > 0, the block minimum for s < 0.
+// Ties go to the lowest sample, like torch.max / pool_fwd_kernel (which compares s*y+t; the two can only disagree on
+// WHICH of two samples with equal activation is reported, or when the pooled activation is <= 0 and carries no gradient).
+__global__ __launch_bounds__(256) void pool_from_candidates_kernel(const float *__restrict__ cand,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift, int G, int K, int C,
+                                                                   float slope, float *__restrict__ out, long long ldo,
+                                                                   int32_t *__restrict__ arg)
+{
+    const long long total = (long long)G * C;
+    const int nb = K >> 5;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long gidx = id / C;
+        const int c = (int)(id - gidx * C);
+        const float s = scale[c], t = shift[c];
+        const float *cd = cand + gidx * nb * 4 * C + c;
+        float best;
+        int bi = 0;
+        if (s > 0.f) {
+            best = -INFINITY;
+            for (int b = 0; b < nb; ++b) {
+                const float v = cd[(long long)(b * 4 + 0) * C];
+                if (v > best) { best = v; bi = b * 32 + __float_as_int(cd[(long long)(b * 4 + 1) * C]); }
+            }
+        } else if (s < 0.f) {
+            best = INFINITY;
+            for (int b = 0; b < nb; ++b) {
+                const float v = cd[(long long)(b * 4 + 2) * C];
+                if (v < best) { best = v; bi = b * 32 + __float_as_int(cd[(long long)(b * 4 + 3) * C]); }
+            }
+        } else {
+            best = cd[0];  // every sample has the activation t: the first one wins
+        }
+        out[gidx * ldo + c] = act(fmaf(best, s, t), slope);
+        arg[id] = bi;
+    }
+}
+
 static inline int ew_grid(long long total)
 {
     long long g = (total + 255) / 256;
@@ -598,6 +637,16 @@ int prifit_pool_bwd_table(const float *gp, long long ldgp, const float *Y, long 
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_bwd_table_kernel, dim3(ew_grid((long long)G * C)), dim3(256), 0, as_stream(stream), gp, ldgp,
                        Y, ldy, arg, scale, shift, coef_a, G, K, C, slope, T);
+    return prifit_check_launch();
+}
+
+int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
+                                float slope, float *out, long long ldo, int32_t *arg, void *stream)
+{
+    if (!cand || !scale || !shift || !out || !arg || G <= 0 || K < 32 || (K & 31) || C <= 0 || ldo < C)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(pool_from_candidates_kernel, dim3(ew_grid((long long)G * C)), dim3(256), 0, as_stream(stream), cand,
+                       scale, shift, G, K, C, slope, out, ldo, arg);
     return prifit_check_launch();
 }
 

@@ -44,13 +44,18 @@ struct StreamArgs {
     const float *pool_T;             // [M / pool_K][K]
     const float *pool_b;             // [K]
     int pool_K;
+    // PMAX (forward of a max-pooled last layer): per 32-row block and column, the largest and the smallest stored C and
+    // the row (0..31) of their first occurrence: cand[M / 32][4][N] = (max, argmax, min, argmin; indices as int bits).
+    // After the BatchNorm statistics are final, max_k relu(s*y+t) = relu(s*(s >= 0 ? max : min)+t) is read from these
+    // candidates instead of from C (prifit_pool_from_candidates).
+    float *cand;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // WN: waves along N (2 or 4; 256 threads = 4 waves, WM = 4 / WN waves along M); KG = K / 8;
 // BKC: B is [N][K] (NT) else [K][N] (NN); AFF: prologue on A
-template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL>
+template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL, bool PMAX>
 __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
 {
     constexpr int K = KG * 8;
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
             const int m0 = tile * SBM + wm * 32 * TM + 4 * lh;
             const bool full = tile * SBM + SBM <= g.M;
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a) {
+                float vmax = -INFINITY, vmin = INFINITY;
+                int imax = 0, imin = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2);
@@ -200,6 +207,11 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
                     csum += v;
                     csq += v * v;
                     g.C[(long long)row * g.ldc + col] = v;
+                    if (PMAX) {  // rows ascend with r inside a lane: strict comparisons keep the first occurrence
+                        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (v > vmax) { vmax = v; imax = ri; }
+                        if (v < vmin) { vmin = v; imin = ri; }
+                    }
                     if (RED) {
                         const float y = yp[a][r];
                         const float gm = fmaf(y, r_s, r_t) > 0.f ? v : 0.f;
@@ -207,6 +219,19 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
                         m2 += gm * ((y - r_mu) * r_is);
                     }
                 }
+                if (PMAX) {
+                    // the other half of the block's rows lives in lane ^ 32; ties go to the lower row
+                    const float ov = __shfl_xor(vmax, 32, 64), on = __shfl_xor(vmin, 32, 64);
+                    const int oi = __shfl_xor(imax, 32, 64), oj = __shfl_xor(imin, 32, 64);
+                    if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }
+                    if (on < vmin || (on == vmin && oj < imin)) { vmin = on; imin = oj; }
+                    const int blk_row = tile * SBM + wm * 32 * TM + 32 * a;
+                    if (lh == 0 && blk_row < g.M) {
+                        float *cd = g.cand + (long long)(blk_row >> 5) * 4 * g.N + col;
+                        cd[0] = vmax; cd[g.N] = __int_as_float(imax); cd[2 * g.N] = vmin; cd[3 * g.N] = __int_as_float(imin);
+                    }
+                }
+            }
         }
     }
     if (RED) { csum = m1; csq = m2; }
@@ -413,11 +438,12 @@ int stream_grid(int M, int K)
 template <int WN, int KG, bool BKC>
 void launch_aff(const StreamArgs &g, int grid, hipStream_t st)
 {
-    if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true>), dim3(grid), dim3(256), 0, st, g);
-    else if (!BKC && g.pool_arg) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true>), dim3(grid), dim3(256), 0, st, g);
-    else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
-    else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false, false>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false, false, false>), dim3(grid), dim3(256), 0, st, g);
+    if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && g.pool_arg) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (BKC && g.cand && g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, true, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false, false, false>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false, false, false, false>), dim3(grid), dim3(256), 0, st, g);
 }
 
 template <int WN, bool BKC>
@@ -466,7 +492,7 @@ int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
-    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr;
     return stream_launch(g, 1, stream);
 }
 
@@ -486,7 +512,7 @@ int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long 
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = bias_dW; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
-    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_K = pool_K;
+    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_K = pool_K; g.cand = nullptr;
     return stream_launch(g, 1, stream);
 }
 
@@ -502,8 +528,23 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
-    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr;
     return stream_launch(g, layout, stream);
+}
+
+int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
+                                float *C, long long ldc, const float *a_scale, const float *a_shift, const float *bias,
+                                float *col_stats, float *cand, void *stream)
+{
+    if (!A || !B || !C || !cand || !a_scale || !a_shift || !prifit_gemm_stream_supported(0, M, N, K) || lda < K ||
+        ldc < N || (lda & 3) || ((uintptr_t)A & 15) || (ldb & 3) || ((uintptr_t)B & 15) || ldb < K || (M & 31))
+        return PRIFIT_EINVAL;
+    StreamArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
+    g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = cand;
+    return stream_launch(g, 0, stream);
 }
 
 int prifit_gemm_stream_tn_supported(int Mo, int No, long long P)

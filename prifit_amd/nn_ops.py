@@ -28,6 +28,7 @@ def _rows_per_slab():
 
 _STREAM = os.environ.get("PRIFIT_GEMM_STREAM", "1") != "0"   # 0: every product takes the tiled kernel (A/B runs)
 _FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate bn_relu_bwd_reduce launches (A/B runs)
+_FUSE_POOL_FWD = os.environ.get("PRIFIT_FUSE_POOL_FWD", "1") != "0"  # 0: pool_fwd re-reads the last layer's Y (A/B runs)
 _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
 
 
@@ -124,6 +125,7 @@ class SharedMLPFn(torch.autograd.Function):
         tile_m = 128
         Ys, affines, stats_saved, Ws = [], [], [], []
         prev, prev_aff = x, None
+        cand = None
         for l in range(L):
             W, b, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 6]
             preact = l == 0 and cfg.get("preact_slab") is not None
@@ -154,7 +156,16 @@ class SharedMLPFn(torch.autograd.Function):
                 tile_m = dll().prifit_gemm_stats_tile_m(P, Cout)
                 nslab = gemm_stats_slabs(P, Cout, Kin) if aligned else (P + tile_m - 1) // tile_m
                 slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
-                gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
+                if (l == L - 1 and cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and _FUSE_POOL_FWD and aligned and
+                        prev_aff is not None and _stream_ok(NT, P, Cout, Kin)):
+                    # max-pooled last layer on the streaming kernel: (max, argmax, min, argmin) per 32 rows and column come
+                    # out of the epilogue; the pool below reads those candidates (1/8 of Y) instead of Y
+                    cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
+                    with profiler.span("gemm_stream_nt", 4.0 * (P * Kin + P * Cout + Cout * Kin)):
+                        call("prifit_gemm_stream_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin),
+                             ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), cur_stream())
+                else:
+                    gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
                 call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
                      _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
                      ptr(mean), ptr(invstd), cur_stream())
@@ -176,8 +187,12 @@ class SharedMLPFn(torch.autograd.Function):
             G = P // pool_K
             out = torch.empty(G, CL, dtype=torch.float32, device=dev)
             arg = torch.empty(G, CL, dtype=torch.int32, device=dev)
-            call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
-                 ptr(out), _LL(CL), ptr(arg), cur_stream())
+            if cand is not None:
+                call("prifit_pool_from_candidates", ptr(cand), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, _F(0.0),
+                     ptr(out), _LL(CL), ptr(arg), cur_stream())
+            else:
+                call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
+                     ptr(out), _LL(CL), ptr(arg), cur_stream())
         else:
             out = torch.empty(P, CL, dtype=torch.float32, device=dev)
             call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, 0, _F(0.0),

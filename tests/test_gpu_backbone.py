@@ -142,7 +142,8 @@ def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
 
 @pytest.mark.parametrize("P,K,dims", [(65536, 64, ((64, 64), (64, 96), (96, 128))),     # streaming dA products, pooled fusion
                                       (131072, 128, ((64, 64), (64, 128))),                # pooled fusion, 128-sample groups, N = 64
-                                      (65536, 32, ((64, 96), (96, 128))),                  # K = 32: pool_bwd_apply stays
+                                      (65536, 32, ((64, 96), (96, 128))),                  # K = 32: pool_bwd_apply stays, pool candidates
+                                      (98304, 96, ((64, 64), (64, 128))),                  # 3 candidate blocks per group
                                       (6144, 32, ((64, 196), (196, 256))),                 # tiled kernel, 128-row tiles
                                       (3072, 0, ((516, 256), (256, 512), (512, 1024)))])   # tiled kernel, 64-row tiles
 def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims):
@@ -161,8 +162,8 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
     gout = _rand((P // K if K else P, dims[-1][1]), 33).cuda()
     res = {}
     for fuse in (True, False):
-        old = nn_ops._FUSE_RED, nn_ops._FUSE_POOL
-        nn_ops._FUSE_RED = nn_ops._FUSE_POOL = fuse
+        old = nn_ops._FUSE_RED, nn_ops._FUSE_POOL, nn_ops._FUSE_POOL_FWD
+        nn_ops._FUSE_RED = nn_ops._FUSE_POOL = nn_ops._FUSE_POOL_FWD = fuse
         try:
             xi = x.clone().requires_grad_(True)
             cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
@@ -170,12 +171,40 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
             grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
             res[fuse] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
         finally:
-            nn_ops._FUSE_RED, nn_ops._FUSE_POOL = old
+            nn_ops._FUSE_RED, nn_ops._FUSE_POOL, nn_ops._FUSE_POOL_FWD = old
     for a, b in zip(res[True], res[False]):
         if b is None:
             assert a is None
             continue
         assert (a - b).norm() <= 5e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
+
+
+@pytest.mark.parametrize("P,K,N,Kin", [(65536, 64, 128, 64), (49152, 96, 64, 96), (32768, 32, 96, 128)])
+def test_pool_candidates_match_pool_fwd(nn_ops, P, K, N, Kin):
+    """prifit_gemm_stream_pool_f32 + prifit_pool_from_candidates against prifit_pool_fwd on the stored Y: identical pooled
+    values; identical winners wherever the pooled activation is positive (rows duplicated inside groups -> ties -> first)."""
+    from prifit_amd.nn_ops import call, ptr, cur_stream, _LL, _F
+    A, W = _rand((P, Kin), 41), _rand((N, Kin), 42)
+    A.view(P // K, K, Kin)[:, K // 2:] = A.view(P // K, K, Kin)[:, :1]          # padding-like duplicates of sample 0
+    sc, sh, bias = _rand((Kin,), 43), _rand((Kin,), 44), _rand((N,), 45)
+    s2, t2 = _rand((N,), 46), _rand((N,), 47)                                   # both signs of the BatchNorm scale
+    s2[3] = 0.0
+    Ad, Wd = A.cuda(), W.cuda()
+    Y = torch.empty(P, N, device="cuda")
+    cand = torch.empty(P // 32, 4, N, device="cuda")
+    slab = torch.empty(nn_ops.gemm_stats_slabs(P, N, Kin), 2, N, device="cuda")
+    call("prifit_gemm_stream_pool_f32", P, N, Kin, ptr(Ad), _LL(Kin), ptr(Wd), _LL(Kin), ptr(Y), _LL(N), ptr(sc.cuda()),
+         ptr(sh.cuda()), ptr(bias.cuda()), ptr(slab), ptr(cand), cur_stream())
+    G = P // K
+    s2d, t2d = s2.cuda(), t2.cuda()
+    out1, arg1 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")
+    out2, arg2 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")
+    call("prifit_pool_from_candidates", ptr(cand), ptr(s2d), ptr(t2d), G, K, N, _F(0.0), ptr(out1), _LL(N), ptr(arg1), cur_stream())
+    call("prifit_pool_fwd", ptr(Y), _LL(N), ptr(s2d), ptr(t2d), G, K, N, 0, _F(0.0), ptr(out2), _LL(N), ptr(arg2), cur_stream())
+    assert torch.equal(out1, out2)
+    live = out2 > 0
+    assert torch.equal(arg1[live], arg2[live])
+    assert live.float().mean() > 0.2
 
 
 def _run_pair(my, orc_mod, args_gpu, args_cpu, gout, n_out=1, pick=lambda o: o):
