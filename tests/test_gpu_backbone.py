@@ -83,6 +83,8 @@ def test_gemm_prologue_bias_stats_splitk_batched(nn_ops):
 def test_gemm_stream_tall_skinny(nn_ops, lay, M, N, K, aff):
     """Weights-stationary streaming kernel (csrc/gemm_stream.hip) on the shared-MLP shapes: forward (NT, BatchNorm+ReLU
     prologue, bias, column statistics) and dA (NN) against float64, ragged M; and against the tiled kernel."""
+    if not nn_ops._STREAM:
+        pytest.skip("PRIFIT_GEMM_STREAM=0")
     assert nn_ops._stream_ok(lay, M, N, K)
     A, W = _rand((M, K), 11), _rand((N, K), 12)
     sc, sh, bias = _rand((K,), 13), _rand((K,), 14), _rand((N,), 15)
@@ -120,6 +122,8 @@ def test_gemm_stream_tall_skinny(nn_ops, lay, M, N, K, aff):
                                          (128, 128, 40000, True), (96, 96, 36000, False)])
 def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
     """LDS-free streaming dW kernel: dW = dY^T relu(bn(A)) over P rows against float64; accumulates into `out`."""
+    if not nn_ops._STREAM:
+        pytest.skip("PRIFIT_GEMM_STREAM=0")
     assert nn_ops.dll().prifit_gemm_stream_tn_supported(Mo, No, nn_ops._LL(P))
     dY, A = _rand((P, Mo), 21), _rand((P, No), 22)
     sc, sh = _rand((No,), 23), _rand((No,), 24)
