@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from prifit_amd.nn_ops import call, ptr, cur_stream, _LL
-B, N, D = 24, 2048, 128
+B, N, D = int(os.environ.get("MSB", "24")), 2048, 128
 X = torch.nn.functional.normalize(torch.randn(B, N, D, device="cuda"), dim=2)
 Z = X.clone()
 bw = torch.full((B,), 0.6, device="cuda")
