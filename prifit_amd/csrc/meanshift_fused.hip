@@ -29,18 +29,20 @@ constexpr int LDSW = D + 4;   // padded row: conflict-free ds_read_b128 fragment
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // global [rows x 128] tile -> registers (8 float4 per thread, 256 threads); rows beyond `nrows` read row 0 and are zeroed
+// when the tile is written to LDS -- NOT at load time: a select right behind the load makes the compiler wait for the
+// data there (s_waitcnt vmcnt(0) directly after the loads), which serialised every step on the global latency
 struct Tile64 {
     float4 v[8];
+    int row0_, nrows_;
     __device__ __forceinline__ void load(const float *__restrict__ base, int row0, int nrows)
     {
+        row0_ = row0; nrows_ = nrows;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int id = threadIdx.x + 256 * p;  // 64 rows x 32 float4
             const int r = id >> 5, c = (id & 31) * 4;
             const bool ok = row0 + r < nrows;
-            float4 x = ld4(base + (size_t)(ok ? row0 + r : 0) * D + c);
-            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            v[p] = x;
+            v[p] = ld4(base + (size_t)(ok ? row0 + r : 0) * D + c);
         }
     }
     __device__ __forceinline__ void store(float *__restrict__ lds) const
@@ -48,14 +50,20 @@ struct Tile64 {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int id = threadIdx.x + 256 * p;
-            *reinterpret_cast<float4 *>(lds + (id >> 5) * LDSW + (id & 31) * 4) = v[p];
+            const bool ok = row0_ + (id >> 5) < nrows_;
+            *reinterpret_cast<float4 *>(lds + (id >> 5) * LDSW + (id & 31) * 4) = ok ? v[p] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 };
 }  // namespace
 
 // Q: the query-side operand rows (Z for MODE 0, gO for MODE 1) [B,N,128]; X: dictionary [B,N,128].
-template <int MODE>
+// FAST (forward mode only): N % 64 == 0 and the K^T stream is present -- every bounds / pointer predicate is compile-time
+// true, the 16 stream stores of a step are plain non-temporal instructions, and they are issued at the start of the NEXT
+// step, ahead of that step's tile loads (see the loop): 549 -> 531 us at B = 24, N = 2048.  The K^T stream costs ~50 us
+// of that (472 us without it): vmcnt is one in-order counter for loads and stores on gfx9, so waiting for a tile also
+// waits for every older store.
+template <int MODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     const float *__restrict__ Q, long long q_stride, const float *__restrict__ X, const float *__restrict__ bw,
     int N, const float *__restrict__ row_add,   // q_stride: batch stride of Q; row_add (MODE 1): g_rowsum [B,N]
@@ -98,10 +106,23 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     float *KTb = KT ? KT + (size_t)b * sk : nullptr;
     float *GSb = (MODE == 1 && GST) ? GST + (size_t)b * sk : nullptr;
 
+    // FAST, MODE 0: the 16 stream values of a step are stored at the START of the next step, ahead of that step's tile loads: the
+    // wait for those loads at the end of the step (vmcnt is in-order and the compiler drains it there) then finds the
+    // stores a whole step old instead of stalling on stores issued after the previous tile's loads
+    float pprev[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
+    float *STb = MODE == 0 ? KTb : GSb;   // the N x N stream written by this mode
     for (int k0 = 0; k0 < N; k0 += KB) {
         __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
         t.store(s_x);
         __syncthreads();
+        if (FAST && MODE == 0 && k0 > 0) {
+            const int kb = k0 - KB + kh * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_nontemporal_store(pprev[r], STb + (size_t)(kb + (r & 3) + 8 * (r >> 2)) * ldk + gq);
+        }
         if (k0 + KB < N) t.load(Xb, k0 + KB, N);
 
         // MODE 1: the saved kernel values under this wave's sub-tile, requested before the S MFMAs so that their
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb0 + (r & 3) + 8 * (r >> 2);
-                kfv[r] = (key < N && q_ok) ? KTb[(size_t)key * ldk + gq] : 0.f;
+                kfv[r] = (FAST || (key < N && q_ok)) ? KTb[(size_t)key * ldk + gq] : 0.f;
             }
         }
         // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key_base + (r & 3) + 8 * (r >> 2);
-            const bool ok = key < N && q_ok;
+            const bool ok = FAST || (key < N && q_ok);
             float p;
             if (MODE == 0) {
                 // src/mean_shift.py:65-68 with src/guard.py:6-11
@@ -144,11 +165,12 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
                 e = fminf(fmaxf(e, -13.0f), 75.0f);
                 p = ok ? __expf(e) : 0.f;
                 rsum += p;
-                if (KTb && ok) KTb[(size_t)key * ldk + gq] = p;
+                if (FAST) pprev[r] = p;
+                else if (KTb && ok) KTb[(size_t)key * ldk + gq] = p;
             } else {
                 const float kf = kfv[r];
                 p = kf > kmin ? (sacc[r] + radd) * kf * rcp_b2 : 0.f;
-                if (GSb && ok) GSb[(size_t)key * ldk + gq] = p;
+                if (FAST || (GSb && ok)) GSb[(size_t)key * ldk + gq] = p;
             }
             sacc[r] = p;
         }
@@ -163,6 +185,12 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
         }
     }
 
+    if (FAST && MODE == 0) {  // the last step's stream values
+        const int kb = N - KB + kh * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_nontemporal_store(pprev[r], STb + (size_t)(kb + (r & 3) + 8 * (r >> 2)) * ldk + gq);
+    }
     // ---- combine the two key halves: waves 2,3 park their partials in LDS (the X tile is dead now)
     __syncthreads();
     // layout of a partial O tile: [d 0..127][33 query slots] so that lanes (d) are conflict-free
@@ -370,9 +398,14 @@ int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, 
     if (!Z || !X || !bw || !Znext || !rowsum || !nrm || B <= 0 || N <= 0 || D_ != D || B > 65535 ||
         (KT && ld_kt < N))
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL((ms_fused_kernel<0>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), Z,
-                       (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                       Znext, O, rowsum, nrm);
+    if (KT && N % QB == 0)
+        hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), Z,
+                           (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                           Znext, O, rowsum, nrm);
+    else
+        hipLaunchKernelGGL((ms_fused_kernel<0, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), Z,
+                           (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                           Znext, O, rowsum, nrm);
     return prifit_check_launch();
 }
 
@@ -383,9 +416,10 @@ int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, co
     if (!gO || !X || !bw || !g_rowsum || !KT || !dZ || B <= 0 || N <= 0 || D_ != D || B > 65535 || ld_kt < N ||
         gO_batch_stride < (long long)N * D)
         return PRIFIT_EINVAL;
-    hipLaunchKernelGGL((ms_fused_kernel<1>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
-                       gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST, (const float *)nullptr, dZ,
-                       (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    // (the unpredicated FAST variant measured slower in this mode: 809 vs 628 us at B = 24, N = 2048)
+    hipLaunchKernelGGL((ms_fused_kernel<1, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
+                       gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
+                       (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     return prifit_check_launch();
 }
 

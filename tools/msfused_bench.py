@@ -15,7 +15,9 @@ def fwd():
     call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), cur_stream())
 def dz():
     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(N * D), ptr(X), ptr(bw), ptr(grs), ptr(KT), _LL(N), _LL(N * N), ptr(gS), B, N, D, ptr(gZ), cur_stream())
-for name, fn in (("fused fwd", fwd), ("fused dz", dz)):
+def fwd_nokt():
+    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, None, _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), cur_stream())
+for name, fn in (("fused fwd", fwd), ("fwd, no K^T stream", fwd_nokt), ("fused dz", dz)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,5 +25,5 @@ for name, fn in (("fused fwd", fwd), ("fused dz", dz)):
     for _ in range(20): fn()
     e.record(); torch.cuda.synchronize()
     us = 1e3 * s.elapsed_time(e) / 20
-    print("%-10s %7.1f us  %6.1f TF/s" % (name, us, 4.0 * B * N * N * D / us / 1e6))
+    print("%-20s %7.1f us  %6.1f TF/s" % (name, us, 4.0 * B * N * N * D / us / 1e6))
 print("checksum", float(Zn.sum()), float(gZ.sum()))
