@@ -103,19 +103,46 @@ struct TileLoader {
         }
     }
 
-    __device__ __forceinline__ void load(int k0, const float *__restrict__ scale, const float *__restrict__ shift)
+    // load(): ONLY the global loads (clamped addresses, nothing that consumes the data) -- the prologue and the zeroing of
+    // out-of-range elements happen in store(), when the tile is written to LDS after the MFMAs of the current tile.  With
+    // the select right behind the load the compiler put an s_waitcnt vmcnt(0) after every load, i.e. the "next tile in
+    // flight during the MFMAs" never was in flight.
+    int kload;
+    __device__ __forceinline__ void load(int k0, const float *__restrict__, const float *__restrict__)
     {
+        kload = k0;
         const int kt = k0 / BK;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            // k validity of this float4 (KC: 4 consecutive k; !KC: one k row)
             const int gk = k0 + klo[p];
             const bool kin = gk < K;                       // element 0 (VEC: K % 4 == 0 covers all four)
             const float *src = ptr[p] + (kin ? (long long)kt * step : 0);
             if (!KC && !kin && klo[p] >= K) src = ptr[p] - (long long)klo[p] * (step / BK);  // K < BK: stay in row 0
-            float4 x;
             if (VEC) {
-                x = ld4(src);
+                v[p] = ld4(src);
+            } else {
+                // scalar path: element j may lie beyond the row / the K extent -> read element 0 again instead
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = KC ? (okmask[p] && (gk + j) < K) : (kin && ((okmask[p] >> j) & 1u));
+                    e[j] = src[ok ? j : 0];
+                }
+                v[p] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+
+    // prologue + masks of the tile loaded last (kload), applied in registers (v keeps the transformed values: the A-row
+    // sums of the caller read them)
+    __device__ __forceinline__ void finish(const float *__restrict__ scale, const float *__restrict__ shift)
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int gk = kload + klo[p];
+            const bool kin = gk < K;
+            float4 x = v[p];
+            if (VEC) {
                 if (AFF) {
                     const int cc = KC ? (kin ? gk : 0) : c0[p];
                     const float4 s = ld4(scale + cc), t = ld4(shift + cc);
@@ -124,11 +151,11 @@ struct TileLoader {
                 }
                 if (!(kin && okmask[p])) x = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                float e[4];
+                float e[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool ok = KC ? (okmask[p] && (gk + j) < K) : (kin && ((okmask[p] >> j) & 1u));
-                    float val = ok ? src[j] : 0.f;
+                    float val = ok ? e[j] : 0.f;
                     if (AFF && ok) {
                         const int cc = KC ? gk + j : c0[p] + j;
                         val = fmaxf(fmaf(val, scale[cc], shift[cc]), 0.f);
@@ -238,6 +265,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     if (kt0 < kt1) {
         la.load(kt0 * BK, g.a_scale, g.a_shift);
         lb.load(kt0 * BK, g.b_scale, g.b_shift);
+        la.finish(g.a_scale, g.a_shift);
+        lb.finish(g.b_scale, g.b_shift);
         la.store(lds);
         lb.store(lds + SZA);
         if (want_rowsum) {
@@ -274,6 +303,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         }
         if (more) {
             float *An = lds + (stage ^ 1) * (SZA + SZB);
+            la.finish(g.a_scale, g.a_shift);
+            lb.finish(g.b_scale, g.b_shift);
             la.store(An);
             lb.store(An + SZA);
             if (want_rowsum) {

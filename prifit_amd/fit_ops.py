@@ -31,10 +31,11 @@ def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
 def _skinny_splitk(M, N, K, batch):
     """Split of the reduction for [M, N] = [M, K] [K, N] products with few, deep output tiles (mean-shift
     backward: 16 x 1 x 24 tiles of 64 k-tiles on 256 CUs): aim at >= 6 workgroups per CU so that the two resident
-    ones per CU stay busy to the end; measured 345 -> 308 us (NN) and 327 -> 286 us (TN) at B=24, N=2048, D=128."""
+    ones per CU stay busy to the end.  At B=24, N=2048, D=128 (384 tiles) with the tile loads truly in flight: NN 278 (sk 1),
+    232 (sk 2), 243 (sk 4), 270 us (sk 8); TN 286 / 237 / 249 / 278 -> aim at ~768 workgroups (sk = 2)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     sk = 1
-    while tiles * sk < 1536 and (K // 32) // (2 * sk) >= 8:
+    while tiles * sk < int(__import__("os").environ.get("PRIFIT_SKINNY_WGS", "768")) and (K // 32) // (2 * sk) >= 8:
         sk *= 2
     return sk
 
