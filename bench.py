@@ -215,7 +215,7 @@ def main():
         detail = {}
         for name, (n, ms, work) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
             per = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps, "avg_us": 1e3 * ms / max(n, 1)}
-            if name.startswith("gemm") and not name.startswith("gemm_stream"):
+            if (name.startswith("gemm") and not name.startswith("gemm_stream")) or name.startswith("ms_fused"):
                 per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s")
             else:
                 per.update(bound="hbm", achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
@@ -229,7 +229,10 @@ def main():
             traffic = None
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh)["families"].get(dom, {}).get("hbm_bytes_per_launch")
+                    # (the PMC tool names kernels, the spans name call sites: the fused mean-shift kernel's two modes)
+                    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true>", "ms_fused_bwd": "ms_fused_kernel<1, false>"}
+                    fams_pmc = json.load(fh)["families"]
+                    traffic = (fams_pmc.get(dom) or fams_pmc.get(alias.get(dom, ""), {})).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],

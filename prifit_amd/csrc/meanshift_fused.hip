@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb0 + (r & 3) + 8 * (r >> 2);
-                kfv[r] = (FAST || (key < N && q_ok)) ? KTb[(size_t)key * ldk + gq] : 0.f;
+                // branch-free: clamped address, the out-of-range lanes are zeroed where the value is used (a predicated
+                // load costs a branch and a full vmcnt(0) each)
+                kfv[r] = KTb[(size_t)(key < N ? key : N - 1) * ldk + (q_ok ? gq : 0)];
             }
         }
         // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
                 if (FAST) pprev[r] = p;
                 else if (KTb && ok) KTb[(size_t)key * ldk + gq] = p;
             } else {
-                const float kf = kfv[r];
+                const float kf = ok ? kfv[r] : 0.f;
                 p = kf > kmin ? (sacc[r] + radd) * kf * rcp_b2 : 0.f;
                 if (FAST || (GSb && ok)) GSb[(size_t)key * ldk + gq] = p;
             }
