@@ -29,10 +29,16 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
     const float *r = M + row * C;
     unsigned key[VPT];
 #pragma unroll
+    // branch-free loads (clamped column), padding applied afterwards: a predicated load costs the compiler a branch and
+    // a full s_waitcnt vmcnt(0) each, which serialised the VPT loads of a row
+    float raw[VPT];
+#pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int c = lane + 64 * j;
-        key[j] = c < C ? f2key(r[c]) : 0xffffffffu;  // padding sorts last
+        raw[j] = r[c < C ? c : C - 1];
     }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) key[j] = (lane + 64 * j) < C ? f2key(raw[j]) : 0xffffffffu;  // padding sorts last
     unsigned prefix = 0;
     int kk = k;  // 1-based rank among the remaining candidates
     int rem = VPT * 64;  // candidates whose decided high bits equal `prefix`
@@ -120,8 +126,9 @@ __global__ __launch_bounds__(256) void ms_update_bwd_kernel(const float *__restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = lane + 64 * j;
-        gg[j] = c < D ? g[row * D + c] : 0.f;
-        oo[j] = c < D ? out[row * D + c] : 0.f;
+        gg[j] = g[row * D + (c < D ? c : 0)];      // branch-free loads, masked below
+        oo[j] = out[row * D + (c < D ? c : 0)];
+        if (c >= D) { gg[j] = 0.f; oo[j] = 0.f; }
         dot += gg[j] * oo[j];
     }
     dot = wave_sum_f32(dot);
