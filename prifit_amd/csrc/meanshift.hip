@@ -28,7 +28,6 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
     const int lane = threadIdx.x & 63;
     const float *r = M + row * C;
     unsigned key[VPT];
-#pragma unroll
     // branch-free loads (clamped column), padding applied afterwards: a predicated load costs the compiler a branch and
     // a full s_waitcnt vmcnt(0) each, which serialised the VPT loads of a row
     float raw[VPT];
