@@ -16,12 +16,16 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(const float *__restrict__
     const float *g = G + row * N;
     const float *xb = xx + b * N;
     const float nxi = -xb[row - b * N];
-    float v[VPT];
+    // branch-free loads (clamped column), padding afterwards: predicated loads are serialised by the compiler
+    float v[VPT], gv[VPT], xv[VPT];
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int c = lane + 64 * j;
-        v[j] = c < N ? (nxi - (-2.0f * g[c])) - xb[c] : -INFINITY;
+        gv[j] = g[c < N ? c : N - 1];
+        xv[j] = xb[c < N ? c : N - 1];
     }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) v[j] = (lane + 64 * j) < N ? (nxi - (-2.0f * gv[j])) - xv[j] : -INFINITY;
     for (int t = 0; t < k; ++t) {
         float best = -INFINITY;
         int bi = 0x7fffffff;
