@@ -160,9 +160,15 @@ __global__ __launch_bounds__(256) void nms_owner_kernel(const float *__restrict_
     const float *r = dist + row * N;
     float best = INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane; c < N; c += 64) {
-        const float v = r[c];
-        if (v < best) { best = v; bi = c; }
+    for (int c0 = lane; c0 < N; c0 += 64 * 8) {  // eight independent loads in flight, then the ordered compares
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = c0 + 64 * j; v[j] = r[c < N ? c : N - 1]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + 64 * j;
+            if (c < N && v[j] < best) { best = v[j]; bi = c; }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -191,9 +197,17 @@ __global__ __launch_bounds__(256) void nms_pick_kernel(const float *__restrict__
     const int32_t *cn = counts + b * N;
     const float thr = bw[b];
     int best = 0, bi = 0x7fffffff;
-    for (int c = lane; c < N; c += 64) {
-        const int v = r[c] < thr ? cn[c] : 0;
-        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    for (int c0 = lane; c0 < N; c0 += 64 * 8) {  // branch-free loads of both rows, eight columns in flight
+        float d[8];
+        int n[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = c0 + 64 * j; const int cc = c < N ? c : N - 1; d[j] = r[cc]; n[j] = cn[cc]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + 64 * j;
+            const int v = d[j] < thr ? n[j] : 0;
+            if (c < N && (v > best || (v == best && c < bi))) { best = v; bi = c; }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
