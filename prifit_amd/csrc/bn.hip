@@ -139,14 +139,22 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float *__restrict__
         float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         int4 bi = make_int4(0, 0, 0, 0);
         const float *row = Y + gidx * K * ldy + c;
-        for (int k = 0; k < K; ++k) {
-            const float4 y = ld4g(row + (long long)k * ldy);
-            const float vx = fmaf(y.x, s.x, t.x), vy = fmaf(y.y, s.y, t.y), vz = fmaf(y.z, s.z, t.z),
-                        vw = fmaf(y.w, s.w, t.w);
-            if (vx > best.x) { best.x = vx; bi.x = k; }
-            if (vy > best.y) { best.y = vy; bi.y = k; }
-            if (vz > best.z) { best.z = vz; bi.z = k; }
-            if (vw > best.w) { best.w = vw; bi.w = k; }
+        for (int k0 = 0; k0 < K; k0 += 8) {  // eight independent row loads in flight, then the ordered compares
+            float4 yv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yv[j] = ld4g(row + (long long)(k0 + j < K ? k0 + j : K - 1) * ldy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                if (k >= K) break;
+                const float4 y = yv[j];
+                const float vx = fmaf(y.x, s.x, t.x), vy = fmaf(y.y, s.y, t.y), vz = fmaf(y.z, s.z, t.z),
+                            vw = fmaf(y.w, s.w, t.w);
+                if (vx > best.x) { best.x = vx; bi.x = k; }
+                if (vy > best.y) { best.y = vy; bi.y = k; }
+                if (vz > best.z) { best.z = vz; bi.z = k; }
+                if (vw > best.w) { best.w = vw; bi.w = k; }
+            }
         }
         st4g(out + gidx * ldo + c,
              make_float4(act(best.x, slope), act(best.y, slope), act(best.z, slope), act(best.w, slope)));
