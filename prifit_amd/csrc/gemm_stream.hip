@@ -99,6 +99,15 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
     const int tiles = (g.M + SBM - 1) / SBM;
     float4 st[NV];
     float4 st_pool = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-thread element offsets of its NV float4 inside a tile (32-bit: the launcher checks M * lda < 2^31)
+    unsigned aoff[NV];
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const int id = threadIdx.x + 256 * p;
+        const int row = id / (K / 4), c4 = id - row * (K / 4);
+        aoff[p] = (unsigned)row * (unsigned)g.lda + 4u * c4;
+    }
+    const unsigned last_row_off = (unsigned)(g.M - 1) * (unsigned)g.lda;
     auto load_tile = [&](int tile) {
         const int m0 = tile * SBM;
         if (POOL && threadIdx.x < 2 * (K / 4)) {  // the (arg, T) rows of this tile's pooling group: 2 x K values
@@ -106,12 +115,17 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
             const float *src = which ? g.pool_T : reinterpret_cast<const float *>(g.pool_arg);
             st_pool = ld4(src + (long long)(m0 / g.pool_K) * K + 4 * c4);
         }
+        const float *At = g.A + (long long)m0 * g.lda;   // wave-uniform tile base
+        const bool full = m0 + SBM <= g.M;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            const int id = threadIdx.x + 256 * p;
-            const int row = id / (K / 4), c4 = id - row * (K / 4);
-            const int gr = m0 + row;
-            st[p] = ld4(g.A + (long long)(gr < g.M ? gr : g.M - 1) * g.lda + 4 * c4);
+            unsigned o = aoff[p];
+            if (!full) {  // tail tile: rows beyond M re-read the last row (zeroed at the LDS store)
+                const int id = threadIdx.x + 256 * p;
+                const int row = id / (K / 4), c4 = id - row * (K / 4);
+                if (m0 + row >= g.M) o = last_row_off - (unsigned)m0 * (unsigned)g.lda + 4u * c4;
+            }
+            st[p] = ld4(At + o);
         }
     };
     auto store_tile = [&](int tile, float *dst, int stage) {
@@ -464,7 +478,8 @@ extern "C" {
 
 int prifit_gemm_stream_supported(int layout, int M, int N, int K)
 {
-    return (layout == 0 || layout == 1) && M >= 32768 && (N == 64 || N == 96 || N == 128) &&
+    // (M < 2^24: the tile loads use 32-bit element offsets, M * lda < 2^31 with lda <= 128 .. checked again per call)
+    return (layout == 0 || layout == 1) && M >= 32768 && M < (1 << 24) && (N == 64 || N == 96 || N == 128) &&
            (K == 64 || K == 96 || K == 128);
 }
 
@@ -472,6 +487,7 @@ int prifit_gemm_stream_slabs(int M, int K) { return stream_grid(M, K); }
 
 static int stream_launch(StreamArgs &g, int layout, void *stream)
 {
+    if ((long long)g.M * g.lda >= 2147483647LL) return PRIFIT_EINVAL;  // 32-bit tile offsets
     const int grid = stream_grid(g.M, g.K);
     hipStream_t st = as_stream(stream);
     if (g.N == 64) return layout == 0 ? launch_k<2, true>(g, grid, st) : launch_k<2, false>(g, grid, st);
