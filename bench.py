@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark of the PRIFIT hot path on MI355X (contract: see the task statement).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
 
 One "step" = one training iteration of the hot path over one batch of B=24 synthetic 2048-point
 clouds per GPU: zero_grad, forward, loss, backward, gradient all-reduce (N>1, RCCL), Adam step.
@@ -9,7 +9,14 @@ clouds per GPU: zero_grad, forward, loss, backward, gradient all-reduce (N>1, RC
   c3: c2's network + mean-shift (10 it, <=25 clusters) + ellipsoid fit + convex loss (configs[2],
       the configuration the metric is quoted on) -- the self-supervised step of
       train_partseg_shapenet.py:436-451.
+  c5: DGCNN backbone (k=20) + the same fit path                (configs[4])
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no RANK in the environment: this process only LAUNCHES -- it starts N copies of
+itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (prifit_amd/launch.py), before anything
+has touched the GPU, waits for them and exits with their code.  Under `python -m torch.distributed.run` (RANK
+already set) it is one of the ranks.  The reference's counterpart is `nn.DataParallel(classifier)`
+(train_partseg_shapenet.py:248-250).
 """
 import argparse
 import gc
@@ -20,11 +27,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# NOTE: torch is imported inside the functions: the launcher parent must stay off the GPU, and the oracle/
+# directory is put on the path by the cpu_baseline leg only (it is the CPU baseline being timed there).
 
 B_PER_GPU = 24
 NPTS = 2048
@@ -34,10 +38,19 @@ HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured by a float4 cop
 # launches of the ball-query + grouping stage: sa_group_linear = ball query + grouping + first MLP layer of a
 # set-abstraction level in one launch (default); the others run with PRIFIT_SA_FUSED=0 / PRIFIT_SA_LINEARITY=0
 GROUPING_FAMILIES = ("sa_group_linear", "ball_query", "group_gather", "gather_linear")
+WORKLOADS = {
+    "c2": "configs[1]: PointNet++-MSG part-seg, B=24x2048 per GPU, seg loss only, fwd+bwd+Adam",
+    "c3": "configs[2]: PointNet++-MSG + mean-shift(10 it, <=25 clusters) + ellipsoid fit + convex loss, "
+          "B=24x2048 per GPU, fwd+bwd+Adam",
+    "c5": "configs[4]: DGCNN (k=20) + mean-shift(10 it, <=25 clusters) + ellipsoid fit + convex loss, "
+          "B=24x2048 per GPU, fwd+bwd+Adam",
+}
 
 
 def make_inputs(workload, rank, device):
-    import synth
+    import numpy as np
+    import torch
+    from prifit_amd import synth
     seed = 1000 * rank  # seed 0 on rank 0
     if workload == "c2":
         xyz = torch.from_numpy(synth.cloud("cube", B_PER_GPU, NPTS, seed)).transpose(1, 2).contiguous()
@@ -52,102 +65,163 @@ def make_inputs(workload, rank, device):
     return {k: v.to(device) for k, v in d.items()}
 
 
-def build_model(device):
-    import synth
-    from prifit_amd.models import pointnet2_part_seg_msg as M
+def build_model(device, workload="c3"):
+    import torch
+    from prifit_amd import synth
     torch.manual_seed(0)
+    if workload == "c5":
+        from prifit_amd.src import dgcnn as D
+        return D.get_model(NUM_PARTS, k=20).to(device).train(), None
+    from prifit_amd.models import pointnet2_part_seg_msg as M
     net = M.get_model(NUM_PARTS)
     synth.xavier_like_trainer(net)  # train_partseg_shapenet.py:240-247
     return net.to(device).train(), M
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload):
     """The oracle (CPU restatement of the reference, kind "port") on a bounded sample of the same
-    workload: B=4 shapes, 1 warm-up + 2 timed forward+backward passes, all host cores."""
+    workload: B=4 shapes, 1 warm-up + 3 timed forward+backward passes, host cores of this box."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import prifit_oracle as orc
-    import synth
+    from prifit_amd import synth
     cores = min(os.cpu_count() or 1, 32)  # torch-CPU oversubscribes badly beyond ~32 threads on these small ops
     torch.set_num_threads(cores)
     Bs = 4
     torch.manual_seed(0)
-    net = orc.OracleMSGPartSeg(NUM_PARTS)
-    synth.xavier_like_trainer(net)
-    net.train()
     xyz = torch.from_numpy(synth.cloud("cube" if workload == "c2" else "blobs", Bs, NPTS, 0)).transpose(1, 2).contiguous()
     cls = torch.zeros(Bs, 1, 16)
     target = torch.from_numpy(synth.labels(Bs, NPTS, NUM_PARTS, 0))
     s = (torch.from_numpy(synth.fps_start(Bs, NPTS, 0)), torch.from_numpy(synth.fps_start(Bs, 512, 100)))
-    extra = {}
-    if workload == "c3":
+    fit = dict(quantile=0.05, iterations=10, max_num_clusters=25)
+    if workload != "c2":
         cham = torch.from_numpy(synth.cloud("blobs", Bs, 5000, 0))
         sel = np.random.default_rng(1).choice(5000, NPTS, replace=False)
         xyz = cham[:, sel].transpose(1, 2).contiguous()
-        extra = dict(chamfer_points=cham.transpose(1, 2).contiguous(), include_convex_loss=True, quantile=0.05,
-                     msc_iterations=10, max_num_clusters=25)
+        cham_t = cham.transpose(1, 2).contiguous()
+    if workload == "c5":
+        net = orc.OracleDGCNGn(emb_size=128, num_channels=3, nn_nb=20).train()
 
-    def one():
-        net.zero_grad()
-        out = net(xyz, cls, fps_start=s, **extra)
-        loss = orc.seg_loss(out[0].reshape(-1, NUM_PARTS), target.view(-1)) if workload == "c2" else out[3].mean()
-        loss.backward()
+        def one():
+            net.zero_grad()
+            emb, _ = net(xyz)                                  # [B,N,128] (src/dgcnn.py:225-267)
+            total = orc.convex_loss(xyz, cham_t, emb.transpose(1, 2), **fit)[0]
+            total.mean().backward()
+    else:
+        net = orc.OracleMSGPartSeg(NUM_PARTS)
+        synth.xavier_like_trainer(net)
+        net.train()
+        extra = {}
+        if workload == "c3":
+            extra = dict(chamfer_points=cham_t, include_convex_loss=True, quantile=0.05, msc_iterations=10,
+                         max_num_clusters=25)
+
+        def one():
+            net.zero_grad()
+            out = net(xyz, cls, fps_start=s, **extra)
+            loss = orc.seg_loss(out[0].reshape(-1, NUM_PARTS), target.view(-1)) if workload == "c2" else out[3].mean()
+            loss.backward()
 
     one()
     ts = []
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         one()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
-    return {"value": Bs / t, "unit": "shapes/s", "cores": cores, "kind": "port",
-            "sample": "oracle/prifit_oracle.py (torch-CPU restatement, %d threads), B=%d x %d pts, %s step fwd+bwd, "
-                      "median of 2 after 1 warm-up (%.2f s per pass)" % (cores, Bs, NPTS, workload, t)}
+    return {"value": Bs / t, "unit": "shapes/s", "cores": cores, "kind": "port", "cpu": _cpu_model(), "B": Bs,
+            "passes": 3, "seconds_per_pass": t,
+            "sample": "oracle/prifit_oracle.py (torch-CPU restatement of the reference, %d threads on %s), B=%d x %d "
+                      "pts, %s step fwd+bwd, median of 3 timed passes after 1 warm-up (%.2f s per pass)"
+                      % (cores, _cpu_model(), Bs, NPTS, workload, t)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 10 warm-up steps bring the clocks and the caching allocator to steady state (with 3 the first timed
-    # steps still run ~10 % slow); 50 timed steps = ~2 s
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("PRIFIT_WORKLOAD", "c3"), choices=["c2", "c3"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def _traffic_per_launch(dom):
+    """HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 cannot run inside this
+    process): profiles/r0X_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE, see the file's "source"."""
+    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true>", "ms_fused_bwd": "ms_fused_kernel<1, false>"}
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                fams_pmc = json.load(fh)["families"]
+            rec = fams_pmc.get(dom) or fams_pmc.get(alias.get(dom, ""), {})
+            if rec.get("hbm_bytes_per_launch") is not None:
+                return rec["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    trace = os.environ.get("PRIFIT_BENCH_TRACE")     # tests: each rank leaves a line saying who it is
+    if trace:
+        with open("%s.%d" % (trace, rank), "w") as f:
+            f.write("rank %d of %d local %d" % (rank, world, local))
+    if "RANK" in os.environ and args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the environment wins" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    # under torch.distributed.run (RANK set) the RCCL path is taken even with one rank, so that a 1-GPU box
-    # rehearses exactly the code the N>1 runs execute (pack, all-reduce, broadcast, barrier)
+    # PRIFIT_BENCH_SHARE_GPU=1 (rehearsal of the N>1 code path on a one-GPU box, with PRIFIT_DIST_BACKEND=gloo):
+    # ranks share the visible devices round-robin.  Never used for a reported number.
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("PRIFIT_BENCH_SHARE_GPU", "0") == "1"
+    if local >= ndev and not share:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, ndev))
+    local_dev = local % ndev
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
+    # under torch.distributed.run / the launcher (RANK set) the RCCL path is taken even with one rank, so that a
+    # 1-GPU box rehearses exactly the code the N>1 runs execute (pack, all-reduce, broadcast, barrier)
     use_dist = world > 1 or "RANK" in os.environ
+    backend = os.environ.get("PRIFIT_DIST_BACKEND", "nccl")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from prifit_amd import _lib, profiler
+    from prifit_amd import _lib, profiler, build
     from prifit_amd.ddp import FlatGradBucket
     if not os.path.exists(_lib.LIB_PATH):
-        from prifit_amd import build
-        build.build_library()
+        build.build_library()   # file-locked + atomic rename: safe when every rank gets here at once
 
-    net, M = build_model(device)
+    net, M = build_model(device, args.workload)
     bucket = FlatGradBucket(net)
     bucket.broadcast_parameters(0)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, fused=True)
     data = make_inputs(args.workload, rank, device)
-    crit = M.get_loss()
+    crit = M.get_loss() if M is not None else None
 
     from prifit_amd.train_step import SpeculativeRunner
     runner = SpeculativeRunner(net)
+    fit_kw = dict(chamfer_points=data.get("chamfer"), include_convex_loss=True, quantile=0.05, msc_iterations=10,
+                  max_num_clusters=25)
 
     def selfsup_fwd_bwd():
-        out = net(data["xyz"], data["cls"], chamfer_points=data["chamfer"], include_convex_loss=True,
-                  quantile=0.05, msc_iterations=10, max_num_clusters=25, fps_start=(data["s1"], data["s2"]))
+        if args.workload == "c5":
+            out = net(data["xyz"], None, **fit_kw)
+        else:
+            out = net(data["xyz"], data["cls"], fps_start=(data["s1"], data["s2"]), **fit_kw)
         loss = out[3].mean()
         loss.backward()
         return loss
@@ -193,8 +267,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_host = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        t_host += time.perf_counter() - h0      # host time to ENQUEUE the step (includes waiting on a full queue)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -216,67 +293,82 @@ def main():
         for name, (n, ms, work) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
             per = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps, "avg_us": 1e3 * ms / max(n, 1)}
             if (name.startswith("gemm") and not name.startswith("gemm_stream")) or name.startswith("ms_fused"):
-                per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s")
+                per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                           flops_per_step=work / args.steps, flops_per_launch=work / max(n, 1))
             else:
-                per.update(bound="hbm", achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+                per.update(bound="hbm", achieved=work / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                           bytes_per_step=work / args.steps, bytes_per_launch=work / max(n, 1))
             per["frac"] = per["achieved"] / per["peak"]
             detail[name] = per
         if detail:
             dom = next(iter(detail))
             d = detail[dom]
-            # HBM bytes per launch of that family from the committed PMC passes (rocprofv3 cannot run inside this
-            # process): profiles/r01_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE, see the file's "source"
-            traffic = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    # (the PMC tool names kernels, the spans name call sites: the fused mean-shift kernel's two modes)
-                    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true>", "ms_fused_bwd": "ms_fused_kernel<1, false>"}
-                    fams_pmc = json.load(fh)["families"]
-                    traffic = (fams_pmc.get(dom) or fams_pmc.get(alias.get(dom, ""), {})).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+            traffic, traffic_src = _traffic_per_launch(dom)
             roof = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": traffic, "avg_us": d["avg_us"],
+                    "frac": d["frac"], "traffic": traffic, "traffic_source": traffic_src, "avg_us": d["avg_us"],
                     "launches_per_step": d["launches_per_step"]}
+            # the numerator, so that the line can be re-derived: achieved = work_per_launch / avg_us
+            for k in ("flops_per_step", "flops_per_launch", "bytes_per_step", "bytes_per_launch"):
+                if k in d:
+                    roof[k] = d[k]
         grp = [detail[k] for k in detail if k in GROUPING_FAMILIES]
         grouping = None
         if grp:
             ms = sum(g["ms_per_step"] for g in grp)
             gb = sum(g["achieved"] * g["ms_per_step"] * 1e-3 for g in grp)
             # compulsory traffic of ball query + MATERIALISED grouping of the MSG backbone per shape
-            # (the work the reference does); the launches above do the same grouping job with fewer bytes
+            # (the work the reference does) -- THE headline fraction of the >= 0.5-of-HBM target
             sa1 = 12 * (2048 + 512) + sum(4 * 512 * k + 4 * 512 * k * 6 for k in (32, 64, 128))
             sa2 = 12 * (512 + 128) + 4 * 512 * 320 + sum(4 * 128 * k + 4 * 128 * k * 323 for k in (64, 128))
             survey_gb = B_PER_GPU * (sa1 + sa2) / 1e9
-            grouping = {"bound": "hbm", "achieved": gb / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gb / (ms * 1e-3) / HBM_PEAK_GBS, "ms_per_step": ms,
-                        "survey_formula": {"gbytes_per_step": survey_gb, "equivalent_gbs": survey_gb / (ms * 1e-3),
-                                           "frac": survey_gb / (ms * 1e-3) / HBM_PEAK_GBS,
-                                           "note": "bytes of the reference's materialised grouping (SURVEY.md 8d) / time "
-                                                   "of the launches that now do that job; with PRIFIT_SA_LINEARITY=0 the "
-                                                   "launches move exactly these bytes"},
-                        "note": "ball-query + grouping launches (sa_group_linear = ball query + grouping + first MLP layer of a "
-                                "set-abstraction level in one launch; its grouped-out term is the C1-wide first-layer "
-                                "output it writes), algorithmic bytes of SURVEY.md 8(d)"}
+            grouping = {"bound": "hbm", "achieved": survey_gb / (ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": survey_gb / (ms * 1e-3) / HBM_PEAK_GBS, "ms_per_step": ms,
+                        "gbytes_per_step": survey_gb,
+                        "note": "SURVEY.md 8(d) formula: bytes of the reference's ball query + materialised grouping "
+                                "(858 MB per B=24 batch) / time of the launches that now do that job",
+                        "own_bytes": {"gbytes_per_step": gb, "achieved": gb / (ms * 1e-3),
+                                      "frac": gb / (ms * 1e-3) / HBM_PEAK_GBS,
+                                      "note": "bytes the launches really move (sa_group_linear = ball query + grouping + "
+                                              "first MLP layer in one launch: clouds, index lists, C1-wide first-layer "
+                                              "rows, U / Vc)"}}
         line = {
             "metric": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG+ellipsoid fit",
             "value": value, "unit": "shapes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"c2": "configs[1]: PointNet++-MSG part-seg, B=24x2048 per GPU, seg loss only, "
-                                          "fwd+bwd+Adam (fit path not yet in the timed step)",
-                                    "c3": "configs[2]: PointNet++-MSG + mean-shift(10 it, <=25 clusters) + ellipsoid "
-                                          "fit + convex loss, B=24x2048 per GPU, fwd+bwd+Adam"}[args.workload],
+            "config": {"workload": WORKLOADS[args.workload],
                        "global_batch": world * B_PER_GPU, "points": NPTS, "parallelism": "dp%d" % world,
                        "loss": float(loss.item())},
             "roofline": roof, "roofline_grouping": grouping, "kernels": detail,
             "speculation_fallbacks": runner.fallbacks,
+            "host_enqueue_ms_per_step": 1e3 * t_host / args.steps,
         }
+        if backend != "nccl" and use_dist:
+            line["rehearsal"] = "backend=%s%s: NOT a reportable number" % (backend, ", ranks share GPUs" if share else "")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    # defaults: 10 warm-up steps bring the clocks and the caching allocator to steady state (with 3 the first timed
+    # steps still run ~10 % slow); 50 timed steps = ~2 s
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("PRIFIT_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launcher: nothing in this branch imports torch or loads the HIP library
+        from prifit_amd import build, launch
+        build.build_library()            # once, before the ranks start (hipcc only; a no-op when up to date)
+        sys.exit(launch.relaunch_self(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE -- runs only in the build container (needs /root/reference):
     python oracle/make_golden.py            # check oracle vs reference, then (re)write fixtures
 
 A fixture is data only: seeds / small inputs and the reference's outputs.  Inputs that are large
-are regenerated from a seed by `oracle/synth.py` (the build's own generator) on both sides.
+are regenerated from a seed by `prifit_amd/synth.py` (the build's own generator) on both sides.
 """
 import contextlib
 import importlib
@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 import refshim  # noqa: E402
 import prifit_oracle as orc  # noqa: E402
-import synth  # noqa: E402
+from prifit_amd import synth  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 

@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 
 import refshim  # noqa: E402
 import prifit_oracle as orc  # noqa: E402
-import synth  # noqa: E402
+from prifit_amd import synth  # noqa: E402
 
 
 def fit_inputs(B, N, D, seed, M=5000, noise=0.03):

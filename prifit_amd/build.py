@@ -49,8 +49,21 @@ def _stale(target, deps):
 
 
 def build_library(force=False, verbose=False):
+    """Compile stale objects and link the shared object.  Safe to call from several processes at once (the ranks of
+    a torch.distributed.run job): the whole build runs under an exclusive file lock and the library is linked to a
+    temporary name and renamed into place, so nobody ever dlopens a half-written file."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "prifit_hip.h"))
     hipcc = _hipcc()
@@ -76,7 +89,9 @@ def build_library(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs)
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -130,12 +130,14 @@ class PartNormalDataset(torch.utils.data.Dataset):
         if split not in wanted:
             raise ValueError('Unknown split: %s' % split)
         self.datapath = []
+        self.meta = {}      # {category: [paths]} -- the trainer builds the self-supervised exclude list from it
         for item in self.cat:
             dir_point = os.path.join(root, self.cat[item])
             fns = [fn for fn in sorted(os.listdir(dir_point)) if fn[0:-4] in wanted[split]]
             if k_shot > 0 and len(fns) > k_shot:
                 fns = list(self.rng.choice(fns, k_shot, replace=False))   # random few-shot subset (:77-79)
-            self.datapath += [(item, os.path.join(dir_point, os.path.splitext(fn)[0] + '.txt')) for fn in fns]
+            self.meta[item] = [os.path.join(dir_point, os.path.splitext(fn)[0] + '.txt') for fn in fns]
+            self.datapath += [(item, fn) for fn in self.meta[item]]
         self.classes = {k: self.classes_original[k] for k in self.cat}
         self.seg_classes = SEG_CLASSES
         self.cache, self.cache_size = {}, 20000
@@ -177,13 +179,18 @@ class ACDSelfSupDataset(torch.utils.data.Dataset):
         subfolders = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
         self.classes_original = dict(zip(subfolders, range(len(subfolders))))
         self.cat = {k: v for k, v in self.classes_original.items() if class_choice is None or k in class_choice}
-        exclude = set(os.path.basename(x) for x in exclude_fns)
+        # overlap removal compares extension-less tokens: the trainer passes the labeled datasets' '.txt' paths
+        # (train_partseg_shapenet.py:194-210) against '.npy' files here (ShapeNetDataLoader.py:305-311)
+        exclude = set(os.path.splitext(os.path.basename(x))[0] for x in exclude_fns)
         self.datapath = []
+        self.meta = {}
         for item in self.cat:
-            fns = [fn for fn in sorted(os.listdir(os.path.join(root, item))) if fn.endswith('.npy') and fn not in exclude]
+            fns = [fn for fn in sorted(os.listdir(os.path.join(root, item)))
+                   if fn.endswith('.npy') and os.path.splitext(fn)[0] not in exclude]
             if k_shot > 0 and len(fns) > k_shot:
                 fns = list(self.rng.choice(fns, k_shot, replace=False))
-            self.datapath += [(item, os.path.join(root, item, fn)) for fn in fns]
+            self.meta[item] = [os.path.join(root, item, fn) for fn in fns]
+            self.datapath += [(item, fn) for fn in self.meta[item]]
         self.classes = {k: self.classes_original[k] for k in self.cat}
         self.cache = {}
 

@@ -18,7 +18,14 @@ class FlatGradBucket:
     Gradients are produced by autograd as ordinary per-parameter tensors (zero() only drops the old
     ones, so backward *writes* instead of accumulating); `allreduce()` packs them into the flat fp32
     bucket with one multi-tensor copy, runs ONE all-reduce, scales by 1/world and points every
-    `p.grad` at its slice of the bucket.  Without an initialised process group nothing is copied or exchanged."""
+    `p.grad` at its slice of the bucket.  Without an initialised process group nothing is exchanged.
+
+    Which parameters the optimizer sees is the reference's (torch 1.6 `optimizer.zero_grad()`,
+    train_partseg_shapenet.py:383,436, zero-FILLS existing gradients): a parameter that has received a
+    gradient in ANY earlier step keeps a (zero) gradient in the steps where autograd produces none for
+    it -- `extra_conv_emb` in supervised steps, `conv2` in self-supervised ones -- so Adam still applies
+    its weight decay and stale moments there; a parameter that never had one stays `None` and is
+    skipped.  The same rule holds with 1 and with N ranks, so the trajectories agree."""
 
     def __init__(self, module, process_group=None):
         self.module = module
@@ -32,6 +39,7 @@ class FlatGradBucket:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.seen = [False] * len(self.params)   # has this parameter ever had a gradient (see the class docstring)
         self.dist = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist else 1
 
@@ -39,19 +47,35 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
+    def _mark_seen(self):
+        for i, p in enumerate(self.params):
+            if p.grad is not None:
+                self.seen[i] = True
+
     def pack(self):
-        """Copy the per-parameter gradients into the bucket (zeros for parameters that got none)."""
+        """Copy the per-parameter gradients into the bucket (zeros for parameters that got none) and point every
+        `p.grad` of a parameter that has ever had a gradient at its slice."""
+        self._mark_seen()
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         if len(have) != len(self.params):
             self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        for v, p in zip(self.views, self.params):
-            p.grad = v
+        for v, p, s in zip(self.views, self.params, self.seen):
+            p.grad = v if s else None
 
     def allreduce(self):
-        """Average gradients over ranks: one sum all-reduce of the flat bucket, then scale by 1/world."""
+        """Average gradients over ranks: one sum all-reduce of the flat bucket, then scale by 1/world.
+        Single process: nothing moves; parameters that got no gradient this step but had one before get their
+        (zeroed) bucket slice as gradient."""
         if not self.dist:
+            self._mark_seen()
+            missing = [v for v, p, s in zip(self.views, self.params, self.seen) if s and p.grad is None]
+            if missing:
+                torch._foreach_zero_(missing)
+                for v, p, s in zip(self.views, self.params, self.seen):
+                    if s and p.grad is None:
+                        p.grad = v
             return
         self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -1,4 +1,5 @@
-"""Seeded synthetic inputs (numpy default_rng) shared by the oracle, the tests and bench.py.
+"""Seeded synthetic inputs (numpy default_rng) shared by the oracle harness, the tests and bench.py (lives in the package, not under oracle/:
+the product entry points never import from oracle/).
 
 TEST/BENCH INFRASTRUCTURE: pure data generation, no reference code and no model code.
 Distributions follow SURVEY.md section 8(d):

@@ -45,6 +45,7 @@ class SpeculativeRunner:
             groups.setdefault(b.dtype, []).append(b)
         self.bufs = list(groups.values())
         self.snap = [[torch.empty_like(b) for b in g] for g in self.bufs]
+        self.model = model
         self.fallbacks = 0
 
     def run(self, fn, reset):
@@ -52,6 +53,10 @@ class SpeculativeRunner:
 
         for dst, src in zip(self.snap, self.bufs):
             torch._foreach_copy_(dst, src)
+        # python-side state the forward mutates: the entropy weight schedule `beta *= 0.99` per convex-loss forward
+        # (models/pointnet2_part_seg_msg.py:96-99) must advance once per ACCEPTED step, not once per attempt
+        beta = getattr(self.model, "beta", None)
+        rng = torch.cuda.get_rng_state() if torch.cuda.is_available() else None
         with fit_ops.speculative() as spec:
             out = fn()
         if spec.ok():
@@ -59,6 +64,10 @@ class SpeculativeRunner:
         self.fallbacks += 1
         for dst, src in zip(self.bufs, self.snap):
             torch._foreach_copy_(dst, src)
+        if beta is not None:
+            self.model.beta = beta
+        if rng is not None:
+            torch.cuda.set_rng_state(rng)   # dropout masks / random tables of the retried step = those of the first try
         reset()
         return fn()
 
@@ -73,6 +82,9 @@ class Trainer:
                                           weight_decay=decay_rate,
                                           fused=bool(fused_adam and next(model.parameters()).is_cuda))
         self.bucket = FlatGradBucket(model)
+        # DataParallel replicates module 0's parameters and buffers onto every GPU at each forward
+        # (train_partseg_shapenet.py:248-250); with one process per GPU the ranks start from rank 0's model instead
+        self.bucket.broadcast_parameters(0)
         self.speculative = SpeculativeRunner(model) if next(model.parameters()).is_cuda else None
         self.epoch = 0
         self.train_acc = 0.0
@@ -146,6 +158,12 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints (upstream :467-475, :263-274)
     def save(self, path):
+        """Collective under torch.distributed: every rank calls it, rank 0's BatchNorm statistics win
+        ("replica 0" of DataParallel) and only rank 0 writes the file."""
+        import torch.distributed as dist
+        self.bucket.sync_buffers(0)
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return
         torch.save({"epoch": self.epoch, "train_acc": self.train_acc, "model_state_dict": self.model.state_dict(),
                     "optimizer_state_dict": self.optimizer.state_dict()}, path)
 
@@ -154,4 +172,5 @@ class Trainer:
         self.model.load_state_dict(ck["model_state_dict"])
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
         self.epoch = ck["epoch"]
+        self.bucket.broadcast_parameters(0)
         return ck

@@ -103,6 +103,14 @@ def test_dataset_readers(tmp_path):
             np.save(acd / sub / ("%s%d.npy" % (sub, i)), np.concatenate([rng.normal(size=(80, 3)), rng.integers(0, 9, size=(80, 1))], 1))
     ad = D.ACDSelfSupDataset(str(acd), npoints=40, exclude_fns=["x/planes1.npy"], rng=np.random.default_rng(3))
     assert len(ad) == 3
+    # the trainer passes the labeled datasets' '.txt' paths (train_partseg_shapenet.py:194-210): tokens are compared
+    # without their extension (ShapeNetDataLoader.py:305-311), and both datasets expose `.meta` for that purpose
+    labeled = ["/some/where/chairs0.txt", "/else/planes1.txt"]
+    ad2 = D.ACDSelfSupDataset(str(acd), npoints=40, exclude_fns=labeled)
+    assert sorted(os.path.basename(f) for _, f in ad2.datapath) == ["chairs1.npy", "planes0.npy"]
+    assert sorted(ad2.meta) == ["chairs", "planes"] and sum(len(v) for v in ad2.meta.values()) == 2
+    assert sorted(ds.meta) == ["Airplane", "Chair"] and all(f.endswith(".txt") for v in ds.meta.values() for f in v)
+    assert [f for v in ds.meta.values() for f in v] == [f for _, f in ds.datapath]
     p, allp, cls, seg = ad[0]
     assert p.shape == (40, 3) and allp.shape == (80, 3) and abs(np.sqrt((allp ** 2).sum(1)).max() - 1.0) < 1e-5
 

@@ -1,6 +1,10 @@
 """CPU, world_size 2 over gloo: the flat-bucket gradient exchange of prifit_amd.ddp (the N>1 path of
-bench.py) averages gradients exactly like one big batch, keeps parameters in lock-step, and
-`sync_buffers` makes rank 0's BatchNorm statistics win (DataParallel semantics)."""
+bench.py / train_step.Trainer) on the REAL MSG part-segmentation network (the oracle's torch-CPU model: the
+exchange only sees parameters, gradients and buffers): the all-reduced gradient equals the mean of the two
+single-process per-shard gradients (per-replica BatchNorm statistics, no SyncBN -- DataParallel semantics,
+train_partseg_shapenet.py:248-250), parameters stay in lock-step, `sync_buffers` makes rank 0's BatchNorm statistics
+win, and Trainer itself starts every rank from rank 0's model and takes the same Adam step as one process fed the
+averaged gradient."""
 import os
 import socket
 import sys
@@ -87,3 +91,150 @@ def test_single_process_bucket_matches_plain_autograd():
         assert torch.equal(net.weight.grad, ref.weight.grad)
         bucket.pack()
         assert torch.equal(net.weight.grad, ref.weight.grad) and net.weight.grad.data_ptr() == bucket.flat.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the real network
+# ----------------------------------------------------------------------------------------------------------------
+B_SHARD, NPTS = 2, 512
+
+
+def _shard_inputs(rank):
+    sys.path.insert(0, ROOT)
+    import numpy as np  # noqa: F401
+    from prifit_amd import synth
+    xyz = torch.from_numpy(synth.cloud("surface", B_SHARD, NPTS, 40 + rank))            # [B,N,3]
+    target = torch.from_numpy(synth.labels(B_SHARD, NPTS, 50, 40 + rank))
+    s = (torch.from_numpy(synth.fps_start(B_SHARD, NPTS, 40 + rank)), torch.from_numpy(synth.fps_start(B_SHARD, 512, 50 + rank)))
+    return xyz, target, s
+
+
+def _msg_model(seed):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import prifit_oracle as orc
+    from prifit_amd import synth
+    torch.manual_seed(seed)
+    net = orc.OracleMSGPartSeg(50)
+    synth.xavier_like_trainer(net)
+    net.train()
+    net.drop1.eval()        # dropout off: its mask is the only randomness of the step
+    return net, orc
+
+
+def _shard_grads(net, orc, rank):
+    torch.set_num_threads(2)       # as in the workers: the same reduction order, so fp32 sums agree to the last bits
+    xyz, target, s = _shard_inputs(rank)
+    net.zero_grad()
+    seg = net(xyz.transpose(1, 2).contiguous(), torch.zeros(B_SHARD, 1, 16), fps_start=s)[0]
+    orc.seg_loss(seg.reshape(-1, 50), target.view(-1)).backward()
+    return [None if p.grad is None else p.grad.detach().clone() for p in net.parameters()]
+
+
+def _msg_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prifit_amd.ddp import FlatGradBucket
+    net, orc = _msg_model(100 + rank)           # different init per rank on purpose
+    bucket = FlatGradBucket(net)
+    bucket.broadcast_parameters(0)
+    xyz, target, s = _shard_inputs(rank)
+    bucket.zero()
+    seg = net(xyz.transpose(1, 2).contiguous(), torch.zeros(B_SHARD, 1, 16), fps_start=s)[0]
+    orc.seg_loss(seg.reshape(-1, 50), target.view(-1)).backward()
+    bucket.allreduce()
+    grads = [None if p.grad is None else p.grad.detach().clone().numpy() for p in net.parameters()]
+    stats_before = net.bn1.running_mean.detach().clone().numpy()
+    bucket.sync_buffers(0)
+    stats_after = net.bn1.running_mean.detach().clone().numpy()
+    out.put((rank, grads, stats_before, stats_after))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_two(worker):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=280) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+def test_msg_network_allreduce_equals_mean_of_shard_gradients():
+    (r0, g0, before0, after0), (r1, g1, before1, after1) = _run_two(_msg_worker)
+    # single-process reference: rank 0's initialisation (what the broadcast installs), each shard on its own
+    # (per-replica BatchNorm batch statistics), gradients averaged
+    net, orc = _msg_model(100)
+    ga = _shard_grads(net, orc, 0)
+    net, orc = _msg_model(100)
+    gb = _shard_grads(net, orc, 1)
+    names = [k for k, _ in net.named_parameters()]
+    for k, a, b, x0, x1 in zip(names, ga, gb, g0, g1):
+        if a is None:                      # extra_conv_emb: not on the supervised path, never had a gradient
+            assert b is None and x0 is None and x1 is None, k
+            continue
+        want = (a + b) / 2
+        assert (x0 == x1).all(), k                                              # both ranks hold the same average
+        tol = 1e-6 * max(1.0, float(want.abs().max()))
+        assert float((torch.from_numpy(x0) - want).abs().max()) <= tol, (k, float((torch.from_numpy(x0) - want).abs().max()))
+    # BatchNorm running statistics differ per rank (different shards) until sync_buffers(0): rank 0 wins
+    assert not (before0 == before1).all()
+    assert (after0 == before0).all() and (after1 == before0).all()
+
+
+def _trainer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prifit_amd.train_step import Trainer
+    net, orc = _msg_model(200 + rank)           # Trainer must start every rank from rank 0's model
+    tr = Trainer(net, learning_rate=0.001, decay_rate=1e-4)
+    real_train = net.train
+    net.train = lambda mode=True: (real_train(mode), net.drop1.eval(), net)[2]
+    xyz, target, s = _shard_inputs(rank)
+    loss, _ = tr.supervised_step(xyz, target, augment=False, fps_start=s)
+    import tempfile
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "ck_rank%d.pth" % rank)
+    tr.save(path)                               # collective: rank 0's statistics win, rank 0 alone writes
+    params = [p.detach().clone().numpy() for p in net.parameters()]
+    out.put((rank, params, net.bn1.running_mean.detach().clone().numpy(), os.path.exists(path)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainer_two_ranks_matches_one_process_on_the_averaged_gradient():
+    (_, p0, bn0, wrote0), (_, p1, bn1, wrote1) = _run_two(_trainer_worker)
+    assert wrote0 and not wrote1
+    assert (bn0 == bn1).all()
+    for a, b in zip(p0, p1):
+        assert (a == b).all(), "ranks diverged"
+    # one process: rank 0's init, averaged per-shard gradients, one Adam step (train_partseg_shapenet.py:252-259)
+    net, orc = _msg_model(200)
+    ga = _shard_grads(net, orc, 0)
+    net, orc = _msg_model(200)
+    gb = _shard_grads(net, orc, 1)
+    opt = torch.optim.Adam(net.parameters(), lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=1e-4)
+    for p, a, b in zip(net.parameters(), ga, gb):
+        p.grad = None if a is None else (a + b) / 2
+    opt.step()
+    for (k, p), got in zip(net.named_parameters(), p0):
+        # Adam's first step is lr * g / (|g| + eps): compare where the gradient is not rounding noise
+        d = (torch.from_numpy(got) - p.detach()).abs()
+        assert float(d.max()) <= 2.1e-3, k                 # |update| <= lr (1 + wd): nobody moved differently by more
+        g = p.grad
+        if g is not None:
+            big = g.abs() > 1e-3 * g.abs().max()
+            assert float(d[big].max()) < 2e-5, (k, float(d[big].max()))
+        else:
+            assert float(d.max()) == 0.0, k                # never had a gradient: Adam skips it on both sides

@@ -1,0 +1,46 @@
+"""GPU box (one MI355X): bench.py's three launch paths run the same step.
+  plain            python bench.py                       (no process group)
+  1-rank RCCL      RANK/WORLD_SIZE set by the launcher   (pack, all-reduce, broadcast, barrier over RCCL)
+  2-rank rehearsal `bench.py --gpus 2` with PRIFIT_DIST_BACKEND=gloo PRIFIT_BENCH_SHARE_GPU=1: the launcher really
+                   starts two ranks (both on the one GPU, gradients exchanged over gloo), the line says n_gpus 2 and is
+                   marked as a rehearsal.  The real thing (RCCL, one GPU per rank) needs a multi-GPU node."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+ARGS = ["--steps", "2", "--warmup", "2", "--workload", "c2", "--no-cpu-baseline"]
+
+
+def _line(cmd, env):
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 1, r.stdout[-2000:]
+    return json.loads(rows[0])
+
+
+@pytest.mark.timeout(1500)
+def test_bench_launch_paths_agree(hiplib):
+    sys.path.insert(0, ROOT)
+    from prifit_amd import launch
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    plain = _line([sys.executable, bench, "--gpus", "1"] + ARGS, base)
+    assert plain["n_gpus"] == 1 and plain["config"]["global_batch"] == 24
+    one = _line([sys.executable, bench, "--gpus", "1"] + ARGS, launch.rank_env(0, 1, launch.free_port(), base))
+    assert one["n_gpus"] == 1
+    # same seeds, same step: the loss after 4 steps agrees (split-K float atomics: reproducible to rounding only)
+    assert abs(one["config"]["loss"] - plain["config"]["loss"]) < 1e-3 * abs(plain["config"]["loss"])
+    env = dict(base, PRIFIT_DIST_BACKEND="gloo", PRIFIT_BENCH_SHARE_GPU="1")
+    with tempfile.TemporaryDirectory() as d:
+        env["PRIFIT_BENCH_TRACE"] = os.path.join(d, "t")
+        two = _line([sys.executable, bench, "--gpus", "2"] + ARGS, env)
+        assert sorted(open(os.path.join(d, f)).read() for f in os.listdir(d)) == ["rank 0 of 2 local 0", "rank 1 of 2 local 1"]
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 48 and two["config"]["parallelism"] == "dp2"
+    assert "rehearsal" in two and two["value"] > 0

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import prifit_oracle as orc
-import synth
+from prifit_amd import synth
 
 pytestmark = pytest.mark.gpu
 

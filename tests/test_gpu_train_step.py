@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import prifit_oracle as orc
-import synth
+from prifit_amd import synth
 from tests_helpers import fit_inputs
 
 pytestmark = pytest.mark.gpu

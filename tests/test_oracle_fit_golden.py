@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 import prifit_oracle as orc
-import synth
+from prifit_amd import synth
 
 
 def _t(a):

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import prifit_oracle as orc
-import synth
+from prifit_amd import synth
 
 
 def _t(a):

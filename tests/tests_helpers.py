@@ -1,7 +1,7 @@
 import numpy as np
 import torch
 
-import synth
+from prifit_amd import synth
 
 
 def fit_inputs(B, N, D, seed, M=5000, noise=0.03):

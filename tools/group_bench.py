@@ -2,7 +2,8 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import torch, synth
+import torch
+from prifit_amd import synth
 from prifit_amd import ops
 def timed(name, fn, bytes_, iters=20):
     for _ in range(3): fn()
