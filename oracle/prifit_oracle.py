@@ -564,20 +564,32 @@ def nms(centers, X, b):
     return kept, ids, labels
 
 
-def mean_shift(X, quantile, iterations):
-    """src/mean_shift.py:18-48 (eff=False)."""
+def mean_shift(X, quantile, iterations, center_ids=None):
+    """src/mean_shift.py:18-48 (eff=False).
+
+    `center_ids` (harness hook): WHICH point represents a collapsed mode is decided by last-bit noise in the
+    reference's own nms (the shifted points of a cluster agree to ~1e-7), yet the gradient enters the mean-shift
+    trajectory of exactly that point -- d loss / d X changes by O(1) with the choice (measured in
+    oracle/make_golden.py).  A harness that compares gradients passes the reference's ids; the partition is checked
+    to be the one nms found."""
     with torch.no_grad():
         bw = compute_bandwidth(X, quantile)
     Z = mean_shift_iterations(X, bw, iterations)
     with torch.no_grad():
         _, ids, labels = nms(Z, Z, bw)
+        if center_ids is not None:
+            center_ids = torch.as_tensor(center_ids, dtype=torch.long)
+            new_labels = (Z[center_ids] @ Z.t()).max(0)[1]
+            pairs = torch.unique(torch.stack([labels, new_labels], 1), dim=0)
+            assert pairs.shape[0] == ids.shape[0] == center_ids.shape[0], "center_ids describe another partition"
+            ids, labels = center_ids, new_labels
     return Z[ids], bw, labels, ids, Z
 
 
-def guard_mean_shift(X, quantile, iterations, max_num_clusters):
+def guard_mean_shift(X, quantile, iterations, max_num_clusters, center_ids=None):
     """src/ellipsoid_utils.py:9-27: double the quantile until <= max_num_clusters distinct labels."""
     while True:
-        centers, bw, labels, ids, Z = mean_shift(X, quantile, iterations)
+        centers, bw, labels, ids, Z = mean_shift(X, quantile, iterations, center_ids)
         if torch.unique(labels).shape[0] > max_num_clusters:
             quantile *= 2
         else:
@@ -592,11 +604,12 @@ def membership(centers, X, bw):
     return e / e.sum(0, keepdim=True)
 
 
-def clustering(X, quantile, iterations, max_num_clusters):
+def clustering(X, quantile, iterations, max_num_clusters, center_ids=None):
     """src/ellipsoid_utils.py:31-73 (visualize=False).  X [B,N,D] -> (list of W_b [N,K_b], list of labels)."""
     Ws, labs, info = [], [], []
     for b in range(X.shape[0]):
-        centers, bw, labels, ids, Z, q = guard_mean_shift(X[b], quantile, iterations, max_num_clusters)
+        centers, bw, labels, ids, Z, q = guard_mean_shift(X[b], quantile, iterations, max_num_clusters,
+                                                          None if center_ids is None else center_ids[b])
         Ws.append(membership(centers, X[b], bw).t())
         labs.append(labels)
         info.append({"bw": bw, "ids": ids, "Z": Z, "quantile": q})
@@ -844,7 +857,8 @@ def intersection_loss_volume_3(params_batch, points, cuboid=False):
 
 def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_clusters=25, rand_table=None,
                 canonical=False, return_info=False, include_entropy_loss=False, entropy_indices=None,
-                include_intersect_loss=False, intersect_jitter=None, alpha=1, beta=1, if_cuboid=False, **_unused):
+                include_intersect_loss=False, intersect_jitter=None, alpha=1, beta=1, if_cuboid=False, center_ids=None,
+                **_unused):
     """convex_loss.py:27-103; the optional terms (entropy, intersection, cuboid primitives) behind their flags.
     points [B,3,N], chamfer_points [B,3,M], X [B,D,N]."""
     X = F.normalize(X.permute(0, 2, 1), dim=2, p=2)
@@ -853,7 +867,7 @@ def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_
     ent = torch.zeros(1)
     if include_entropy_loss:  # convex_loss.py:59-62: a random quarter of the points (indices passed in explicitly)
         ent = entropy(X[:, entropy_indices])
-    Ws, labels, info = clustering(X, quantile, iterations, max_num_clusters)
+    Ws, labels, info = clustering(X, quantile, iterations, max_num_clusters, center_ids)
     params = fit_ellipsoids_batch(pts, Ws, rand_table, canonical)
     samples = sample_from_params(params, cuboid=if_cuboid)
     loss, parts = analytic_chamfer(params, samples, chamfer_points.permute(0, 2, 1), cuboid=if_cuboid)

@@ -44,7 +44,12 @@ def _stub(name, **attrs):
     m.__all__ = list(attrs)
     for k, v in attrs.items():
         setattr(m, k, v)
-    m.__getattr__ = lambda n: _Anything()  # type: ignore[attr-defined]
+    def _missing(n):
+        if n.startswith("__"):      # inspect.getmodule() probes __file__ of every module in sys.modules
+            raise AttributeError(n)
+        return _Anything()
+
+    m.__getattr__ = _missing  # type: ignore[attr-defined]
     sys.modules[name] = m
     return m
 

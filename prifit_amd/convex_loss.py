@@ -9,7 +9,9 @@ Explicit inputs that replace hidden randomness / absent third-party code (SURVEY
   * `rand_table`  the U[0,1) 3x3 matrices of src/ellipsoid_fitting.py:38 ([3,3] shared or [B,KM,3,3]);
                   drawn with torch.rand when omitted, like upstream;
   * `canonical`   pin the SVD column signs (largest component positive);
-  * the surface sampler is the build's deterministic Fibonacci (U,V) table (trimesh is not used).
+  * the surface sampler is the build's deterministic Fibonacci (U,V) table (trimesh is not used);
+  * `center_ids`  (gradient-parity harness only) which point represents each mode -- last-bit noise in upstream's nms,
+                  yet the gradient enters through that point (fit_ops._pin_representatives).
 Optional terms (off in the README configuration): `include_entropy_loss` (upstream :59-62,209-225),
 `include_intersect_loss` (:96-99,374-413 -- upstream's scatter_mean import is commented out, so this term is
 parity-unpinned and restates the documented intent), `include_pruning` (:78-82: upstream computes the pruned
@@ -132,7 +134,8 @@ def intersection_loss_volume_3(r, V, c, valid, points, cuboid=False):
 def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, quantile=0.01, iterations=5,
                 visualize=False, max_num_clusters=25, class_list=[], include_intersect_loss=False, alpha=1, beta=1,
                 if_cuboid=False, include_pruning=False, include_entropy_loss=False, evaluation=False,
-                rand_table=None, canonical=True, return_info=False, entropy_indices=None, intersect_jitter=None):
+                rand_table=None, canonical=True, return_info=False, entropy_indices=None, intersect_jitter=None,
+                center_ids=None):
     """points [B,3,N], chamfer_points [B,3,M], X [B,D,N] (per-point embedding)."""
     emb = X.permute(0, 2, 1)
     if emb.shape[2] <= 256 and emb.dtype == torch.float32:
@@ -146,7 +149,7 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
         if entropy_indices is None:
             entropy_indices = torch.randperm(emb.shape[1], device=emb.device)[: emb.shape[1] // 4]
         entropy_loss = entropy(emb[:, entropy_indices.to(emb.device)])
-    cl = fit_ops.cluster(emb, quantile, iterations, max_num_clusters)   # clustering(): :68
+    cl = fit_ops.cluster(emb, quantile, iterations, max_num_clusters, center_ids=center_ids)   # clustering(): :68
     if rand_table is None:
         rand_table = torch.rand(pts.shape[0], fit_ops.KM, 3, 3, device=pts.device)
     r, V, c, valid = fit_ops.EllipsoidFitFn.apply(pts, cl["W"], cl["count"], rand_table.to(pts.device), canonical)  # :70

@@ -407,7 +407,35 @@ def _cluster_speculative(X, quantile, iterations, max_num_clusters):
             "quantile": [quantile] * Bt, "Z": Z}
 
 
-def cluster(X, quantile, iterations, max_num_clusters):
+def _pin_representatives(res, center_ids):
+    """Harness hook: use the given point of every mode as its representative.  Which member of a collapsed
+    mode nms keeps is last-bit noise in the reference itself, but `center = new_X[indices]` (src/mean_shift.py:46) is a
+    differentiable gather, so the gradient of everything downstream enters the mean-shift trajectory of exactly that
+    point (d loss / d X moves by ~10 % with the pick, oracle/make_golden.py:golden_selfsup_step).  A gradient
+    comparison against the reference therefore passes the reference's picks: [B,KM] int64, -1 padded, in the
+    reference's (ascending id) order.  The partition must be the one nms found (checked, on the host)."""
+    Z = res["Z"].detach()
+    Bt, N, D = Z.shape
+    ids = torch.as_tensor(center_ids).to(Z.device).long()
+    if ids.shape[1] < KM:
+        ids = torch.cat([ids, ids.new_full((Bt, KM - ids.shape[1]), -1)], 1)
+    ids = ids[:, :KM]
+    k = (ids >= 0).sum(1)
+    if not torch.equal(k.cpu(), res["count"].long().cpu()):
+        raise RuntimeError("center_ids: %s representatives for %s clusters" % (k.tolist(), res["count"].tolist()))
+    ids = ids.clamp(min=0)
+    cen = torch.gather(Z, 1, ids.unsqueeze(-1).expand(-1, -1, D))
+    dots = torch.bmm(cen, Z.transpose(1, 2))                                    # labels = argmax_k centres_k . x (ms:199-201)
+    dots.masked_fill_(torch.arange(KM, device=Z.device).view(1, KM, 1) >= k.view(Bt, 1, 1), float("-inf"))
+    labels = dots.argmax(dim=1)
+    for b in range(Bt):
+        pairs = torch.unique(torch.stack([res["labels"][b], labels[b]], 1), dim=0)
+        if pairs.shape[0] != int(k[b]):
+            raise RuntimeError("center_ids describe another partition than nms found (shape %d)" % b)
+    res["ids"], res["labels"] = ids, labels
+
+
+def cluster(X, quantile, iterations, max_num_clusters, center_ids=None):
     """src/ellipsoid_utils.py:9-73 batched: mean-shift + nms with the quantile-doubling retry
     (one host read-back per round).  X [B,N,D] unit rows.
     Returns dict(Z, bw, ids [B,KM], count [B], labels [B,N] int64, centres [B,KM,D], W [B,N,KM], quantile list)."""
@@ -415,6 +443,8 @@ def cluster(X, quantile, iterations, max_num_clusters):
     dev = X.device
     if _spec is not None:
         res = _cluster_speculative(X, quantile, iterations, max_num_clusters)
+        if center_ids is not None:
+            _pin_representatives(res, center_ids)
         res["centres"] = torch.gather(res["Z"], 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))
         res["W"] = MembershipFn.apply(res["centres"], X, res["bw"], res["count"])
         return res
@@ -454,6 +484,8 @@ def cluster(X, quantile, iterations, max_num_clusters):
     else:
         Zfull = torch.zeros(Bt, N, D, device=dev).index_copy(0, torch.cat(idx_sets), torch.cat(Zs))
     res["Z"] = Zfull
+    if center_ids is not None:
+        _pin_representatives(res, center_ids)
     centres = torch.gather(Zfull, 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))  # center = new_X[indices] (:46)
     res["centres"] = centres
     res["W"] = MembershipFn.apply(centres, X, res["bw"], res["count"])

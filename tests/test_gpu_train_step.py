@@ -62,6 +62,50 @@ def test_supervised_step_matches_oracle_adam(hiplib):
     assert lr == 1e-5 and mom == 0.01
 
 
+def test_selfsup_step_matches_reference_golden(hiplib, golden):
+    """SURVEY 8a row a29 step (2) on the HIP backend, through Trainer.selfsup_step itself (zero_grad, train(), forward
+    with the convex loss, mean(loss) * lambda, backward, Adam): total / chamfer loss, K, labels, beta, every
+    parameter-gradient norm, the embedding head's gradient and its values after the Adam step against what the
+    reference's own network file produced (tests/golden/step_selfsup.npz, train_partseg_shapenet.py:436-451)."""
+    import step_selfsup_common as C
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    from prifit_amd.train_step import Trainer
+    g = golden("step_selfsup")
+    d = C.inputs(g)
+    ref = C.seeded_state(g, orc.OracleMSGPartSeg)          # seeded parameters (construction order of the reference)
+    net = M.get_model(50)
+    net.load_state_dict(ref.state_dict())
+    net.cuda()
+    tr = Trainer(net, learning_rate=0.001, decay_rate=1e-4, lmbda=1.0)
+    real_train = net.train
+    net.train = lambda mode=True: (real_train(mode), net.drop1.eval(), net)[2]
+    before = {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
+    captured = {}
+    real_forward = net.forward
+
+    def forward(*a, **k):                                    # keep the model's outputs and gradients of this step
+        out = real_forward(*a, **k)
+        captured["out"] = out
+        return out
+
+    net.forward = forward
+    real_step = tr.optimizer.step
+
+    def step(*a, **k):
+        captured["grads"] = {kk: (None if p.grad is None else p.grad.detach().cpu().clone()) for kk, p in net.named_parameters()}
+        return real_step(*a, **k)
+
+    tr.optimizer.step = step
+    subset = torch.from_numpy(np.random.default_rng(int(g["seed"]) + 1).choice(5000, C.N, replace=False)).cuda()
+    loss = tr.selfsup_step(d["cham"].transpose(1, 2).contiguous().cuda(), npoint=C.N, quantile=C.Q, msc_iterations=C.ITERS,
+                           max_num_clusters=25, augment=False, subset=subset, fps_start=(d["s1"].cuda(), d["s2"].cuda()),
+                           fit_inputs=dict(rand_table=d["R"].cuda(), canonical=True, center_ids=d["center_ids"]))
+    after = {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
+    assert abs(loss.item() - float(np.asarray(g["total_loss"]).reshape(-1)[0])) < 1e-4 * abs(loss.item())
+    worst = C.check(g, captured["out"], captured["grads"], before, after, net.beta, loss_tol=1e-4, grad_tol=2e-2)
+    print("self-supervised step vs reference: worst relative gradient deviation %.2e" % worst)
+
+
 def test_selfsup_step_and_checkpoint(hiplib):
     from prifit_amd.models import pointnet2_part_seg_msg as M
     from prifit_amd.train_step import Trainer

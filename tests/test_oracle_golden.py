@@ -105,3 +105,43 @@ def test_model_matches_reference(golden):
         if k in norms and not (k.endswith(".bias") and "conv" in k and k != "conv2.bias") and norms[k] > 0:
             assert abs(p.grad.norm().item() - norms[k]) <= 3e-2 * norms[k], k
     torch.testing.assert_close(net.conv2.weight.grad, _t(g["g_conv2_weight"]), rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_real_shape_sa_levels_match_reference(golden, i):
+    """SA1 / SA2 of the MSG network at their real shapes (B=4): the oracle against the reference's outputs and
+    gradients (tests/golden/module_sa_real.npz)."""
+    import sa_real_common as C
+    g = golden("module_sa_real")
+    xyz, feat, start, gout = C.inputs(g, i)
+    sa = C.seeded_module(orc.OracleSetAbstractionMsg, i)
+    f = feat.clone().requires_grad_(True)
+    nx, out = sa(xyz, f, start)
+    (out * gout).sum().backward()
+    last = sa.bn_blocks[-1][-1]
+    C.check(g, i, nx, out.detach(), f.grad, {k: p.grad for k, p in sa.named_parameters()},
+            (last.running_mean, last.running_var), out_tol=2e-5)
+
+
+def test_selfsup_training_step_matches_reference(golden):
+    """zero_grad, forward with the convex loss on a 2048-subset of the chamfer points,
+    mean(loss) * lambda, backward, Adam step (train_partseg_shapenet.py:436-451) -- the oracle against the values
+    captured from the reference's own network file (tests/golden/step_selfsup.npz)."""
+    import step_selfsup_common as C
+    g = golden("step_selfsup")
+    d = C.inputs(g)
+    net = C.seeded_state(g, orc.OracleMSGPartSeg)
+    net.train()
+    net.drop1.eval()
+    opt = torch.optim.Adam(net.parameters(), lr=0.001, betas=(0.9, 0.999), eps=1e-08, weight_decay=1e-4)
+    opt.zero_grad()
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    out = net(d["xyz"], d["cls"], chamfer_points=d["cham"], include_convex_loss=True, quantile=C.Q, msc_iterations=C.ITERS,
+              max_num_clusters=25, fps_start=(d["s1"], d["s2"]),
+              fit_inputs=dict(rand_table=[[d["R"]] * 64] * C.B, canonical=True,
+                              center_ids=[r[r >= 0] for r in d["center_ids"]]))
+    (torch.mean(out[3]) * 1.0).backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in net.named_parameters()}
+    opt.step()
+    after = {k: p.detach().clone() for k, p in net.named_parameters()}
+    C.check(g, out, grads, before, after, net.beta, loss_tol=1e-5, grad_tol=5e-3)
