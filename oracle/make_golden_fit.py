@@ -110,6 +110,24 @@ def run(save, eq, close):
         out[f"W_head_{b}"] = Wr.detach().t()[:64][:, order]
     save("fit_meanshift", **out)
 
+    # ---- sub-sampled bandwidth (src/mean_shift.py:148-151, num_samples < N: the default of clustering(X), fitting.py:43).
+    # The reference draws the subset with np.random.shuffle; the harness seeds numpy, replays the shuffle and hands the
+    # same rows to the oracle.
+    sub = {"seed": seed}
+    for b in range(B):
+        np.random.seed(500 + b)
+        L = np.arange(N)
+        np.random.shuffle(L)
+        rows = L[:1000].copy()
+        np.random.seed(500 + b)
+        with torch.no_grad():
+            bw_r = ms.compute_bandwidth(emb[b], 1000, q)
+        bw_o = orc.compute_bandwidth(emb[b], q, rows=rows)
+        close(bw_o, bw_r, f"sub-sampled bandwidth b={b}", rtol=1e-6)
+        sub[f"rows_{b}"] = rows.astype(np.int16)
+        sub[f"bw_{b}"] = bw_r
+    save("fit_bandwidth_sub", **sub)
+
     # ---- ellipsoid fit: soft weights from the clustering + a hard one-hot known-answer case
     def ref_customsvd_canonical(M):
         U, S, V = refshim.ref("src.fitting_utils").customsvd(M)

@@ -5,7 +5,8 @@
 
 After `install()` the names the reference's trainer / loss import -- `models.pointnet_util`,
 `models.pointnet2_part_seg_msg`, `models.pretrain_pointnet2_part_seg_msg`, `convex_loss`,
-`src.mean_shift`, `src.ellipsoid_fitting`, `src.ellipsoid_utils` -- are this package's modules.
+`src.mean_shift`, `src.ellipsoid_fitting`, `src.ellipsoid_utils`, `src.fitting_utils`, `src.sample_ellipsoid`, `src.utils`,
+`src.guard` (everything fitting.py:1-18 imports that is not visualisation) -- are this package's modules.
 Nothing is imported from the reference tree."""
 import importlib
 import sys
@@ -26,6 +27,10 @@ _ALIASES = {
     "src.mean_shift": "prifit_amd.src.mean_shift",
     "src.ellipsoid_fitting": "prifit_amd.src.ellipsoid_fitting",
     "src.ellipsoid_utils": "prifit_amd.src.ellipsoid_utils",
+    "src.fitting_utils": "prifit_amd.src.fitting_utils",
+    "src.sample_ellipsoid": "prifit_amd.src.sample_ellipsoid",
+    "src.utils": "prifit_amd.src.utils",
+    "src.guard": "prifit_amd.src.guard",
     "src.dgcnn": "prifit_amd.src.dgcnn",
 }
 

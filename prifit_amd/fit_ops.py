@@ -49,11 +49,25 @@ def chord_matrix(A, B_):
     return out
 
 
-def compute_bandwidth(X, quantile):
-    """src/mean_shift.py:138-160 with num_samples == N, batched: X [B,N,D] (unit rows) -> bw [B]."""
+def compute_bandwidth(X, quantile, num_samples=None, rows=None):
+    """src/mean_shift.py:138-160, batched: X [B,N,D] (unit rows) -> bw [B].
+
+    num_samples < N (upstream :148-151: a random row subset, the default of `clustering(X)`, num_samples=1000): the
+    statistic is taken over `rows` [B, num_samples] (int64 row indices; hidden randomness made an explicit input like
+    the other ones) or, when omitted, over a fresh random subset per shape, as upstream."""
     Bt, N, D = X.shape
+    if num_samples is not None and num_samples < N:
+        if rows is None:
+            rows = torch.stack([torch.randperm(N, device=X.device)[:num_samples] for _ in range(Bt)])
+        rows = rows.to(X.device).long()
+        if rows.shape != (Bt, num_samples):
+            raise ValueError("bandwidth rows must be [B, num_samples]")
+        X = torch.gather(X, 1, rows.unsqueeze(-1).expand(-1, -1, D)).contiguous()
+        N = num_samples
     dist = chord_matrix(X, X)
     k = int(quantile * N)
+    if k < 1:
+        raise ValueError("quantile * num_samples < 1: torch.topk(k=0) upstream")
     kth = torch.empty(Bt * N, dtype=torch.float32, device=X.device)
     call("prifit_kth_smallest_rows", ptr(dist), _LL(Bt * N), N, k, ptr(kth), cur_stream())
     return torch.sqrt(torch.clamp(kth, min=1e-6)).view(Bt, N).mean(dim=1)
@@ -389,10 +403,10 @@ def speculative():
         _spec = prev
 
 
-def _cluster_speculative(X, quantile, iterations, max_num_clusters):
+def _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples=None, bandwidth_rows=None):
     Bt, N, D = X.shape
     with torch.no_grad():
-        bw = compute_bandwidth(X, quantile)
+        bw = compute_bandwidth(X, quantile, num_samples, bandwidth_rows)
     Z = MeanShiftFn.apply(X, bw, iterations)
     with torch.no_grad():
         ids, count, labels, used = nms(Z.detach(), bw)
@@ -435,14 +449,14 @@ def _pin_representatives(res, center_ids):
     res["ids"], res["labels"] = ids, labels
 
 
-def cluster(X, quantile, iterations, max_num_clusters, center_ids=None):
+def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samples=None, bandwidth_rows=None):
     """src/ellipsoid_utils.py:9-73 batched: mean-shift + nms with the quantile-doubling retry
     (one host read-back per round).  X [B,N,D] unit rows.
     Returns dict(Z, bw, ids [B,KM], count [B], labels [B,N] int64, centres [B,KM,D], W [B,N,KM], quantile list)."""
     Bt, N, D = X.shape
     dev = X.device
     if _spec is not None:
-        res = _cluster_speculative(X, quantile, iterations, max_num_clusters)
+        res = _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples, bandwidth_rows)
         if center_ids is not None:
             _pin_representatives(res, center_ids)
         res["centres"] = torch.gather(res["Z"], 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))
@@ -457,7 +471,10 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None):
     while pending.numel():
         Xp = X if pending.numel() == Bt else X.index_select(0, pending)
         with torch.no_grad():
-            bw = compute_bandwidth(Xp, q)
+            rows_p = bandwidth_rows
+            if rows_p is not None and pending.numel() != Bt:
+                rows_p = rows_p.to(dev).index_select(0, pending)
+            bw = compute_bandwidth(Xp, q, num_samples, rows_p)
         Z = MeanShiftFn.apply(Xp, bw, iterations)
         with torch.no_grad():
             ids, count, labels, used = nms(Z.detach(), bw)

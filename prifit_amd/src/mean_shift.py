@@ -28,11 +28,11 @@ class MeanShift:
         bwb = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(1)
         return fit_ops.MeanShiftFn.apply(X.unsqueeze(0).contiguous(), bwb, iterations)[0], X
 
-    def compute_bandwidth(self, X, num_samples, quantile):
-        """upstream :138-160 (num_samples must equal N, as in convex_loss.py:68)."""
-        if num_samples != X.shape[0]:
-            raise NotImplementedError("sub-sampled bandwidth estimation")
-        return fit_ops.compute_bandwidth(X.unsqueeze(0).contiguous(), quantile)[0]
+    def compute_bandwidth(self, X, num_samples, quantile, rows=None):
+        """upstream :138-160; num_samples < N takes the statistic over a random row subset (`rows` [num_samples]
+        makes it reproducible)."""
+        rows = None if rows is None else torch.as_tensor(rows).reshape(1, -1)
+        return fit_ops.compute_bandwidth(X.unsqueeze(0).contiguous(), quantile, min(num_samples, X.shape[0]), rows)[0]
 
     def nms(self, centers, X, b):
         """upstream :162-202 for centers is X (the only way it is called, :44)."""

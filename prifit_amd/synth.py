@@ -98,3 +98,30 @@ def xavier_like_trainer(module):
         if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
             torch.nn.init.xavier_normal_(m.weight.data)
             torch.nn.init.constant_(m.bias.data, 0.0)
+
+
+def ellipsoid_scene(B, seed, n_per=500, D=32):
+    """The stand-alone fitting demo's data (fitting.py:26-31 / src/ellipsoid_fitting.py:144-193, with the build's
+    Fibonacci table in place of trimesh's sampler): per shape 3 ellipsoids with integer semi-axes in [2, 20), a random
+    rotation about z and a random centre in [0, max axis)^3, `n_per` surface points each, and D-dimensional one-hot
+    "embeddings".  Returns points [B,3*n_per,3] f32, X [B,3*n_per,D] f32, abc [B,3,3], centres [B,3,3]."""
+    rng = np.random.default_rng(seed)
+    j = np.arange(n_per, dtype=np.float64)
+    z = 1.0 - (2.0 * j + 1.0) / n_per
+    lon = 2.0 * np.pi * np.modf(j * 0.6180339887498949)[0]
+    sv = np.sqrt(1.0 - z * z)
+    unit = np.stack([np.cos(lon) * sv, np.sin(lon) * sv, z], 1)
+    pts = np.zeros((B, 3 * n_per, 3), np.float32)
+    X = np.zeros((B, 3 * n_per, D), np.float32)
+    abc = np.zeros((B, 3, 3))
+    ctr = np.zeros((B, 3, 3))
+    for b in range(B):
+        for k in range(3):
+            axes = rng.integers(2, 20, size=3).astype(np.float64)
+            th = rng.uniform(0, 2 * np.pi)
+            Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+            c = rng.uniform(0, 1, size=3) * axes.max()
+            pts[b, k * n_per:(k + 1) * n_per] = ((unit * axes) @ Rz + c).astype(np.float32)
+            X[b, k * n_per:(k + 1) * n_per, k] = 1.0
+            abc[b, k], ctr[b, k] = axes, c
+    return pts, X, abc, ctr

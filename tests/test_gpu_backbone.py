@@ -2,8 +2,10 @@
 (torch-CPU restatement) and the golden vectors captured from the reference.
 
 Tolerances (fp32): GEMM 2e-5 relative to |A||B| row/col norms; module outputs 1e-4; module gradients
-2e-4 (+ abs floor scaled by the largest gradient, see oracle/make_golden.py); whole-network gradients
-3e-2 relative norm (fp32 reproducibility limit of the reference itself, measured in make_golden.py)."""
+2e-4 (+ abs floor scaled by the largest gradient, see oracle/make_golden.py) at toy shapes; at the network's REAL
+shapes (module_sa_real.npz) and for the whole network the gradient bars are 2 x the fp32 irreproducibility measured
+between reference-fp32, oracle-fp32 and oracle-fp64 on the same inputs (sparse ReLU-mask / max-pool-winner flips):
+5.6e-3 on whole-network gradient norms, 1.1e-2 / 1.2e-2 (relative L2) on the SA1 / SA2 parameter gradients."""
 import numpy as np
 import pytest
 import torch
@@ -376,15 +378,78 @@ def test_full_model_supervised_step(hiplib, golden):
     torch.testing.assert_close(feat[:, :, :64].detach().cpu(), _t(g["feat_head"]), rtol=1e-3, atol=2e-4)
     torch.testing.assert_close(l3.detach().cpu(), _t(g["l3"]), rtol=1e-3, atol=2e-4)
     torch.testing.assert_close(net.conv2.weight.grad.cpu(), _t(g["g_conv2_weight"]), rtol=1e-3, atol=1e-6)
+    # bars = 2 x the fp32 irreproducibility MEASURED between reference-fp32, oracle-fp32 and oracle-fp64 on this very
+    # step (oracle/make_golden.py:golden_model -> model_msg_sup_noise.npz: norms 2.8e-3, vectors 9.3e-3)
+    noise = golden("model_msg_sup_noise")
+    norm_tol, vec_tol = float(noise["norm_tol"]), float(noise["vec_tol"])
+    assert norm_tol <= 1e-2 and vec_tol <= 2e-2
     norms = dict(zip([str(s) for s in g["grad_names"]], g["grad_norms"]))
+    worst = 0.0
     for k, p in net.named_parameters():
         if k in norms and norms[k] > 0 and not (k.endswith(".bias") and "conv" in k and k != "conv2.bias"):
             assert p.grad is not None, k
-            assert abs(p.grad.norm().item() - norms[k]) <= 3e-2 * norms[k], (k, p.grad.norm().item(), norms[k])
+            worst = max(worst, abs(p.grad.norm().item() - norms[k]) / norms[k])
+            assert abs(p.grad.norm().item() - norms[k]) <= norm_tol * norms[k], (k, p.grad.norm().item(), norms[k])
     for k, ref in (("sa1.conv_blocks.0.0.weight", g["g_sa1_first"]), ("fp1.mlp_convs.1.weight", g["g_fp1_last"])):
         got = dict(net.named_parameters())[k].grad.cpu()
         rel = (got - _t(ref)).norm() / _t(ref).norm()
-        assert rel < 3e-2, (k, rel)
+        assert rel < vec_tol, (k, rel)
+    print("full model: worst gradient-norm deviation %.2e (bar %.2e)" % (worst, norm_tol))
+
+
+def test_normal_channel_and_l2_norm_variants(hiplib):
+    """models/pointnet2_part_seg_msg.py:12-25,69-75: normal_channel=True (6 input channels: sa1 sees [xyz+normals | rel],
+    fp1's skip is 16+3+6) forward + backward against the oracle with the same parameters; l2_norm=True normalises the
+    embedding once more before the loss, which normalises anyway -- the loss must not move."""
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    B, N = 2, 1024
+    torch.manual_seed(31)
+    ref = orc.OracleMSGPartSeg(50, normal_channel=True)
+    synth.xavier_like_trainer(ref)
+    synth.perturb_bn(ref, 6)
+    net = M.get_model(50, normal_channel=True)
+    net.load_state_dict(ref.state_dict())
+    net.cuda().train()
+    ref.train()
+    net.drop1.eval()
+    ref.drop1.eval()
+    pts = _t(synth.cloud("surface", B, N, 33))
+    nrm = torch.nn.functional.normalize(_t(synth.features(B, N, 3, 34)), dim=2)
+    x6 = torch.cat([pts, nrm], 2).transpose(1, 2).contiguous()                 # [B,6,N]
+    cls = torch.zeros(B, 1, 16)
+    target = _t(synth.labels(B, N, 50, 35))
+    s = (_t(synth.fps_start(B, N, 36)), _t(synth.fps_start(B, 512, 37)))
+    seg_r = ref(x6, cls, fps_start=s)[0]
+    loss_r = orc.seg_loss(seg_r.reshape(-1, 50), target.view(-1))
+    loss_r.backward()
+    out = net(x6.cuda(), cls.cuda(), fps_start=(s[0].cuda(), s[1].cuda()))
+    loss = M.get_loss()(out[0].reshape(-1, 50), target.cuda().view(-1), None)
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) < 1e-5 * abs(loss_r.item())
+    torch.testing.assert_close(out[0].detach().cpu(), seg_r.detach(), rtol=1e-3, atol=2e-4)
+    for k, p in ref.named_parameters():
+        if p.grad is None or (k.endswith(".bias") and "conv" in k and k != "conv2.bias"):
+            continue
+        g = dict(net.named_parameters())[k].grad.cpu()
+        assert abs(g.norm().item() - p.grad.norm().item()) <= 1e-2 * p.grad.norm().item(), k
+    assert net.sa1.conv_blocks[0][0].weight.shape[1] == 9 and net.fp1.mlp_convs[0].weight.shape[1] == 153
+    # l2_norm=True with the convex loss
+    from tests_helpers import fit_inputs
+    _, cham, _ = fit_inputs(2, 1024, 128, 8)
+    subset = cham[:, :1024]
+    x = subset.transpose(1, 2).contiguous().cuda()
+    losses = []
+    for l2 in (False, True):
+        torch.manual_seed(32)
+        m = M.get_model(50, l2_norm=l2).cuda().train()
+        R = _t(synth.uniform01((3, 3), 3)).cuda()
+        o = m(x, torch.zeros(2, 1, 16, device="cuda"), chamfer_points=cham.transpose(1, 2).contiguous().cuda(),
+              include_convex_loss=True, quantile=0.05, msc_iterations=5, max_num_clusters=25,
+              fps_start=(s[0][:2].cuda(), s[1][:2].cuda()), fit_inputs=dict(rand_table=R))
+        o[3].mean().backward()
+        assert torch.isfinite(m.extra_conv_emb.weight.grad).all()
+        losses.append(o[3].item())
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[0]) + 1e-7, losses
 
 
 def test_ssg_model_config1(hiplib, golden):

@@ -412,3 +412,19 @@ def test_normalize_twice_kernel_vs_torch(F):
     torch.testing.assert_close(yd.detach().cpu(), yr.detach(), rtol=1e-6, atol=1e-7)
     ok = x.norm(dim=2) > 1e-10   # rows at the eps clamp: torch differentiates the clamp as constant, same here, but 0/0 noise
     torch.testing.assert_close(xd.grad.cpu()[ok], xr.grad[ok], rtol=1e-4, atol=1e-5)
+
+
+def test_subsampled_bandwidth_matches_reference_golden(hiplib, golden):
+    """num_samples < N bandwidth (src/mean_shift.py:148-151) on the reference's row subset; and the random-subset
+    default stays close to it (same statistic, other rows)."""
+    from prifit_amd import fit_ops
+    g = golden("fit_bandwidth_sub")
+    _, _, emb = fit_inputs(2, 2048, 128, int(g["seed"]))
+    rows = torch.from_numpy(np.stack([g["rows_%d" % b].astype(np.int64) for b in range(2)]))
+    bw = fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000, rows=rows.cuda()).cpu()
+    ref = torch.tensor([float(g["bw_0"]), float(g["bw_1"])])
+    torch.testing.assert_close(bw, ref, rtol=1e-5, atol=1e-7)
+    rnd = fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000).cpu()
+    assert ((rnd - ref).abs() < 0.1 * ref).all()
+    with pytest.raises(ValueError):
+        fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000, rows=rows[:, :10].cuda())

@@ -105,3 +105,14 @@ def test_sample_budget_and_table():
     params = [(torch.tensor([1.0, 1.0, 1.0]), torch.eye(3), torch.zeros(3)), (torch.tensor([2.0, 2.0, 2.0]), torch.eye(3), torch.zeros(3))]
     n = orc.sample_budget(params)
     assert n.sum() == 10000 and abs(n[1] / n[0] - 4.0) < 0.01
+
+
+def test_subsampled_bandwidth_matches_reference(golden):
+    """src/mean_shift.py:148-151 with num_samples = 1000 < N = 2048 (the default of clustering(X), fitting.py:43): the
+    oracle on the reference's own row subset."""
+    from tests_helpers import fit_inputs
+    g = golden("fit_bandwidth_sub")
+    _, _, emb = fit_inputs(2, 2048, 128, int(g["seed"]))
+    for b in range(2):
+        bw = orc.compute_bandwidth(emb[b], 0.05, rows=g["rows_%d" % b].astype(np.int64))
+        assert abs(float(bw) - float(g["bw_%d" % b])) <= 1e-6 * float(g["bw_%d" % b])
