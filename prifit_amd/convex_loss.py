@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from . import fit_ops
+from . import arena as zero_pool
 from .nn_ops import EPI_CHORD, NN, NT, gemm
 from ._lib import call, cur_stream, ptr
 
@@ -111,7 +112,7 @@ class SdfMatrixFn(torch.autograd.Function):
         points, r, V, c, valid = ctx.saved_tensors
         B, M, _ = points.shape
         K = r.shape[1]
-        g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
+        g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
         call("prifit_%s_sdf_matrix_bwd" % ctx.prim, ptr(points), B, M, ptr(r), ptr(V), ptr(c), ptr(valid),
              ptr(g.contiguous()), K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return None, g_r, g_V, g_c, None, None

@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from . import profiler
+from . import arena as zero_pool
 from ._lib import call, cur_stream, dll, ptr
 from .nn_ops import EPI_CHORD, EPI_MSBWD, EPI_MSKERNEL, NN, NT, TN, gemm
 
@@ -142,7 +143,7 @@ class MeanShiftFn(torch.autograd.Function):
         Bt, N, D = X.shape
         dev = X.device
         g = g.contiguous()
-        gX = torch.zeros(Bt, N, D, dtype=torch.float32, device=dev)
+        gX = zero_pool.zeros(Bt, N, D, device=dev)
         # Backward engine for the fused (K^T) layout, 4 N^2 D products per iteration in every case but "fused":
         #   "hybrid" (default): flash-style dZ kernel (gS = (gO X^T + g_rowsum) * K / b^2 in registers, dZ = gS X, gS^T
         #             streamed out once) + ONE dual-source MFMA GEMM for dX += gS^T Z + K^T gO;
@@ -250,7 +251,7 @@ class MembershipFn(torch.autograd.Function):
         # dcentres = gd^T X: one 32 x 128 output tile per shape over N = 2048 rows -- split the reduction so that
         # more than 24 workgroups run (242 us -> tens of us at B = 24)
         sk = _skinny_splitk(K, D, N, Bt)
-        gc = (torch.zeros_like if sk > 1 else torch.empty_like)(centres)
+        gc = (zero_pool.zeros_like if sk > 1 else torch.empty_like)(centres)
         _bgemm(TN, K, D, N, gd, K, X, D, gc, D, Bt, N * K, N * D, K * D, splitk=sk)
         gX = torch.empty_like(X)
         _bgemm(NN, N, D, K, gd, K, centres, D, gX, D, Bt, N * K, K * D, N * D)  # dX = gd centres
@@ -272,7 +273,7 @@ class EllipsoidFitFn(torch.autograd.Function):
         V = torch.empty(Bt, K, 3, 3, dtype=torch.float32, device=dev)
         c = torch.empty(Bt, K, 3, dtype=torch.float32, device=dev)
         valid = torch.empty(Bt, K, dtype=torch.int32, device=dev)
-        state = torch.zeros(Bt, K, dll().prifit_fit_state_floats(), dtype=torch.float32, device=dev)
+        state = zero_pool.zeros(Bt, K, dll().prifit_fit_state_floats(), device=dev)
         call("prifit_ellipsoid_fit_fwd", ptr(points), ptr(W), ptr(count), ptr(rnd), _LL(sb), _LL(sk), int(canonical),
              Bt, N, K, ptr(r), ptr(V), ptr(c), ptr(valid), ptr(state), cur_stream())
         ctx.save_for_backward(points, W, count, rnd, state, valid)
@@ -316,7 +317,7 @@ class SdfLossFn(torch.autograd.Function):
         targets, r, V, c, arg = ctx.saved_tensors
         Bt, M, _ = targets.shape
         K = r.shape[1]
-        g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
+        g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
         call("prifit_%s_sdf_bwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(arg), ptr(gs.contiguous()),
              K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return None, g_r, g_V, g_c, None, None
@@ -353,7 +354,7 @@ class SampleNNLossFn(torch.autograd.Function):
         r, V, c, n, off, targets, nn_idx = ctx.saved_tensors
         Bt, M, _ = targets.shape
         K = r.shape[1]
-        g_r, g_V, g_c = torch.zeros_like(r), torch.zeros_like(V), torch.zeros_like(c)
+        g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
         call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
              ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return g_r, g_V, g_c, None, None, None

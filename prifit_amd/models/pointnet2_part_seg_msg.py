@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..nn_ops import LinearFn, SharedMLPFn
+from .. import arena as zero_pool
 from .pointnet_util import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
                             _mlp_cfg, _mlp_tensors, batched_bn_counters)
 
@@ -77,6 +78,8 @@ class get_model(nn.Module):
                 msc_iterations=5, max_num_clusters=25, visualize=False, seed=0, batch_id=0, class_list=[],
                 epoch=-1, alpha=1, beta=1, evaluation=False, embed=False, fps_start=None, fit_inputs=None):
         B, C, N = xyz.shape
+        if xyz.is_cuda:
+            zero_pool.begin_step(xyz.device)   # one zero-fill per step for all zero-initialised fp32 buffers
         l1, l2, l3, feat = self.embed_features(xyz, cls_label, fps_start)
         total_loss = torch.zeros(1, device=xyz.device)
         chamfer_loss = torch.zeros(1, device=xyz.device)

@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import profiler
+from . import arena as zero_pool
 from ._lib import call, cur_stream, dll, ptr
 
 NT, NN, TN = 0, 1, 2
@@ -87,7 +88,7 @@ def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
     [Cout, Kin] destination (several layers share one zeroed arena: one fill instead of one per layer)."""
     if _STREAM and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)):
         # tall reduction, small output: the LDS-free streaming kernel (csrc/gemm_stream.hip), HBM-bound
-        dW = out if out is not None else torch.zeros(Cout, Kin, dtype=torch.float32, device=dY.device)
+        dW = out if out is not None else zero_pool.zeros(Cout, Kin, device=dY.device)
         ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dY.device)
         with profiler.span("gemm_stream_tn", 4.0 * P * (Cout + Kin)):
             call("prifit_gemm_stream_tn_f32", Cout, Kin, _LL(P), ptr(dY), _LL(dY.stride(0)), ptr(Ain), _LL(Ain.stride(0)),
@@ -101,7 +102,7 @@ def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
     elif sk == 1:
         dW = torch.empty(Cout, Kin, dtype=torch.float32, device=dY.device)
     else:
-        dW = torch.zeros(Cout, Kin, dtype=torch.float32, device=dY.device)
+        dW = zero_pool.zeros(Cout, Kin, device=dY.device)
     gemm(TN, Cout, Kin, P, dY, dY.stride(0), Ain, Ain.stride(0), dW, Kin, splitk=sk, b_affine=a_affine)
     return dW
 
@@ -226,7 +227,7 @@ class SharedMLPFn(torch.autograd.Function):
             nb = Ws[l].shape[0] if (training and ctx.needs_input_grad[2 + 6 * l + 1]) else 0
             wslots[l] = (total, n, total + n, nb)
             total += n + nb
-        arena = torch.zeros(total, dtype=torch.float32, device=dev) if total else None
+        arena = zero_pool.zeros(total, device=dev) if total else None
         G_in = gout  # gradient w.r.t. the ReLU output of layer l (or pooled output for the last layer)
         fused_red = None
         for l in range(L - 1, -1, -1):
@@ -310,7 +311,7 @@ class SharedMLPFn(torch.autograd.Function):
                              Dq, int(info["feat_first"]), nblk, ptr(part), cur_stream())
                     grads[0] = part.sum(dim=0)
                 if ctx.needs_input_grad[3]:
-                    grads[1] = torch.zeros(Cout, dtype=torch.float32, device=dev)  # bias in front of a batch-stat BatchNorm
+                    grads[1] = zero_pool.zeros(Cout, device=dev)  # bias in front of a batch-stat BatchNorm
                 G_in = None
                 break
             if pooled:
@@ -398,13 +399,13 @@ class GatherLinearFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, S, K, C, training = ctx.meta
         gY = gY.contiguous()
-        dU = torch.zeros(B, N, C, dtype=torch.float32, device=gY.device)
+        dU = zero_pool.zeros(B, N, C, device=gY.device)
         dVc = torch.empty(B, S, C, dtype=torch.float32, device=gY.device)
         call("prifit_gather_linear_bwd", ptr(gY), ptr(idx), B, N, S, K, C, ptr(dU), ptr(dVc), cur_stream())
         db = None
         if ctx.needs_input_grad[2]:
             # a bias in front of a batch-statistics BatchNorm has zero gradient
-            db = torch.zeros(C, device=gY.device) if training else gY.sum(dim=0)
+            db = zero_pool.zeros(C, device=gY.device) if training else gY.sum(dim=0)
         return dU, dVc, db, None, None
 
 
@@ -498,7 +499,7 @@ class SAGroupDirectFn(torch.autograd.Function):
                 dW = part.sum(dim=0)
                 if has_bias[r]:
                     # a bias in front of a batch-statistics BatchNorm has zero gradient
-                    db = torch.zeros(C, device=gY.device) if training else gY.sum(dim=0)
+                    db = zero_pool.zeros(C, device=gY.device) if training else gY.sum(dim=0)
             grads += [dW, db]
         return (None, None, None, None) + tuple(grads)
 
@@ -534,11 +535,11 @@ class SAGroupGatherFn(torch.autograd.Function):
             dU = dVc = db = None
             if gY is not None:
                 gY = gY.contiguous()
-                dU = torch.zeros(B, N, C, dtype=torch.float32, device=gY.device)
+                dU = zero_pool.zeros(B, N, C, device=gY.device)
                 dVc = torch.empty(B, S, C, dtype=torch.float32, device=gY.device)
                 call("prifit_gather_linear_bwd", ptr(gY), ptr(idxs[r]), B, N, S, K, C, ptr(dU), ptr(dVc), cur_stream())
                 if has_bias[r]:
-                    db = torch.zeros(C, device=gY.device) if training else gY.sum(dim=0)
+                    db = zero_pool.zeros(C, device=gY.device) if training else gY.sum(dim=0)
             grads += [dU, dVc, db]
         return (None, None, None) + tuple(grads)
 

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib, profiler
+from . import arena as zero_pool
 from ._lib import call, cf, cur_stream, ptr, require_cuda
 
 
@@ -101,7 +102,7 @@ def group_scatter_add(gout, col0, idx, B, N, C, dfeat=None):
     """Backward of the feature columns of group_gather: returns dfeat [B,N,C]."""
     _, S, K = idx.shape
     if dfeat is None:
-        dfeat = torch.zeros(B, N, C, dtype=torch.float32, device=gout.device)
+        dfeat = zero_pool.zeros(B, N, C, device=gout.device)
     call("prifit_group_scatter_add", ptr(gout), gout.stride(0), col0, ptr(idx), B, N, S, K, C, ptr(dfeat),
          cur_stream())
     return dfeat
@@ -120,7 +121,7 @@ def three_interpolate(points2, idx, weight, out=None, col0=0):
 
 def three_interpolate_bwd(gout, col0, idx, weight, B, S, C):
     N = idx.shape[1]
-    dp2 = torch.zeros(B, S, C, dtype=torch.float32, device=gout.device)
+    dp2 = zero_pool.zeros(B, S, C, device=gout.device)
     call("prifit_three_interpolate_bwd", ptr(gout), gout.stride(0), col0, ptr(idx), ptr(weight), B, N, S, C,
          ptr(dp2), cur_stream())
     return dp2

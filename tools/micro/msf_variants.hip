@@ -9,6 +9,7 @@
 #include <math.h>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int D = 128, QB = 64, KB = 64, LDSW = D + 4;
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 struct Tile64 {
@@ -85,6 +86,16 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
         }
         const int nxt = k0 + (DBUF ? 2 : 1) * KB;
         if (nxt < N && !(SKIP & 1)) t.load(Xb, nxt);
+        if (SORD == 2 && k0 > 0 && !(SKIP & 2)) {
+            // tiled layout: tile (key block of 32, query block of 32) = 4 KiB; inside: [g 0..3][lane 0..63][4 floats]
+            const int kt = (k0 - KB) / 32 + kh, qt = (q0 >> 5) + qg;
+            float *tp = KTb + ((size_t)kt * (N / 32) + qt) * 1024 + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {pprev[4 * g], pprev[4 * g + 1], pprev[4 * g + 2], pprev[4 * g + 3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(tp + g * 256));
+            }
+        }
         if (SORD == 1 && k0 > 0 && !(SKIP & 2)) {
             const int kb = k0 - KB + kh * 32 + 4 * lh;
 #pragma unroll
@@ -125,11 +136,19 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
         }
         if (DBUF) __syncthreads();
     }
-    {
+    if (SORD != 2) {
         const int kb = N - KB + kh * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             __builtin_nontemporal_store(pprev[r], KTb + (size_t)(kb + (r & 3) + 8 * (r >> 2)) * N + gq);
+    } else {
+        const int kt = (N - KB) / 32 + kh, qt = (q0 >> 5) + qg;
+        float *tp = KTb + ((size_t)kt * (N / 32) + qt) * 1024 + lane * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {pprev[4 * g], pprev[4 * g + 1], pprev[4 * g + 2], pprev[4 * g + 3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(tp + g * 256));
+        }
     }
     __syncthreads();
     float *s_part = s_x0;
@@ -219,6 +238,8 @@ int main()
     run<true, true, 1>("V3 V2 + K^T stores after the tile loads", X, X, bw, B, N, KT, out, rs, ro, rk);
     run<false, true, 1>("V4 V3 without QREG (needs s_q: invalid)", X, X, bw, B, N, KT, out, rs, ro, rk);
     run<true, false, 1>("V5 V1 + stores after loads", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<false, false, 2>("V6 V0 + tiled K^T layout (4 x dwordx4 stores)", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<true, true, 2>("V7 V2 + tiled K^T layout", X, X, bw, B, N, KT, out, rs, ro, rk);
     // timing-only eliminations on V0 (results are wrong by construction)
     run<false, false, 0, 2>("T  no K^T stores", X, X, bw, B, N, KT, out, rs, ro, rk);
     run<false, false, 0, 1>("T  no tile loads", X, X, bw, B, N, KT, out, rs, ro, rk);
