@@ -28,21 +28,35 @@ constexpr int LDSW = D + 4;   // padded row: conflict-free ds_read_b128 fragment
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-// global [rows x 128] tile -> registers (8 float4 per thread, 256 threads); rows beyond `nrows` read row 0 and are zeroed
-// when the tile is written to LDS -- NOT at load time: a select right behind the load makes the compiler wait for the
-// data there (s_waitcnt vmcnt(0) directly after the loads), which serialised every step on the global latency
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer addressing (SGPR resource + ONE constant VGPR offset per lane + a scalar offset per access) for every global
+// access of the loop: the flat form costs two 64-bit VALU adds per access (16 stream stores, 8 tile loads and, in MODE 1,
+// 16 stream loads per lane and step), and that address arithmetic -- not the memory system -- was what the streams cost:
+// forward 530 -> 478 us with identical instructions otherwise (tools/micro/msf_variants.hip V0 -> V13).  The hardware
+// bounds check of the resource (num_records = the exact extent) returns 0 for rows beyond N and drops stores beyond
+// the matrix, so no access is predicated and nothing is selected after a load.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, long long bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+}
+constexpr int OOB = 0x7fffffff;   // lane offset that fails the bounds check (invalid query column)
+
+// global [rows x 128] tile -> registers (8 float4 per thread, 256 threads); rows beyond the matrix read as zeros
+// (the scalar offset is not part of the bounds check: EXACT = every row of the tile exists, the row goes into the scalar
+// offset; otherwise it goes into the lane offset, OOB for rows beyond the matrix)
 struct Tile64 {
     float4 v[8];
-    int row0_, nrows_;
-    __device__ __forceinline__ void load(const float *__restrict__ base, int row0, int nrows)
+    template <bool EXACT>
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff, int row0, int nrows)
     {
-        row0_ = row0; nrows_ = nrows;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int id = threadIdx.x + 256 * p;  // 64 rows x 32 float4
-            const int r = id >> 5, c = (id & 31) * 4;
-            const bool ok = row0 + r < nrows;
-            v[p] = ld4(base + (size_t)(ok ? row0 + r : 0) * D + c);
+        for (int p = 0; p < 8; ++p) {   // thread's float4 p: row 8p + (tid >> 5), columns 4 (tid & 31) ..
+            const int row = row0 + 8 * p;
+            const f32x4 t = __builtin_bit_cast(f32x4, EXACT
+                ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row * D * 4, 0)
+                : __builtin_amdgcn_raw_buffer_load_b128(rs, row + (int)(threadIdx.x >> 5) < nrows ? voff + row * D * 4 : OOB, 0, 0));
+            v[p] = make_float4(t.x, t.y, t.z, t.w);
         }
     }
     __device__ __forceinline__ void store(float *__restrict__ lds) const
@@ -50,19 +64,18 @@ struct Tile64 {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int id = threadIdx.x + 256 * p;
-            const bool ok = row0_ + (id >> 5) < nrows_;
-            *reinterpret_cast<float4 *>(lds + (id >> 5) * LDSW + (id & 31) * 4) = ok ? v[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(lds + (id >> 5) * LDSW + (id & 31) * 4) = v[p];
         }
     }
 };
 }  // namespace
 
 // Q: the query-side operand rows (Z for MODE 0, gO for MODE 1) [B,N,128]; X: dictionary [B,N,128].
-// FAST (forward mode only): N % 64 == 0 and the K^T stream is present -- every bounds / pointer predicate is compile-time
-// true, the 16 stream stores of a step are plain non-temporal instructions, and they are issued at the start of the NEXT
-// step, ahead of that step's tile loads (see the loop): 549 -> 531 us at B = 24, N = 2048.  The K^T stream costs ~50 us
-// of that (472 us without it): vmcnt is one in-order counter for loads and stores on gfx9, so waiting for a tile also
-// waits for every older store.
+// FAST: N % 64 == 0 -- every row / column of every tile exists, so the row part of each address is a SCALAR offset (no
+// vector arithmetic per access at all); otherwise rows beyond the matrix are masked through the lane offset (OOB).
+// MODE 0: the 16 stream values of a step are stored at the start of the NEXT step, ahead of that step's tile loads (vmcnt
+// is one in-order counter for loads and stores on gfx9: the wait for a tile also waits for every older store, and a
+// whole step later the stores have long retired).
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     const float *__restrict__ Q, long long q_stride, const float *__restrict__ X, const float *__restrict__ bw,
@@ -88,10 +101,12 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     const float rcp_b2 = 1.0f / (bwv * bwv);
     const float kmin = __expf(-13.0f);
 
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(Qb, (long long)N * D * 4), x_rs = make_rsrc(Xb, (long long)N * D * 4);
+    const int t_voff = ((threadIdx.x >> 5) * D + (threadIdx.x & 31) * 4) * 4;
     Tile64 t;
-    t.load(Qb, q0, N);
+    t.load<FAST>(q_rs, t_voff, q0, N);
     t.store(s_q);
-    t.load(Xb, 0, N);
+    t.load<FAST>(x_rs, t_voff, 0, N);
 
     f32x16 oacc[4];
 #pragma unroll
@@ -105,38 +120,61 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     const float radd = (MODE == 1 && q_ok) ? row_add[(size_t)b * N + gq] : 0.f;
     float *KTb = KT ? KT + (size_t)b * sk : nullptr;
     float *GSb = (MODE == 1 && GST) ? GST + (size_t)b * sk : nullptr;
+    // the N x N streams: element (key, query) at key * ldk + query; this lane's constant part = its query column and
+    // the first key row of its accumulator registers, the scalar part = the step's key block and the register's row
+    const long long nn_bytes = ((long long)(N - 1) * ldk + N) * 4;
+    const __amdgpu_buffer_rsrc_t kt_rs = make_rsrc(KTb, KTb ? nn_bytes : 0), gs_rs = make_rsrc(GSb, GSb ? nn_bytes : 0);
+    const int nn_voff = q_ok ? (int)(((long long)(kh * 32 + 4 * lh) * ldk + gq) * 4) : OOB;
+    // (readfirstlane: the scalar offsets must BE scalar for the compiler -- with the row stride in a VGPR every buffer access
+    // became a readfirstlane "waterfall" loop)
+    const int ldk4 = __builtin_amdgcn_readfirstlane((int)ldk * 4);
+    // (lane offset, scalar offset) of stream element (key block k + accumulator register r, this lane's query)
+    auto st_voff = [&](int k, int r) {
+        const int key = k + (r & 3) + 8 * (r >> 2);
+        return FAST ? nn_voff : ((q_ok && key + kh * 32 + 4 * lh < N) ? nn_voff + key * ldk4 : OOB);
+    };
+    int row_off[16];   // loop-invariant scalar byte offsets of the 16 accumulator rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) row_off[r] = __builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * ldk4);
+    auto st_soff = [&](int kbase_bytes, int r) { return FAST ? kbase_bytes + row_off[r] : 0; };
+    // MODE 0: the query fragments (B operand of the S product) stay in registers for the whole kernel
+    float4 qf[MODE == 0 ? D / 8 : 1];
+    if (MODE == 0) {
+        const int q_voff = q_ok ? (gq * D + lh * 4) * 4 : OOB;
+#pragma unroll
+        for (int g = 0; g < D / 8; ++g) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_voff, g * 32, 0));
+            qf[g] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    }
 
-    // FAST, MODE 0: the 16 stream values of a step are stored at the START of the next step, ahead of that step's tile loads: the
-    // wait for those loads at the end of the step (vmcnt is in-order and the compiler drains it there) then finds the
-    // stores a whole step old instead of stalling on stores issued after the previous tile's loads
     float pprev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
-    float *STb = MODE == 0 ? KTb : GSb;   // the N x N stream written by this mode
     for (int k0 = 0; k0 < N; k0 += KB) {
         __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
         t.store(s_x);
         __syncthreads();
-        if (FAST && MODE == 0 && k0 > 0) {
-            const int kb = k0 - KB + kh * 32 + 4 * lh;
+        const int kb_bytes = __builtin_amdgcn_readfirstlane(k0 * ldk4);          // this step's key block
+        if ((MODE == 0 ? KTb : GSb) && k0 > 0) {   // the previous step's stream values (K^T / gS^T)
+            const int pb_bytes = __builtin_amdgcn_readfirstlane((k0 - KB) * ldk4);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                __builtin_nontemporal_store(pprev[r], STb + (size_t)(kb + (r & 3) + 8 * (r >> 2)) * ldk + gq);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), MODE == 0 ? kt_rs : gs_rs,
+                                                      st_voff(k0 - KB, r), st_soff(pb_bytes, r), MODE == 0 ? 2 : 0);
         }
-        if (k0 + KB < N) t.load(Xb, k0 + KB, N);
+        if (k0 + KB < N) t.load<FAST>(x_rs, t_voff, k0 + KB, N);
 
         // MODE 1: the saved kernel values under this wave's sub-tile, requested before the S MFMAs so that their
         // latency hides behind the 64 matrix instructions (they were the exposed part of this mode)
         float kfv[16];
         if (MODE == 1) {
-            const int kb0 = k0 + kh * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb0 + (r & 3) + 8 * (r >> 2);
-                // branch-free: clamped address, the out-of-range lanes are zeroed where the value is used (a predicated
-                // load costs a branch and a full vmcnt(0) each)
-                kfv[r] = KTb[(size_t)(key < N ? key : N - 1) * ldk + (q_ok ? gq : 0)];
-            }
+            for (int r = 0; r < 16; ++r)   // rows / columns beyond the matrix come back as 0 (bounds check): K = 0 < kmin below
+                kfv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kt_rs, st_voff(k0, r), st_soff(kb_bytes, r), 0));
+            // keep them HERE: left alone, the scheduler sinks the 16 loads behind the S MFMAs, right in front of their use
+            // (fewer live registers), and every step then waits out the full memory latency
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
         const float *xa = s_x + (kh * 32 + li) * LDSW + lh * 4;
@@ -147,12 +185,14 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
 #pragma unroll
         for (int g = 0; g < D / 8; ++g) {
             const float4 a = *reinterpret_cast<const float4 *>(xa + g * 8);
-            const float4 bq = *reinterpret_cast<const float4 *>(qb + g * 8);
+            const float4 bq = MODE == 0 ? qf[g] : *reinterpret_cast<const float4 *>(qb + g * 8);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, sacc, 0, 0, 0);
         }
+        // (MODE 1: nothing of the transform -- e.g. the compares on the just-requested K values -- may move above the S MFMAs)
+        if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
         // ---- elementwise transform; accumulator register r of lane (query li, half lh) is key (r&3)+8(r>>2)+4lh
         const int key_base = k0 + kh * 32 + 4 * lh;
 #pragma unroll
@@ -167,12 +207,11 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
                 e = fminf(fmaxf(e, -13.0f), 75.0f);
                 p = ok ? __expf(e) : 0.f;
                 rsum += p;
-                if (FAST) pprev[r] = p;
-                else if (KTb && ok) KTb[(size_t)key * ldk + gq] = p;
+                pprev[r] = p;
             } else {
-                const float kf = ok ? kfv[r] : 0.f;
+                const float kf = kfv[r];
                 p = kf > kmin ? (sacc[r] + radd) * kf * rcp_b2 : 0.f;
-                if (FAST || (GSb && ok)) GSb[(size_t)key * ldk + gq] = p;
+                pprev[r] = p;
             }
             sacc[r] = p;
         }
@@ -187,11 +226,13 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
         }
     }
 
-    if (FAST && MODE == 0) {  // the last step's stream values
-        const int kb = N - KB + kh * 32 + 4 * lh;
+    if (MODE == 0 ? KTb != nullptr : GSb != nullptr) {  // the last step's stream values
+        const int kl = ((N + KB - 1) / KB - 1) * KB;
+        const int kl_bytes = __builtin_amdgcn_readfirstlane(kl * ldk4);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            __builtin_nontemporal_store(pprev[r], STb + (size_t)(kb + (r & 3) + 8 * (r >> 2)) * ldk + gq);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), MODE == 0 ? kt_rs : gs_rs,
+                                                  st_voff(kl, r), st_soff(kl_bytes, r), MODE == 0 ? 2 : 0);
     }
     // ---- combine the two key halves: waves 2,3 park their partials in LDS (the X tile is dead now)
     __syncthreads();
@@ -311,16 +352,18 @@ __global__ __launch_bounds__(256, 2) void ms_fused_dx_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(Gb, (long long)N * D * 4), z_rs = make_rsrc(Zb, (long long)N * D * 4);
+    const int t_voff = ((threadIdx.x >> 5) * D + (threadIdx.x & 31) * 4) * 4;
     Tile64 tg, tz;
-    tg.load(Gb, 0, N);
-    tz.load(Zb, 0, N);
+    tg.load<false>(g_rs, t_voff, 0, N);
+    tz.load<false>(z_rs, t_voff, 0, N);
     for (int q0 = 0; q0 < N; q0 += QB) {
         __syncthreads();
         tg.store(s_g);
         tz.store(s_z);
         if (threadIdx.x < QB) s_ra[threadIdx.x] = (q0 + threadIdx.x) < N ? RAb[q0 + threadIdx.x] : 0.f;
         __syncthreads();
-        if (q0 + QB < N) { tg.load(Gb, q0 + QB, N); tz.load(Zb, q0 + QB, N); }
+        if (q0 + QB < N) { tg.load<false>(g_rs, t_voff, q0 + QB, N); tz.load<false>(z_rs, t_voff, q0 + QB, N); }
 
         // K values for (query register r, key lane): K^T[key][q0 + qh*32 + 8g + 4lh .. +3], 4 float4 per lane
         const int qbase = q0 + qh * 32 + 4 * lh;
@@ -400,7 +443,7 @@ int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, 
     if (!Z || !X || !bw || !Znext || !rowsum || !nrm || B <= 0 || N <= 0 || D_ != D || B > 65535 ||
         (KT && ld_kt < N))
         return PRIFIT_EINVAL;
-    if (KT && N % QB == 0)
+    if (N % QB == 0)
         hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
                            Znext, O, rowsum, nrm);
@@ -418,10 +461,14 @@ int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, co
     if (!gO || !X || !bw || !g_rowsum || !KT || !dZ || B <= 0 || N <= 0 || D_ != D || B > 65535 || ld_kt < N ||
         gO_batch_stride < (long long)N * D)
         return PRIFIT_EINVAL;
-    // (the unpredicated FAST variant measured slower in this mode: 809 vs 628 us at B = 24, N = 2048)
-    hipLaunchKernelGGL((ms_fused_kernel<1, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
-                       gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
-                       (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    if (N % QB == 0)
+        hipLaunchKernelGGL((ms_fused_kernel<1, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), gO,
+                           gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    else
+        hipLaunchKernelGGL((ms_fused_kernel<1, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
+                           gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
     return prifit_check_launch();
 }
 

@@ -12,8 +12,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int D = 128, QB = 64, KB = 64, LDSW = D + 4;
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+typedef float f32x4b __attribute__((ext_vector_type(4)));
 struct Tile64 {
     float4 v[8];
+    // buffer form: SGPR base, one constant VGPR offset per thread, scalar offset per (step, p)
+    __device__ __forceinline__ void loadb(__amdgpu_buffer_rsrc_t rs, int voff, int row0)
+    {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const f32x4b t = __builtin_bit_cast(f32x4b, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (row0 + 8 * p) * D * 4, 0));
+            v[p] = make_float4(t.x, t.y, t.z, t.w);
+        }
+    }
     __device__ __forceinline__ void load(const float *__restrict__ base, int row0)
     {
 #pragma unroll
@@ -32,7 +42,7 @@ struct Tile64 {
     }
 };
 
-template <bool QREG, bool DBUF, int SORD, int SKIP = 0>
+template <bool QREG, bool DBUF, int SORD, int SKIP = 0, bool BLD = false>
 __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const float *__restrict__ X,
                                               const float *__restrict__ bw, int N, float *__restrict__ KT,
                                               float *__restrict__ out, float *__restrict__ rsum_out)
@@ -49,6 +59,8 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
     const int qrow = qg * 32 + li, gq = q0 + qrow;
     float *KTb = KT + (size_t)b * N * N;
 
+    const __amdgpu_buffer_rsrc_t kt_rsrc = __builtin_amdgcn_make_buffer_rsrc(KTb, 0, N * N * 4, 0x00020000);
+    const int kt_voff = ((kh * 32 + 4 * lh) * N + gq) * 4;
     float4 qf[QREG ? 16 : 1];
     Tile64 t;
     if (QREG) {
@@ -56,8 +68,10 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
         for (int g = 0; g < 16; ++g) qf[g] = ld4(Qb + (size_t)gq * D + g * 8 + lh * 4);
     }
     if (!DBUF) { t.load(Qb, q0); t.store(s_x1); }
-    t.load(Xb, 0);
-    if (DBUF) { t.store(s_x0); if (KB < N) t.load(Xb, KB); __syncthreads(); }
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Xb), 0, N * D * 4, 0x00020000);
+    const int x_voff = ((threadIdx.x >> 5) * D + (threadIdx.x & 31) * 4) * 4;
+    if (BLD) t.loadb(x_rsrc, x_voff, 0); else t.load(Xb, 0);
+    if (DBUF) { t.store(s_x0); if (KB < N) { if (BLD) t.loadb(x_rsrc, x_voff, KB); else t.load(Xb, KB); } __syncthreads(); }
 
     f32x16 oacc[4];
 #pragma unroll
@@ -85,7 +99,14 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
                 __builtin_nontemporal_store(pprev[r], KTb + (size_t)(kb + (r & 3) + 8 * (r >> 2)) * N + gq);
         }
         const int nxt = k0 + (DBUF ? 2 : 1) * KB;
-        if (nxt < N && !(SKIP & 1)) t.load(Xb, nxt);
+        if (nxt < N && !(SKIP & 1)) { if (BLD) t.loadb(x_rsrc, x_voff, nxt); else t.load(Xb, nxt); }
+        if ((SORD == 3 || SORD == 4) && k0 > 0 && !(SKIP & 2)) {
+            const int sbase = (k0 - KB) * N * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), kt_rsrc, kt_voff,
+                                                      sbase + ((r & 3) + 8 * (r >> 2)) * N * 4, SORD == 4 ? 2 : 0);
+        }
         if (SORD == 2 && k0 > 0 && !(SKIP & 2)) {
             // tiled layout: tile (key block of 32, query block of 32) = 4 KiB; inside: [g 0..3][lane 0..63][4 floats]
             const int kt = (k0 - KB) / 32 + kh, qt = (q0 >> 5) + qg;
@@ -95,6 +116,13 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
                 f32x4 v = {pprev[4 * g], pprev[4 * g + 1], pprev[4 * g + 2], pprev[4 * g + 3]};
                 __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(tp + g * 256));
             }
+        }
+        if (SORD == 5 && k0 > 0 && !(SKIP & 2)) {
+            const int sbase = (k0 - KB) * N * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), kt_rsrc, kt_voff,
+                                                      sbase + ((r & 3) + 8 * (r >> 2)) * N * 4, 2);
         }
         if (SORD == 1 && k0 > 0 && !(SKIP & 2)) {
             const int kb = k0 - KB + kh * 32 + 4 * lh;
@@ -136,7 +164,13 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
         }
         if (DBUF) __syncthreads();
     }
-    if (SORD != 2) {
+    if (SORD == 3 || SORD == 4 || SORD == 5) {
+        const int sbase = (N - KB) * N * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), kt_rsrc, kt_voff,
+                                                  sbase + ((r & 3) + 8 * (r >> 2)) * N * 4, SORD == 4 ? 2 : 0);
+    } else if (SORD != 2) {
         const int kb = N - KB + kh * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -185,19 +219,19 @@ __global__ __launch_bounds__(256, 2) void msf(const float *__restrict__ Q, const
     }
 }
 
-template <bool QREG, bool DBUF, int SORD, int SKIP = 0>
+template <bool QREG, bool DBUF, int SORD, int SKIP = 0, bool BLD = false>
 static void run(const char *name, const float *Z, const float *X, const float *bw, int B, int N, float *KT, float *out,
                 float *rs, std::vector<float> &ref_out, std::vector<float> &ref_kt)
 {
     const size_t lds = (2 * KB * LDSW + 2 * QB) * sizeof(float);
-    (void)hipFuncSetAttribute((const void *)msf<QREG, DBUF, SORD, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)msf<QREG, DBUF, SORD, SKIP, BLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t s, e;
     (void)hipEventCreate(&s); (void)hipEventCreate(&e);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((msf<QREG, DBUF, SORD, SKIP>), dim3(N / QB, B), dim3(256), lds, 0, Z, X, bw, N, KT, out, rs);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((msf<QREG, DBUF, SORD, SKIP, BLD>), dim3(N / QB, B), dim3(256), lds, 0, Z, X, bw, N, KT, out, rs);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(s);
     const int reps = 20;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((msf<QREG, DBUF, SORD, SKIP>), dim3(N / QB, B), dim3(256), lds, 0, Z, X, bw, N, KT, out, rs);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((msf<QREG, DBUF, SORD, SKIP, BLD>), dim3(N / QB, B), dim3(256), lds, 0, Z, X, bw, N, KT, out, rs);
     (void)hipEventRecord(e);
     (void)hipEventSynchronize(e);
     float ms;
@@ -240,6 +274,14 @@ int main()
     run<true, false, 1>("V5 V1 + stores after loads", X, X, bw, B, N, KT, out, rs, ro, rk);
     run<false, false, 2>("V6 V0 + tiled K^T layout (4 x dwordx4 stores)", X, X, bw, B, N, KT, out, rs, ro, rk);
     run<true, true, 2>("V7 V2 + tiled K^T layout", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<false, false, 3>("V8 V0 + buffer stores (scalar offsets)", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<false, false, 4>("V9 V8 with nt", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<true, true, 4>("V10 V2 + nt buffer stores", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<false, false, 4, 0, true>("V11 V9 + buffer tile loads", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<true, true, 4, 0, true>("V12 V10 + buffer tile loads", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<true, false, 4, 0, true>("V13 QREG + buffer loads/stores", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<true, false, 5, 0, true>("V14 V13 with the stores AFTER the tile loads", X, X, bw, B, N, KT, out, rs, ro, rk);
+    run<true, false, 4, 2, true>("T  V13 without stores", X, X, bw, B, N, KT, out, rs, ro, rk);
     // timing-only eliminations on V0 (results are wrong by construction)
     run<false, false, 0, 2>("T  no K^T stores", X, X, bw, B, N, KT, out, rs, ro, rk);
     run<false, false, 0, 1>("T  no tile loads", X, X, bw, B, N, KT, out, rs, ro, rk);
