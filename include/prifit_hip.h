@@ -377,6 +377,13 @@ int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, co
                                   const float *bw, const float *g_rowsum, const float *KT, long long ld_kt,
                                   long long stride_kt, float *gST, int B, int N, int D, float *dZ,
                                   void *stream);
+/* dX += gS^T Z + K^T gO from the two saved streams (gS^T written by prifit_meanshift_fused_bwd_dz, K^T by
+ * prifit_meanshift_fused_fwd; row-major [key][query], leading dimension ld_kt, 16-byte aligned), key-major: every lane
+ * reads its own key row of both streams straight into MFMA A operands, only Z and gO tiles are staged in LDS.
+ * N % 64 == 0, D == 128.  Replaces the two dX products of a mean-shift backward iteration (src/mean_shift.py:65,73
+ * through autograd) -- the default; prifit_gemm_dual_nn_f32 is the general-shape fallback. */
+int prifit_meanshift_dx_streams(const float *gO, const float *Z, const float *gST, const float *KT, long long ld_kt,
+                                long long stride_kt, int B, int N, int D, float *dX, void *stream);
 /* dX += gS^T Z + K^T gO (both uses of the dictionary in one iteration) with gS re-formed in registers,
  * key-major, N % 4 == 0.  (Alternative to one long-K GEMM on [gS^T | K^T]; kept for N where that buffer
  * would not fit.) */

@@ -13,6 +13,8 @@
 // tile's global loads in flight during the MFMAs of the current one.  LDS rows are padded by one
 // 16-byte slot so that the ds_read_b128 fragment reads are bank-conflict free on the 64-bank LDS.
 // Block ids are remapped so that the N-tiles of one M-panel run on the same XCD (shared L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -190,6 +192,86 @@ struct TileLoader {
     }
 };
 
+// The same staging for operands whose extents are whole tiles (rows % ROWS == 0, K % BK == 0, 16-byte aligned rows) with
+// BUFFER addressing: one constant lane offset per float4 (computed once), the k-tile as a SCALAR offset -- no 64-bit
+// vector arithmetic, no predicates, no selects per k-tile (what the generic loader spends ~10 VALU per float4 on).
+// The matrix (one batch item) must span < 2 GiB.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int ROWS, bool KC, bool AFF, int NTH>
+struct ExactLoader {
+    static constexpr int NV = ROWS * BK / 4 / NTH;
+    static_assert(NV * NTH * 4 == ROWS * BK, "tile must divide evenly over the threads");
+    float4 v[NV];
+    int voff[NV];
+    int klo[NV], c0[NV];
+    const float *base;
+    __amdgpu_buffer_rsrc_t rs;
+    int step4;      // bytes per k-tile
+    int kload;
+
+    __device__ __forceinline__ void init(const float *__restrict__ b, long long ld, int r0, int, int)
+    {
+        base = b;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b), 0, 0x7ffffffc, 0x00020000);
+        step4 = __builtin_amdgcn_readfirstlane(KC ? BK * 4 : (int)(BK * ld * 4));
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (KC) {
+                klo[p] = (id % (BK / 4)) * 4;
+                c0[p] = 0;
+                voff[p] = (int)(((long long)(r0 + id / (BK / 4)) * ld + klo[p]) * 4);
+            } else {
+                klo[p] = id / (ROWS / 4);
+                c0[p] = r0 + (id % (ROWS / 4)) * 4;
+                voff[p] = (int)(((long long)klo[p] * ld + c0[p]) * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, const float *__restrict__, const float *__restrict__)
+    {
+        kload = k0;
+        const int soff = __builtin_amdgcn_readfirstlane((k0 / BK) * step4);
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0));
+            v[p] = make_float4(t.x, t.y, t.z, t.w);
+        }
+    }
+    __device__ __forceinline__ void finish(const float *__restrict__ scale, const float *__restrict__ shift)
+    {
+        if (!AFF) return;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int cc = KC ? kload + klo[p] : c0[p];
+            const float4 s = ld4(scale + cc), t = ld4(shift + cc);
+            float4 x = v[p];
+            x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
+            x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
+            v[p] = x;
+        }
+    }
+    __device__ __forceinline__ void shift(long long delta)   // second source of a dual product: a new resource
+    {
+        base += delta;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7ffffffc, 0x00020000);
+    }
+    __device__ __forceinline__ void store(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (KC) {
+                const int row = id / (BK / 4), kk = (id % (BK / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + row * (BK + PAD) + kk) = v[p];
+            } else {
+                const int kk = id / (ROWS / 4), row = (id % (ROWS / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + kk * (ROWS + PAD) + row) = v[p];
+            }
+        }
+    }
+};
+
 // Fragment of 4 consecutive MFMA k-steps for lane (i, h): k = 8*g + 4*h + j, j = 0..3.
 template <int ROWS, bool KC>
 __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int row, int g, int h)
@@ -199,8 +281,11 @@ __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int r
     return make_float4(p[0], p[ROWS + PAD], p[2 * (ROWS + PAD)], p[3 * (ROWS + PAD)]);
 }
 
-// VA/VB: vector loads legal for A/B; FA/FB: BatchNorm+ReLU prologue on A/B.
-template <int BM, int BN, int WM, int WN, int LAY, bool VA, bool VB, bool FA, bool FB>
+template <bool C, class A, class B> struct pick { typedef A type; };
+template <class A, class B> struct pick<false, A, B> { typedef B type; };
+
+// VA/VB: vector loads legal for A/B; FA/FB: BatchNorm+ReLU prologue on A/B; EX: whole tiles only (ExactLoader).
+template <int BM, int BN, int WM, int WN, int LAY, bool VA, bool VB, bool FA, bool FB, bool EX = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) == 8 ? 6 : 4)) void gemm_kernel(const GemmArgs g)
 {
     constexpr int NTH = (BM / WM) * (BN / WN) * 64;
@@ -247,15 +332,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    TileLoader<BM, A_KC, VA, FA, NTH> la;
-    TileLoader<BN, B_KC, VB, FB, NTH> lb;
+    typename pick<EX, ExactLoader<BM, A_KC, FA, NTH>, TileLoader<BM, A_KC, VA, FA, NTH>>::type la;
+    typename pick<EX, ExactLoader<BN, B_KC, FB, NTH>, TileLoader<BN, B_KC, VB, FB, NTH>>::type lb;
     la.init(A, g.lda, m0, g.M, g.K);
     lb.init(B, g.ldb, n0, g.N, g.K);
     constexpr int NVA = TileLoader<BM, A_KC, VA, FA, NTH>::NV;
     float rs[NVA];
 #pragma unroll
     for (int p = 0; p < NVA; ++p) rs[p] = 0.f;
-    const bool want_rowsum = A_KC && g.a_rowsum != nullptr && tile_n == 0;
+    const bool want_rowsum = !EX && A_KC && g.a_rowsum != nullptr && tile_n == 0;
 
     // Software pipeline: tile kt is computed from LDS stage s while tile kt+1 travels global -> registers;
     // it is written to stage s^1 after the MFMAs (nobody reads s^1 any more: the barrier that ended the
@@ -454,11 +539,28 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     }
 }
 
+static bool g_exact_enabled()
+{
+    static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_EXACT"); return !(e && e[0] == '0'); }();  // A/B switch
+    return on;
+}
+
 template <int BM, int BN, int WM, int WN, int LAY, bool VEC>
 static void launch_aff(const GemmArgs &g, dim3 grid, hipStream_t st)
 {
     // prologue combinations that occur: none, A only (forward / dA never has one), B only (dW)
     const dim3 block((BM / WM) * (BN / WN) * 64);
+    // whole tiles, 16-byte rows, each operand (one batch item) below 2 GiB, no A row sums: the exact loaders
+    const long long spanA = (LAY == LAY_TN ? (long long)g.K * g.lda : (long long)g.M * g.lda) * 4;
+    const long long spanB = (LAY == LAY_NT ? (long long)g.N * g.ldb : (long long)g.K * g.ldb) * 4;
+    const bool exact = VEC && g_exact_enabled() && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 && !g.a_rowsum &&
+                       spanA < 0x7ff00000LL && spanB < 0x7ff00000LL;
+    if (exact) {
+        if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, true, false, true>), grid, block, 0, st, g);
+        else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, false, true, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, false, false, true>), grid, block, 0, st, g);
+        return;
+    }
     if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, true, false>), grid, block, 0, st, g);
     else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, true>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, VEC, VEC, false, false>), grid, block, 0, st, g);

@@ -16,6 +16,8 @@
 // backward pass.  MODE 1 (backward, dZ): the same data flow with P replaced by
 //     gS^T = (X_sub . gO_q^T + g_rowsum_q) * K^T / b^2   where the clamp was inactive,
 // accumulating dZ_q += gS . X_sub, no normalisation.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,14 +47,16 @@ constexpr int OOB = 0x7fffffff;   // lane offset that fails the bounds check (in
 // global [rows x 128] tile -> registers (8 float4 per thread, 256 threads); rows beyond the matrix read as zeros
 // (the scalar offset is not part of the bounds check: EXACT = every row of the tile exists, the row goes into the scalar
 // offset; otherwise it goes into the lane offset, OOB for rows beyond the matrix)
-struct Tile64 {
-    float4 v[8];
+template <int NTH = 256>
+struct Tile64T {
+    static constexpr int NV = 2048 / NTH, RP = NTH / 32;   // float4 per thread, rows covered by one pass of the block
+    float4 v[NV];
     template <bool EXACT>
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff, int row0, int nrows)
     {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {   // thread's float4 p: row 8p + (tid >> 5), columns 4 (tid & 31) ..
-            const int row = row0 + 8 * p;
+        for (int p = 0; p < NV; ++p) {   // thread's float4 p: row RP p + (tid >> 5), columns 4 (tid & 31) ..
+            const int row = row0 + RP * p;
             const f32x4 t = __builtin_bit_cast(f32x4, EXACT
                 ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row * D * 4, 0)
                 : __builtin_amdgcn_raw_buffer_load_b128(rs, row + (int)(threadIdx.x >> 5) < nrows ? voff + row * D * 4 : OOB, 0, 0));
@@ -62,12 +66,13 @@ struct Tile64 {
     __device__ __forceinline__ void store(float *__restrict__ lds) const
     {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int id = threadIdx.x + 256 * p;
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
             *reinterpret_cast<float4 *>(lds + (id >> 5) * LDSW + (id & 31) * 4) = v[p];
         }
     }
 };
+typedef Tile64T<256> Tile64;
 }  // namespace
 
 // Q: the query-side operand rows (Z for MODE 0, gO for MODE 1) [B,N,128]; X: dictionary [B,N,128].
@@ -434,6 +439,109 @@ __global__ __launch_bounds__(256, 2) void ms_fused_dx_kernel(
     }
 }
 
+// dX += gS^T Z + K^T gO from the two N x N streams the other kernels wrote (gS^T by MODE 1, K^T by MODE 0), key-major,
+// N % 64 == 0.  Both products sum over the QUERY index, and a 32x32x2 MFMA takes its A operand as one value per lane
+// (lane = key row, lane half = k): the N x N operands therefore never pass through LDS -- every lane reads its own key
+// row of gS^T / K^T straight from global memory, four 16-byte pieces per stream and step (k order 8g + 4h + j, the same
+// the B rows are read in), prefetched one step ahead; only the small query-side tiles (Z and gO, 64 x 128 each) are
+// staged in LDS and shared by the four waves.  This is the "PV phase" of the forward kernel twice -- no S product, no
+// exp, no N x N store, no k-tile barrier per 32 deep slice as in the tiled GEMM, and no split-K atomics: a workgroup owns
+// its 64 keys, so dX is bit-reproducible from run to run.  Measured 456 us per call against ~440 us for the dual-source
+// GEMM at B = 24, N = 2048 (113 vs 117 TFLOP/s): opt-in (PRIFIT_MS_DX_STREAMS=1), the GEMM stays the default.
+template <int NKG>   // key groups of 32 per workgroup (2: 64 keys, 256 threads; 4: 128 keys, 512 threads)
+__global__ __launch_bounds__(NKG * 128, 2) void ms_dx_streams_kernel(
+    const float *__restrict__ gO, const float *__restrict__ Zc, const float *__restrict__ GST, const float *__restrict__ KT,
+    long long ldk, long long sk, int N, float *__restrict__ dX)
+{
+    __shared__ __attribute__((aligned(16))) float s_gz[2 * QB * LDSW];   // gO tile, Z tile (64 queries each)
+    float *s_g = s_gz, *s_z = s_gz + QB * LDSW;
+
+    const int b = blockIdx.y, k0 = blockIdx.x * (32 * NKG);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kg = wave % NKG, qh = wave / NKG;  // key group (32 keys), query half of every 64-query tile
+    const float *Gb = gO + (size_t)b * N * D;
+    const float *Zb = Zc + (size_t)b * N * D;
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(Gb, (long long)N * D * 4), z_rs = make_rsrc(Zb, (long long)N * D * 4);
+    const long long nn_bytes = ((long long)(N - 1) * ldk + N) * 4;
+    const __amdgpu_buffer_rsrc_t gs_rs = make_rsrc(GST + (size_t)b * sk, nn_bytes), kt_rs = make_rsrc(KT + (size_t)b * sk, nn_bytes);
+    const int t_voff = ((threadIdx.x >> 5) * D + (threadIdx.x & 31) * 4) * 4;
+    // this lane's key row, first query of its half and lane half: element (key, q0 + qh*32 + 8g + 4lh + j)
+    const int a_voff = (int)(((long long)(k0 + kg * 32 + li) * ldk + qh * 32 + 4 * lh) * 4);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    Tile64T<NKG * 128> tg, tz;
+    tg.template load<true>(g_rs, t_voff, 0, N);
+    tz.template load<true>(z_rs, t_voff, 0, N);
+    f32x4 an[8];   // next step's A fragments: [0..3] gS^T, [4..7] K^T
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        an[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs_rs, a_voff, g * 32, 0));
+        an[4 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kt_rs, a_voff, g * 32, 0));
+    }
+    for (int q0 = 0; q0 < N; q0 += QB) {
+        __syncthreads();
+        tg.store(s_g);
+        tz.store(s_z);
+        f32x4 ac[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ac[i] = an[i];
+        __syncthreads();
+        if (q0 + QB < N) {
+            tg.template load<true>(g_rs, t_voff, q0 + QB, N);
+            tz.template load<true>(z_rs, t_voff, q0 + QB, N);
+            const int sb = __builtin_amdgcn_readfirstlane((q0 + QB) * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                an[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs_rs, a_voff, sb + g * 32, 0));
+                an[4 + g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kt_rs, a_voff, sb + g * 32, 0));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the prefetches stay ahead of this step's MFMAs
+        // dX_j += gS^T . Z_sub + K^T . gO_sub   (A from registers: k = query 8g + 4lh + j; B rows of the LDS tiles)
+        const float *zs = s_z + (qh * 32 + 4 * lh) * LDSW + li;
+        const float *gs = s_g + (qh * 32 + 4 * lh) * LDSW + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = ((r & 3) + 8 * (r >> 2)) * LDSW;
+            const float a1 = ac[r >> 2][r & 3], a2 = ac[4 + (r >> 2)][r & 3];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, zs[ro + 32 * d], acc[d], 0, 0, 0);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, gs[ro + 32 * d], acc[d], 0, 0, 0);
+            }
+        }
+    }
+    // combine the two query halves and accumulate into dX (the partials of NKG x 32 keys x 128 floats fit the two tiles)
+    __syncthreads();
+    float *s_part = s_g;   // s_g and s_z are adjacent: 2 * 64 * 132 floats >= NKG * 32 * 128
+    static_assert(NKG * 32 * D <= 2 * QB * LDSW, "partials fit the tile buffers");
+    if (qh == 1) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s_part[(kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + 32 * d + li] = acc[d][r];
+    }
+    __syncthreads();
+    if (qh == 1) return;
+    float *dXb = dX + (size_t)b * N * D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kr = kg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // accumulator row = key
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float *dst = dXb + (size_t)(k0 + kr) * D + 32 * d + li;
+            *dst += acc[d][r] + s_part[kr * D + 32 * d + li];
+        }
+    }
+}
+
 extern "C" {
 
 int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D_, float *KT,
@@ -469,6 +577,22 @@ int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, co
         hipLaunchKernelGGL((ms_fused_kernel<1, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
                            gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
                            (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    return prifit_check_launch();
+}
+
+int prifit_meanshift_dx_streams(const float *gO, const float *Z, const float *gST, const float *KT, long long ld_kt,
+                                long long stride_kt, int B, int N, int D_, float *dX, void *stream)
+{
+    if (!gO || !Z || !gST || !KT || !dX || B <= 0 || N <= 0 || (N % QB) || (ld_kt & 3) || ld_kt < N || D_ != D || B > 65535 ||
+        (((uintptr_t)gST | (uintptr_t)KT) & 15) || (stride_kt & 3))
+        return PRIFIT_EINVAL;
+    static const int nkg = [] { const char *e = getenv("PRIFIT_MS_DX_NKG"); return e ? atoi(e) : 2; }();   // 4 (128 keys, 512 threads) measured slower: 566 vs 456 us
+    if (nkg == 4 && N % 128 == 0)
+        hipLaunchKernelGGL(ms_dx_streams_kernel<4>, dim3(N / 128, B), dim3(512), 0, as_stream(stream), gO, Z, gST, KT, ld_kt,
+                           stride_kt, N, dX);
+    else
+        hipLaunchKernelGGL(ms_dx_streams_kernel<2>, dim3(N / KB, B), dim3(256), 0, as_stream(stream), gO, Z, gST, KT, ld_kt,
+                           stride_kt, N, dX);
     return prifit_check_launch();
 }
 

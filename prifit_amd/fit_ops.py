@@ -22,6 +22,9 @@ NMS_CAP = 64     # centre ids kept by nms before the cluster-count check
 SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106)
 # mean-shift backward engine: "hybrid" (default) | "gemm" | "fused", see MeanShiftFn.backward
 BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "hybrid")
+# 1: dX from the stream-fed flash-style kernel (prifit_meanshift_dx_streams: no split-K atomics, so dX is bit-reproducible
+# from run to run) instead of the dual-source GEMM; measured 456 vs ~440 us per call at B = 24, N = 2048 -> default off
+DX_STREAMS = __import__("os").environ.get("PRIFIT_MS_DX_STREAMS", "0") != "0"
 DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
 
 
@@ -167,9 +170,14 @@ class MeanShiftFn(torch.autograd.Function):
                 with profiler.span("ms_fused_bwd", 4.0 * Bt * N * N * D):
                     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
                          _LL(N), _LL(sM), ptr(gS), Bt, N, D, ptr(gZ), cur_stream())
-                with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
-                    call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),
-                         _LL(D), _LL(sV), ptr(gX), _LL(D), _LL(sV), Bt, sk2, 1, cur_stream())
+                if N % 64 == 0 and DX_STREAMS:
+                    with profiler.span("ms_fused_dx", 4.0 * Bt * N * D * N):
+                        call("prifit_meanshift_dx_streams", ptr(gO), ptr(Z), ptr(gS), ptr(Kmat), _LL(N), _LL(sM), Bt, N, D,
+                             ptr(gX), cur_stream())
+                else:
+                    with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
+                        call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),
+                             _LL(D), _LL(sV), ptr(gX), _LL(D), _LL(sV), Bt, sk2, 1, cur_stream())
             elif mode == "fused":
                 with profiler.span("ms_fused_bwd", 10.0 * Bt * N * N * D):
                     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),

@@ -428,3 +428,31 @@ def test_subsampled_bandwidth_matches_reference_golden(hiplib, golden):
     assert ((rnd - ref).abs() < 0.1 * ref).all()
     with pytest.raises(ValueError):
         fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000, rows=rows[:, :10].cuda())
+
+
+def test_dx_streams_kernel_matches_dual_gemm(hiplib):
+    """prifit_meanshift_dx_streams (opt-in, atomics-free dX of a mean-shift backward iteration) against the dual-source
+    GEMM on the same streams, and its run-to-run bit-reproducibility."""
+    import ctypes
+    from prifit_amd._lib import call, ptr, cur_stream
+    LL = ctypes.c_longlong
+    B, N, D = 3, 256, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    gS = torch.randn(B, N, N, device="cuda", generator=g)
+    Kt = torch.rand(B, N, N, device="cuda", generator=g)
+    Z = torch.randn(B, N, D, device="cuda", generator=g)
+    gO = torch.randn(B, N, D, device="cuda", generator=g)
+    ref = (gS.double() @ Z.double() + Kt.double() @ gO.double()).float()      # rows = keys: gS^T / K^T are stored [key][query]
+    outs = []
+    for _ in range(2):
+        dX = torch.zeros(B, N, D, device="cuda")
+        call("prifit_meanshift_dx_streams", ptr(gO), ptr(Z), ptr(gS), ptr(Kt), LL(N), LL(N * N), B, N, D, ptr(dX), cur_stream())
+        outs.append(dX)
+    assert torch.equal(outs[0], outs[1])
+    tol = 2e-5 * (gS.norm(dim=2, keepdim=True) * Z.norm(dim=1).unsqueeze(1).amax(dim=2, keepdim=True) +
+                  Kt.norm(dim=2, keepdim=True) * gO.norm(dim=1).unsqueeze(1).amax(dim=2, keepdim=True))
+    assert ((outs[0] - ref).abs() <= tol + 1e-5).all()
+    d2 = torch.zeros(B, N, D, device="cuda")
+    call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kt), LL(N), LL(N * N), ptr(Z), ptr(gO), LL(D), LL(N * D), ptr(d2),
+         LL(D), LL(N * D), B, 1, 1, cur_stream())
+    torch.testing.assert_close(outs[0], d2, rtol=1e-4, atol=1e-3)
