@@ -55,11 +55,8 @@ __device__ __forceinline__ void st4nt(float *p, float4 v)
 
 // R radii, MODE (0 direct / 1 gather), D feature channels of the direct mode (0, 3 or 6), FX: features 0..2 are the
 // coordinates (no global loads for them), NW waves per workgroup
-// (second launch-bounds argument, coordinates-from-LDS form with 8 waves: 3 workgroups per CU = 6 waves per SIMD, i.e.
-// <= 80 VGPRs -- the compiler's own choice of 86 left room for 2 only: 157 -> 151 us on SA1.  The form that gathers
-// feature channels from HBM spills under that bound (182 -> 305 us) and keeps the default.)
 template <int R, int MODE, int D, bool FX, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 && FX) ? 6 : 1) void sa_group_kernel(const SAGroupArgs a)
+__global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
 {
     constexpr int KP = D + 3;
     __shared__ float4 s_pts[SG_TILE];
