@@ -460,10 +460,13 @@ int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, in
                          int32_t *off, void *stream);
 
 /* Surface samples on the Fibonacci (U,V) table evaluated as src/sample_ellipsoid.py:55-63, their exact
- * nearest target (src/utils.py:413-416): nn_idx [B,cap], sum_d2 [B] = sum of squared distances. */
+ * nearest target (src/utils.py:413-416): nn_idx [B,cap], sum_d2 [B] = sum of squared distances.
+ * workspace: prifit_sample_nn_workspace_floats(B, cap) floats of scratch (8-byte aligned): the search runs over
+ * several target ranges in parallel and a second launch keeps the first minimum. */
+long long prifit_sample_nn_workspace_floats(int B, int cap);
 int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n,
                          const int32_t *off, int B, int KM, const float *targets, int M, int cap,
-                         int32_t *nn_idx, float *sum_d2, void *stream);
+                         int32_t *nn_idx, float *sum_d2, float *workspace, void *stream);
 int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n,
                          const int32_t *off, int B, int KM, const float *targets, int M, int cap,
                          const int32_t *nn_idx, const float *gscale, float *g_r, float *g_V, float *g_c,
@@ -490,7 +493,7 @@ int prifit_cuboid_sample_budget(const float *r, const int32_t *valid, int B, int
                                 int32_t *off, void *stream);
 int prifit_cuboid_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n,
                                 const int32_t *off, int B, int KM, const float *targets, int M, int cap,
-                                int32_t *nn_idx, float *sum_d2, void *stream);
+                                int32_t *nn_idx, float *sum_d2, float *workspace, void *stream);
 int prifit_cuboid_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n,
                                 const int32_t *off, int B, int KM, const float *targets, int M, int cap,
                                 const int32_t *nn_idx, const float *gscale, float *g_r, float *g_V,

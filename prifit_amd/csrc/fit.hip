@@ -709,58 +709,118 @@ __device__ __forceinline__ void unit_param(int kind, int j, int n, const float r
 constexpr int NN_TILE_T = 1024;
 
 // Sample s of shape b: point on ellipsoid k(s), nearest target, squared distance (src/utils.py:413-416).
+// Brute-force exact search (10^4 samples x 5 10^3 targets per shape): VALU-bound, so the inner loop is built for the
+// vector pipe -- every thread carries TWO samples (s and s + 256) through the target tile, their distances are computed
+// with packed fp32 instructions (one LDS read and 6 packed operations for two distances instead of 2 x 6 scalar ones;
+// same operation order d = fma(dz, dz, fma(dy, dy, dx * dx)) and the same first-minimum rule as before, so the
+// neighbours are the ones the scalar loop found), four targets per trip.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void sample_point(int kind, const float *__restrict__ r, const float *__restrict__ V,
+                                             const float *__restrict__ c, const int32_t *__restrict__ n_k,
+                                             const int32_t *__restrict__ off, int KM, int b, int s, float &px, float &py,
+                                             float &pz)
+{
+    int k = 0;
+    while (k + 1 < KM && s >= off[k + 1]) ++k;
+    const size_t sl = (size_t)b * KM + k;
+    const float rk[3] = {r[sl * 3], r[sl * 3 + 1], r[sl * 3 + 2]};
+    float ex, ey, ez;
+    if (kind == KIND_CUBOID) {
+        float u[3];
+        cuboid_unit(s - off[k], n_k[sl], rk, u);
+        ex = u[0] * rk[0]; ey = u[1] * rk[1]; ez = u[2] * rk[2];
+    } else {
+        float cu, su, cv, sv;
+        fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
+        ex = rk[0] * cu * sv; ey = rk[1] * su * sv; ez = rk[2] * cv;
+    }
+    const float *Vk = V + sl * 9;
+    px = Vk[0] * ex + Vk[1] * ey + Vk[2] * ez + c[sl * 3];
+    py = Vk[3] * ex + Vk[4] * ey + Vk[5] * ez + c[sl * 3 + 1];
+    pz = Vk[6] * ex + Vk[7] * ey + Vk[8] * ez + c[sl * 3 + 2];
+}
+
+// The targets are cut into NN_SPLIT ranges (blockIdx.z): 4 x as many workgroups (624 -> 2496 at B = 24: the search is a
+// long serial loop per thread, and 2.4 workgroups per CU left the chip half idle at the end); every range writes its
+// (distance, index) candidate and sample_nn_pick_kernel keeps the first minimum over the ranges in ascending order --
+// the same neighbour the unsplit loop finds.
+constexpr int NN_SPLIT = 8;
+
 __global__ __launch_bounds__(256) void sample_nn_fwd_kernel(
     int kind, const float *__restrict__ r, const float *__restrict__ V, const float *__restrict__ c,
     const int32_t *__restrict__ n_k, const int32_t *__restrict__ off_k, int KM, const float *__restrict__ tgt,
-    int M, int cap, int32_t *__restrict__ nn_idx, float *__restrict__ sum_o)
+    int M, int cap, float *__restrict__ ws)
 {
     __shared__ float4 s_t[NN_TILE_T];
-    __shared__ float s_red[4];
     const int b = blockIdx.y;
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int s0 = blockIdx.x * 512 + threadIdx.x, s1 = s0 + 256;
     const int32_t *off = off_k + (size_t)b * (KM + 1);
     const int total = off[KM];
+    if (blockIdx.x * 512 >= total) return;  // block-uniform
+    const bool act0 = s0 < total, act1 = s1 < total;
+    float p0x = 0.f, p0y = 0.f, p0z = 0.f, p1x = 0.f, p1y = 0.f, p1z = 0.f;
+    if (act0) sample_point(kind, r, V, c, n_k, off, KM, b, s0, p0x, p0y, p0z);
+    if (act1) sample_point(kind, r, V, c, n_k, off, KM, b, s1, p1x, p1y, p1z);
+    float best0 = INFINITY, best1 = INFINITY;
+    int bi0 = 0, bi1 = 0;
+    const float *T = tgt + (size_t)b * M * 3;
+    const int chunk = (M + NN_SPLIT - 1) / NN_SPLIT;
+    const int m_lo = blockIdx.z * chunk, m_hi = min(M, m_lo + chunk);
+    for (int base = m_lo; base < m_hi; base += NN_TILE_T) {
+        const int tn = min(NN_TILE_T, m_hi - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < NN_TILE_T; i += 256) {
+            // rows beyond the tile repeat its last target: a duplicate never wins the strict comparison
+            const int ii = base + (i < tn ? i : tn - 1);
+            s_t[i] = make_float4(T[(size_t)ii * 3], T[(size_t)ii * 3 + 1], T[(size_t)ii * 3 + 2], 0.f);
+        }
+        __syncthreads();
+        const int tn4 = (tn + 3) & ~3;
+        for (int i = 0; i < tn4; i += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = s_t[i + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // (scalar fp32 on purpose: the packed v_pk_*_f32 forms of the same six operations measured slower here)
+                const float ax = p0x - t[u].x, ay = p0y - t[u].y, az = p0z - t[u].z;
+                const float bx = p1x - t[u].x, by = p1y - t[u].y, bz = p1z - t[u].z;
+                const float d0 = fmaf(az, az, fmaf(ay, ay, ax * ax));
+                const float d1 = fmaf(bz, bz, fmaf(by, by, bx * bx));
+                if (d0 < best0) { best0 = d0; bi0 = base + i + u; }
+                if (d1 < best1) { best1 = d1; bi1 = base + i + u; }
+            }
+        }
+    }
+    // (a padded duplicate can only tie with the real last target of the range, which came first: never taken)
+    float2 *cand = reinterpret_cast<float2 *>(ws) + ((size_t)b * NN_SPLIT + blockIdx.z) * cap;
+    if (act0) cand[s0] = make_float2(best0, __int_as_float(bi0));
+    if (act1) cand[s1] = make_float2(best1, __int_as_float(bi1));
+}
+
+// first minimum over the target ranges (ascending), nearest index out, sum of the squared distances per shape
+__global__ __launch_bounds__(256) void sample_nn_pick_kernel(const float *__restrict__ ws, const int32_t *__restrict__ off_k,
+                                                             int KM, int M, int cap, int32_t *__restrict__ nn_idx,
+                                                             float *__restrict__ sum_o)
+{
+    __shared__ float s_red[4];
+    const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    const int total = off_k[(size_t)b * (KM + 1) + KM];
     if (blockIdx.x * 256 >= total) return;  // block-uniform
     const bool act = s < total;
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (act) {
-        int k = 0;
-        while (k + 1 < KM && s >= off[k + 1]) ++k;
-        const size_t sl = (size_t)b * KM + k;
-        const float rk[3] = {r[sl * 3], r[sl * 3 + 1], r[sl * 3 + 2]};
-        float ex, ey, ez;
-        if (kind == KIND_CUBOID) {
-            float u[3];
-            cuboid_unit(s - off[k], n_k[sl], rk, u);
-            ex = u[0] * rk[0]; ey = u[1] * rk[1]; ez = u[2] * rk[2];
-        } else {
-            float cu, su, cv, sv;
-            fib_dir(s - off[k], n_k[sl], cu, su, cv, sv);
-            ex = rk[0] * cu * sv; ey = rk[1] * su * sv; ez = rk[2] * cv;
-        }
-        const float *Vk = V + sl * 9;
-        px = Vk[0] * ex + Vk[1] * ey + Vk[2] * ez + c[sl * 3];
-        py = Vk[3] * ex + Vk[4] * ey + Vk[5] * ez + c[sl * 3 + 1];
-        pz = Vk[6] * ex + Vk[7] * ey + Vk[8] * ez + c[sl * 3 + 2];
-    }
     float best = INFINITY;
     int bi = 0;
-    const float *T = tgt + (size_t)b * M * 3;
-    for (int base = 0; base < M; base += NN_TILE_T) {
-        const int tn = min(NN_TILE_T, M - base);
-        __syncthreads();
-        for (int i = threadIdx.x; i < tn; i += 256)
-            s_t[i] = make_float4(T[(size_t)(base + i) * 3], T[(size_t)(base + i) * 3 + 1],
-                                 T[(size_t)(base + i) * 3 + 2], 0.f);
-        __syncthreads();
-        for (int i = 0; i < tn; ++i) {
-            const float4 t = s_t[i];
-            const float dx = px - t.x, dy = py - t.y, dz = pz - t.z;
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (d < best) { best = d; bi = base + i; }
+    if (act) {
+        const int chunk = (M + NN_SPLIT - 1) / NN_SPLIT;
+#pragma unroll
+        for (int z = 0; z < NN_SPLIT; ++z) {
+            if (z * chunk >= M) break;
+            const float2 e = reinterpret_cast<const float2 *>(ws)[((size_t)b * NN_SPLIT + z) * cap + s];
+            if (e.x < best) { best = e.x; bi = __float_as_int(e.y); }
         }
+        nn_idx[(size_t)b * cap + s] = min(bi, M - 1);
     }
-    if (act) nn_idx[(size_t)b * cap + s] = bi;
     float v = act ? best : 0.f;
     v = wave_sum_f32(v);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
@@ -909,15 +969,17 @@ static int impl_sample_budget(int kind, const float *r, const int32_t *valid, in
 
 static int impl_sample_nn_fwd(int kind, const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
                          int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
-                         void *stream)
+                         float *workspace, void *stream)
 {
-    if (!r || !V || !c || !n || !off || !targets || !nn_idx || !sum_d2 || B <= 0 || KM <= 0 || KM > KM_MAX ||
-        M <= 0 || cap <= 0)
+    if (!r || !V || !c || !n || !off || !targets || !nn_idx || !sum_d2 || !workspace || B <= 0 || KM <= 0 || KM > KM_MAX ||
+        M <= 0 || cap <= 0 || ((uintptr_t)workspace & 7))
         return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(sum_d2, 0, sizeof(float) * B, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    hipLaunchKernelGGL(sample_nn_fwd_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, st, kind, r, V, c, n, off, KM,
-                       targets, M, cap, nn_idx, sum_d2);
+    hipLaunchKernelGGL(sample_nn_fwd_kernel, dim3((cap + 511) / 512, B, NN_SPLIT), dim3(256), 0, st, kind, r, V, c, n, off,
+                       KM, targets, M, cap, workspace);
+    hipLaunchKernelGGL(sample_nn_pick_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, st, workspace, off, KM, M, cap,
+                       nn_idx, sum_d2);
     return prifit_check_launch();
 }
 
@@ -997,18 +1059,20 @@ int prifit_cuboid_sample_budget(const float *r, const int32_t *valid, int B, int
     return impl_sample_budget(KIND_CUBOID, r, valid, B, KM, cap, n, off, stream);
 }
 
+long long prifit_sample_nn_workspace_floats(int B, int cap) { return 2LL * NN_SPLIT * B * cap; }
+
 int prifit_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
                          int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
-                         void *stream)
+                         float *workspace, void *stream)
 {
-    return impl_sample_nn_fwd(KIND_ELLIPSOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, sum_d2, stream);
+    return impl_sample_nn_fwd(KIND_ELLIPSOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, sum_d2, workspace, stream);
 }
 
 int prifit_cuboid_sample_nn_fwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,
                          int B, int KM, const float *targets, int M, int cap, int32_t *nn_idx, float *sum_d2,
-                         void *stream)
+                         float *workspace, void *stream)
 {
-    return impl_sample_nn_fwd(KIND_CUBOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, sum_d2, stream);
+    return impl_sample_nn_fwd(KIND_CUBOID, r, V, c, n, off, B, KM, targets, M, cap, nn_idx, sum_d2, workspace, stream);
 }
 
 int prifit_sample_nn_bwd(const float *r, const float *V, const float *c, const int32_t *n, const int32_t *off,

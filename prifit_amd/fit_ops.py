@@ -349,9 +349,10 @@ class SampleNNLossFn(torch.autograd.Function):
         call(ctx.pre + "_budget", ptr(r), ptr(valid), Bt, K, SAMPLE_CAP, ptr(n), ptr(off), cur_stream())
         nn_idx = torch.empty(Bt, SAMPLE_CAP, dtype=torch.int32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
+        ws = torch.empty(dll().prifit_sample_nn_workspace_floats(Bt, SAMPLE_CAP), dtype=torch.float32, device=dev)
         with profiler.span("sample_nn", 0.0):
             call(ctx.pre + "_nn_fwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M,
-                 SAMPLE_CAP, ptr(nn_idx), ptr(s), cur_stream())
+                 SAMPLE_CAP, ptr(nn_idx), ptr(s), ptr(ws), cur_stream())
         total = off[:, K].clone()
         ctx.save_for_backward(r, V, c, n, off, targets, nn_idx)
         ctx.mark_non_differentiable(total)
