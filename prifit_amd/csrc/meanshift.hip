@@ -6,8 +6,8 @@
 
 // ---------------------------------------------------------------------------------------------
 // k-th smallest entry of every row (torch.topk(dist, k, largest=False)[0][:, -1], mean_shift.py:156-158)
-// One wave per row; the row lives in registers (C <= 64*VPT) and a 32-step MSB-first radix
-// select over the order-preserving integer image of the floats finds the exact k-th value.
+// One wave per row; the row lives in registers (C <= 64*VPT) and a 32-step bisection over the
+// order-preserving integer image of the floats finds the exact k-th value.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned f2key(float f)
 {
@@ -38,27 +38,30 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) key[j] = (lane + 64 * j) < C ? f2key(raw[j]) : 0xffffffffu;  // padding sorts last
+    // Bisection on the key value instead of a masked radix step: the k-th smallest key is the largest p with
+    // count(key < p) < k, found bit by bit from the top -- ONE compare-and-count per key and round (2 VALU operations)
+    // where the masked digit test of the radix select took five, and no candidate bookkeeping (the padding keys
+    // 0xffffffff are never below a pivot, they simply never count).  32 rounds of (VPT counts + one wave sum).
+    // Early exit: c_lo / c_hi = number of keys below the current lower / upper bound of the answer; once exactly one key
+    // lies between them it IS the answer (a row of distinct distances gets there after ~12 of the 32 rounds).
     unsigned prefix = 0;
-    int kk = k;  // 1-based rank among the remaining candidates
-    int rem = VPT * 64;  // candidates whose decided high bits equal `prefix`
+    int c_lo = 0, c_hi = 64 * VPT;
     for (int bit = 31; bit >= 0; --bit) {
-        const unsigned hi_mask = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
-        if (rem == 1) {
-            // a single candidate is left: it is the answer, whatever its remaining bits (typically after ~12 of
-            // the 32 steps for a row of distinct distances)
-            unsigned m = 0;
-#pragma unroll
-            for (int j = 0; j < VPT; ++j) m = max(m, (key[j] & hi_mask) == prefix ? key[j] : 0u);
-            prefix = wave_max_u32_dpp(m);
-            break;
-        }
+        const unsigned p = prefix | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j)
-            cnt += ((key[j] & hi_mask) == prefix && !((key[j] >> bit) & 1u)) ? 1 : 0;
+        for (int j = 0; j < VPT; ++j) cnt += key[j] < p ? 1 : 0;
         cnt = wave_sum_i32_dpp(cnt);
-        if (kk > cnt) { kk -= cnt; rem -= cnt; prefix |= (1u << bit); }
-        else rem = cnt;
+        if (cnt < k) { prefix = p; c_lo = cnt; }   // fewer than k keys below p: the answer is >= p
+        else c_hi = cnt;
+        if (c_hi - c_lo == 1) {
+            // the single key in [prefix, prefix + 2^bit): smallest key >= prefix
+            unsigned m = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) m = min(m, key[j] >= prefix ? key[j] : 0xffffffffu);
+            prefix = ~wave_max_u32_dpp(~m);
+            break;
+        }
     }
     if (lane == 0) out[row] = key2f(prefix);
 }
