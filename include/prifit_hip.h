@@ -516,6 +516,18 @@ int prifit_edge_gather(const float *x, const int32_t *idx, int B, int N, int C, 
 int prifit_edge_scatter(const float *gout, int ld_gout, const int32_t *idx, int B, int N, int C, int k,
                         float *dx, void *stream);
 
+/* ---- gradient exchange: ONE sum all-reduce of the flat fp32 gradient bucket per optimizer
+ * step over RCCL / xGMI, on the caller's stream -- what the gradient reduce of nn.DataParallel
+ * (train_partseg_shapenet.py:248-250) becomes with one process per GPU.  RCCL is resolved at run time (the copy already
+ * loaded in the process first).  Protocol: rank 0 calls prifit_comm_unique_id and hands the
+ * prifit_comm_unique_id_bytes() bytes to every rank (any side channel); every rank calls prifit_comm_init with its
+ * device current; then prifit_allreduce_flat(buf, count, comm, stream) in place; prifit_comm_destroy at the end. */
+int prifit_comm_unique_id_bytes(void);
+int prifit_comm_unique_id(void *out);
+int prifit_comm_init(void **comm, int nranks, int rank, const void *unique_id);
+int prifit_allreduce_flat(float *buf, long long count, void *comm, void *stream);
+int prifit_comm_destroy(void *comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,7 @@ SOURCES = {
     "meanshift_fused.hip": [],
     "fit.hip": [],
     "dgcnn.hip": ["-ffp-contract=off"],
+    "comm.hip": [],        # host-only: the RCCL export (RCCL itself is resolved with dlopen at run time)
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
           "-I" + CSRC, "-Wall", "-Wno-unused-function"]
@@ -90,7 +91,7 @@ def _build_locked(force, verbose):
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         tmp = LIB + ".tmp.%d" % os.getpid()
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs)
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs + ["-ldl"])
         os.replace(tmp, LIB)
     return LIB
 

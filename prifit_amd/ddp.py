@@ -27,7 +27,7 @@ class FlatGradBucket:
     its weight decay and stale moments there; a parameter that never had one stays `None` and is
     skipped.  The same rule holds with 1 and with N ranks, so the trajectories agree."""
 
-    def __init__(self, module, process_group=None):
+    def __init__(self, module, process_group=None, native=None):
         self.module = module
         self.group = process_group
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -42,6 +42,15 @@ class FlatGradBucket:
         self.seen = [False] * len(self.params)   # has this parameter ever had a gradient (see the class docstring)
         self.dist = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist else 1
+        # native=True / PRIFIT_NATIVE_RCCL=1: the all-reduce goes through the library's own RCCL communicator
+        # (prifit_allreduce_flat, include/prifit_hip.h) instead of torch.distributed; device buckets only
+        if native is None:
+            import os
+            native = os.environ.get("PRIFIT_NATIVE_RCCL", "0") == "1"
+        self.native = None
+        if native and self.dist and dev.type == "cuda":
+            from .rccl import NativeComm
+            self.native = NativeComm.from_process_group(process_group)
 
     def zero(self):
         for p in self.params:
@@ -78,7 +87,10 @@ class FlatGradBucket:
                         p.grad = v
             return
         self.pack()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.native is not None:
+            self.native.allreduce_(self.flat)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.mul_(1.0 / self.world)
 
     def broadcast_parameters(self, src=0):

@@ -1,0 +1,52 @@
+"""Native RCCL communicator for the gradient exchange (the C-ABI path of SURVEY.md 8b: `prifit_allreduce_flat`).
+
+    comm = NativeComm.from_process_group()     # unique id from rank 0 through the initialised torch.distributed group
+    comm.allreduce_(flat_bucket)               # ONE sum all-reduce, in place, on PyTorch's current stream
+
+`FlatGradBucket(model, native=True)` (or PRIFIT_NATIVE_RCCL=1) uses it instead of `torch.distributed.all_reduce`; the
+process group is then only the side channel that carries the 128-byte unique id and the parameter broadcast.  The
+default stays `torch.distributed` (backend "nccl" IS RCCL on ROCm): same collective, one code path fewer to set up.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from ._lib import call, cur_stream, dll, ptr
+
+
+class NativeComm:
+    def __init__(self, nranks, rank, unique_id: bytes):
+        n = dll().prifit_comm_unique_id_bytes()
+        if len(unique_id) != n:
+            raise ValueError("unique id must be %d bytes" % n)
+        self.nranks, self.rank = nranks, rank
+        self._comm = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, n)
+        call("prifit_comm_init", ctypes.byref(self._comm), nranks, rank, buf)
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        n = dll().prifit_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(n)
+        call("prifit_comm_unique_id", buf)
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """Rank 0 draws the id, the initialised torch.distributed group (any backend) carries it to the others."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0])
+
+    def allreduce_(self, flat):
+        if not (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()):
+            raise ValueError("flat fp32 device buffer expected")
+        call("prifit_allreduce_flat", ptr(flat), ctypes.c_longlong(flat.numel()), self._comm, cur_stream())
+        return flat
+
+    def destroy(self):
+        if self._comm:
+            call("prifit_comm_destroy", self._comm)
+            self._comm = ctypes.c_void_p()

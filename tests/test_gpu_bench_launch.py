@@ -44,3 +44,38 @@ def test_bench_launch_paths_agree(hiplib):
         assert sorted(open(os.path.join(d, f)).read() for f in os.listdir(d)) == ["rank 0 of 2 local 0", "rank 1 of 2 local 1"]
     assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 48 and two["config"]["parallelism"] == "dp2"
     assert "rehearsal" in two and two["value"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_native_rccl_allreduce_one_rank(hiplib):
+    """prifit_allreduce_flat (the C-ABI RCCL export) with a one-rank communicator on the one GPU of this box:
+    unique id -> communicator -> in-place sum all-reduce on the current stream = identity, through NativeComm and
+    through FlatGradBucket(native=True).  Runs in a child process (its own process group)."""
+    code = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from prifit_amd import launch
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=0, world_size=1)
+from prifit_amd.rccl import NativeComm
+from prifit_amd.ddp import FlatGradBucket
+c = NativeComm.from_process_group()
+x = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+y = x.clone()
+c.allreduce_(y)
+torch.cuda.synchronize()
+assert torch.equal(x, y)
+net = torch.nn.Linear(8, 4).cuda()
+b = FlatGradBucket(net, native=True)
+assert b.native is not None
+net(torch.randn(3, 8, device="cuda")).sum().backward()
+g = net.weight.grad.clone()
+b.allreduce()
+torch.cuda.synchronize()
+assert torch.equal(net.weight.grad, g)
+c.destroy(); b.native.destroy()
+print("native rccl ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0 and "native rccl ok" in r.stdout, r.stderr[-3000:]
