@@ -238,3 +238,45 @@ def test_trainer_two_ranks_matches_one_process_on_the_averaged_gradient():
             assert float(d[big].max()) < 2e-5, (k, float(d[big].max()))
         else:
             assert float(d.max()) == 0.0, k                # never had a gradient: Adam skips it on both sides
+
+
+def test_zero_grad_semantics_match_reference_optimizer_loop():
+    """Alternating steps that reach different heads (supervised: conv2, not extra_conv_emb; self-supervised: the other
+    way round -- train_partseg_shapenet.py:382-399 / :436-451).  The reference's `optimizer.zero_grad()` (torch 1.6)
+    zero-FILLS existing gradients: a head that has had a gradient before still gets Adam's weight decay and
+    stale-moment update in the steps that do not reach it; one that never had one is skipped.  FlatGradBucket must
+    reproduce that trajectory exactly (single process: the same rule the N-rank path applies in pack())."""
+    sys.path.insert(0, ROOT)
+    from prifit_amd.ddp import FlatGradBucket
+
+    class TwoHeads(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = torch.nn.Linear(6, 8)
+            self.head_a = torch.nn.Linear(8, 3)
+            self.head_b = torch.nn.Linear(8, 2)
+
+    torch.manual_seed(9)
+    net, ref = TwoHeads(), TwoHeads()
+    ref.load_state_dict(net.state_dict())
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    opt, opt_ref = torch.optim.Adam(net.parameters(), **kw), torch.optim.Adam(ref.parameters(), **kw)
+    bucket = FlatGradBucket(net)
+    x = torch.randn(5, 6)
+    for step in range(5):
+        use_a = step % 2 == 0                       # a, b, a, b, a
+        # the reference loop: zero-fill what exists, backward, step
+        opt_ref.zero_grad(set_to_none=False)
+        h = torch.relu(ref.trunk(x))
+        (ref.head_a(h) if use_a else ref.head_b(h)).pow(2).mean().backward()
+        opt_ref.step()
+        # this package's loop
+        bucket.zero()
+        h = torch.relu(net.trunk(x))
+        (net.head_a(h) if use_a else net.head_b(h)).pow(2).mean().backward()
+        bucket.allreduce()
+        opt.step()
+        for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p, q), (step, k)
+    # head_b had no gradient in step 0 and must not have moved then; from step 1 on it moves in every step
+    assert bucket.seen == [True] * len(bucket.params)

@@ -125,3 +125,41 @@ def test_selfsup_step_and_checkpoint(hiplib):
         Trainer(net2).load(path)
         for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
             assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_speculative_retry_restores_python_state(hiplib):
+    """A step whose clustering verdict asks for the quantile-doubling retry is discarded and re-run: BatchNorm buffers,
+    the entropy-weight schedule `beta *= 0.99` (models/pointnet2_part_seg_msg.py:96-99: once per ACCEPTED step) and the
+    device RNG stream are put back first."""
+    from prifit_amd import fit_ops
+    from prifit_amd.train_step import SpeculativeRunner
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = torch.nn.BatchNorm1d(4)
+            self.beta = 1.0
+
+    m = Toy().cuda()
+    runner = SpeculativeRunner(m)
+    calls = []
+
+    def fn():
+        m.beta *= 0.99
+        m.bn(torch.ones(3, 4, device="cuda") * (len(calls) + 1))          # moves the running statistics
+        draw = torch.rand(4, device="cuda")
+        if fit_ops._spec is not None:                                     # first (speculative) attempt: verdict "retry"
+            flag = torch.ones(1, dtype=torch.int32).pin_memory()
+            ev = torch.cuda.Event()
+            ev.record()
+            fit_ops._spec.checks.append((ev, flag))
+        calls.append((m.bn.running_mean.clone(), draw))
+        return draw
+
+    rm0 = m.bn.running_mean.clone()
+    runner.run(fn, lambda: None)
+    assert len(calls) == 2 and runner.fallbacks == 1
+    assert abs(m.beta - 0.99) < 1e-12                                     # advanced once, not twice
+    assert torch.equal(calls[0][1], calls[1][1])                          # same random draw in the retried step
+    expect = rm0 * 0.9 + 0.1 * 2.0                                        # one momentum update, from the second call's input
+    torch.testing.assert_close(m.bn.running_mean, expect)
