@@ -53,6 +53,9 @@ struct GemmArgs {
     int vecA, vecB;                  // 16-byte loads legal for the operand
 };
 
+#ifndef GEMM_W8
+#define GEMM_W8 6
+#endif
 constexpr int BK = 32;
 constexpr int PAD = 4;
 
@@ -286,7 +289,7 @@ template <class A, class B> struct pick<false, A, B> { typedef B type; };
 
 // VA/VB: vector loads legal for A/B; FA/FB: BatchNorm+ReLU prologue on A/B; EX: whole tiles only (ExactLoader).
 template <int BM, int BN, int WM, int WN, int LAY, bool VA, bool VB, bool FA, bool FB, bool EX = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) == 8 ? 6 : 4)) void gemm_kernel(const GemmArgs g)
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) == 8 ? GEMM_W8 : 4)) void gemm_kernel(const GemmArgs g)
 {
     constexpr int NTH = (BM / WM) * (BN / WN) * 64;
     constexpr bool A_KC = (LAY != LAY_TN);
@@ -545,6 +548,96 @@ static bool g_exact_enabled()
     return on;
 }
 
+// Stream-K form of the dual-source NN product of the mean-shift backward (dX += gS^T Z + K^T gO; M = N_points, N = 128,
+// K = 2 x N_points): the (tile, k-tile) work units of ALL tiles and batch items are laid out in one line and cut into
+// equal contiguous ranges, one per PERSISTENT workgroup (grid = resident slots: 2 per CU).  The data-parallel launch has
+// 16 x 24 = 384 output tiles x split-K 2 = 768 workgroups for 512 slots: one and a half rounds, i.e. a quarter of the
+// machine idle on average (per-wave the kernel keeps its matrix pipe 88 % busy at full occupancy, PMC; 70 % overall);
+// split-K 4 fills three rounds exactly but doubles the per-workgroup prologue / epilogue.  Here every workgroup runs
+// 96 consecutive k-tiles (at most two segments of different tiles), each segment ends with float atomics into C.
+// Same tile shape, loaders, fragment reads and k order inside a segment as gemm_kernel<128,128,32,64,LAY_NN,...,EX>.
+__global__ __launch_bounds__(512, 4) void gemm_dual_sk_kernel(const GemmArgs g)
+{
+    constexpr int BM = 128, BN = 128, WN = 64, NTH = 512, TN = 2, WAVES_N = 2;
+    constexpr int SZA = BM * (BK + PAD), SZB = BK * (BN + PAD);
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];
+    const int tilesM = g.M / BM;
+    const int ktiles = g.K / BK;
+    const long long total = (long long)g.batch * tilesM * ktiles;
+    int u = (int)(total * blockIdx.x / gridDim.x);
+    const int uend = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * 32, wn0 = (wave % WAVES_N) * WN;
+    const int kswitch = g.kswitch ? g.kswitch : 0x7fffffff;
+
+    while (u < uend) {
+        const int t = u / ktiles;
+        const int kt0 = u - t * ktiles, kt1 = min(ktiles, kt0 + (uend - u));
+        const int z = t / tilesM, tile_m = t - z * tilesM;
+        const int m0 = tile_m * BM;
+        const float *A = g.A + (long long)z * g.sA;
+        const float *B = g.B + (long long)z * g.sB;
+        float *C = g.C + (long long)z * g.sC;
+
+        f32x16 acc[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        ExactLoader<BM, true, false, NTH> la;
+        ExactLoader<BN, false, false, NTH> lb;
+        la.init(A, g.lda, m0, g.M, g.K);
+        lb.init(B, g.ldb, 0, g.N, g.K);
+        if (kt0 >= kswitch) { la.shift(g.dA2); lb.shift(g.dB2); }
+        la.load(kt0 * BK, nullptr, nullptr);
+        lb.load(kt0 * BK, nullptr, nullptr);
+        la.store(lds);
+        lb.store(lds + SZA);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int stage = (kt - kt0) & 1;
+            const float *As = lds + stage * (SZA + SZB), *Bs = As + SZA;
+            const bool more = kt + 1 < kt1;
+            if (more) {
+                if (kt + 1 == kswitch) { la.shift(g.dA2); lb.shift(g.dB2); }
+                la.load((kt + 1) * BK, nullptr, nullptr);
+                lb.load((kt + 1) * BK, nullptr, nullptr);
+            }
+#pragma unroll
+            for (int gk = 0; gk < BK / 8; ++gk) {
+                const float4 fa = read_frag<BM, true>(As, wm0 + li, gk, lh);
+                float4 fb[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, false>(Bs, wn0 + 32 * b + li, gk, lh);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
+                }
+            }
+            if (more) {
+                float *An = lds + (stage ^ 1) * (SZA + SZB);
+                la.store(An);
+                lb.store(An + SZA);
+            }
+            __syncthreads();
+        }
+        // segment epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); always atomics
+        const int rbase = m0 + wm0 + 4 * lh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = wn0 + 32 * b + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                unsafeAtomicAdd(C + (long long)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldc + col, acc[b][r]);
+        }
+        u += kt1 - kt0;
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int LAY, bool VEC>
 static void launch_aff(const GemmArgs &g, dim3 grid, hipStream_t st)
 {
@@ -681,6 +774,22 @@ int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const
     g.dA2 = (A2 - A1) - (long long)K1;
     g.dB2 = (B2 - B1) - (long long)K1 * ldb;
     g.kswitch = K1 / BK;
+    // stream-K over persistent workgroups when the shape is whole tiles (the mean-shift backward: M = K1 = K2 = N_points)
+    static const bool streamk = [] { const char *e = getenv("PRIFIT_GEMM_STREAMK"); return !(e && e[0] == '0'); }();
+    if (streamk && accumulate && N == 128 && M % 128 == 0 && K1 == K2 && aligned16(A1) && aligned16(B1) && (lda % 4 == 0) &&
+        (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) && (long long)M * lda * 4 < 0x7ff00000LL &&
+        (long long)(K1 + K2) * ldb * 4 < 0x7ff00000LL) {
+        static const int slots = [] {
+            int dev = 0;
+            hipDeviceProp_t p;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 512;
+            return 2 * p.multiProcessorCount;   // two workgroups per CU fit (70.6 KB of LDS each)
+        }();
+        const long long total = (long long)batch * (M / 128) * ((K1 + K2) / BK);
+        const int grid = (int)(total < slots ? total : slots);
+        hipLaunchKernelGGL(gemm_dual_sk_kernel, dim3(grid), dim3(512), 0, as_stream(stream), g);
+        return prifit_check_launch();
+    }
     return dispatch(g, LAY_NN, stream);
 }
 
