@@ -81,7 +81,16 @@ typedef Tile64T<256> Tile64;
 // MODE 0: the 16 stream values of a step are stored at the start of the NEXT step, ahead of that step's tile loads (vmcnt
 // is one in-order counter for loads and stores on gfx9: the wait for a tile also waits for every older store, and a
 // whole step later the stores have long retired).
-template <int MODE, bool FAST>
+//
+// SK (stream-K, needs FAST): B x N/64 query blocks of N/64 key steps each are 768 workgroups of equal length at B = 24,
+// N = 2048, for 512 resident slots: one and a half rounds.  A lone wave keeps its SIMD's matrix pipe ~55 % busy, two
+// co-resident ones ~90 % (SQ counters: MFMA busy per wave cycle 0.50 at an average residency of 1.57 waves per SIMD), so
+// the half-empty second round runs at half efficiency.  With SK the (query block, key step) units of the whole launch are
+// cut into equal contiguous ranges for a grid of exactly the resident slots; a range is a sequence of SEGMENTS (part of
+// one query block each).  A segment that covers all key steps of its block ends as before; a partial one adds its
+// contribution with float atomics into a zero-initialised output (MODE 1: dZ; MODE 0: O and the row sums, the
+// normalisation epilogue of those blocks runs in a second small launch).
+template <int MODE, bool FAST, bool SK = false>
 __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     const float *__restrict__ Q, long long q_stride, const float *__restrict__ X, const float *__restrict__ bw,
     int N, const float *__restrict__ row_add,   // q_stride: batch stride of Q; row_add (MODE 1): g_rowsum [B,N]
@@ -90,16 +99,36 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     float *__restrict__ GST,             // MODE 1: optional output gS^T, same layout as KT
     const float *__restrict__ Zin,       // MODE 0: current points (== Q) for the epilogue
     float *__restrict__ out,             // MODE 0: normalised new points; MODE 1: dZ   [B,N,128]
-    float *__restrict__ O_out, float *__restrict__ rsum_out, float *__restrict__ nrm_out)  // MODE 0 saves
+    float *__restrict__ O_out, float *__restrict__ rsum_out, float *__restrict__ nrm_out,  // MODE 0 saves
+    int nbatch)                          // SK: number of shapes (the grid is 1-D)
 {
     __shared__ __attribute__((aligned(16))) float s_q[QB * LDSW];
     __shared__ __attribute__((aligned(16))) float s_x[KB * LDSW];
     __shared__ float s_rs[2 * QB];
 
-    const int b = blockIdx.y, q0 = blockIdx.x * QB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int qg = wave & 1, kh = wave >> 1;  // query group (32 rows), key half
+    // segments of this workgroup: [u, uend) in units of (query block, key step)
+    const int nsteps = (N + KB - 1) / KB, nqb = (N + QB - 1) / QB;
+    int u = 0, uend = 1;
+  for (bool first_seg = true; first_seg || (SK && u < uend); first_seg = false) {
+    int b, q0, kbeg, kend;
+    if (SK) {
+        if (first_seg) {
+            const long long total = (long long)nbatch * nqb * nsteps;
+            u = (int)(total * blockIdx.x / gridDim.x);
+            uend = (int)(total * (blockIdx.x + 1) / gridDim.x);
+            if (u >= uend) return;
+        }
+        const int blk = u / nsteps, s0 = u - blk * nsteps;
+        const int s1 = min(nsteps, s0 + (uend - u));
+        b = blk / nqb; q0 = (blk - b * nqb) * QB; kbeg = s0 * KB; kend = s1 * KB;
+        u += s1 - s0;
+    } else {
+        b = blockIdx.y; q0 = blockIdx.x * QB; kbeg = 0; kend = N;
+    }
+    const bool whole = !SK || (kend - kbeg >= N);
     const float *Qb = Q + (size_t)b * q_stride;
     const float *Xb = X + (size_t)b * N * D;
     const float bwv = bw[b];
@@ -111,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     Tile64 t;
     t.load<FAST>(q_rs, t_voff, q0, N);
     t.store(s_q);
-    t.load<FAST>(x_rs, t_voff, 0, N);
+    t.load<FAST>(x_rs, t_voff, kbeg, N);
 
     f32x16 oacc[4];
 #pragma unroll
@@ -156,19 +185,19 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     float pprev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
-    for (int k0 = 0; k0 < N; k0 += KB) {
+    for (int k0 = kbeg; k0 < kend; k0 += KB) {
         __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
         t.store(s_x);
         __syncthreads();
         const int kb_bytes = __builtin_amdgcn_readfirstlane(k0 * ldk4);          // this step's key block
-        if ((MODE == 0 ? KTb : GSb) && k0 > 0) {   // the previous step's stream values (K^T / gS^T)
+        if ((MODE == 0 ? KTb : GSb) && k0 > kbeg) {   // the previous step's stream values (K^T / gS^T)
             const int pb_bytes = __builtin_amdgcn_readfirstlane((k0 - KB) * ldk4);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), MODE == 0 ? kt_rs : gs_rs,
                                                       st_voff(k0 - KB, r), st_soff(pb_bytes, r), MODE == 0 ? 2 : 0);
         }
-        if (k0 + KB < N) t.load<FAST>(x_rs, t_voff, k0 + KB, N);
+        if (k0 + KB < kend) t.load<FAST>(x_rs, t_voff, k0 + KB, N);
 
         // MODE 1: the saved kernel values under this wave's sub-tile, requested before the S MFMAs so that their
         // latency hides behind the 64 matrix instructions (they were the exposed part of this mode)
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     }
 
     if (MODE == 0 ? KTb != nullptr : GSb != nullptr) {  // the last step's stream values
-        const int kl = ((N + KB - 1) / KB - 1) * KB;
+        const int kl = ((kend + KB - 1) / KB - 1) * KB;
         const int kl_bytes = __builtin_amdgcn_readfirstlane(kl * ldk4);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
             }
     }
     __syncthreads();
-    if (kh == 1) return;
+    if (kh == 0) {
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -273,10 +302,23 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
             const int gr = q0 + qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (gr >= N) continue;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) outb[(size_t)gr * D + 32 * d + li] = oacc[d][r];
+            for (int d = 0; d < 4; ++d) {
+                if (whole) outb[(size_t)gr * D + 32 * d + li] = oacc[d][r];
+                else unsafeAtomicAdd(outb + (size_t)gr * D + 32 * d + li, oacc[d][r]);   // dZ is zero-initialised (SK)
+            }
         }
-        return;
-    }
+    } else if (!whole) {
+        // MODE 0, partial segment: O and the row sums accumulate in the (zero-initialised) saved buffers; the
+        // normalisation of these blocks is prifit_meanshift_update_fwd's job (second launch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int gr = q0 + qr;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) unsafeAtomicAdd(O_out + ((size_t)b * N + gr) * D + 32 * d + li, oacc[d][r]);
+            if (li == 0) unsafeAtomicAdd(rsum_out + (size_t)b * N + gr, s_rs[qr] + s_rs[QB + qr]);
+        }
+    } else {
     // ---- MODE 0 epilogue (src/mean_shift.py:70-82): Mv = O / rowsum; new = Z + (Mv - Z); out = new / |new|
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -309,6 +351,10 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
             }
         }
     }
+    }
+    }   // kh == 0
+    if (SK) __syncthreads();   // the next segment overwrites s_q / s_x
+  }     // segments
 }
 
 // Backward w.r.t. the dictionary X (both of its uses in one iteration), key-major:
@@ -542,41 +588,110 @@ __global__ __launch_bounds__(NKG * 128, 2) void ms_dx_streams_kernel(
     }
 }
 
+// Normalisation epilogue (src/mean_shift.py:70-82) of the query blocks that the stream-K schedule of the forward kernel
+// split over two workgroups: their O rows and row sums were accumulated with atomics, nobody has the totals in
+// registers.  One wave per point; a workgroup whose block was NOT split (its whole range lies inside one workgroup's
+// units) returns at once.  `grid` = the grid size of the forward launch.
+__global__ __launch_bounds__(256) void ms_sk_epilogue_kernel(const float *__restrict__ O, const float *__restrict__ rsum,
+                                                             const float *__restrict__ Z, int N, int nbatch, int grid,
+                                                             float *__restrict__ out, float *__restrict__ nrm_o)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // 4 rows of the same query block
+    const int nsteps = N / KB, nqb = N / QB;
+    const long long total = (long long)nbatch * nqb * nsteps;
+    const long long blk = row / QB;
+    const long long lo = blk * nsteps, hi = lo + nsteps;
+    // a boundary total * w / grid strictly inside (lo, hi) <=> the block was split
+    const long long w = lo * grid / total + 1;
+    bool split = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long bnd = total * (w + i) / grid;
+        split = split || (bnd > lo && bnd < hi);
+    }
+    if (!split) return;
+    const int lane = threadIdx.x & 63;
+    const float *o = O + row * D;
+    const float *z = Z + row * D;
+    const float dinv = 1.0f / rsum[row];
+    float nv[2], ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float zz = z[lane + 64 * j];
+        const float m = o[lane + 64 * j] * dinv - zz;
+        nv[j] = zz + m;
+        ss += nv[j] * nv[j];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float n = sqrtf(ss);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) out[row * D + lane + 64 * j] = nv[j] / n;
+    if (lane == 0) nrm_o[row] = n;
+}
+
+static int sk_slots()
+{
+    static const int n = [] {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 512;
+        return 2 * p.multiProcessorCount;   // two workgroups of the fused kernels per CU (68 KB of LDS, <= 256 VGPRs)
+    }();
+    return n;
+}
+
 extern "C" {
 
 int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D_, float *KT,
                                long long ld_kt, long long stride_kt, float *Znext, float *O, float *rowsum,
-                               float *nrm, void *stream)
+                               float *nrm, int balanced, void *stream)
 {
     if (!Z || !X || !bw || !Znext || !rowsum || !nrm || B <= 0 || N <= 0 || D_ != D || B > 65535 ||
         (KT && ld_kt < N))
         return PRIFIT_EINVAL;
+    const int slots = sk_slots();
+    if (balanced && O && N % QB == 0 && (long long)B * (N / QB) > slots && ((long long)B * (N / QB)) % slots != 0) {
+        // stream-K: O and rowsum arrive ZERO-INITIALISED; split query blocks get their epilogue from the second launch
+        hipLaunchKernelGGL((ms_fused_kernel<0, true, true>), dim3(slots), dim3(256), 0, as_stream(stream), Z,
+                           (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                           Znext, O, rowsum, nrm, B);
+        hipLaunchKernelGGL(ms_sk_epilogue_kernel, dim3((unsigned)((long long)B * N / 4)), dim3(256), 0, as_stream(stream), O,
+                           rowsum, Z, N, B, slots, Znext, nrm);
+        return prifit_check_launch();
+    }
     if (N % QB == 0)
         hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm);
+                           Znext, O, rowsum, nrm, B);
     else
         hipLaunchKernelGGL((ms_fused_kernel<0, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm);
+                           Znext, O, rowsum, nrm, B);
     return prifit_check_launch();
 }
 
 int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, const float *X, const float *bw,
                                   const float *g_rowsum, const float *KT, long long ld_kt, long long stride_kt,
-                                  float *gST, int B, int N, int D_, float *dZ, void *stream)
+                                  float *gST, int B, int N, int D_, float *dZ, int balanced, void *stream)
 {
     if (!gO || !X || !bw || !g_rowsum || !KT || !dZ || B <= 0 || N <= 0 || D_ != D || B > 65535 || ld_kt < N ||
         gO_batch_stride < (long long)N * D)
         return PRIFIT_EINVAL;
-    if (N % QB == 0)
+    // stream-K: a grid of exactly the resident slots (2 workgroups per CU); dZ must then arrive zero-initialised
+    const int slots = sk_slots();
+    if (N % QB == 0 && balanced && (long long)B * (N / QB) > slots && ((long long)B * (N / QB)) % slots != 0)
+        hipLaunchKernelGGL((ms_fused_kernel<1, true, true>), dim3(slots), dim3(256), 0, as_stream(stream), gO,
+                           gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B);
+    else if (N % QB == 0)
         hipLaunchKernelGGL((ms_fused_kernel<1, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), gO,
                            gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
-                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B);
     else
         hipLaunchKernelGGL((ms_fused_kernel<1, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
                            gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
-                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B);
     return prifit_check_launch();
 }
 

@@ -25,6 +25,11 @@ BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "hybrid")
 # 1: dX from the stream-fed flash-style kernel (prifit_meanshift_dx_streams: no split-K atomics, so dX is bit-reproducible
 # from run to run) instead of the dual-source GEMM; measured 456 vs ~440 us per call at B = 24, N = 2048 -> default off
 DX_STREAMS = __import__("os").environ.get("PRIFIT_MS_DX_STREAMS", "0") != "0"
+# stream-K schedule of the fused mean-shift kernels (grid = resident slots, split query blocks combine through atomics):
+# the dZ mode gains 7 % (488 -> 452 us at B = 24, N = 2048); the forward does not (484 -> 497 us with its zero-fills,
+# atomics and second-launch epilogue), so it stays on the plain grid unless asked for
+MS_BALANCED = __import__("os").environ.get("PRIFIT_MS_BALANCED", "1") != "0"
+MS_BALANCED_FWD = __import__("os").environ.get("PRIFIT_MS_BALANCED_FWD", "0") != "0"
 DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
 
 
@@ -117,14 +122,18 @@ class MeanShiftFn(torch.autograd.Function):
         saved = []
         for _ in range(iterations):
             Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)  # fused: K^T [key][query]; else K
-            O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
-            rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+            if fused and MS_BALANCED_FWD:   # stream-K schedule: split query blocks accumulate O / rowsum with atomics
+                O = zero_pool.zeros(Bt, N, D, device=dev)
+                rsum = zero_pool.zeros(Bt, N, device=dev)
+            else:
+                O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
+                rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
             Zn = torch.empty_like(Z)
             nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
             if fused:
                 with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
                     call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
-                         _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), cur_stream())
+                         _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), int(MS_BALANCED_FWD), cur_stream())
             else:
                 _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
                 _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X, rowsum(K)
@@ -164,12 +173,16 @@ class MeanShiftFn(torch.autograd.Function):
                  _LL(sV), ptr(grs), cur_stream())
             sk = _skinny_splitk(N, D, N, Bt)
             sk2 = _skinny_splitk(N, D, 2 * N, Bt)
-            gZ = (torch.zeros if sk > 1 and mode == "gemm" else torch.empty)(Bt, N, D, dtype=torch.float32, device=dev)
+            balanced = mode == "hybrid" and MS_BALANCED
+            if balanced:
+                gZ = zero_pool.zeros(Bt, N, D, device=dev)   # stream-K schedule: split query blocks add their halves
+            else:
+                gZ = (torch.zeros if sk > 1 and mode == "gemm" else torch.empty)(Bt, N, D, dtype=torch.float32, device=dev)
             if mode == "hybrid":
                 # flash-style dZ kernel (products 1 + 2, streams gS^T out) + both dX terms as one dual-source product
                 with profiler.span("ms_fused_bwd", 4.0 * Bt * N * N * D):
                     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
-                         _LL(N), _LL(sM), ptr(gS), Bt, N, D, ptr(gZ), cur_stream())
+                         _LL(N), _LL(sM), ptr(gS), Bt, N, D, ptr(gZ), int(balanced), cur_stream())
                 if N % 64 == 0 and DX_STREAMS:
                     with profiler.span("ms_fused_dx", 4.0 * Bt * N * D * N):
                         call("prifit_meanshift_dx_streams", ptr(gO), ptr(Z), ptr(gS), ptr(Kmat), _LL(N), _LL(sM), Bt, N, D,
@@ -181,7 +194,7 @@ class MeanShiftFn(torch.autograd.Function):
             elif mode == "fused":
                 with profiler.span("ms_fused_bwd", 10.0 * Bt * N * N * D):
                     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(sV), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
-                         _LL(N), _LL(sM), None, Bt, N, D, ptr(gZ), cur_stream())              # dZ  = gS X
+                         _LL(N), _LL(sM), None, Bt, N, D, ptr(gZ), 0, cur_stream())           # dZ  = gS X
                     call("prifit_meanshift_fused_bwd_dx", ptr(gO), ptr(Z), ptr(X), ptr(bw), ptr(grs), ptr(Kmat),
                          _LL(N), _LL(sM), Bt, N, D, ptr(gX), cur_stream())                    # dX += gS^T Z + K^T gO
             elif ctx.fused:

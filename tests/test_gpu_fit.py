@@ -456,3 +456,34 @@ def test_dx_streams_kernel_matches_dual_gemm(hiplib):
     call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kt), LL(N), LL(N * N), ptr(Z), ptr(gO), LL(D), LL(N * D), ptr(d2),
          LL(D), LL(N * D), B, 1, 1, cur_stream())
     torch.testing.assert_close(outs[0], d2, rtol=1e-4, atol=1e-3)
+
+
+def test_stream_k_schedules_of_the_fused_mean_shift_kernels(hiplib):
+    """The stream-K (balanced) forms of the fused forward / dZ kernels against their plain-grid forms on a size where the
+    plain grid leaves a partial round (B x N/64 > resident slots, not a multiple of them): same Z / O / row sums / dZ to
+    rounding (split query blocks add two partial sums), identical K^T / gS^T streams."""
+    import ctypes
+    from prifit_amd._lib import call, ptr, cur_stream
+    LL = ctypes.c_longlong
+    B, N, D = 35, 1024, 128            # 560 query blocks for 512 slots
+    g = torch.Generator(device="cuda").manual_seed(3)
+    X = torch.nn.functional.normalize(torch.randn(B, N, D, device="cuda", generator=g), dim=2)
+    Z = torch.nn.functional.normalize(X + 0.1 * torch.randn(B, N, D, device="cuda", generator=g), dim=2)
+    bw = torch.full((B,), 0.5, device="cuda")
+    res = []
+    for bal in (0, 1):
+        KT = torch.empty(B, N, N, device="cuda")
+        Zn, O = torch.empty_like(Z), torch.zeros_like(Z)
+        rs, nrm = torch.zeros(B, N, device="cuda"), torch.empty(B, N, device="cuda")
+        call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), LL(N), LL(N * N), ptr(Zn), ptr(O), ptr(rs),
+             ptr(nrm), bal, cur_stream())
+        gO = torch.randn(B, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+        grs = torch.randn(B, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        gS, dZ = torch.empty(B, N, N, device="cuda"), torch.zeros(B, N, D, device="cuda")
+        call("prifit_meanshift_fused_bwd_dz", ptr(gO), LL(N * D), ptr(X), ptr(bw), ptr(grs), ptr(KT), LL(N), LL(N * N), ptr(gS),
+             B, N, D, ptr(dZ), bal, cur_stream())
+        res.append((KT, Zn, O, rs, nrm, gS, dZ))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[5], b[5])                 # the N x N streams: element for element
+    for i, tol in ((1, 1e-6), (2, 1e-4), (3, 1e-4), (4, 1e-6), (6, 1e-4)):
+        torch.testing.assert_close(a[i], b[i], rtol=1e-5, atol=tol)
