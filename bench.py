@@ -151,7 +151,9 @@ def cpu_baseline(workload):
 def _traffic_per_launch(dom):
     """HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 cannot run inside this
     process): profiles/r0X_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE, see the file's "source"."""
-    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true>", "ms_fused_bwd": "ms_fused_kernel<1, true>"}
+    # (the PMC tool names kernels, the spans name call sites)
+    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false>", "ms_fused_bwd": "ms_fused_kernel<1, true, true>",
+             "gemm_dual_nn": "gemm_dual_sk_kernel"}
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:

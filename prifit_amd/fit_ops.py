@@ -188,7 +188,7 @@ class MeanShiftFn(torch.autograd.Function):
                         call("prifit_meanshift_dx_streams", ptr(gO), ptr(Z), ptr(gS), ptr(Kmat), _LL(N), _LL(sM), Bt, N, D,
                              ptr(gX), cur_stream())
                 else:
-                    with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
+                    with profiler.span("gemm_dual_nn", 4.0 * Bt * N * D * N):
                         call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),
                              _LL(D), _LL(sV), ptr(gX), _LL(D), _LL(sV), Bt, sk2, 1, cur_stream())
             elif mode == "fused":
