@@ -259,7 +259,9 @@ def run_rank(args):
     dominant = max(cal.items(), key=lambda kv: kv[1][1])[0] if cal else None
     profiler.disable()
     profiler.reset()
-    if os.environ.get("PRIFIT_BENCH_EVENTS", "1") != "0":  # 0: diagnosis only (no roofline objects in the line)
+    if os.environ.get("PRIFIT_BENCH_EVENTS", "1") == "all":   # diagnosis: every family bracketed (slows the step down)
+        profiler.enable("*")
+    elif os.environ.get("PRIFIT_BENCH_EVENTS", "1") != "0":  # 0: diagnosis only (no roofline objects in the line)
         profiler.enable(*[n for n in (dominant,) + GROUPING_FAMILIES if n])
     # no cyclic-GC pauses inside the timed region (a generation-2 pass over the autograd graphs stalls the launch
     # thread for tens of ms; nothing on the step relies on the cycle collector, see MeanShiftFn.forward)
