@@ -32,7 +32,7 @@ SOURCES = {
     "comm.hip": [],        # host-only: the RCCL export (RCCL itself is resolved with dlopen at run time)
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
-          "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+          "-I" + CSRC, "-Wall", "-Wno-unused-function"] + os.environ.get("PRIFIT_BUILD_DEFS", "").split()  # diagnosis builds: -DTN_DEBUG=1 ...
 
 
 def _hipcc():

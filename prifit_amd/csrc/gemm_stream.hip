@@ -267,13 +267,18 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 
 // dW = G^T . relu(bn(A)) over the grouped samples: out[Mo, No] += sum_rows G[row, 0:Mo]^T A[row, 0:No]  (TN, the
 // reduction runs over 10^5..10^6 rows, the output is at most 128 x 128).  Both operands stream; there is nothing to
-// share between tiles, so there is no LDS and no barrier at all: every WAVE walks its own rows, loads the MFMA
-// fragments straight from global memory (lane = output row / column, 2 x 128 contiguous bytes per load instruction),
-// keeps one 8-row group in flight while the previous one is multiplied, and accumulates an output sub-block of at
-// most 64 x 64 in registers.  The four waves of a workgroup cover (sub-blocks) x (interleaved row groups), so the
-// second reader of a row finds it in L1 / L2.  The row-group streams of a workgroup are combined through LDS, every
-// workgroup stores one partial [Mo, No] slab into the caller's workspace (plain stores: 768 workgroups hammering the
-// same few KB with atomics cost more than the streaming itself), and a second tiny launch adds the slabs to `out`.
+// share between tiles, so there is no LDS and no barrier at all: every WAVE walks its own rows and loads the MFMA
+// fragments straight from global memory (lane = output row / column, 2 x 128 contiguous bytes per load instruction).
+//   * AM x AN (32 x 32 tiles of the output per wave) is chosen by the launcher so that the tiles divide EVENLY over
+//     the four waves (128 x 96 = 4 waves of 1 x 3 tiles, 96 x 64 = 2 sub-blocks of 3 x 1 tiles x 2 row streams, ...):
+//     every SIMD gets the same number of matrix instructions per row group;
+//   * PF 8-row groups per wave are in flight: the loop is unrolled PF times over statically indexed register
+//     stages (a rotating copy would wait for the newest load at the end of every iteration), loads are
+//     unconditional (rows past the end of the wave's range are clamped to its last group and multiplied by zero),
+//     so the steady state is straight-line code with exact vmcnt waits;
+//   * the row-group streams of a workgroup are combined through LDS, every workgroup stores one partial [Mo, No]
+//     slab into the caller's workspace (plain stores: hundreds of workgroups hammering the same few KB with atomics
+//     cost more than the streaming itself), and a second tiny launch adds the slabs to `out`.
 struct StreamTNArgs {
     const float *G, *A;
     float *ws;   // [gridDim.x][Mo * No] partial slabs
@@ -286,132 +291,211 @@ struct StreamTNArgs {
     const float *pool_T;             // [P / pool_K][Mo]
     const float *pool_b, *pool_d;    // [Mo]
     int pool_K;                      // multiple of 8
+    int interleave;
 };
+#ifndef TN_DEBUG
+#define TN_DEBUG 0
+#endif
 
-template <bool AFF, bool POOL>
-__global__ __launch_bounds__(256, 3) void gemm_stream_tn_kernel(const StreamTNArgs g)
+// RAG: the output is not a whole number of AM x AN sub-blocks (96 x 96 only): tiles beyond it are skipped at run time
+template <int AM, int AN, int PF, int OCC, bool AFF, bool POOL, bool RAG>
+__global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTNArgs g)
 {
-    __shared__ float s_part[3][64 * 64];  // partial sub-blocks of the row-group streams ks = 1..3
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NT = AM * AN;
+    __shared__ float s_part[3][NT * 1024];  // partial sub-blocks of the row-group streams ks = 1..3
+    // (readfirstlane: everything derived from the wave index is wave-uniform, and the compiler has to know it -- as a
+    // "divergent" value it wrapped every load and every MFMA in its own exec-mask branch and waited vmcnt(0) in the loop)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int mt_total = g.Mo >> 5, nt_total = g.No >> 5;
-    const int mb = (mt_total + 1) >> 1, nb = (nt_total + 1) >> 1;
+    const int mb = (mt_total + AM - 1) / AM, nb = (nt_total + AN - 1) / AN;
     const int SB = mb * nb, KS = 4 / SB;          // sub-blocks (1, 2 or 4) x interleaved row-group streams
     const int sb = wave % SB, ks = wave / SB;
     const int mblk = sb / nb, nblk = sb - mblk * nb;
-    const int m0 = 64 * mblk, n0 = 64 * nblk;
-    const bool m2 = mt_total - 2 * mblk >= 2, n2 = nt_total - 2 * nblk >= 2;  // wave-uniform
+    const int m0 = 32 * AM * mblk, n0 = 32 * AN * nblk;
+    const int m_cnt = RAG ? min(AM, mt_total - AM * mblk) : AM, n_cnt = RAG ? min(AN, nt_total - AN * nblk) : AN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[AM][AN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < AN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
-    if (AFF) {
-        sc[0] = g.b_scale[n0 + li]; sh[0] = g.b_shift[n0 + li];
-        if (n2) { sc[1] = g.b_scale[n0 + 32 + li]; sh[1] = g.b_shift[n0 + 32 + li]; }
+    float sc[AN], sh[AN];
+#pragma unroll
+    for (int b = 0; b < AN; ++b) {
+        sc[b] = 1.f; sh[b] = 0.f;
+        if (AFF && b < n_cnt) { sc[b] = g.b_scale[n0 + 32 * b + li]; sh[b] = g.b_shift[n0 + 32 * b + li]; }
     }
-    float pb[2] = {0.f, 0.f}, pd[2] = {0.f, 0.f};
-    if (POOL) {
-        pb[0] = g.pool_b[m0 + li]; pd[0] = g.pool_d[m0 + li];
-        if (m2) { pb[1] = g.pool_b[m0 + 32 + li]; pd[1] = g.pool_d[m0 + 32 + li]; }
+    float pb[AM], pd[AM];
+#pragma unroll
+    for (int a = 0; a < AM; ++a) {
+        pb[a] = 0.f; pd[a] = 0.f;
+        if (POOL && a < m_cnt) { pb[a] = g.pool_b[m0 + 32 * a + li]; pd[a] = g.pool_d[m0 + 32 * a + li]; }
     }
-    const long long r0 = (long long)blockIdx.x * g.rows_per_wg;
-    const long long r1 = r0 + g.rows_per_wg < g.P ? r0 + g.rows_per_wg : g.P;
-    const float *Gp = g.G + m0 + li + (long long)(4 * lh) * g.ldg;
-    const float *Ap = g.A + n0 + li + (long long)(4 * lh) * g.lda;
-    const long long stride = 8 * KS;
+    // rows of this wave's stream.  interleave: the 8-row groups of the whole launch are dealt round-robin over all
+    // (workgroup, stream) pairs, so at any moment the chip reads ONE contiguous window of the operands; otherwise every
+    // workgroup walks its own contiguous range.  Everything about a row group is wave-uniform and lives in SGPRs.
+    const int P = (int)g.P, rpw = (int)g.rows_per_wg;
+    const int r0 = g.interleave ? 0 : blockIdx.x * rpw;
+    const int r1 = g.interleave ? P : (r0 + rpw < P ? r0 + rpw : P);  // r1 - r0: a positive multiple of 8
+    const int stride = g.interleave ? 8 * KS * (int)gridDim.x : 8 * KS;
+    // Addressing: one buffer resource per 8-row group (base = the group's first row, a scalar 64-bit add), the lane's
+    // part of the address is ONE loop-invariant VGPR per operand, the row inside the group a loop-invariant SGPR offset:
+    // no vector instruction per load at all.  (With flat loads every load carried its own 64-bit VALU address chain;
+    // the waves of a SIMD fell into step -- all computing addresses, then all queueing for the matrix pipe -- and the
+    // MFMA rate of this kernel was ~0.55 of peak even with every load hitting the cache.)
+    const int ldg4 = (int)g.ldg * 4, lda4 = (int)g.lda * 4;
+    const int g_voff = (4 * lh * (int)g.ldg + m0 + li) * 4, a_voff = (4 * lh * (int)g.lda + n0 + li) * 4;
+    const int g_bytes = (7 * (int)g.ldg + g.Mo) * 4, a_bytes = (7 * (int)g.lda + g.No) * 4;
+    const int p_voff = (m0 + li) * 4;
+    const __amdgpu_buffer_rsrc_t arg_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t *>(POOL ? g.pool_arg : nullptr), 0, POOL ? (P / g.pool_K) * g.Mo * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t t_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(POOL ? g.pool_T : nullptr), 0, POOL ? (P / g.pool_K) * g.Mo * 4 : 0, 0x00020000);
+    // pooling group (quotient) and sample index (remainder) of a row advance incrementally: no division in the loop
+    const int pk = POOL ? g.pool_K : 1;
+    const int sq = stride / pk, sr = stride - sq * pk, q_last = (r1 - 8) / pk;
 
-    float cg[2][4], ca[2][4], ng[2][4], na[2][4];
-    int cw[2] = {0, 0}, nw[2] = {0, 0};          // POOL: winning sample of this lane's channel in the row group's pool
-    float ct[2] = {0.f, 0.f}, nt[2] = {0.f, 0.f};  //       and its gradient
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { cg[1][j] = 0.f; ca[1][j] = 0.f; ng[1][j] = 0.f; na[1][j] = 0.f; }
-    auto load = [&](long long row, float (&fg)[2][4], float (&fa)[2][4], int (&fw)[2], float (&ft)[2]) {
-        const float *gp = Gp + row * g.ldg;
-        const float *ap = Ap + row * g.lda;
+    float fg[PF][AM][4], fa[PF][AN][4];
+    int fw[PF][AM];      // POOL: winning sample of this lane's channel in the row group's pool
+    float ft[PF][AM];    //       and its gradient
+    auto load = [&](int row_, int q_, float (&xg)[AM][4], float (&xa)[AN][4], int (&xw)[AM], float (&xt)[AM]) {
+        const bool live = row_ < r1;
+        const int row = live ? row_ : r1 - 8;   // past the end: any valid group (its product is zeroed)
+        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.G + (long long)row * g.ldg), 0, g_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.A + (long long)row * g.lda), 0, a_bytes, 0x00020000);
         if (POOL) {
-            const long long o = (row / g.pool_K) * g.Mo + m0 + li;
-            fw[0] = g.pool_arg[o]; ft[0] = g.pool_T[o];
-            if (m2) { fw[1] = g.pool_arg[o + 32]; ft[1] = g.pool_T[o + 32]; }
+            const int so = (live ? q_ : q_last) * g.Mo * 4;
+#pragma unroll
+            for (int a = 0; a < AM; ++a) {
+                xw[a] = 0; xt[a] = 0.f;
+                if (a < m_cnt) {
+                    xw[a] = (int)__builtin_amdgcn_raw_buffer_load_b32(arg_rs, p_voff + 128 * a, so, 0);
+                    xt[a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t_rs, p_voff + 128 * a, so, 0));
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fg[0][j] = gp[(long long)j * g.ldg];
+        for (int a = 0; a < AM; ++a) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fa[0][j] = ap[(long long)j * g.lda];
-        if (m2) {
+            for (int j = 0; j < 4; ++j) xg[a][j] = 0.f;
+            if (a < m_cnt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fg[1][j] = gp[(long long)j * g.ldg + 32];
+                for (int j = 0; j < 4; ++j)
+                    xg[a][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, g_voff + 128 * a, j * ldg4, 0));
+            }
         }
-        if (n2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fa[1][j] = ap[(long long)j * g.lda + 32];
+        for (int b = 0; b < AN; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[b][j] = 0.f;
+            if (b < n_cnt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xa[b][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, a_voff + 128 * b, j * lda4, 0));
+            }
         }
     };
-    long long row = r0 + 8 * ks;
-    if (row < r1) load(row, cg, ca, cw, ct);
-    for (; row < r1; row += stride) {
-        if (row + stride < r1) load(row + stride, ng, na, nw, nt);
+    auto multiply = [&](int row, int rem, float (&xg)[AM][4], float (&xa)[AN][4], const int (&xw)[AM], const float (&xt)[AM]) {
+        const bool live = row < r1;   // wave-uniform
         if (POOL) {
-            const int kb = (int)(row % g.pool_K) + 4 * lh;  // sample index of this lane's first row in its pooling group
+            const int kb = rem + 4 * lh;  // sample index of this lane's first row in its pooling group
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                cg[0][j] = fmaf(pb[0], cg[0][j], pd[0]) + (cw[0] == kb + j ? ct[0] : 0.f);
-                cg[1][j] = fmaf(pb[1], cg[1][j], pd[1]) + (cw[1] == kb + j ? ct[1] : 0.f);
-            }
+            for (int a = 0; a < AM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xg[a][j] = fmaf(pb[a], xg[a][j], pd[a]) + (xw[a] == kb + j ? xt[a] : 0.f);
         }
+#pragma unroll
+        for (int a = 0; a < AM; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xg[a][j] = live ? xg[a][j] : 0.f;
         if (AFF) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ca[0][j] = fmaxf(fmaf(ca[0][j], sc[0], sh[0]), 0.f);
-                ca[1][j] = fmaxf(fmaf(ca[1][j], sc[1], sh[1]), 0.f);
-            }
+            for (int b = 0; b < AN; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xa[b][j] = fmaxf(fmaf(xa[b][j], sc[b], sh[b]), 0.f);
+        }
+        if (TN_DEBUG == 1) {   // DIAGNOSIS: memory side only (one VALU op per fragment pair keeps the loads alive)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < AM; ++a)
+#pragma unroll
+                    for (int b = 0; b < AN; ++b) acc[a][b][0] = fmaf(xg[a][j], xa[b][j], acc[a][b][0]);
+            return;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[0][j], ca[0][j], acc[0][0], 0, 0, 0);
-            if (n2) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[0][j], ca[1][j], acc[0][1], 0, 0, 0);
-            if (m2) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[1][j], ca[0][j], acc[1][0], 0, 0, 0);
-            if (m2 && n2) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cg[1][j], ca[1][j], acc[1][1], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { cg[0][j] = ng[0][j]; cg[1][j] = ng[1][j]; ca[0][j] = na[0][j]; ca[1][j] = na[1][j]; }
-        if (POOL) { cw[0] = nw[0]; cw[1] = nw[1]; ct[0] = nt[0]; ct[1] = nt[1]; }
+            for (int a = 0; a < AM; ++a)
+#pragma unroll
+                for (int b = 0; b < AN; ++b)
+                    if (a < m_cnt && b < n_cnt)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xg[a][j], xa[b][j], acc[a][b], 0, 0, 0);
+    };
+    int row = g.interleave ? 8 * ((int)blockIdx.x * KS + ks) : r0 + 8 * ks;   // the group being multiplied
+    int mrem = row % pk;
+    int lrow = row, lq = row / pk, lrem = mrem;                                // the group being requested
+    auto advance = [&](int &r, int &q, int &rem) {
+        r += stride; q += sq; rem += sr;
+        if (rem >= pk) { rem -= pk; ++q; }
+    };
+    if (TN_DEBUG == 2) { lrow = 8 * wave; lq = 0; }   // DIAGNOSIS: matrix side only (every load hits the same lines)
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s) {
+        load(lrow, lq, fg[s], fa[s], fw[s], ft[s]);
+        if (TN_DEBUG != 2) advance(lrow, lq, lrem);
+    }
+    while (row < r1) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int t = (s + PF - 1) % PF;
+            load(lrow, lq, fg[t], fa[t], fw[t], ft[t]);
+            if (TN_DEBUG != 2) advance(lrow, lq, lrem);
+            // the loads stay HERE, a whole PF - 1 groups ahead of their use: left alone, the scheduler sinks each one to
+            // just before its MFMA (fewer live registers) and the wave waits out the memory latency every time
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(row, mrem, fg[s], fa[s], fw[s], ft[s]);
+            __builtin_amdgcn_sched_barrier(0);
+            int dummy_q = 0;
+            advance(row, dummy_q, mrem);
+        }
     }
     // combine the KS row-group streams of every sub-block through LDS (stream 0 of each sub-block collects)
     if (KS > 1) {
         if (ks > 0) {
             float *dst = s_part[wave - SB];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < AM; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < AN; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+                    for (int r = 0; r < 16; ++r) dst[((a * AN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
         }
         __syncthreads();
         if (ks > 0) return;
         for (int k = 1; k < KS; ++k) {
             const float *src = s_part[k * SB + sb - SB];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < AM; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < AN; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * 2 + b) * 16 + r) * 64 + lane];
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += src[((a * AN + b) * 16 + r) * 64 + lane];
         }
     }
     // C/D layout: col = lane & 31 (n), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (m)
     float *slab = g.ws + (long long)blockIdx.x * g.Mo * g.No;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        if (a == 1 && !m2) continue;
+    for (int a = 0; a < AM; ++a) {
+        if (a >= m_cnt) continue;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (b == 1 && !n2) continue;
+        for (int b = 0; b < AN; ++b) {
+            if (b >= n_cnt) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -473,6 +557,75 @@ int launch_k(const StreamArgs &g, int grid, hipStream_t st)
 }
 
 }  // namespace
+
+// (AM, AN) tiles per wave, prefetch depth and resident workgroups per CU for an [Mo, No] output: AM x AN <= 4 tiles
+// dividing the output into 1, 2 or 4 sub-blocks (only 96 x 96 has no such split: ragged 2 x 2)
+struct TNPlan { int am, an, pf, occ, ragged; };
+static TNPlan stream_tn_plan(int Mo, int No)
+{
+    const int mt = Mo >> 5, nt = No >> 5;
+    static const int env_pf = [] { const char *e = getenv("PRIFIT_TN_PF"); return e ? atoi(e) : 0; }();
+    TNPlan p;
+    p.ragged = 0;
+    if (mt == 3 && nt == 3) { p.am = 2; p.an = 2; p.ragged = 1; }
+    else if (mt == 3) { p.am = 3; p.an = 1; }
+    else if (nt == 3) { p.am = 1; p.an = 3; }
+    else { p.am = mt >= 2 ? 2 : 1; p.an = nt >= 2 ? 2 : 1; }
+    p.pf = env_pf >= 2 && env_pf <= 4 ? env_pf : 3;
+    p.occ = (p.am * p.an == 4 && p.pf == 4) ? 2 : 3;
+    return p;
+}
+
+static long long stream_tn_split(int Mo, int No, long long P, long long *per_out)
+{
+    long long nwg = 256 * stream_tn_plan(Mo, No).occ;   // the resident workgroups
+    if (nwg > P / 256) nwg = P / 256 > 0 ? P / 256 : 1; // short reductions: fewer, longer ranges (fewer slabs to add up)
+    long long per = (P + nwg - 1) / nwg;
+    per = (per + 31) / 32 * 32;                 // whole 8-row groups for every interleaved stream
+    *per_out = per;
+    return (P + per - 1) / per;
+}
+
+template <int AM, int AN, int PF, int OCC, bool RAG>
+static void stream_tn_launch_t(const StreamTNArgs &g, dim3 grid, hipStream_t st)
+{
+    const dim3 block(256);
+    if (g.pool_arg) {
+        if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, true, true, RAG>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, false, true, RAG>), grid, block, 0, st, g);
+    } else {
+        if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, true, false, RAG>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, false, false, RAG>), grid, block, 0, st, g);
+    }
+}
+
+template <int AM, int AN, bool RAG = false>
+static void stream_tn_launch_pf(const StreamTNArgs &g, const TNPlan &p, dim3 grid, hipStream_t st)
+{
+    if (p.pf == 2) stream_tn_launch_t<AM, AN, 2, 3, RAG>(g, grid, st);
+    else if (p.pf == 4) stream_tn_launch_t<AM, AN, 4, (AM * AN == 4 ? 2 : 3), RAG>(g, grid, st);
+    else stream_tn_launch_t<AM, AN, 3, 3, RAG>(g, grid, st);
+}
+
+static int stream_tn_launch(StreamTNArgs &g, float *out, long long ldo, void *stream)
+{
+    const long long nwg = stream_tn_split(g.Mo, g.No, g.P, &g.rows_per_wg);
+    const TNPlan p = stream_tn_plan(g.Mo, g.No);
+    static const int env_il = [] { const char *e = getenv("PRIFIT_TN_INTERLEAVE"); return e ? atoi(e) : 1; }();
+    g.interleave = env_il;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((unsigned)nwg);
+    if (p.ragged) stream_tn_launch_pf<2, 2, true>(g, p, grid, st);
+    else if (p.am == 3) stream_tn_launch_pf<3, 1>(g, p, grid, st);
+    else if (p.an == 3) stream_tn_launch_pf<1, 3>(g, p, grid, st);
+    else if (p.am == 2 && p.an == 2) stream_tn_launch_pf<2, 2>(g, p, grid, st);
+    else if (p.am == 2) stream_tn_launch_pf<2, 1>(g, p, grid, st);
+    else if (p.an == 2) stream_tn_launch_pf<1, 2>(g, p, grid, st);
+    else stream_tn_launch_pf<1, 1>(g, p, grid, st);
+    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((g.Mo * g.No + 255) / 256, nwg < 32 ? (unsigned)nwg : 32u), dim3(256), 0, st,
+                       g.ws, (int)nwg, g.Mo, g.No, ldo, out);
+    return prifit_check_launch();
+}
 
 extern "C" {
 
@@ -566,39 +719,13 @@ int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long l
 int prifit_gemm_stream_tn_supported(int Mo, int No, long long P)
 {
     return Mo >= 32 && Mo <= 128 && (Mo & 31) == 0 && No >= 32 && No <= 128 && (No & 31) == 0 && P >= 32768 &&
-           (P & 7) == 0;
-}
-
-static long long stream_tn_split(long long P, long long *per_out)
-{
-    long long nwg = 768;                        // 3 resident workgroups per CU (about 140 VGPRs per wave)
-    long long per = (P + nwg - 1) / nwg;
-    per = (per + 31) / 32 * 32;                 // whole 8-row groups for every interleaved stream
-    *per_out = per;
-    return (P + per - 1) / per;
+           (P & 7) == 0 && P < (1ll << 30);   // row indices and pool offsets are 32-bit scalars in the kernel
 }
 
 long long prifit_gemm_stream_tn_workspace(int Mo, int No, long long P)
 {
     long long per;
-    return stream_tn_split(P, &per) * Mo * No;
-}
-
-static int stream_tn_launch(StreamTNArgs &g, float *out, long long ldo, void *stream)
-{
-    const long long nwg = stream_tn_split(g.P, &g.rows_per_wg);
-    hipStream_t st = as_stream(stream);
-    const dim3 grid((unsigned)nwg), block(256);
-    if (g.pool_arg) {
-        if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true, true>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((gemm_stream_tn_kernel<false, true>), grid, block, 0, st, g);
-    } else {
-        if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<true, false>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((gemm_stream_tn_kernel<false, false>), grid, block, 0, st, g);
-    }
-    hipLaunchKernelGGL(stream_tn_reduce_kernel, dim3((g.Mo * g.No + 255) / 256, 32), dim3(256), 0, st, g.ws, (int)nwg,
-                       g.Mo, g.No, ldo, out);
-    return prifit_check_launch();
+    return stream_tn_split(Mo, No, P, &per) * Mo * No;
 }
 
 int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long long ldg, const float *A,
@@ -606,6 +733,7 @@ int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long 
                               const float *b_shift, float *workspace, void *stream)
 {
     if (!G || !A || !out || !workspace || !prifit_gemm_stream_tn_supported(Mo, No, P) || ldg < Mo || lda < No ||
+        ldg >= (1 << 24) || lda >= (1 << 24) ||
         ldo < No || ((b_scale == nullptr) != (b_shift == nullptr)))
         return PRIFIT_EINVAL;
     StreamTNArgs g;
@@ -622,7 +750,7 @@ int prifit_gemm_stream_tn_pool_f32(int Mo, int No, long long P, const float *Y, 
                                    void *stream)
 {
     if (!Y || !A || !out || !workspace || !pool_arg || !pool_T || !coef_b || !coef_d ||
-        !prifit_gemm_stream_tn_supported(Mo, No, P) || ldy < Mo || lda < No || ldo < No ||
+        !prifit_gemm_stream_tn_supported(Mo, No, P) || ldy < Mo || lda < No || ldo < No || ldy >= (1 << 24) || lda >= (1 << 24) ||
         ((b_scale == nullptr) != (b_shift == nullptr)) || pool_K < 8 || (pool_K & 7) || (P % pool_K))
         return PRIFIT_EINVAL;
     StreamTNArgs g;

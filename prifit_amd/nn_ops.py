@@ -60,14 +60,14 @@ def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, spl
     if (not (tiled_stats and stats is not None) and _stream_ok(layout, M, N, K, batch, splitk, epi, b_affine, a_rowsum, accumulate, aux, row_add) and lda % 4 == 0 and
             A.data_ptr() % 16 == 0 and (layout == NN or (ldb % 4 == 0 and B.data_ptr() % 16 == 0))):
         # HBM-bound: the span's work is the algorithmic bytes (A read once, C written once, B once)
-        with profiler.span("gemm_stream_%s" % ("nt", "nn")[layout], 4.0 * (M * K + M * N + N * K)):
+        with profiler.span(profiler.tag("gemm_stream_%s" % ("nt", "nn")[layout], M, N, K), 4.0 * (M * K + M * N + N * K)):
             call("prifit_gemm_stream_f32", layout, M, N, K, ptr(A), _LL(lda), ptr(B), _LL(ldb), ptr(C), _LL(ldc),
                  ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None, ptr(bias), ptr(stats),
                  cur_stream())
         return
     # span name = the kernel instantiation (layout, BN tile) so that it lines up with rocprofv3's per-kernel rows
-    with profiler.span("gemm_%s_bn%d" % (("nt", "nn", "tn")[layout], 32 if N <= 32 else (64 if N <= 64 else (96 if N <= 96 else 128))),
-                       2.0 * M * N * K * batch):
+    with profiler.span(profiler.tag("gemm_%s_bn%d" % (("nt", "nn", "tn")[layout], 32 if N <= 32 else (64 if N <= 64 else (96 if N <= 96 else 128))),
+                                    M, N, K, batch, splitk), 2.0 * M * N * K * batch):
         call("prifit_gemm_f32", layout, M, N, K, ptr(A), _LL(lda), _LL(sA), ptr(B), _LL(ldb), _LL(sB), ptr(C),
              _LL(ldc), _LL(sC), batch, splitk,
              ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
@@ -90,7 +90,7 @@ def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
         # tall reduction, small output: the LDS-free streaming kernel (csrc/gemm_stream.hip), HBM-bound
         dW = out if out is not None else zero_pool.zeros(Cout, Kin, device=dY.device)
         ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dY.device)
-        with profiler.span("gemm_stream_tn", 4.0 * P * (Cout + Kin)):
+        with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P), 4.0 * P * (Cout + Kin)):
             call("prifit_gemm_stream_tn_f32", Cout, Kin, _LL(P), ptr(dY), _LL(dY.stride(0)), ptr(Ain), _LL(Ain.stride(0)),
                  ptr(dW), _LL(Kin), ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
                  ptr(ws), cur_stream())
@@ -162,7 +162,7 @@ class SharedMLPFn(torch.autograd.Function):
                     # max-pooled last layer on the streaming kernel: (max, argmax, min, argmin) per 32 rows and column come
                     # out of the epilogue; the pool below reads those candidates (1/8 of Y) instead of Y
                     cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
-                    with profiler.span("gemm_stream_nt", 4.0 * (P * Kin + P * Cout + Cout * Kin)):
+                    with profiler.span(profiler.tag("gemm_stream_nt", P, Cout, Kin, 1), 4.0 * (P * Kin + P * Cout + Cout * Kin)):
                         call("prifit_gemm_stream_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin),
                              ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), cur_stream())
                 else:
@@ -272,7 +272,7 @@ class SharedMLPFn(torch.autograd.Function):
                 dW = arena[wo:wo + wn].view(Cout, Kin)
                 ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
                 a_aff = affines[l - 1]
-                with profiler.span("gemm_stream_tn", 4.0 * P * (Cout + Kin)):
+                with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P, 1), 4.0 * P * (Cout + Kin)):
                     call("prifit_gemm_stream_tn_pool_f32", Cout, Kin, _LL(P), ptr(Y), _LL(Cout), ptr(Ys[l - 1]),
                          _LL(Ys[l - 1].stride(0)), ptr(dW), _LL(Kin), ptr(a_aff[0]), ptr(a_aff[1]), ptr(arg), ptr(Ttab),
                          ptr(cb), ptr(cd), K, ptr(ws), cur_stream())
@@ -288,7 +288,7 @@ class SharedMLPFn(torch.autograd.Function):
                     ns = dll().prifit_gemm_stream_slabs(P, Cout)
                     rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
                 (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
-                with profiler.span("gemm_stream_nn", 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
+                with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, 1), 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
                     call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
                          _LL(Kin), ptr(bias_dw), ptr(arg), ptr(Ttab), ptr(cb), K, ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)),
                          ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), cur_stream())
@@ -343,7 +343,7 @@ class SharedMLPFn(torch.autograd.Function):
                     ns = dll().prifit_gemm_stream_slabs(P, Cout)
                     rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
                     (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
-                    with profiler.span("gemm_stream_nn", 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
+                    with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, 0), 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
                         call("prifit_gemm_stream_dgrad_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
                              _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
                              ptr(rslab), cur_stream())
@@ -354,8 +354,8 @@ class SharedMLPFn(torch.autograd.Function):
                     ns = (P + t - 1) // t
                     rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
                     (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
-                    with profiler.span("gemm_nn_bn%d" % (32 if Kin <= 32 else (64 if Kin <= 64 else (96 if Kin <= 96 else 128))),
-                                       2.0 * P * Kin * Cout):
+                    with profiler.span(profiler.tag("gemm_nn_bn%d" % (32 if Kin <= 32 else (64 if Kin <= 64 else (96 if Kin <= 96 else 128))),
+                                                    P, Kin, Cout, "red"), 2.0 * P * Kin * Cout):
                         call("prifit_gemm_dgrad_bnred_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
                              _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
                              ptr(rslab), cur_stream())

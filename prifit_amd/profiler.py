@@ -9,8 +9,15 @@ import contextlib
 
 import torch
 
+import os
+
 _enabled = set()
 _records = {}
+SHAPES = os.environ.get("PRIFIT_SPAN_SHAPES", "0") == "1"   # diagnosis: callers append the problem shape to the span name
+
+
+def tag(name, *dims):
+    return name + ("[" + "x".join(str(d) for d in dims) + "]" if SHAPES else "")
 
 
 def enable(*names):
