@@ -16,6 +16,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -49,6 +50,7 @@ struct StreamArgs {
     // After the BatchNorm statistics are final, max_k relu(s*y+t) = relu(s*(s >= 0 ? max : min)+t) is read from these
     // candidates instead of from C (prifit_pool_from_candidates).
     float *cand;
+    int nslab;                       // slabs the caller reads (stream_grid(M, K)); >= the launched grid
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -56,7 +58,7 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // WN: waves along N (2 or 4; 256 threads = 4 waves, WM = 4 / WN waves along M); KG = K / 8;
 // BKC: B is [N][K] (NT) else [K][N] (NN); AFF: prologue on A
 template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL, bool PMAX>
-__global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
+__global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (KG <= 12 ? ((RED || PMAX || POOL) ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
 {
     constexpr int K = KG * 8;
     constexpr int WM = 4 / WN;
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
     __shared__ __attribute__((aligned(16))) float s_pool[2][2][POOL ? K : 4];  // [stage][arg | T][channel]
     __shared__ float s_red[WM][2][32 * WN];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (readfirstlane: wm / wn are wave-uniform and the compiler has to know it, see gemm_stream_tn_kernel)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int col = 32 * wn + li;
@@ -98,42 +101,45 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 
     const int tiles = (g.M + SBM - 1) / SBM;
     float4 st[NV];
-    float4 st_pool = make_float4(0.f, 0.f, 0.f, 0.f);
-    // per-thread element offsets of its NV float4 inside a tile (32-bit: the launcher checks M * lda < 2^31)
-    unsigned aoff[NV];
+    float st_pool = 0.f;
+    // Addressing: one buffer resource per tile (base = the tile's first row, exact extent: rows beyond M read as zeros and
+    // stores to them are dropped by the bounds check); a thread's part of an address is a loop-invariant VGPR, the rest
+    // is scalar -- no 64-bit VALU address chain per access (the launcher checks SBM * ld * 4 < 2^31).
+    int aoff[NV];
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
         const int id = threadIdx.x + 256 * p;
         const int row = id / (K / 4), c4 = id - row * (K / 4);
-        aoff[p] = (unsigned)row * (unsigned)g.lda + 4u * c4;
+        aoff[p] = (row * (int)g.lda + 4 * c4) * 4;
     }
-    const unsigned last_row_off = (unsigned)(g.M - 1) * (unsigned)g.lda;
+    const float *pool_src = nullptr;
+    if (POOL) {
+        const int which = (threadIdx.x / K) & 1, k = threadIdx.x % K;
+        pool_src = (which ? g.pool_T : reinterpret_cast<const float *>(g.pool_arg)) + k;
+    }
+    auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
+        const int rows = g.M - m0 < SBM ? g.M - m0 : SBM;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0,
+                                                 ((rows - 1) * (int)ld + width) * 4, 0x00020000);
+    };
     auto load_tile = [&](int tile) {
         const int m0 = tile * SBM;
-        if (POOL && threadIdx.x < 2 * (K / 4)) {  // the (arg, T) rows of this tile's pooling group: 2 x K values
-            const int which = threadIdx.x / (K / 4), c4 = threadIdx.x - which * (K / 4);
-            const float *src = which ? g.pool_T : reinterpret_cast<const float *>(g.pool_arg);
-            st_pool = ld4(src + (long long)(m0 / g.pool_K) * K + 4 * c4);
-        }
-        const float *At = g.A + (long long)m0 * g.lda;   // wave-uniform tile base
-        const bool full = m0 + SBM <= g.M;
+        // the (arg, T) rows of this tile's pooling group: 2 x K values, ONE dword per thread, loaded by every thread (no
+        // branch).  (As a float4 of the first 2 * K / 4 threads the value was copied to other registers right after the
+        // load -- a split live range, or the join of the branch -- and that copy waited for the load and, vmcnt being one
+        // in-order counter, for all of the previous tile's stores: a full memory round trip per tile.)
+        if (POOL) st_pool = pool_src[(long long)(m0 / g.pool_K) * K];
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g.A, g.lda, m0, K);
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            unsigned o = aoff[p];
-            if (!full) {  // tail tile: rows beyond M re-read the last row (zeroed at the LDS store)
-                const int id = threadIdx.x + 256 * p;
-                const int row = id / (K / 4), c4 = id - row * (K / 4);
-                if (m0 + row >= g.M) o = last_row_off - (unsigned)m0 * (unsigned)g.lda + 4u * c4;
-            }
-            st[p] = ld4(At + o);
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aoff[p], 0, 0));
+            st[p] = make_float4(v.x, v.y, v.z, v.w);
         }
     };
     auto store_tile = [&](int tile, float *dst, int stage) {
         const int m0 = tile * SBM;
-        if (POOL && threadIdx.x < 2 * (K / 4)) {
-            const int which = threadIdx.x / (K / 4), c4 = threadIdx.x - which * (K / 4);
-            *reinterpret_cast<float4 *>(&s_pool[stage][which][4 * c4]) = st_pool;
-        }
+        if (POOL && threadIdx.x < 2 * K) s_pool[stage][threadIdx.x / K][threadIdx.x % K] = st_pool;
+        const bool full = m0 + SBM <= g.M;   // block-uniform: only the tail tile pays for the row checks
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int id = threadIdx.x + 256 * p;
@@ -144,21 +150,32 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
                 const float4 t = *reinterpret_cast<const float4 *>(&s_aff[1][4 * c4]);
                 x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
                 x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
+                if (!full && m0 + row >= g.M) x = make_float4(0.f, 0.f, 0.f, 0.f);   // (without AFF the load returned zeros)
             }
-            if (m0 + row >= g.M) x = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4 *>(dst + row * LD + 4 * c4) = x;
         }
     };
 
+    const int ldc4 = (int)g.ldc * 4, ldry4 = RED ? (int)g.ldry * 4 : 0;
+    const int c_voff = col_ok ? ((wm * 32 * TM + 4 * lh) * (int)g.ldc + col) * 4 : 0x7fffffff;
+    const int y_voff = (RED && col_ok) ? ((wm * 32 * TM + 4 * lh) * (int)g.ldry + col) * 4 : 0x7fffffff;
+    // Pipeline: the next tile travels global -> registers during the MFMAs of the current one and is staged into the other
+    // LDS buffer at the END of the iteration, after the epilogue's stores.  (Staged at the top of the next iteration, the
+    // wait for the tile sat at the loop header, where the compiler merges the first iteration's state -- eight loads in
+    // flight -- with the back edge's and settles for vmcnt(7): a wait for all but seven of the epilogue's 32 stores, a
+    // full write round trip per tile.  Inside one iteration the count is exact.)  Loads and staging are unconditional:
+    // the last iteration fetches its own tile again (32 KB per workgroup) instead of branching around the prefetch.
     int tile = blockIdx.x;
-    if (tile < tiles) load_tile(tile);
+    if (tile >= tiles) tile = tiles - 1;   // (the launcher never starts more workgroups than tiles)
+    load_tile(tile);
     if (AFF || POOL) __syncthreads();  // s_aff visible before the first staging
+    store_tile(tile, s_a[0], 0);
+    __syncthreads();
     for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
         float *As = s_a[it & 1];
-        store_tile(tile, As, it & 1);
-        __syncthreads();
         const int next = tile + gridDim.x;
-        if (next < tiles) load_tile(next);
+        const int ntile = next < tiles ? next : tile;
+        load_tile(ntile);
 
         f32x16 acc[TM];
 #pragma unroll
@@ -167,16 +184,18 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
             for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
         // RED: the previous layer's pre-activations under this wave's output elements, in flight during the MFMAs
         float yp[TM][16];
-        if (RED && col_ok) {
-            const int mr = tile * SBM + wm * 32 * TM + 4 * lh;
+        if (RED) {
+            const __amdgpu_buffer_rsrc_t yrs = tile_rsrc(g.red_Y, g.ldry, tile * SBM, g.N);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mr + 32 * a + (r & 3) + 8 * (r >> 2);
-                    yp[a][r] = g.red_Y[(long long)(row < g.M ? row : g.M - 1) * g.ldry + col];
-                }
+                for (int r = 0; r < 16; ++r)
+                    yp[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        yrs, y_voff, (32 * a + (r & 3) + 8 * (r >> 2)) * ldry4, 0));
         }
+        // the prefetch (and the RED loads) are issued HERE, ahead of the MFMAs: left alone, the scheduler sinks them behind
+        // the matrix instructions (fewer live registers) and their latency is exposed in the epilogue
+        __builtin_amdgcn_sched_barrier(0);
         const float *ap = As + (wm * 32 * TM + li) * LD + 4 * lh;
 #pragma unroll
         for (int q = 0; q < KG; ++q) {
@@ -206,9 +225,10 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
             }
         }
         // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-        if (col_ok) {
+        if (col_ok) {   // wave-uniform
             const int m0 = tile * SBM + wm * 32 * TM + 4 * lh;
             const bool full = tile * SBM + SBM <= g.M;
+            const __amdgpu_buffer_rsrc_t crs = tile_rsrc(g.C, g.ldc, tile * SBM, g.N);
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 float vmax = -INFINITY, vmin = INFINITY;
@@ -216,19 +236,21 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + 32 * a + (r & 3) + 8 * (r >> 2);
-                    if (!full && row >= g.M) continue;
+                    const bool rok = full || row < g.M;   // (tail tile only; its stores are dropped by the bounds check)
                     const float v = acc[a][r] + bias;
-                    csum += v;
-                    csq += v * v;
-                    g.C[(long long)row * g.ldc + col] = v;
+                    const float vs = rok ? v : 0.f;
+                    csum += vs;
+                    csq += vs * vs;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff,
+                                                          (32 * a + (r & 3) + 8 * (r >> 2)) * ldc4, 0);
                     if (PMAX) {  // rows ascend with r inside a lane: strict comparisons keep the first occurrence
                         const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (v > vmax) { vmax = v; imax = ri; }
-                        if (v < vmin) { vmin = v; imin = ri; }
+                        if (rok && v > vmax) { vmax = v; imax = ri; }
+                        if (rok && v < vmin) { vmin = v; imin = ri; }
                     }
                     if (RED) {
                         const float y = yp[a][r];
-                        const float gm = fmaf(y, r_s, r_t) > 0.f ? v : 0.f;
+                        const float gm = fmaf(y, r_s, r_t) > 0.f ? vs : 0.f;
                         m1 += gm;
                         m2 += gm * ((y - r_mu) * r_is);
                     }
@@ -247,6 +269,8 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
                 }
             }
         }
+        store_tile(ntile, s_a[(it + 1) & 1], (it + 1) & 1);
+        __syncthreads();
     }
     if (RED) { csum = m1; csq = m2; }
     float *slab_out = RED ? g.red_slab : g.stats;
@@ -261,6 +285,9 @@ __global__ __launch_bounds__(256, (KG <= 8 ? (RED ? 3 : 4) : (KG <= 12 ? (RED ? 
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += s_red[w][which][c];
             slab_out[((long long)blockIdx.x * 2 + which) * g.N + c] = s;
+            // the caller sums g.nslab slabs (prifit_gemm_stream_slabs); this variant may run on fewer workgroups
+            for (int extra = blockIdx.x + gridDim.x; extra < g.nslab; extra += gridDim.x)
+                slab_out[((long long)extra * 2 + which) * g.N + c] = 0.f;
         }
     }
 }
@@ -534,8 +561,15 @@ int stream_grid(int M, int K)
 }
 
 template <int WN, int KG, bool BKC>
-void launch_aff(const StreamArgs &g, int grid, hipStream_t st)
+void launch_aff(const StreamArgs &g_, int nslab, hipStream_t st)
 {
+    // persistent grid = the workgroups that are resident at once for THIS variant (its __launch_bounds__; a grid sized for
+    // the plain variant put the register-heavy ones through 1.33 - 1.5 rounds); the statistics slabs beyond it are zeroed
+    StreamArgs g = g_;
+    g.nslab = nslab;
+    const bool heavy = g.pool_arg || g.red_slab || g.cand;
+    const int occ = KG <= 8 ? (heavy ? 3 : 4) : (KG <= 12 ? (heavy ? 2 : 3) : 2);
+    const int grid = nslab < 256 * occ ? nslab : 256 * occ;
     if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
     else if (!BKC && g.pool_arg) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
     else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
@@ -640,7 +674,8 @@ int prifit_gemm_stream_slabs(int M, int K) { return stream_grid(M, K); }
 
 static int stream_launch(StreamArgs &g, int layout, void *stream)
 {
-    if ((long long)g.M * g.lda >= 2147483647LL) return PRIFIT_EINVAL;  // 32-bit tile offsets
+    // 32-bit byte offsets inside a 64-row tile
+    if (g.lda >= (1 << 22) || g.ldc >= (1 << 22) || (g.red_Y && g.ldry >= (1 << 22))) return PRIFIT_EINVAL;
     const int grid = stream_grid(g.M, g.K);
     hipStream_t st = as_stream(stream);
     if (g.N == 64) return layout == 0 ? launch_k<2, true>(g, grid, st) : launch_k<2, false>(g, grid, st);
