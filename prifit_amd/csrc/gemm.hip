@@ -51,6 +51,7 @@ struct GemmArgs {
     int kswitch;
     int accumulate;                  // 1: C += result (atomics when split-K); 0: store
     int vecA, vecB;                  // 16-byte loads legal for the operand
+    int ntiles;                      // gemm_pers_kernel: output tiles, walked with a grid stride
 };
 
 #ifndef GEMM_W8
@@ -542,6 +543,286 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent form of the 128 x 128 kernel for the shared-MLP products with ONE z slice and a plain store: the forward
+// C = relu(bn(A)) W^T + b with the column statistics (NT) and the dA product with the BatchNorm-backward partials (NN,
+// EPI_BNRED).  A grid of the resident workgroups (two per CU) walks the output tiles; the first k-tile of the NEXT
+// output tile is requested before the last k-tile's MFMAs of the current one and staged after the epilogue, so a
+// workgroup goes from one tile's matrix instructions to the next one's with only the store issue in between.
+// (One workgroup per tile leaves the first loads' round trip and the epilogue outside any overlap, and the two
+// co-resident workgroups of a CU, started together and equally long, run their MFMA phases and their memory phases in
+// step: the time of such a launch was the SUM of its MFMA time and its HBM time -- 0.44 of either peak.)
+// All addressing is buffer addressing: rows / columns beyond the operands read as zeros and stores beyond C are dropped
+// by the bounds check, the k-tile and the accumulator row are scalar offsets -- ragged extents (K = 196, N = 196) cost a
+// compare per load in the last k-tile only, and the epilogue needs two address registers instead of sixty-four.
+template <int ROWS, bool KC, bool AFF, int NTH>
+struct BufLoader {
+    static constexpr int NV = ROWS * BK / 4 / NTH;
+    static_assert(NV * NTH * 4 == ROWS * BK, "tile must divide evenly over the threads");
+    static constexpr int OOBV = 0x7fffffff;
+    float4 v[NV];
+    int voff[NV];       // byte offset of this thread's float4 in k-tile 0, OOBV when its row / column group does not exist
+    int klo[NV], c0[NV];
+    __amdgpu_buffer_rsrc_t rs;
+    int step4, K, kload;
+
+    __device__ __forceinline__ void init(const float *__restrict__ b, long long ld, int r0, int R, int K_)
+    {
+        K = K_;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b), 0, 0x7ffffffc, 0x00020000);
+        step4 = KC ? BK * 4 : (int)(BK * ld * 4);
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (KC) {
+                const int row = r0 + id / (BK / 4);
+                klo[p] = (id % (BK / 4)) * 4;
+                c0[p] = 0;
+                voff[p] = row < R ? (int)(((long long)row * ld + klo[p]) * 4) : OOBV;
+            } else {
+                klo[p] = id / (ROWS / 4);
+                c0[p] = r0 + (id % (ROWS / 4)) * 4;   // R % 4 == 0: the four rows exist together
+                voff[p] = c0[p] < R ? (int)(((long long)klo[p] * ld + c0[p]) * 4) : OOBV;
+                if (c0[p] >= R) c0[p] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int k0)
+    {
+        kload = k0;
+        const int soff = (k0 / BK) * step4;
+        if (k0 + BK <= K) {   // block-uniform
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0));
+                v[p] = make_float4(t.x, t.y, t.z, t.w);
+            }
+        } else {              // last, partial k-tile (K % 4 == 0: a float4 is inside or outside as a whole)
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int vo = k0 + klo[p] < K ? voff[p] : OOBV;
+                const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
+                v[p] = make_float4(t.x, t.y, t.z, t.w);
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const float *__restrict__ scale, const float *__restrict__ shift)
+    {
+        if (!AFF) return;     // (elements that do not exist arrived as zeros)
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int gk = kload + klo[p];
+            const bool ok = voff[p] != OOBV && gk < K;
+            const int cc = KC ? (gk < K ? gk : 0) : c0[p];
+            const float4 s = ld4(scale + cc), t = ld4(shift + cc);
+            float4 x = v[p];
+            x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
+            x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
+            v[p] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (KC) {
+                const int row = id / (BK / 4), kk = (id % (BK / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + row * (BK + PAD) + kk) = v[p];
+            } else {
+                const int kk = id / (ROWS / 4), row = (id % (ROWS / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + kk * (ROWS + PAD) + row) = v[p];
+            }
+        }
+    }
+};
+
+template <int LAY, bool FA, bool RED>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_pers_kernel(const GemmArgs g)
+{
+    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr bool B_KC = (LAY == LAY_NT);
+    constexpr int SZA = BM * (BK + PAD);
+    constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];  // two stages
+
+    const int tilesN = (g.N + BN - 1) / BN;
+    const int nwg = g.ntiles;
+    auto tile_of = [&](int bid, int &tm, int &tn) {   // XCD-aware bijective remap (see gemm_kernel); bid & 7 is kept by the grid stride
+        const int xcd = bid & 7, pos = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+        tm = L / tilesN; tn = L - tm * tilesN;
+    };
+    int tix = blockIdx.x, tile_m, tile_n;
+    tile_of(tix, tile_m, tile_n);
+    const int ktiles = (g.K + BK - 1) / BK;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    BufLoader<BM, true, FA, NTH> la;
+    BufLoader<BN, B_KC, false, NTH> lb;
+    la.init(g.A, g.lda, tile_m * BM, g.M, g.K);
+    lb.init(g.B, g.ldb, tile_n * BN, g.N, g.K);
+    la.load(0); lb.load(0);
+    la.finish(g.a_scale, g.a_shift);
+    la.store(lds); lb.store(lds + SZA);
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((long long)g.M * g.ldc * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(RED ? g.aux : nullptr), 0, RED ? (int)((long long)g.M * g.ldaux * 4) : 0, 0x00020000);
+    const int ldc4 = (int)g.ldc * 4, ldy4 = RED ? (int)g.ldaux * 4 : 0;
+
+    for (;;) {
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        const int ntix = tix + (int)gridDim.x;
+        const bool has_next = ntix < nwg;
+        int ntile_m = 0, ntile_n = 0;
+        if (has_next) tile_of(ntix, ntile_m, ntile_n);
+        f32x16 acc[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int stage = kt & 1;
+            const float *As = lds + stage * (SZA + SZB), *Bs = As + SZA;
+            const bool more = kt + 1 < ktiles;
+            if (more) {
+                la.load((kt + 1) * BK); lb.load((kt + 1) * BK);
+            } else if (has_next) {
+                la.init(g.A, g.lda, ntile_m * BM, g.M, g.K);
+                lb.init(g.B, g.ldb, ntile_n * BN, g.N, g.K);
+                la.load(0); lb.load(0);
+            }
+#pragma unroll
+            for (int gk = 0; gk < BK / 8; ++gk) {
+                const float4 fa = read_frag<BM, true>(As, wm0 + li, gk, lh);
+                float4 fb[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, B_KC>(Bs, wn0 + 32 * b + li, gk, lh);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
+                }
+            }
+            if (more) {
+                float *An = lds + (stage ^ 1) * (SZA + SZB);
+                la.finish(g.a_scale, g.a_shift);
+                la.store(An); lb.store(An + SZA);
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const bool full_rows = m0 + BM <= g.M;   // block-uniform
+        const int rbase = m0 + wm0 + 4 * lh;
+        float csum[TN], csq[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            csum[b] = 0.f; csq[b] = 0.f;
+            const int col = n0 + wn0 + 32 * b + li;
+            const bool cok = col < g.N;
+            const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
+            float rs = 0.f, rt = 0.f, rmu = 0.f, ris = 0.f;
+            if (RED && cok) { rs = g.red_scale[col]; rt = g.red_shift[col]; rmu = g.red_mean[col]; ris = g.red_invstd[col]; }
+            // lane part of the address (the first of this lane's rows, its column); not an existing column: fails the bounds check
+            const int c_voff = cok ? (int)(((long long)rbase * g.ldc + col) * 4) : 0x7fffffff;
+            const int y_voff = (RED && cok) ? (int)(((long long)rbase * g.ldaux + col) * 4) : 0x7fffffff;
+            float kf[16];
+            if (RED) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = ((r & 3) + 8 * (r >> 2)) * ldy4;
+                    kf[r] = __builtin_bit_cast(float, full_rows ? __builtin_amdgcn_raw_buffer_load_b32(yrs, y_voff, ro, 0)
+                                                                 : __builtin_amdgcn_raw_buffer_load_b32(yrs, cok ? y_voff + ro : y_voff, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                const float v = acc[b][r] + bias;
+                const float vs = (cok && (full_rows || row < g.M)) ? v : 0.f;
+                if (RED) {
+                    const float gm = fmaf(kf[r], rs, rt) > 0.f ? vs : 0.f;
+                    csum[b] += gm;
+                    csq[b] += gm * ((kf[r] - rmu) * ris);
+                } else {
+                    csum[b] += vs;
+                    csq[b] += vs * vs;
+                }
+                const int ro = ((r & 3) + 8 * (r >> 2)) * ldc4;
+                if (full_rows) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, ro, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, cok ? c_voff + ro : c_voff, 0, 0);
+            }
+        }
+        if (g.stats) {
+            float *red = lds;   // both stages are dead: everybody passed the barrier that ended the k-loop
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
+                const float q = csq[b] + __shfl_xor(csq[b], 32, 64);
+                if (lh == 0) {
+                    red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
+                    red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < 2 * BN; t += NTH) {
+                const int which = t / BN, c = t - which * BN;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < BM / WM; ++w) s += red[(w * 2 + which) * BN + c];
+                if (n0 + c < g.N) g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
+            }
+            if (has_next) __syncthreads();   // `red` is read before the next tile is staged over it
+        }
+        if (!has_next) break;
+        tix = ntix; tile_m = ntile_m; tile_n = ntile_n;
+        la.finish(g.a_scale, g.a_shift);
+        la.store(lds); lb.store(lds + SZA);
+        __syncthreads();
+    }
+}
+
+static bool g_persistent_enabled()
+{
+    static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();  // A/B switch
+    return on;
+}
+
+// the persistent kernel's cases: NT / NN, one z slice, plain store, (bias + statistics) or EPI_BNRED, 16-byte rows,
+// 32-bit byte offsets everywhere, more tiles than resident workgroups
+static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st)
+{
+    GemmArgs g = g_;
+    if (!g_persistent_enabled() || lay == LAY_TN || g.batch != 1 || g.splitk != 1 || g.accumulate || g.a_rowsum || g.kswitch ||
+        g.b_scale || !(g.epi == EPI_NONE || g.epi == EPI_BNRED) || !(g.vecA && g.vecB) || (g.K & 3) || (lay == LAY_NN && (g.N & 3)))
+        return false;
+    const long long lim = 0x7ff00000LL;
+    if ((long long)g.M * g.lda * 4 >= lim || (long long)(lay == LAY_NT ? g.N : g.K) * g.ldb * 4 >= lim ||
+        (long long)g.M * g.ldc * 4 >= lim || (g.epi == EPI_BNRED && (long long)g.M * g.ldaux * 4 >= lim))
+        return false;
+    g.ntiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int slots = 512;   // two 8-wave workgroups per CU (73 KB of LDS, <= 128 VGPRs)
+    if (g.ntiles <= slots) return false;
+    const dim3 grid(slots), block(512);
+    if (lay == LAY_NT) {
+        if (g.epi != EPI_NONE) return false;
+        if (g.a_scale) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, false, false>), grid, block, 0, st, g);
+    } else {
+        if (g.a_scale) return false;
+        if (g.epi == EPI_BNRED) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NN, false, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NN, false, false>), grid, block, 0, st, g);
+    }
+    return true;
+}
+
 static bool g_exact_enabled()
 {
     static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_EXACT"); return !(e && e[0] == '0'); }();  // A/B switch
@@ -706,6 +987,7 @@ static int dispatch(GemmArgs &g, int layout, void *stream)
     if (N <= 32) return launch_cfg<128, 32, 32, 32>(g, layout, st);
     if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
     if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);
+    if (launch_persistent(g, layout, st)) return prifit_check_launch();
     return launch_cfg<128, 128, 32, 64>(g, layout, st);  // 8 waves of 32x64: more waves per SIMD hide the staging waits
 }
 

@@ -119,6 +119,32 @@ def test_gemm_stream_tall_skinny(nn_ops, lay, M, N, K, aff):
     assert torch.equal(C, C2)  # same k-ordered fp32 MFMA chain -> bit-identical products
 
 
+@pytest.mark.parametrize("lay,M,N,K,aff", [(0, 70001, 256, 196, True), (0, 66000, 196, 128, True), (0, 65600, 256, 128, False),
+                                           (1, 70001, 196, 256, False), (1, 65600, 128, 196, False)])
+def test_gemm_persistent_tiles(nn_ops, lay, M, N, K, aff):
+    """More output tiles than resident workgroups: the persistent 128 x 128 kernel (csrc/gemm.hip, gemm_pers_kernel) with
+    ragged M, K = 196 / N = 196 (partial last k-tile, partial column tile), prologue, bias and column statistics, against
+    float64."""
+    A, W = _rand((M, K), 51), _rand((N, K), 52)
+    sc, sh, bias = _rand((K,), 53), _rand((K,), 54), _rand((N,), 55)
+    An = torch.relu(A * sc + sh) if aff else A
+    ref = An.double() @ W.double().T + (bias.double() if lay == 0 else 0)
+    Ad = A.cuda()
+    Wd = (W if lay == 0 else W.T.contiguous()).cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    kw = dict(a_affine=(sc.cuda(), sh.cuda())) if aff else {}
+    slab = None
+    if lay == 0:
+        slab = torch.full((nn_ops.gemm_stats_slabs(M, N, K), 2, N), float("nan"), device="cuda")
+        kw.update(bias=bias.cuda(), stats=slab)
+    nn_ops.gemm(lay, M, N, K, Ad, K, Wd, Wd.stride(0), C, N, **kw)
+    tol = 2e-5 * (An.norm(dim=1, keepdim=True) * W.norm(dim=1).unsqueeze(0))
+    assert ((C.cpu().double() - ref).abs() <= tol + 1e-5).all()
+    if lay == 0:
+        torch.testing.assert_close(slab[:, 0].double().sum(0).cpu(), ref.sum(0), rtol=1e-4, atol=5e-2)
+        torch.testing.assert_close(slab[:, 1].double().sum(0).cpu(), (ref ** 2).sum(0), rtol=1e-4, atol=5e-2)
+
+
 @pytest.mark.parametrize("Mo,No,P,aff", [(128, 96, 40008, True), (96, 64, 65536, True), (64, 64, 33000, False),
                                          (128, 64, 100000, True), (64, 32, 32768, True), (32, 32, 50000, False),
                                          (128, 128, 40000, True), (96, 96, 36000, False)])
@@ -151,6 +177,7 @@ def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
                                       (65536, 32, ((64, 96), (96, 128))),                  # K = 32: pool_bwd_apply stays, pool candidates
                                       (98304, 96, ((64, 64), (64, 128))),                  # 3 candidate blocks per group
                                       (6144, 32, ((64, 196), (196, 256))),                 # tiled kernel, 128-row tiles
+                                      (69632, 32, ((64, 196), (196, 256))),                # persistent tiled kernel (> 512 tiles)
                                       (3072, 0, ((516, 256), (256, 512), (512, 1024)))])   # tiled kernel, 64-row tiles
 def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims):
     """The BatchNorm-backward column sums emitted by the dA epilogues (prifit_gemm_stream_dgrad_f32 /
