@@ -73,6 +73,24 @@ struct Tile64T {
     }
 };
 typedef Tile64T<256> Tile64;
+
+// the key tile of a step: ROWS = 64 or 128 rows loaded by NTH threads (one or two 64-row passes)
+template <int NTH, int ROWS>
+struct KeyTile {
+    static constexpr int NT = ROWS / 64;
+    Tile64T<NTH> t[NT];
+    template <bool EXACT>
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff, int row0, int nrows)
+    {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) t[i].template load<EXACT>(rs, voff, row0 + 64 * i, nrows);
+    }
+    __device__ __forceinline__ void store(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) t[i].store(lds + 64 * i * LDSW);
+    }
+};
 }  // namespace
 
 // Q: the query-side operand rows (Z for MODE 0, gO for MODE 1) [B,N,128]; X: dictionary [B,N,128].
@@ -90,8 +108,17 @@ typedef Tile64T<256> Tile64;
 // one query block each).  A segment that covers all key steps of its block ends as before; a partial one adds its
 // contribution with float atomics into a zero-initialised output (MODE 1: dZ; MODE 0: O and the row sums, the
 // normalisation epilogue of those blocks runs in a second small launch).
-template <int MODE, bool FAST, bool SK = false>
-__global__ __launch_bounds__(256, 2) void ms_fused_kernel(
+//
+// NW (4 or 8 waves): the 8-wave form keeps the 64 queries and steps through the keys 128 at a time (four key sub-tiles
+// instead of two; the four partial (O, rowsum) pairs are added through LDS in two rounds).  It needs 102 KB of LDS, so it
+// runs ONE workgroup per CU with the same 2 waves per SIMD as two 4-wave workgroups: the launcher uses it for the
+// blocks that are left over after the full rounds of 4-wave workgroups (B x N / 64 = 768 blocks on 512 slots: the last
+// 256 used to run one 4-wave workgroup per CU, a lone wave per SIMD, at ~55 % of the matrix pipe).
+// NQG (2 or 1 query groups of 32): NW = 4, NQG = 1 is the "narrow" form -- 32 queries, the four waves take four key
+// sub-tiles of a 128-key step, no query tile in LDS (MODE 0 keeps the query fragments in registers; the epilogue reads Z
+// from global): 68 KB of LDS, so TWO independent workgroups per CU like the standard form.
+template <int MODE, bool FAST, bool SK = false, int NW = 4, int NQG = 2>
+__global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     const float *__restrict__ Q, long long q_stride, const float *__restrict__ X, const float *__restrict__ bw,
     int N, const float *__restrict__ row_add,   // q_stride: batch stride of Q; row_add (MODE 1): g_rowsum [B,N]
     float *__restrict__ KT,              // MODE 0: out (may be NULL); MODE 1: in.  [B, N(keys), ldk] (queries contiguous)
@@ -100,15 +127,23 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     const float *__restrict__ Zin,       // MODE 0: current points (== Q) for the epilogue
     float *__restrict__ out,             // MODE 0: normalised new points; MODE 1: dZ   [B,N,128]
     float *__restrict__ O_out, float *__restrict__ rsum_out, float *__restrict__ nrm_out,  // MODE 0 saves
-    int nbatch)                          // SK: number of shapes (the grid is 1-D)
+    int nbatch,                          // number of shapes
+    int blk0,                            // !SK: linear index (shape-major) of this launch's first query block
+    int xcd_map)                         // place whole shapes on one XCD (see below)
 {
-    __shared__ __attribute__((aligned(16))) float s_q[QB * LDSW];
+    static_assert((NW == 4 && NQG == 2) || (!SK && ((NW == 8 && NQG == 2) || (NW == 4 && NQG == 1 && MODE == 0))),
+                  "standard, wide or (forward only) narrow form");
+    constexpr int QB = 32 * NQG;         // queries per workgroup (shadows the standard form's constant)
+    constexpr int NKH = NW / NQG;        // key sub-tiles per step
+    constexpr int KB = 32 * NKH;         // keys per step
+    constexpr bool SQ = NQG == 2;        // the query tile lives in LDS
+    __shared__ __attribute__((aligned(16))) float s_q[SQ ? QB * LDSW : 4];
     __shared__ __attribute__((aligned(16))) float s_x[KB * LDSW];
-    __shared__ float s_rs[2 * QB];
+    __shared__ float s_rs[NKH * QB];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    const int qg = wave & 1, kh = wave >> 1;  // query group (32 rows), key half
+    const int qg = wave % NQG, kh = wave / NQG;  // query group (32 rows), key sub-tile
     // segments of this workgroup: [u, uend) in units of (query block, key step)
     const int nsteps = (N + KB - 1) / KB, nqb = (N + QB - 1) / QB;
     int u = 0, uend = 1;
@@ -116,9 +151,13 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     int b, q0, kbeg, kend;
     if (SK) {
         if (first_seg) {
+            // XCD placement (consecutive workgroup ids are dealt round-robin over the 8 XCDs): the workgroups of one XCD
+            // take CONSECUTIVE unit ranges, i.e. whole shapes -- a shape's dictionary X stays in one L2 and the rows of its
+            // K^T / gS^T streams are read / written by neighbours on the same L2
+            const int vid = (xcd_map && (gridDim.x & 7) == 0) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
             const long long total = (long long)nbatch * nqb * nsteps;
-            u = (int)(total * blockIdx.x / gridDim.x);
-            uend = (int)(total * (blockIdx.x + 1) / gridDim.x);
+            u = (int)(total * vid / gridDim.x);
+            uend = (int)(total * (vid + 1) / gridDim.x);
             if (u >= uend) return;
         }
         const int blk = u / nsteps, s0 = u - blk * nsteps;
@@ -126,7 +165,14 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
         b = blk / nqb; q0 = (blk - b * nqb) * QB; kbeg = s0 * KB; kend = s1 * KB;
         u += s1 - s0;
     } else {
-        b = blockIdx.y; q0 = blockIdx.x * QB; kbeg = 0; kend = N;
+        const int L = blockIdx.y * gridDim.x + blockIdx.x + blk0;
+        if (xcd_map && blk0 == 0 && (nbatch & 7) == 0) {   // same placement: XCD x works on the shapes x, x + 8, ...
+            const int xcd = L & 7, j = L >> 3;
+            b = (j / nqb) * 8 + xcd; q0 = (j % nqb) * QB;
+        } else {
+            b = L / nqb; q0 = (L - b * nqb) * QB;
+        }
+        kbeg = 0; kend = N;
     }
     const bool whole = !SK || (kend - kbeg >= N);
     const float *Qb = Q + (size_t)b * q_stride;
@@ -137,10 +183,13 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
 
     const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(Qb, (long long)N * D * 4), x_rs = make_rsrc(Xb, (long long)N * D * 4);
     const int t_voff = ((threadIdx.x >> 5) * D + (threadIdx.x & 31) * 4) * 4;
-    Tile64 t;
-    t.load<FAST>(q_rs, t_voff, q0, N);
-    t.store(s_q);
-    t.load<FAST>(x_rs, t_voff, kbeg, N);
+    KeyTile<NW * 64, KB> t;
+    if (SQ) {
+        Tile64T<NW * 64> tq;
+        tq.template load<FAST>(q_rs, t_voff, q0, N);
+        tq.store(s_q);
+    }
+    t.template load<FAST>(x_rs, t_voff, kbeg, N);
 
     f32x16 oacc[4];
 #pragma unroll
@@ -197,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), MODE == 0 ? kt_rs : gs_rs,
                                                       st_voff(k0 - KB, r), st_soff(pb_bytes, r), MODE == 0 ? 2 : 0);
         }
-        if (k0 + KB < kend) t.load<FAST>(x_rs, t_voff, k0 + KB, N);
+        if (k0 + KB < kend) t.template load<FAST>(x_rs, t_voff, k0 + KB, N);
 
         // MODE 1: the saved kernel values under this wave's sub-tile, requested before the S MFMAs so that their
         // latency hides behind the 64 matrix instructions (they were the exposed part of this mode)
@@ -268,32 +317,39 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), MODE == 0 ? kt_rs : gs_rs,
                                                   st_voff(kl, r), st_soff(kl_bytes, r), MODE == 0 ? 2 : 0);
     }
-    // ---- combine the two key halves: waves 2,3 park their partials in LDS (the X tile is dead now)
+    // ---- combine the key sub-tiles: a binary tree through LDS (the X tile is dead now); one slot = a partial O tile of both
+    // query groups [64 queries][128], 32 KiB; NW = 4: one round (waves 2, 3 park, waves 0, 1 add), NW = 8: two rounds
     __syncthreads();
-    // layout of a partial O tile: [d 0..127][33 query slots] so that lanes (d) are conflict-free
-    float *s_part = s_x;  // needs 2 * 32 * 128 floats = 32 KiB <= 33 KiB
+    float *s_part = s_x;  // NKH / 2 slots of 32 KiB <= KB * LDSW floats
     if (MODE == 0) {
         rsum += __shfl_xor(rsum, 32, 64);  // both key sub-rows of this wave
         if (lh == 0) s_rs[kh * QB + qrow] = rsum;
     }
-    if (kh == 1) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+    for (int step = 1; step < NKH; step <<= 1) {
+        float *slot = s_part + (kh / (2 * step)) * (QB * D);
+        if ((kh & (2 * step - 1)) == step) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;  // O accumulator: row = query, col (lane) = d
-                s_part[(qg * 32 + qr) * D + 32 * d + li] = oacc[d][r];
-            }
-    }
-    __syncthreads();
-    if (kh == 0) {
+            for (int d = 0; d < 4; ++d)
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            oacc[d][r] += s_part[(qg * 32 + qr) * D + 32 * d + li];
+                for (int r = 0; r < 16; ++r) {
+                    const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;  // O accumulator: row = query, col (lane) = d
+                    slot[(qg * 32 + qr) * D + 32 * d + li] = oacc[d][r];
+                }
         }
+        __syncthreads();
+        if ((kh & (2 * step - 1)) == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    oacc[d][r] += slot[(qg * 32 + qr) * D + 32 * d + li];
+                }
+        }
+        if (2 * step < NKH) __syncthreads();   // the slot is parked into again
+    }
+    if (kh == 0) {
 
     float *outb = out + (size_t)b * N * D;
     if (MODE == 1) {
@@ -324,13 +380,15 @@ __global__ __launch_bounds__(256, 2) void ms_fused_kernel(
     for (int r = 0; r < 16; ++r) {
         const int qr = qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int gr = q0 + qr;
-        const float rs = s_rs[qr] + s_rs[QB + qr];
+        float rs = s_rs[qr];
+#pragma unroll
+        for (int k = 1; k < NKH; ++k) rs += s_rs[k * QB + qr];
         const float dinv = 1.0f / rs;
         float nv[4];
         float ss = 0.f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const float z = s_q[qr * LDSW + 32 * d + li];
+            const float z = SQ ? s_q[qr * LDSW + 32 * d + li] : (gr < N ? Zin[((size_t)b * N + gr) * D + 32 * d + li] : 0.f);
             const float m = oacc[d][r] * dinv - z;
             nv[d] = z + m;
             ss += nv[d] * nv[d];
@@ -630,6 +688,12 @@ __global__ __launch_bounds__(256) void ms_sk_epilogue_kernel(const float *__rest
     if (lane == 0) nrm_o[row] = n;
 }
 
+static int xcd_map()
+{
+    static const int on = [] { const char *e = getenv("PRIFIT_MS_XCD"); return e ? atoi(e) : 1; }();   // A/B switch
+    return on;
+}
+
 static int sk_slots()
 {
     static const int n = [] {
@@ -655,19 +719,40 @@ int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, 
         // stream-K: O and rowsum arrive ZERO-INITIALISED; split query blocks get their epilogue from the second launch
         hipLaunchKernelGGL((ms_fused_kernel<0, true, true>), dim3(slots), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm, B);
+                           Znext, O, rowsum, nrm, B, 0, xcd_map());
         hipLaunchKernelGGL(ms_sk_epilogue_kernel, dim3((unsigned)((long long)B * N / 4)), dim3(256), 0, as_stream(stream), O,
                            rowsum, Z, N, B, slots, Znext, nrm);
+        return prifit_check_launch();
+    }
+    // Left-over blocks after the full rounds (B x N / 64 = 768 blocks on 512 slots: the last 256 would run one workgroup
+    // per CU, a lone wave per SIMD): PRIFIT_MS_TAIL = 2 runs them as twice as many NARROW workgroups (32 queries, two per CU
+    // again), 1 as 8-wave workgroups (one per CU), 0 (default) as they are: measured, the forward kernel's time is
+    // linear in the number of blocks (B = 16 / 24 / 32: 345 / 504 / 655 us) -- it has no tail to win back -- and both
+    // forms lose 3-4 % to the second launch.
+    static const int tail_mode = [] { const char *e = getenv("PRIFIT_MS_TAIL"); return e ? atoi(e) : 0; }();
+    const long long blocks = (long long)B * (N / QB), tail = blocks % slots;
+    if (tail_mode && N % 128 == 0 && blocks > slots && tail != 0 && tail <= slots / 2) {
+        hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3((unsigned)(blocks - tail)), dim3(256), 0, as_stream(stream), Z,
+                           (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                           Znext, O, rowsum, nrm, B, 0, 0);
+        if (tail_mode == 1)
+            hipLaunchKernelGGL((ms_fused_kernel<0, true, false, 8, 2>), dim3((unsigned)tail), dim3(512), 0, as_stream(stream), Z,
+                               (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                               Znext, O, rowsum, nrm, B, (int)(blocks - tail), 0);
+        else
+            hipLaunchKernelGGL((ms_fused_kernel<0, true, false, 4, 1>), dim3((unsigned)(2 * tail)), dim3(256), 0, as_stream(stream), Z,
+                               (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
+                               Znext, O, rowsum, nrm, B, (int)(2 * (blocks - tail)), 0);
         return prifit_check_launch();
     }
     if (N % QB == 0)
         hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm, B);
+                           Znext, O, rowsum, nrm, B, 0, xcd_map());
     else
         hipLaunchKernelGGL((ms_fused_kernel<0, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm, B);
+                           Znext, O, rowsum, nrm, B, 0, xcd_map());
     return prifit_check_launch();
 }
 
@@ -683,15 +768,15 @@ int prifit_meanshift_fused_bwd_dz(const float *gO, long long gO_batch_stride, co
     if (N % QB == 0 && balanced && (long long)B * (N / QB) > slots && ((long long)B * (N / QB)) % slots != 0)
         hipLaunchKernelGGL((ms_fused_kernel<1, true, true>), dim3(slots), dim3(256), 0, as_stream(stream), gO,
                            gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
-                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B);
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B, 0, xcd_map());
     else if (N % QB == 0)
         hipLaunchKernelGGL((ms_fused_kernel<1, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), gO,
                            gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
-                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B);
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B, 0, xcd_map());
     else
         hipLaunchKernelGGL((ms_fused_kernel<1, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), gO,
                            gO_batch_stride, X, bw, N, g_rowsum, const_cast<float *>(KT), ld_kt, stride_kt, gST,
-                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B);
+                           (const float *)nullptr, dZ, (float *)nullptr, (float *)nullptr, (float *)nullptr, B, 0, xcd_map());
     return prifit_check_launch();
 }
 
