@@ -276,6 +276,99 @@ struct ExactLoader {
     }
 };
 
+// Buffer-addressed staging for ANY extents (16-byte rows): what ExactLoader does for whole tiles, plus rows / columns
+// beyond the operand (lane offset that fails the bounds check: zeros) and a partial last k-tile (one compare per load,
+// in that k-tile only).  The matrix (one batch item) must span < 2 GiB.
+template <int ROWS, bool KC, bool AFF, int NTH>
+struct BufLoader {
+    static constexpr int NV = ROWS * BK / 4 / NTH;
+    static_assert(NV * NTH * 4 == ROWS * BK, "tile must divide evenly over the threads");
+    static constexpr int OOBV = 0x7fffffff;
+    float4 v[NV];
+    int voff[NV];       // byte offset of this thread's float4 in k-tile 0, OOBV when its row / column group does not exist
+    int klo[NV], c0[NV];
+    __amdgpu_buffer_rsrc_t rs;
+    const float *base;
+    int step4, K, kload;
+
+    __device__ __forceinline__ void init(const float *__restrict__ b, long long ld, int r0, int R, int K_)
+    {
+        K = K_;
+        base = b;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b), 0, 0x7ffffffc, 0x00020000);
+        step4 = KC ? BK * 4 : (int)(BK * ld * 4);
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (KC) {
+                const int row = r0 + id / (BK / 4);
+                klo[p] = (id % (BK / 4)) * 4;
+                c0[p] = 0;
+                voff[p] = row < R ? (int)(((long long)row * ld + klo[p]) * 4) : OOBV;
+            } else {
+                klo[p] = id / (ROWS / 4);
+                c0[p] = r0 + (id % (ROWS / 4)) * 4;   // R % 4 == 0: the four rows exist together
+                voff[p] = c0[p] < R ? (int)(((long long)klo[p] * ld + c0[p]) * 4) : OOBV;
+                if (c0[p] >= R) c0[p] = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, const float *__restrict__, const float *__restrict__) { load(k0); }
+    __device__ __forceinline__ void shift(long long delta)   // second source of a dual product: a new resource
+    {
+        base += delta;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7ffffffc, 0x00020000);
+    }
+    __device__ __forceinline__ void load(int k0)
+    {
+        kload = k0;
+        const int soff = (k0 / BK) * step4;
+        if (k0 + BK <= K) {   // block-uniform
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0));
+                v[p] = make_float4(t.x, t.y, t.z, t.w);
+            }
+        } else {              // last, partial k-tile (K % 4 == 0: a float4 is inside or outside as a whole)
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int vo = k0 + klo[p] < K ? voff[p] : OOBV;
+                const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
+                v[p] = make_float4(t.x, t.y, t.z, t.w);
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(const float *__restrict__ scale, const float *__restrict__ shift)
+    {
+        if (!AFF) return;     // (elements that do not exist arrived as zeros)
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int gk = kload + klo[p];
+            const bool ok = voff[p] != OOBV && gk < K;
+            const int cc = KC ? (gk < K ? gk : 0) : c0[p];
+            const float4 s = ld4(scale + cc), t = ld4(shift + cc);
+            float4 x = v[p];
+            x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
+            x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
+            v[p] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (KC) {
+                const int row = id / (BK / 4), kk = (id % (BK / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + row * (BK + PAD) + kk) = v[p];
+            } else {
+                const int kk = id / (ROWS / 4), row = (id % (ROWS / 4)) * 4;
+                *reinterpret_cast<float4 *>(lds + kk * (ROWS + PAD) + row) = v[p];
+            }
+        }
+    }
+};
+
 // Fragment of 4 consecutive MFMA k-steps for lane (i, h): k = 8*g + 4*h + j, j = 0..3.
 template <int ROWS, bool KC>
 __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int row, int g, int h)
@@ -336,8 +429,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    typename pick<EX, ExactLoader<BM, A_KC, FA, NTH>, TileLoader<BM, A_KC, VA, FA, NTH>>::type la;
-    typename pick<EX, ExactLoader<BN, B_KC, FB, NTH>, TileLoader<BN, B_KC, VB, FB, NTH>>::type lb;
+    typename pick<EX, BufLoader<BM, A_KC, FA, NTH>, TileLoader<BM, A_KC, VA, FA, NTH>>::type la;
+    typename pick<EX, BufLoader<BN, B_KC, FB, NTH>, TileLoader<BN, B_KC, VB, FB, NTH>>::type lb;
     la.init(A, g.lda, m0, g.M, g.K);
     lb.init(B, g.ldb, n0, g.N, g.K);
     constexpr int NVA = TileLoader<BM, A_KC, VA, FA, NTH>::NV;
@@ -555,88 +648,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
 // All addressing is buffer addressing: rows / columns beyond the operands read as zeros and stores beyond C are dropped
 // by the bounds check, the k-tile and the accumulator row are scalar offsets -- ragged extents (K = 196, N = 196) cost a
 // compare per load in the last k-tile only, and the epilogue needs two address registers instead of sixty-four.
-template <int ROWS, bool KC, bool AFF, int NTH>
-struct BufLoader {
-    static constexpr int NV = ROWS * BK / 4 / NTH;
-    static_assert(NV * NTH * 4 == ROWS * BK, "tile must divide evenly over the threads");
-    static constexpr int OOBV = 0x7fffffff;
-    float4 v[NV];
-    int voff[NV];       // byte offset of this thread's float4 in k-tile 0, OOBV when its row / column group does not exist
-    int klo[NV], c0[NV];
-    __amdgpu_buffer_rsrc_t rs;
-    int step4, K, kload;
-
-    __device__ __forceinline__ void init(const float *__restrict__ b, long long ld, int r0, int R, int K_)
-    {
-        K = K_;
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b), 0, 0x7ffffffc, 0x00020000);
-        step4 = KC ? BK * 4 : (int)(BK * ld * 4);
-#pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            const int id = threadIdx.x + NTH * p;
-            if (KC) {
-                const int row = r0 + id / (BK / 4);
-                klo[p] = (id % (BK / 4)) * 4;
-                c0[p] = 0;
-                voff[p] = row < R ? (int)(((long long)row * ld + klo[p]) * 4) : OOBV;
-            } else {
-                klo[p] = id / (ROWS / 4);
-                c0[p] = r0 + (id % (ROWS / 4)) * 4;   // R % 4 == 0: the four rows exist together
-                voff[p] = c0[p] < R ? (int)(((long long)klo[p] * ld + c0[p]) * 4) : OOBV;
-                if (c0[p] >= R) c0[p] = 0;
-            }
-        }
-    }
-    __device__ __forceinline__ void load(int k0)
-    {
-        kload = k0;
-        const int soff = (k0 / BK) * step4;
-        if (k0 + BK <= K) {   // block-uniform
-#pragma unroll
-            for (int p = 0; p < NV; ++p) {
-                const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff, 0));
-                v[p] = make_float4(t.x, t.y, t.z, t.w);
-            }
-        } else {              // last, partial k-tile (K % 4 == 0: a float4 is inside or outside as a whole)
-#pragma unroll
-            for (int p = 0; p < NV; ++p) {
-                const int vo = k0 + klo[p] < K ? voff[p] : OOBV;
-                const f32x4v t = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
-                v[p] = make_float4(t.x, t.y, t.z, t.w);
-            }
-        }
-    }
-    __device__ __forceinline__ void finish(const float *__restrict__ scale, const float *__restrict__ shift)
-    {
-        if (!AFF) return;     // (elements that do not exist arrived as zeros)
-#pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            const int gk = kload + klo[p];
-            const bool ok = voff[p] != OOBV && gk < K;
-            const int cc = KC ? (gk < K ? gk : 0) : c0[p];
-            const float4 s = ld4(scale + cc), t = ld4(shift + cc);
-            float4 x = v[p];
-            x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
-            x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
-            v[p] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    __device__ __forceinline__ void store(float *__restrict__ lds) const
-    {
-#pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            const int id = threadIdx.x + NTH * p;
-            if (KC) {
-                const int row = id / (BK / 4), kk = (id % (BK / 4)) * 4;
-                *reinterpret_cast<float4 *>(lds + row * (BK + PAD) + kk) = v[p];
-            } else {
-                const int kk = id / (ROWS / 4), row = (id % (ROWS / 4)) * 4;
-                *reinterpret_cast<float4 *>(lds + kk * (ROWS + PAD) + row) = v[p];
-            }
-        }
-    }
-};
-
 template <int LAY, bool FA, bool RED>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_pers_kernel(const GemmArgs g)
 {
@@ -924,11 +935,10 @@ static void launch_aff(const GemmArgs &g, dim3 grid, hipStream_t st)
 {
     // prologue combinations that occur: none, A only (forward / dA never has one), B only (dW)
     const dim3 block((BM / WM) * (BN / WN) * 64);
-    // whole tiles, 16-byte rows, each operand (one batch item) below 2 GiB, no A row sums: the exact loaders
+    // 16-byte rows, each operand (one batch item) below 2 GiB, no A row sums: the buffer loaders
     const long long spanA = (LAY == LAY_TN ? (long long)g.K * g.lda : (long long)g.M * g.lda) * 4;
     const long long spanB = (LAY == LAY_NT ? (long long)g.N * g.ldb : (long long)g.K * g.ldb) * 4;
-    const bool exact = VEC && g_exact_enabled() && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 && !g.a_rowsum &&
-                       spanA < 0x7ff00000LL && spanB < 0x7ff00000LL;
+    const bool exact = VEC && g_exact_enabled() && !g.a_rowsum && spanA < 0x7ff00000LL && spanB < 0x7ff00000LL;
     if (exact) {
         if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, true, false, true>), grid, block, 0, st, g);
         else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, false, true, true>), grid, block, 0, st, g);
