@@ -17,6 +17,8 @@
 // the C-wide rows once (+ U/Vc reads in gather mode); this is the bandwidth-bound kernel of the grouping stage.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "distance.h"
 
@@ -75,7 +77,9 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
     if (b >= a.B) return;  // whole workgroup
     const int slab_id = b * nb + tile;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (readfirstlane: the wave index, hence the query centre and everything derived from it, is wave-uniform, and the
+    // compiler has to know it: the row stores use a per-wave buffer resource)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const float *P = a.xyz + (size_t)b * N * 3;
     for (int i = threadIdx.x; i < N; i += NW * 64) {
         const float x = P[(size_t)i * 3 + 0], y = P[(size_t)i * 3 + 1], z = P[(size_t)i * 3 + 2];
@@ -175,7 +179,6 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
         if (valid) {
             const float4 bb = a.bias[r] ? ld4g(a.bias[r] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float *Yq = a.Y[r] + ((size_t)b * S + qid) * K * C + 4 * c4;
             const int *l = lst + off[r];
             float w[4][KP];
             float4 vc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -195,7 +198,15 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                 Ub = a.U[r] + (size_t)b * N * C + 4 * c4;
             }
             const float *Fb = (MODE == 0 && D > 0) ? a.feat + (size_t)b * N * D : nullptr;
-            for (int k0 = 0; k0 < K; k0 += rpi * SG_UNR) {
+            // the rows of this (centre, radius): one buffer resource, the lane's part of the address (its row inside a wave
+            // instruction, its 4 channels) is a loop-invariant VGPR -- one 32-bit add per store instead of a 64-bit chain
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+                a.Y[r] + ((size_t)b * S + qid) * K * C, 0, K * C * 4, 0x00020000);
+            const int y_voff = (rsel * C + 4 * c4) * 4;
+            const int C4 = C * 4;
+            // ALL: K is a whole number of row blocks (every configured layer): no per-row predicates, straight-line code
+            auto body = [&](int k0, auto all_tag) {
+                constexpr bool ALL = decltype(all_tag)::value;
                 bool okk[SG_UNR], inb[SG_UNR];
                 int n[SG_UNR];
                 float4 p[SG_UNR];
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
 #pragma unroll
                 for (int u = 0; u < SG_UNR; ++u) {
                     const int k = k0 + u * rpi + rsel;
-                    okk[u] = k < K;
+                    okk[u] = ALL || k < K;
                     const int nn = l[okk[u] ? k : K - 1];
                     inb[u] = nn >= 0 && nn < N;
                     n[u] = inb[u] ? nn : 0;
@@ -241,13 +252,23 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
                         y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w;
                     }
-                    if (okk[u]) {
-                        if (a.nt) st4nt(Yq + (size_t)(k0 + u * rpi + rsel) * C, y);
-                        else st4g(Yq + (size_t)(k0 + u * rpi + rsel) * C, y);
-                        s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
-                        s1.x += y.x * y.x; s1.y += y.y * y.y; s1.z += y.z * y.z; s1.w += y.w * y.w;
-                    }
+                    // branch-free: rows beyond K (partial last block) fail the bounds check of the store -- their row goes into
+                    // the checked lane offset -- and enter the statistics as zeros
+                    const f32x4 t = {y.x, y.y, y.z, y.w};
+                    const auto tv = __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, t);
+                    // (the row block goes into the LANE offset, one v_add per store, not into the scalar offset: with an SGPR
+                    // offset hipcc 7.2 leaves out the wait state between a 128-bit buffer store and the next VALU write of its
+                    // data registers -- lanes 12-15 of every 16 stored the following row's second dword)
+                    __builtin_amdgcn_raw_buffer_store_b128(tv, yrs, y_voff + (k0 + u * rpi) * C4, 0, 2 /* nt */);
+                    if (!okk[u]) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
+                    s1.x += y.x * y.x; s1.y += y.y * y.y; s1.z += y.z * y.z; s1.w += y.w * y.w;
                 }
+            };
+            if (K % (rpi * SG_UNR) == 0) {
+                for (int k0 = 0; k0 < K; k0 += rpi * SG_UNR) body(k0, std::true_type());
+            } else {
+                for (int k0 = 0; k0 < K; k0 += rpi * SG_UNR) body(k0, std::false_type());
             }
         }
         if (a.slab[r]) {  // block-uniform
