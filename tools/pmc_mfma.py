@@ -21,6 +21,8 @@ for r in csv.DictReader(open(f[0])):
         fam = "gemm_stream_%s" % ("nt" if ms.group(3) == "true" else "nn")
     elif "gemm_stream_tn_kernel" in name:
         fam = "gemm_stream_tn"
+    elif re.match(r"void gemm_pers_kernel<(\d+)", name):   # persistent form of the 128 x 128 kernel: same span family
+        fam = "gemm_%s_bn128" % ("nt", "nn")[int(re.match(r"void gemm_pers_kernel<(\d+)", name).group(1))]
     else:
         fam = name.split("(")[0].replace("void ", "")[:40]
     key = (fam, r["Dispatch_Id"])

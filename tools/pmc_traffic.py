@@ -22,6 +22,8 @@ def load(d, counter):
             fam = "gemm_stream_%s" % ("nt" if ms.group(3) == "true" else "nn")
         elif "gemm_stream_tn_kernel" in name:
             fam = "gemm_stream_tn"
+        elif re.match(r"void gemm_pers_kernel<(\d+)", name):   # persistent form of the 128 x 128 kernel: same span family
+            fam = "gemm_%s_bn128" % ("nt", "nn")[int(re.match(r"void gemm_pers_kernel<(\d+)", name).group(1))]
         elif "sa_group_kernel" in name:
             fam = "sa_group_linear"
         else:
