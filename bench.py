@@ -152,13 +152,16 @@ def _traffic_per_launch(dom):
     """HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 cannot run inside this
     process): profiles/r0X_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE, see the file's "source"."""
     # (the PMC tool names kernels, the spans name call sites)
-    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false>", "ms_fused_bwd": "ms_fused_kernel<1, true, true>",
+    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false", "ms_fused_bwd": "ms_fused_kernel<1, true, true",
              "gemm_dual_nn": "gemm_dual_sk_kernel"}
     for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 fams_pmc = json.load(fh)["families"]
-            rec = fams_pmc.get(dom) or fams_pmc.get(alias.get(dom, ""), {})
+            rec = fams_pmc.get(dom)
+            if rec is None and dom in alias:   # kernel names carry further template arguments: match the prefix
+                rec = next((v for k, v in fams_pmc.items() if k.startswith(alias[dom])), None)
+            rec = rec or {}
             if rec.get("hbm_bytes_per_launch") is not None:
                 return rec["hbm_bytes_per_launch"], name
         except Exception:
