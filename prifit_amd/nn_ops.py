@@ -76,10 +76,15 @@ def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, spl
              ptr(a_rowsum), int(accumulate), cur_stream())
 
 
+# split-K of the tiled dW products: one round of resident workgroups (512: two 8-wave workgroups per CU) measured best
+# ([256 x 196 x 393 K]: 549 / 455 / 466 / 494 us at 256 / 512 / 1024 / 2048 workgroups)
+_SPLITK_WGS = int(os.environ.get("PRIFIT_SPLITK_WGS", "512"))
+
+
 def _splitk_for(P, tiles):
-    """Workgroups along the reduction for dW = dY^T A: aim at ~1024 workgroups, >= 8 k-tiles each."""
+    """Workgroups along the reduction for dW = dY^T A: aim at _SPLITK_WGS workgroups, >= 8 k-tiles each."""
     ktiles = (P + 31) // 32
-    want = max(1, 1024 // max(1, tiles))
+    want = max(1, _SPLITK_WGS // max(1, tiles))
     return int(max(1, min(want, ktiles // 8 if ktiles >= 8 else 1, 4096)))
 
 
