@@ -212,6 +212,22 @@ int prifit_gemm_stream_tn_pool_f32(int Mo, int No, long long P, const float *Y, 
  * the caller (zeros, or a gradient to accumulate into).  Every wave streams its own rows as MFMA fragments (no
  * LDS staging); per-workgroup partial slabs go to `workspace` (prifit_gemm_stream_tn_workspace(Mo,No,P) floats,
  * caller-owned scratch) and a second small launch adds them to `out`. */
+/* The same two streaming products for a MIDDLE layer of a shared MLP (autograd of models/pointnet_util.py:195-199 /
+ * :252-256): the layer's dY = a*(Y*scale+shift > 0 ? G : 0) + b*Y + d -- prifit_bn_relu_bwd_apply's expression with
+ * the coefficients of prifit_bn_bwd_finalize -- is formed from G (gradient w.r.t. relu(bn(Y)), leading dimension ldy)
+ * and the pre-activation Y inside the kernels: no pass writing dY.
+ *   prifit_gemm_stream_tn_bn_f32:    out += dY^T relu(bn(A))
+ *   prifit_gemm_stream_dgrad_bn_f32: Gprev = dY W, with the BatchNorm-backward partials of the previous layer in
+ *                                    red_slab (as prifit_gemm_stream_dgrad_f32) */
+int prifit_gemm_stream_tn_bn_f32(int Mo, int No, long long P, const float *G, const float *Y, long long ldy, const float *A,
+                                 long long lda, float *out, long long ldo, const float *b_scale, const float *b_shift,
+                                 const float *scale, const float *shift, const float *coef_a, const float *coef_b,
+                                 const float *coef_d, float *workspace, void *stream);
+int prifit_gemm_stream_dgrad_bn_f32(int M, int N, int K, const float *Gin, const float *Y, long long lda, const float *W,
+                                    long long ldb, float *G, long long ldc, const float *scale_l, const float *shift_l,
+                                    const float *coef_a, const float *coef_b, const float *coef_d, const float *Yprev,
+                                    long long ldy, const float *scale, const float *shift, const float *mean,
+                                    const float *invstd, float *red_slab, void *stream);
 int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long long ldg, const float *A,
                               long long lda, float *out, long long ldo, const float *b_scale,
                               const float *b_shift, float *workspace, void *stream);

@@ -51,15 +51,21 @@ struct StreamArgs {
     // candidates instead of from C (prifit_pool_from_candidates).
     float *cand;
     int nslab;                       // slabs the caller reads (stream_grid(M, K)); >= the launched grid
+    // BNA (dA of a middle layer): A is the layer's pre-activation Y, bna_G (same leading dimension) the gradient w.r.t.
+    // relu(bn(Y)); the operand dY = a * (Y * s + t > 0 ? G : 0) + (b * Y + d) -- bn_relu_bwd_apply's expression -- is
+    // formed when the tile is staged (coefficients [K] each)
+    const float *bna_G;
+    const float *bna_s, *bna_t, *bna_a, *bna_b, *bna_d;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // WN: waves along N (2 or 4; 256 threads = 4 waves, WM = 4 / WN waves along M); KG = K / 8;
 // BKC: B is [N][K] (NT) else [K][N] (NN); AFF: prologue on A
-template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL, bool PMAX>
+template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL, bool PMAX, bool BNA = false>
 __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (KG <= 12 ? ((RED || PMAX || POOL) ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
 {
+    static_assert(!BNA || (!AFF && !POOL && !PMAX && !BKC), "BNA: a plain NN product with the operand transform");
     constexpr int K = KG * 8;
     constexpr int WM = 4 / WN;
     constexpr int TM = SBM / (32 * WM);       // 32-row accumulator tiles per wave
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     __shared__ __attribute__((aligned(16))) float s_aff[2][K];   // POOL: [0] = b
     __shared__ __attribute__((aligned(16))) float s_pool[2][2][POOL ? K : 4];  // [stage][arg | T][channel]
     __shared__ float s_red[WM][2][32 * WN];
+    __shared__ __attribute__((aligned(16))) float s_bna[BNA ? 5 : 1][BNA ? K : 4];   // s, t, a, b, d
 
     // (readfirstlane: wm / wn are wave-uniform and the compiler has to know it, see gemm_stream_tn_kernel)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -83,6 +90,12 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     }
     if (POOL) {
         for (int t = threadIdx.x; t < K; t += 256) s_aff[0][t] = g.pool_b[t];
+    }
+    if (BNA) {
+        for (int t = threadIdx.x; t < K; t += 256) {
+            s_bna[0][t] = g.bna_s[t]; s_bna[1][t] = g.bna_t[t]; s_bna[2][t] = g.bna_a[t]; s_bna[3][t] = g.bna_b[t];
+            s_bna[4][t] = g.bna_d[t];
+        }
     }
     // this wave's slice of B as fragments: lane (li, lh) of k-group q holds B[col][8q + 4lh + 0..3]
     float4 bf[KG];
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
 
     const int tiles = (g.M + SBM - 1) / SBM;
     float4 st[NV];
+    float4 stg[BNA ? NV : 1];   // BNA: the gradient tile beside the pre-activation tile
     float st_pool = 0.f;
     // Addressing: one buffer resource per tile (base = the tile's first row, exact extent: rows beyond M read as zeros and
     // stores to them are dropped by the bounds check); a thread's part of an address is a loop-invariant VGPR, the rest
@@ -135,6 +149,14 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aoff[p], 0, 0));
             st[p] = make_float4(v.x, v.y, v.z, v.w);
         }
+        if (BNA) {
+            const __amdgpu_buffer_rsrc_t rg = tile_rsrc(g.bna_G, g.lda, m0, K);
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, aoff[p], 0, 0));
+                stg[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        }
     };
     auto store_tile = [&](int tile, float *dst, int stage) {
         const int m0 = tile * SBM;
@@ -152,6 +174,19 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
                 x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
                 if (!full && m0 + row >= g.M) x = make_float4(0.f, 0.f, 0.f, 0.f);   // (without AFF the load returned zeros)
             }
+            if (BNA) {   // bn_relu_bwd_apply's expression, term by term
+                const float4 cs = *reinterpret_cast<const float4 *>(&s_bna[0][4 * c4]);
+                const float4 ct = *reinterpret_cast<const float4 *>(&s_bna[1][4 * c4]);
+                const float4 ca = *reinterpret_cast<const float4 *>(&s_bna[2][4 * c4]);
+                const float4 cb = *reinterpret_cast<const float4 *>(&s_bna[3][4 * c4]);
+                const float4 cd = *reinterpret_cast<const float4 *>(&s_bna[4][4 * c4]);
+                const float4 gg = stg[p];
+                x.x = fmaf(ca.x, fmaf(x.x, cs.x, ct.x) > 0.f ? gg.x : 0.f, fmaf(cb.x, x.x, cd.x));
+                x.y = fmaf(ca.y, fmaf(x.y, cs.y, ct.y) > 0.f ? gg.y : 0.f, fmaf(cb.y, x.y, cd.y));
+                x.z = fmaf(ca.z, fmaf(x.z, cs.z, ct.z) > 0.f ? gg.z : 0.f, fmaf(cb.z, x.z, cd.z));
+                x.w = fmaf(ca.w, fmaf(x.w, cs.w, ct.w) > 0.f ? gg.w : 0.f, fmaf(cb.w, x.w, cd.w));
+                if (!full && m0 + row >= g.M) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             *reinterpret_cast<float4 *>(dst + row * LD + 4 * c4) = x;
         }
     };
@@ -168,7 +203,7 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     int tile = blockIdx.x;
     if (tile >= tiles) tile = tiles - 1;   // (the launcher never starts more workgroups than tiles)
     load_tile(tile);
-    if (AFF || POOL) __syncthreads();  // s_aff visible before the first staging
+    if (AFF || POOL || BNA) __syncthreads();  // s_aff / s_bna visible before the first staging
     store_tile(tile, s_a[0], 0);
     __syncthreads();
     for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
@@ -319,15 +354,21 @@ struct StreamTNArgs {
     const float *pool_b, *pool_d;    // [Mo]
     int pool_K;                      // multiple of 8
     int interleave;
+    // BNA (dW of a middle layer): G is the layer's pre-activation Y and bn_G the gradient w.r.t. relu(bn(Y)); the operand
+    // dY = a * (Y * s + t > 0 ? bn_G : 0) + (b * Y + d) -- exactly bn_relu_bwd_apply's expression -- is formed on load
+    // (lane = channel: s, t, a, b, d are per-lane constants; bn_G shares Y's leading dimension)
+    const float *bn_G;
+    const float *bn_s, *bn_t, *bn_a, *bn_b, *bn_d;   // [Mo]
 };
 #ifndef TN_DEBUG
 #define TN_DEBUG 0
 #endif
 
 // RAG: the output is not a whole number of AM x AN sub-blocks (96 x 96 only): tiles beyond it are skipped at run time
-template <int AM, int AN, int PF, int OCC, bool AFF, bool POOL, bool RAG>
+template <int AM, int AN, int PF, int OCC, bool AFF, bool POOL, bool RAG, bool BNA = false>
 __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTNArgs g)
 {
+    static_assert(!(POOL && BNA), "one operand transform at a time");
     constexpr int NT = AM * AN;
     __shared__ float s_part[3][NT * 1024];  // partial sub-blocks of the row-group streams ks = 1..3
     // (readfirstlane: everything derived from the wave index is wave-uniform, and the compiler has to know it -- as a
@@ -356,10 +397,15 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTN
         if (AFF && b < n_cnt) { sc[b] = g.b_scale[n0 + 32 * b + li]; sh[b] = g.b_shift[n0 + 32 * b + li]; }
     }
     float pb[AM], pd[AM];
+    float ns[AM], nt[AM], na[AM];   // BNA: scale, shift, a (b and d share pb / pd)
 #pragma unroll
     for (int a = 0; a < AM; ++a) {
-        pb[a] = 0.f; pd[a] = 0.f;
+        pb[a] = 0.f; pd[a] = 0.f; ns[a] = 0.f; nt[a] = 0.f; na[a] = 0.f;
         if (POOL && a < m_cnt) { pb[a] = g.pool_b[m0 + 32 * a + li]; pd[a] = g.pool_d[m0 + 32 * a + li]; }
+        if (BNA && a < m_cnt) {
+            const int c = m0 + 32 * a + li;
+            pb[a] = g.bn_b[c]; pd[a] = g.bn_d[c]; ns[a] = g.bn_s[c]; nt[a] = g.bn_t[c]; na[a] = g.bn_a[c];
+        }
     }
     // rows of this wave's stream.  interleave: the 8-row groups of the whole launch are dealt round-robin over all
     // (workgroup, stream) pairs, so at any moment the chip reads ONE contiguous window of the operands; otherwise every
@@ -386,9 +432,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTN
     const int sq = stride / pk, sr = stride - sq * pk, q_last = (r1 - 8) / pk;
 
     float fg[PF][AM][4], fa[PF][AN][4];
+    float fgg[PF][BNA ? AM : 1][4];   // BNA: the gradient fragments beside the pre-activation fragments
     int fw[PF][AM];      // POOL: winning sample of this lane's channel in the row group's pool
     float ft[PF][AM];    //       and its gradient
-    auto load = [&](int row_, int q_, float (&xg)[AM][4], float (&xa)[AN][4], int (&xw)[AM], float (&xt)[AM]) {
+    auto load = [&](int row_, int q_, float (&xg)[AM][4], float (&xa)[AN][4], int (&xw)[AM], float (&xt)[AM], float (&xgg)[BNA ? AM : 1][4]) {
         const bool live = row_ < r1;
         const int row = live ? row_ : r1 - 8;   // past the end: any valid group (its product is zeroed)
         const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
@@ -416,6 +463,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTN
                     xg[a][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, g_voff + 128 * a, j * ldg4, 0));
             }
         }
+        if (BNA) {
+            const __amdgpu_buffer_rsrc_t ggrs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(g.bn_G + (long long)row * g.ldg), 0, g_bytes, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < AM; ++a) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xgg[a][j] = 0.f;
+                if (a < m_cnt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xgg[a][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ggrs, g_voff + 128 * a, j * ldg4, 0));
+                }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < AN; ++b) {
 #pragma unroll
@@ -427,8 +488,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTN
             }
         }
     };
-    auto multiply = [&](int row, int rem, float (&xg)[AM][4], float (&xa)[AN][4], const int (&xw)[AM], const float (&xt)[AM]) {
+    auto multiply = [&](int row, int rem, float (&xg)[AM][4], float (&xa)[AN][4], const int (&xw)[AM], const float (&xt)[AM],
+                        const float (&xgg)[BNA ? AM : 1][4]) {
         const bool live = row < r1;   // wave-uniform
+        if (BNA) {   // bn_relu_bwd_apply's expression, term by term
+#pragma unroll
+            for (int a = 0; a < AM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xg[a][j] = fmaf(na[a], fmaf(xg[a][j], ns[a], nt[a]) > 0.f ? xgg[a][j] : 0.f, fmaf(pb[a], xg[a][j], pd[a]));
+        }
         if (POOL) {
             const int kb = rem + 4 * lh;  // sample index of this lane's first row in its pooling group
 #pragma unroll
@@ -474,19 +543,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTN
     if (TN_DEBUG == 2) { lrow = 8 * wave; lq = 0; }   // DIAGNOSIS: matrix side only (every load hits the same lines)
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s) {
-        load(lrow, lq, fg[s], fa[s], fw[s], ft[s]);
+        load(lrow, lq, fg[s], fa[s], fw[s], ft[s], fgg[s]);
         if (TN_DEBUG != 2) advance(lrow, lq, lrem);
     }
     while (row < r1) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const int t = (s + PF - 1) % PF;
-            load(lrow, lq, fg[t], fa[t], fw[t], ft[t]);
+            load(lrow, lq, fg[t], fa[t], fw[t], ft[t], fgg[t]);
             if (TN_DEBUG != 2) advance(lrow, lq, lrem);
             // the loads stay HERE, a whole PF - 1 groups ahead of their use: left alone, the scheduler sinks each one to
             // just before its MFMA (fewer live registers) and the wave waits out the memory latency every time
             __builtin_amdgcn_sched_barrier(0);
-            multiply(row, mrem, fg[s], fa[s], fw[s], ft[s]);
+            multiply(row, mrem, fg[s], fa[s], fw[s], ft[s], fgg[s]);
             __builtin_amdgcn_sched_barrier(0);
             int dummy_q = 0;
             advance(row, dummy_q, mrem);
@@ -567,10 +636,11 @@ void launch_aff(const StreamArgs &g_, int nslab, hipStream_t st)
     // the plain variant put the register-heavy ones through 1.33 - 1.5 rounds); the statistics slabs beyond it are zeroed
     StreamArgs g = g_;
     g.nslab = nslab;
-    const bool heavy = g.pool_arg || g.red_slab || g.cand;
+    const bool heavy = g.pool_arg || g.red_slab || g.cand || g.bna_G;
     const int occ = KG <= 8 ? (heavy ? 3 : 4) : (KG <= 12 ? (heavy ? 2 : 3) : 2);
     const int grid = nslab < 256 * occ ? nslab : 256 * occ;
-    if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
+    if (!BKC && g.bna_G && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
     else if (!BKC && g.pool_arg) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
     else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
     else if (BKC && g.cand && g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, true, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
@@ -624,6 +694,10 @@ template <int AM, int AN, int PF, int OCC, bool RAG>
 static void stream_tn_launch_t(const StreamTNArgs &g, dim3 grid, hipStream_t st)
 {
     const dim3 block(256);
+    if (g.bn_G) {   // (a middle layer always has the prologue on A)
+        hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, true, false, RAG, true>), grid, block, 0, st, g);
+        return;
+    }
     if (g.pool_arg) {
         if (g.b_scale) hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, true, true, RAG>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((gemm_stream_tn_kernel<AM, AN, PF, OCC, false, true, RAG>), grid, block, 0, st, g);
@@ -636,7 +710,8 @@ static void stream_tn_launch_t(const StreamTNArgs &g, dim3 grid, hipStream_t st)
 template <int AM, int AN, bool RAG = false>
 static void stream_tn_launch_pf(const StreamTNArgs &g, const TNPlan &p, dim3 grid, hipStream_t st)
 {
-    if (p.pf == 2) stream_tn_launch_t<AM, AN, 2, 3, RAG>(g, grid, st);
+    // (the BatchNorm-apply variant of the 2 x 2 plan spills two registers at depth 3)
+    if (p.pf == 2 || (g.bn_G && AM * AN == 4 && p.pf == 3)) stream_tn_launch_t<AM, AN, 2, 3, RAG>(g, grid, st);
     else if (p.pf == 4) stream_tn_launch_t<AM, AN, 4, (AM * AN == 4 ? 2 : 3), RAG>(g, grid, st);
     else stream_tn_launch_t<AM, AN, 3, 3, RAG>(g, grid, st);
 }
@@ -696,7 +771,27 @@ int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
+    return stream_launch(g, 1, stream);
+}
+
+int prifit_gemm_stream_dgrad_bn_f32(int M, int N, int K, const float *Gin, const float *Y, long long lda, const float *W,
+                                    long long ldb, float *G, long long ldc, const float *scale_l, const float *shift_l,
+                                    const float *coef_a, const float *coef_b, const float *coef_d, const float *Yprev,
+                                    long long ldy, const float *scale, const float *shift, const float *mean,
+                                    const float *invstd, float *red_slab, void *stream)
+{
+    if (!Gin || !Y || !W || !G || !scale_l || !shift_l || !coef_a || !coef_b || !coef_d || !Yprev || !scale || !shift ||
+        !mean || !invstd || !red_slab || !prifit_gemm_stream_supported(1, M, N, K) || lda < K || ldc < N || ldb < N ||
+        ldy < N || (lda & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)Gin & 15))
+        return PRIFIT_EINVAL;
+    StreamArgs g;
+    g.A = Y; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
+    g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
+    g.red_slab = red_slab;
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr;
+    g.bna_G = Gin; g.bna_s = scale_l; g.bna_t = shift_l; g.bna_a = coef_a; g.bna_b = coef_b; g.bna_d = coef_d;
     return stream_launch(g, 1, stream);
 }
 
@@ -716,7 +811,7 @@ int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long 
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = bias_dW; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
-    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_K = pool_K; g.cand = nullptr;
+    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_K = pool_K; g.cand = nullptr; g.bna_G = nullptr;
     return stream_launch(g, 1, stream);
 }
 
@@ -732,7 +827,7 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
-    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
     return stream_launch(g, layout, stream);
 }
 
@@ -747,7 +842,7 @@ int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long l
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
-    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = cand;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = cand; g.bna_G = nullptr;
     return stream_launch(g, 0, stream);
 }
 
@@ -775,6 +870,7 @@ int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long 
     g.G = G; g.A = A; g.ws = workspace; g.Mo = Mo; g.No = No; g.P = P; g.ldg = ldg; g.lda = lda;
     g.b_scale = b_scale; g.b_shift = b_shift;
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = g.pool_d = nullptr; g.pool_K = 0;
+    g.bn_G = nullptr; g.bn_s = g.bn_t = g.bn_a = g.bn_b = g.bn_d = nullptr;
     return stream_tn_launch(g, out, ldo, stream);
 }
 
@@ -792,6 +888,23 @@ int prifit_gemm_stream_tn_pool_f32(int Mo, int No, long long P, const float *Y, 
     g.G = Y; g.A = A; g.ws = workspace; g.Mo = Mo; g.No = No; g.P = P; g.ldg = ldy; g.lda = lda;
     g.b_scale = b_scale; g.b_shift = b_shift;
     g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_d = coef_d; g.pool_K = pool_K;
+    g.bn_G = nullptr; g.bn_s = g.bn_t = g.bn_a = g.bn_b = g.bn_d = nullptr;
+    return stream_tn_launch(g, out, ldo, stream);
+}
+
+int prifit_gemm_stream_tn_bn_f32(int Mo, int No, long long P, const float *G, const float *Y, long long ldy, const float *A,
+                                 long long lda, float *out, long long ldo, const float *b_scale, const float *b_shift,
+                                 const float *scale, const float *shift, const float *coef_a, const float *coef_b,
+                                 const float *coef_d, float *workspace, void *stream)
+{
+    if (!G || !Y || !A || !out || !workspace || !b_scale || !b_shift || !scale || !shift || !coef_a || !coef_b || !coef_d ||
+        !prifit_gemm_stream_tn_supported(Mo, No, P) || ldy < Mo || lda < No || ldo < No || ldy >= (1 << 24) || lda >= (1 << 24))
+        return PRIFIT_EINVAL;
+    StreamTNArgs g;
+    g.G = Y; g.A = A; g.ws = workspace; g.Mo = Mo; g.No = No; g.P = P; g.ldg = ldy; g.lda = lda;
+    g.b_scale = b_scale; g.b_shift = b_shift;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = g.pool_d = nullptr; g.pool_K = 0;
+    g.bn_G = G; g.bn_s = scale; g.bn_t = shift; g.bn_a = coef_a; g.bn_b = coef_b; g.bn_d = coef_d;
     return stream_tn_launch(g, out, ldo, stream);
 }
 

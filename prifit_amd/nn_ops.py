@@ -30,6 +30,7 @@ def _rows_per_slab():
 _STREAM = os.environ.get("PRIFIT_GEMM_STREAM", "1") != "0"   # 0: every product takes the tiled kernel (A/B runs)
 _FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate bn_relu_bwd_reduce launches (A/B runs)
 _FUSE_POOL_FWD = os.environ.get("PRIFIT_FUSE_POOL_FWD", "1") != "0"  # 0: pool_fwd re-reads the last layer's Y (A/B runs)
+_FUSE_BN_APPLY = os.environ.get("PRIFIT_FUSE_BN_APPLY", "1") != "0"  # 0: bn_relu_bwd_apply writes a middle layer's dY (A/B runs)
 _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
 
 
@@ -250,7 +251,12 @@ class SharedMLPFn(torch.autograd.Function):
                              ctx.needs_input_grad[2 + 6 * l] and _stream_ok(NN, P, Kin, Cout) and
                              dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
             direct0 = l == 0 and ctx.preact_direct is not None
-            dY = None if (fuse_pool or direct0) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            # a middle layer on streaming shapes: dY = a*(relu mask)*G + b*Y + d is formed inside its two consumers (the dW and
+            # the dA kernel read G and Y instead of dY: no bn_relu_bwd_apply pass writing dY, one read of it less)
+            fuse_bn = bool(_FUSE_BN_APPLY and _FUSE_RED and not pooled and not direct0 and training and l > 0 and W is not None and
+                           ctx.needs_input_grad[2 + 6 * l] and G_in.stride(0) == Cout and G_in.data_ptr() % 16 == 0 and
+                           _stream_ok(NN, P, Kin, Cout) and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
+            dY = None if (fuse_pool or direct0 or fuse_bn) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
@@ -319,6 +325,31 @@ class SharedMLPFn(torch.autograd.Function):
                     grads[1] = zero_pool.zeros(Cout, device=dev)  # bias in front of a batch-stat BatchNorm
                 G_in = None
                 break
+            if fuse_bn:
+                wo, wn, bo, bn_ = wslots[l]
+                dW = arena[wo:wo + wn].view(Cout, Kin)
+                ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
+                a_aff = affines[l - 1]
+                with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P, "bn"), 4.0 * P * (2 * Cout + Kin)):
+                    call("prifit_gemm_stream_tn_bn_f32", Cout, Kin, _LL(P), ptr(G_in), ptr(Y), _LL(Cout), ptr(Ys[l - 1]),
+                         _LL(Ys[l - 1].stride(0)), ptr(dW), _LL(Kin), ptr(a_aff[0]), ptr(a_aff[1]), ptr(scale), ptr(shift),
+                         ptr(ca), ptr(cb), ptr(cd), ptr(ws), cur_stream())
+                grads[6 * l] = dW
+                if ctx.needs_input_grad[2 + 6 * l + 1]:
+                    grads[6 * l + 1] = arena[bo:bo + bn_]   # bias in front of a batch-stat BatchNorm: zero gradient
+                grads[6 * l + 2] = dgamma
+                grads[6 * l + 3] = dbeta
+                G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+                ns = dll().prifit_gemm_stream_slabs(P, Cout)
+                rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
+                with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, "bn"), 4.0 * (2 * P * Cout + 2 * P * Kin + Kin * Cout)):
+                    call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G_in), ptr(Y), _LL(Cout), ptr(W), _LL(Kin),
+                         ptr(G_prev), _LL(Kin), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), ptr(Ys[l - 1]),
+                         _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), cur_stream())
+                fused_red = (rslab, ns)
+                G_in = G_prev
+                continue
             if pooled:
                 call("prifit_pool_bwd_apply", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
                      ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), G, K, Cout, 0, _F(0.0), ptr(dY), _LL(Cout),

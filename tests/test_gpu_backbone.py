@@ -182,8 +182,9 @@ def test_gemm_stream_weight_grad(nn_ops, Mo, No, P, aff):
 def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims):
     """The BatchNorm-backward column sums emitted by the dA epilogues (prifit_gemm_stream_dgrad_f32 /
     prifit_gemm_dgrad_bnred_f32) against the separate bn_relu_bwd_reduce launches, and the pooled last layer's dY formed
-    in the streaming consumers (prifit_gemm_stream_dgrad_pool_f32 / _tn_pool_f32) against pool_bwd_apply: same gradients
-    up to summation order."""
+    in the streaming consumers (prifit_gemm_stream_dgrad_pool_f32 / _tn_pool_f32) against pool_bwd_apply, and a middle
+    layer's dY formed in its consumers (prifit_gemm_stream_dgrad_bn_f32 / _tn_bn_f32) against bn_relu_bwd_apply: same
+    gradients up to summation order."""
     x = _rand((P, dims[0][0]), 31).cuda()
     g = torch.Generator().manual_seed(32)
     tens = []
@@ -195,8 +196,8 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
     gout = _rand((P // K if K else P, dims[-1][1]), 33).cuda()
     res = {}
     for fuse in (True, False):
-        old = nn_ops._FUSE_RED, nn_ops._FUSE_POOL, nn_ops._FUSE_POOL_FWD
-        nn_ops._FUSE_RED = nn_ops._FUSE_POOL = nn_ops._FUSE_POOL_FWD = fuse
+        old = nn_ops._FUSE_RED, nn_ops._FUSE_POOL, nn_ops._FUSE_POOL_FWD, nn_ops._FUSE_BN_APPLY
+        nn_ops._FUSE_RED = nn_ops._FUSE_POOL = nn_ops._FUSE_POOL_FWD = nn_ops._FUSE_BN_APPLY = fuse
         try:
             xi = x.clone().requires_grad_(True)
             cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
@@ -204,7 +205,7 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
             grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
             res[fuse] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
         finally:
-            nn_ops._FUSE_RED, nn_ops._FUSE_POOL, nn_ops._FUSE_POOL_FWD = old
+            nn_ops._FUSE_RED, nn_ops._FUSE_POOL, nn_ops._FUSE_POOL_FWD, nn_ops._FUSE_BN_APPLY = old
     for a, b in zip(res[True], res[False]):
         if b is None:
             assert a is None

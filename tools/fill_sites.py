@@ -32,7 +32,10 @@ def wrap(obj, name):
         return orig(*a, **k)
     setattr(obj, name, f)
 for obj, name in ((torch, "zeros"), (torch, "zeros_like"), (torch, "full"), (torch.Tensor, "new_zeros"), (torch.Tensor, "zero_"),
-                  (torch.Tensor, "fill_"), (torch.Tensor, "masked_fill"), (torch, "ones"), (torch, "ones_like")):
+                  (torch.Tensor, "fill_"), (torch.Tensor, "masked_fill"), (torch, "ones"), (torch, "ones_like"),
+                  # copies / concatenations (the other third of the small torch launches)
+                  (torch, "cat"), (torch, "stack"), (torch.Tensor, "contiguous"), (torch.Tensor, "clone"), (torch.Tensor, "copy_"),
+                  (torch.Tensor, "float"), (torch.Tensor, "sum"), (torch, "sum")):
     wrap(obj, name)
 full(); torch.cuda.synchronize()
 for (name, s), n in sorted(sites.items(), key=lambda kv: -kv[1]):
