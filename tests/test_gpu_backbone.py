@@ -213,6 +213,39 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
         assert (a - b).norm() <= 5e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
 
 
+@pytest.mark.parametrize("P,Cout,Kin", [(40008, 96, 64), (65536, 64, 64), (33000, 128, 128), (50000, 128, 96)])
+def test_bn_apply_on_load_matches_apply_pass(nn_ops, P, Cout, Kin):
+    """prifit_gemm_stream_tn_bn_f32 / prifit_gemm_stream_dgrad_bn_f32 (a middle layer's dY formed from G and Y inside the
+    dW / dA kernels) against prifit_bn_relu_bwd_apply followed by the plain streaming kernels: the SAME numbers (the
+    operand is the apply kernel's expression term by term, the products run in the same order); ragged P."""
+    from prifit_amd.nn_ops import call, ptr, cur_stream, _LL, _F, dll
+    G, Y, A = _rand((P, Cout), 61).cuda(), _rand((P, Cout), 62).cuda(), _rand((P, Kin), 63).cuda()
+    W = _rand((Cout, Kin), 64).cuda()
+    s, t, ca, cb, cd = [_rand((Cout,), 65 + i).cuda() for i in range(5)]
+    s1, t1, mu1, is1 = [_rand((Kin,), 71 + i).cuda() for i in range(4)]
+    dY = torch.empty(P, Cout, device="cuda")
+    call("prifit_bn_relu_bwd_apply", ptr(G), _LL(Cout), ptr(Y), _LL(Cout), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), P, Cout, 0,
+         _F(0.0), ptr(dY), _LL(Cout), cur_stream())
+    # dW
+    ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), device="cuda")
+    dW_ref, dW = torch.zeros(Cout, Kin, device="cuda"), torch.zeros(Cout, Kin, device="cuda")
+    call("prifit_gemm_stream_tn_f32", Cout, Kin, _LL(P), ptr(dY), _LL(Cout), ptr(A), _LL(Kin), ptr(dW_ref), _LL(Kin), ptr(s1), ptr(t1),
+         ptr(ws), cur_stream())
+    call("prifit_gemm_stream_tn_bn_f32", Cout, Kin, _LL(P), ptr(G), ptr(Y), _LL(Cout), ptr(A), _LL(Kin), ptr(dW), _LL(Kin), ptr(s1),
+         ptr(t1), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), ptr(ws), cur_stream())
+    assert (dW - dW_ref).norm() <= 2e-6 * dW_ref.norm()      # (slab sums may be added in a different order)
+    # dA with the BatchNorm-backward partials of the previous layer
+    ns = dll().prifit_gemm_stream_slabs(P, Cout)
+    Gp_ref, Gp = torch.empty(P, Kin, device="cuda"), torch.full((P, Kin), float("nan"), device="cuda")
+    sl_ref, sl = torch.empty(ns, 2, Kin, device="cuda"), torch.full((ns, 2, Kin), float("nan"), device="cuda")
+    call("prifit_gemm_stream_dgrad_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp_ref), _LL(Kin), ptr(A), _LL(Kin),
+         ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), cur_stream())
+    call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G), ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp), _LL(Kin), ptr(s), ptr(t),
+         ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), cur_stream())
+    assert torch.equal(Gp, Gp_ref)
+    torch.testing.assert_close(sl.double().sum(0), sl_ref.double().sum(0), rtol=1e-6, atol=1e-3)
+
+
 @pytest.mark.parametrize("P,K,N,Kin", [(65536, 64, 128, 64), (49152, 96, 64, 96), (32768, 32, 96, 128)])
 def test_pool_candidates_match_pool_fwd(nn_ops, P, K, N, Kin):
     """prifit_gemm_stream_pool_f32 + prifit_pool_from_candidates against prifit_pool_fwd on the stored Y: identical pooled
