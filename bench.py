@@ -306,7 +306,7 @@ def run_rank(args):
         detail = {}
         for name, (n, ms, work) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
             per = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps, "avg_us": 1e3 * ms / max(n, 1)}
-            if (name.startswith("gemm") and not name.startswith("gemm_stream")) or name.startswith("ms_fused"):
+            if (name.startswith("gemm") and not name.startswith("gemm_stream")) or name.startswith(("ms_fused", "chord_sym")):
                 per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                            flops_per_step=work / args.steps, flops_per_launch=work / max(n, 1))
             else:

@@ -138,6 +138,13 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
                     void *stream);
 
+/* Chord-distance matrix of a point set with itself (src/mean_shift.py:154 bandwidth statistic, :185 non-maximum
+ * suppression): C[z] = 2 - 2 A[z] A[z]^T for unit rows, [n, n] per batch item; n % 128 == 0, K % 32 == 0, 16-byte rows.
+ * Only the tiles on and above the diagonal are computed, the others written as their transposes: the same bits as
+ * prifit_gemm_f32(NT, A, A, epilogue = chord). */
+int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
+                         int n, int K, int batch, void *stream);
+
 /* Weights-stationary streaming variant for the tall-and-skinny (HBM-bound) layers of the shared MLPs: layout
  * PRIFIT_GEMM_NT (C = A B^T, B [N,K]) or PRIFIT_GEMM_NN (C = A B, B [K,N]) with M >= 32768, N in {64,96,128},
  * K in {64,96,128}; A [M,K] with lda % 4 == 0.  Persistent workgroups keep B in registers and stream 64-row tiles

@@ -800,6 +800,92 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chord-distance matrix of ONE point set with itself (src/mean_shift.py:154 / :185: 2 - 2 X X^T for the bandwidth
+// statistic and the final non-maximum suppression): C[z] = 2 - 2 A[z] A[z]^T, [n, n] per shape, n % 128 == 0, K % 32 == 0.
+// The matrix is symmetric and so is its arithmetic -- C[i][j] and C[j][i] are the same products added in the same
+// k order -- so only the tiles on and above the diagonal are computed (136 of 256 at n = 2048); an off-diagonal tile
+// is also written transposed, through LDS, as whole coalesced rows.  Bit-identical to the full product.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chord_sym_kernel(
+    const float *__restrict__ A, long long lda, long long sA, float *__restrict__ C, long long ldc, long long sC, int n, int K)
+{
+    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr int SZ = BM * (BK + PAD);
+    constexpr int TLD = BM + 4;   // transposed staging: [column of the tile][row], 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) float lds[4 * SZ];   // two stages of (row panel, column panel); 73.7 KB >= 128 * TLD * 4
+    static_assert(4 * SZ >= BN * TLD, "the transposed tile fits the staging buffers");
+    // upper-triangular tile index -> (tile_m <= tile_n)
+    const int T = n / BM;
+    int t = blockIdx.x, tile_m = 0;
+    while (t >= T - tile_m) { t -= T - tile_m; ++tile_m; }
+    const int tile_n = tile_m + t;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float *Az = A + (long long)blockIdx.z * sA;
+    float *Cz = C + (long long)blockIdx.z * sC;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    BufLoader<BM, true, false, NTH> la, lb;
+    la.init(Az, lda, m0, n, K);
+    lb.init(Az, lda, n0, n, K);
+    const int ktiles = K / BK;
+    la.load(0); lb.load(0);
+    la.store(lds); lb.store(lds + SZ);
+    __syncthreads();
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int stage = kt & 1;
+        const float *As = lds + stage * 2 * SZ, *Bs = As + SZ;
+        const bool more = kt + 1 < ktiles;
+        if (more) { la.load((kt + 1) * BK); lb.load((kt + 1) * BK); }
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            const float4 fa = read_frag<BM, true>(As, wm0 + li, gk, lh);
+            float4 fb[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, true>(Bs, wn0 + 32 * b + li, gk, lh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
+            }
+        }
+        if (more) {
+            float *An = lds + (stage ^ 1) * 2 * SZ;
+            la.store(An); lb.store(An + SZ);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool mirror = tile_m != tile_n;   // block-uniform
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = wn0 + 32 * b + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float v = 2.0f - 2.0f * acc[b][r];   // src/mean_shift.py:154 / :168
+            Cz[(long long)(m0 + row) * ldc + n0 + col] = v;
+            if (mirror) lds[col * TLD + row] = v;
+        }
+    }
+    if (mirror) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < BN * (BM / 4); i += NTH) {
+            const int trow = i / (BM / 4), c4 = i - trow * (BM / 4);
+            *reinterpret_cast<float4 *>(Cz + (long long)(n0 + trow) * ldc + m0 + 4 * c4) =
+                *reinterpret_cast<const float4 *>(lds + trow * TLD + 4 * c4);
+        }
+    }
+}
+
 static bool g_persistent_enabled()
 {
     static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();  // A/B switch
@@ -1103,6 +1189,19 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
     g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.dA2 = g.dB2 = 0; g.kswitch = 0;
     return dispatch(g, LAY_NN, stream);
+}
+
+int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
+                         int n, int K, int batch, void *stream)
+{
+    if (!A || !C || n <= 0 || (n % 128) || K <= 0 || (K % BK) || batch <= 0 || batch > 65535 || lda < K || ldc < n || (lda & 3) ||
+        (ldc & 3) || (strideA & 3) || (strideC & 3) || ((uintptr_t)A & 15) || ((uintptr_t)C & 15) ||
+        (long long)n * lda * 4 >= 0x7ff00000LL)
+        return PRIFIT_EINVAL;
+    const int T = n / 128;
+    hipLaunchKernelGGL(chord_sym_kernel, dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0, as_stream(stream), A, lda, strideA, C, ldc,
+                       strideC, n, K);
+    return prifit_check_launch();
 }
 
 }  // extern "C"

@@ -30,6 +30,7 @@ DX_STREAMS = __import__("os").environ.get("PRIFIT_MS_DX_STREAMS", "0") != "0"
 # atomics and second-launch epilogue), so it stays on the plain grid unless asked for
 MS_BALANCED = __import__("os").environ.get("PRIFIT_MS_BALANCED", "1") != "0"
 MS_BALANCED_FWD = __import__("os").environ.get("PRIFIT_MS_BALANCED_FWD", "0") != "0"
+CHORD_SYM = __import__("os").environ.get("PRIFIT_CHORD_SYM", "1") != "0"   # symmetric kernel for chord_matrix(X, X)
 DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
 
 
@@ -54,6 +55,12 @@ def chord_matrix(A, B_):
     Bt, N, D = A.shape
     M = B_.shape[1]
     out = torch.empty(Bt, N, M, dtype=torch.float32, device=A.device)
+    if (CHORD_SYM and A.data_ptr() == B_.data_ptr() and N == M and N % 128 == 0 and D % 32 == 0 and A.is_contiguous() and
+            A.data_ptr() % 16 == 0):
+        # a set against itself: the symmetric kernel computes the upper triangle of tiles only (same bits)
+        with profiler.span(profiler.tag("chord_sym", N, D, Bt), 2.0 * Bt * N * N * D):
+            call("prifit_chord_sym_f32", ptr(A), _LL(D), _LL(N * D), ptr(out), _LL(N), _LL(N * N), N, D, Bt, cur_stream())
+        return out
     _bgemm(NT, N, M, D, A, D, B_, D, out, M, Bt, N * D, M * D, N * M, epi=EPI_CHORD)
     return out
 

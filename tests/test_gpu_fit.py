@@ -36,6 +36,24 @@ def F(hiplib):
     return fit_ops
 
 
+@pytest.mark.parametrize("B,N,D", [(3, 2048, 128), (2, 256, 64), (1, 128, 32)])
+def test_chord_matrix_symmetric_kernel(F, B, N, D):
+    """chord_matrix(X, X) through prifit_chord_sym_f32 (upper triangle of tiles + transposed writes) against the general
+    batched GEMM with the chord epilogue: the same bits."""
+    X = torch.nn.functional.normalize(torch.randn(B, N, D, generator=torch.Generator().manual_seed(5)), dim=2).cuda()
+    old = F.CHORD_SYM
+    try:
+        F.CHORD_SYM = True
+        a = F.chord_matrix(X, X)
+        F.CHORD_SYM = False
+        b = F.chord_matrix(X, X)
+    finally:
+        F.CHORD_SYM = old
+    assert torch.equal(a, b)
+    ref = 2 - 2 * X.double() @ X.double().transpose(1, 2)
+    assert (a.double() - ref).abs().max() < 1e-5
+
+
 def test_kth_smallest_and_bandwidth(F, golden):
     from prifit_amd._lib import call, cur_stream, ptr
     import ctypes
