@@ -17,11 +17,19 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import arena as zero_pool
 from ..nn_ops import (GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
                       ThreeInterpolateFn, _sa_group_launch, sa_group_supported)
 
 
 # ------------------------------------------------------------------ functional surface (:19-107)
+
+def _z(like, *shape):
+    """Zero padding blocks from the step's one pre-zeroed pool (prifit_amd/arena.py) instead of a fill launch each."""
+    if like.is_cuda and like.dtype == torch.float32:
+        return zero_pool.zeros(*shape, device=like.device)
+    return like.new_zeros(*shape)
+
 def square_distance(src, dst):
     """upstream :19-40 -- src [B,N,3], dst [B,M,3] -> [B,N,M] (expanded form, bitwise)."""
     return ops.square_distance(src, dst)
@@ -55,7 +63,7 @@ def _pack_weight(conv, perm_slices, kp):
     parts = [w[:, a:b] for a, b in perm_slices]
     k = sum(b - a for a, b in perm_slices)
     if kp > k:
-        parts.append(w.new_zeros(w.shape[0], kp - k))
+        parts.append(_z(w, w.shape[0], kp - k))
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
@@ -90,12 +98,12 @@ def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first):
         wf, wx = w[:, 3:3 + D], w[:, :3]
     parts = ([feats] if feats is not None else []) + [xyz]
     if kp > D + 3:
-        parts.append(xyz.new_zeros(B, N, kp - D - 3))
+        parts.append(_z(xyz, B, N, kp - D - 3))
     rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
-    w_pt = torch.cat([wf, wx] + ([w.new_zeros(C1, kp - D - 3)] if kp > D + 3 else []), dim=1)
+    w_pt = torch.cat([wf, wx] + ([_z(w, C1, kp - D - 3)] if kp > D + 3 else []), dim=1)
     U = LinearFn.apply(rows, w_pt, None).reshape(B, N, C1)
-    c4 = torch.cat([new_xyz, new_xyz.new_zeros(B, S, 1)], dim=-1).reshape(B * S, 4)
-    Vc = LinearFn.apply(c4, torch.cat([wx, w.new_zeros(C1, 1)], dim=1), None).reshape(B, S, C1)
+    c4 = torch.cat([new_xyz, _z(new_xyz, B, S, 1)], dim=-1).reshape(B * S, 4)
+    Vc = LinearFn.apply(c4, torch.cat([wx, _z(w, C1, 1)], dim=1), None).reshape(B, S, C1)
     return U, Vc
 
 
@@ -243,7 +251,7 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz = torch.zeros(B, 1, 3, device=xyz.device, dtype=xyz.dtype)
             parts = [xyz] + ([feats] if feats is not None else [])  # :154 order [xyz, features]
             if kp > D + 3:
-                parts.append(xyz.new_zeros(B, N, kp - D - 3))
+                parts.append(_z(xyz, B, N, kp - D - 3))
             rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
             w0 = _pack_weight(self.mlp_convs[0], [(0, D + 3)], kp)
         else:
@@ -368,7 +376,7 @@ class PointNetFeaturePropagation(nn.Module):
         if points1 is not None:
             parts.append(points1.reshape(B * N, D1))
         if kp > D1 + D2:
-            parts.append(interp.new_zeros(B * N, kp - D1 - D2))
+            parts.append(_z(interp, B * N, kp - D1 - D2))
         rows = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
         if len(self.mlp_convs) == 0:
             return rows[:, :D1 + D2].reshape(B, N, -1)
