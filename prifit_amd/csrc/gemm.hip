@@ -15,6 +15,8 @@
 // Block ids are remapped so that the N-tiles of one M-panel run on the same XCD (shared L2).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -886,6 +888,110 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-K form of the 128 x 128 kernel for the weight gradients dW[M, N] (+)= dY[P, M]^T relu(bn(A[P, N])) (TN: both
+// operands stream from HBM over the reduction index -- 32 KB per workgroup and k-tile, 4.6 TB/s at the full matrix
+// rate).  The general kernel keeps ONE k-tile in flight per workgroup and moved ~3 TB/s on these products whatever the
+// split; this one keeps TWO (a second register set: it has nothing but the k-loop and the atomic epilogue, 100 VGPRs).
+template <bool FB>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tnsk_kernel(const GemmArgs g)
+{
+    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr int SZA = BK * (BM + PAD), SZB = BK * (BN + PAD);
+    __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];  // two stages
+    const int tilesN = (g.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tilesN, tile_n = blockIdx.x - tile_m * tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int ktiles = (g.K + BK - 1) / BK;
+    const int per = (ktiles + g.splitk - 1) / g.splitk;
+    const int kt0 = blockIdx.z * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;   // block-uniform
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+
+    BufLoader<BM, false, false, NTH> la[2];
+    BufLoader<BN, false, FB, NTH> lb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { la[i].init(g.A, g.lda, m0, g.M, g.K); lb[i].init(g.B, g.ldb, n0, g.N, g.K); }
+    // tile kt0 -> LDS stage 0; tile kt0 + 1 -> register set 1 (in flight)
+    la[0].load(kt0 * BK); lb[0].load(kt0 * BK);
+    if (kt0 + 1 < kt1) { la[1].load((kt0 + 1) * BK); lb[1].load((kt0 + 1) * BK); }
+    lb[0].finish(g.b_scale, g.b_shift);
+    la[0].store(lds); lb[0].store(lds + SZA);
+    __syncthreads();
+    f32x16 acc[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    // iteration i (tile kt = kt0 + i): LDS stage i & 1 is multiplied, register set i & 1 receives tile kt + 2, register
+    // set (i + 1) & 1 (tile kt + 1, requested one iteration ago) is staged into the other LDS stage
+    auto step = [&](int kt, auto par) {
+        constexpr int S = decltype(par)::value;
+        const float *As = lds + S * (SZA + SZB), *Bs = As + SZA;
+        if (kt + 2 < kt1) { la[S].load((kt + 2) * BK); lb[S].load((kt + 2) * BK); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gk = 0; gk < BK / 8; ++gk) {
+            const float4 fa = read_frag<BM, false>(As, wm0 + li, gk, lh);
+            float4 fb[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, false>(Bs, wn0 + 32 * b + li, gk, lh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < kt1) {
+            float *An = lds + (S ^ 1) * (SZA + SZB);
+            lb[S ^ 1].finish(g.b_scale, g.b_shift);
+            la[S ^ 1].store(An); lb[S ^ 1].store(An + SZA);
+        }
+        __syncthreads();
+    };
+    int kt = kt0;
+    for (; kt + 1 < kt1; kt += 2) {
+        step(kt, std::integral_constant<int, 0>());
+        step(kt + 1, std::integral_constant<int, 1>());
+    }
+    if (kt < kt1) step(kt, std::integral_constant<int, 0>());
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int rbase = m0 + wm0 + 4 * lh;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn0 + 32 * b + li;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row >= g.M) continue;
+            float *dst = g.C + (long long)row * g.ldc + col;
+            if (g.splitk > 1) unsafeAtomicAdd(dst, acc[b][r]);
+            else if (g.accumulate) *dst += acc[b][r];
+            else *dst = acc[b][r];
+        }
+    }
+}
+
+// the split-K kernel's cases: TN, one batch item, no epilogue / statistics / bias / A prologue, 16-byte rows, spans < 2 GiB
+static bool launch_tnsk(const GemmArgs &g, hipStream_t st)
+{
+    static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_TNSK"); return !(e && e[0] == '0'); }();  // A/B switch
+    if (!on || g.batch != 1 || g.a_scale || g.bias || g.stats || g.epi != EPI_NONE || g.a_rowsum || g.kswitch ||
+        !(g.vecA && g.vecB) || (g.M & 3) || (g.N & 3) || (g.splitk > 1 && !g.accumulate) || g.splitk > 65535)
+        return false;
+    const long long lim = 0x7ff00000LL;
+    if ((long long)g.K * g.lda * 4 >= lim || (long long)g.K * g.ldb * 4 >= lim) return false;
+    const dim3 grid(((g.M + 127) / 128) * ((g.N + 127) / 128), 1, g.splitk), block(512);
+    if (g.b_scale) hipLaunchKernelGGL((gemm_tnsk_kernel<true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_tnsk_kernel<false>), grid, block, 0, st, g);
+    return true;
+}
+
 static bool g_persistent_enabled()
 {
     static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();  // A/B switch
@@ -1084,6 +1190,7 @@ static int dispatch(GemmArgs &g, int layout, void *stream)
     if (N <= 64) return launch_cfg<128, 64, 32, 64>(g, layout, st);
     if (N <= 96) return launch_cfg<128, 96, 32, 96>(g, layout, st);
     if (launch_persistent(g, layout, st)) return prifit_check_launch();
+    if (layout == LAY_TN && launch_tnsk(g, st)) return prifit_check_launch();
     return launch_cfg<128, 128, 32, 64>(g, layout, st);  // 8 waves of 32x64: more waves per SIMD hide the staging waits
 }
 
