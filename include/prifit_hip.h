@@ -145,6 +145,16 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
 int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
                          int n, int K, int batch, void *stream);
 
+/* Forward of a max-pooled last layer on the tiled (persistent 128 x 128) kernel, as prifit_gemm_stream_pool_f32 does on
+ * the streaming shapes (models/pointnet_util.py:252-257): Y = relu(bn(A)) W^T + bias with the column statistics AND the
+ * pool candidates cand[M / 32][4][N] (max, argmax, min, argmin per 32 rows and column) for
+ * prifit_pool_from_candidates.  prifit_gemm_pool_supported(M, N, K): 1 when the shape is taken (M % 32 == 0, N > 96, more
+ * than 512 output tiles, 16-byte rows). */
+int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, const float *W, long long ldb, float *Y,
+                         long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
+                         float *cand, void *stream);
+int prifit_gemm_pool_supported(int M, int N, int K);
+
 /* Weights-stationary streaming variant for the tall-and-skinny (HBM-bound) layers of the shared MLPs: layout
  * PRIFIT_GEMM_NT (C = A B^T, B [N,K]) or PRIFIT_GEMM_NN (C = A B, B [K,N]) with M >= 32768, N in {64,96,128},
  * K in {64,96,128}; A [M,K] with lda % 4 == 0.  Persistent workgroups keep B in registers and stream 64-row tiles

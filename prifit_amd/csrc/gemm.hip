@@ -54,6 +54,7 @@ struct GemmArgs {
     int accumulate;                  // 1: C += result (atomics when split-K); 0: store
     int vecA, vecB;                  // 16-byte loads legal for the operand
     int ntiles;                      // gemm_pers_kernel: output tiles, walked with a grid stride
+    float *cand;                     // gemm_pers_kernel<.., PMAX>: [M / 32][4][N] pool candidates
 };
 
 #ifndef GEMM_W8
@@ -650,7 +651,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
 // All addressing is buffer addressing: rows / columns beyond the operands read as zeros and stores beyond C are dropped
 // by the bounds check, the k-tile and the accumulator row are scalar offsets -- ragged extents (K = 196, N = 196) cost a
 // compare per load in the last k-tile only, and the epilogue needs two address registers instead of sixty-four.
-template <int LAY, bool FA, bool RED>
+// PMAX (forward of a max-pooled last layer): per 32-row block and column, the largest and the smallest stored C and the
+// row (0..31) of their first occurrence: cand[M / 32][4][N] = (max, argmax, min, argmin; indices as int bits), read by
+// prifit_pool_from_candidates instead of C (as the streaming kernel does, csrc/gemm_stream.hip).
+template <int LAY, bool FA, bool RED, bool PMAX = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_pers_kernel(const GemmArgs g)
 {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
@@ -755,11 +759,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                                  : __builtin_amdgcn_raw_buffer_load_b32(yrs, cok ? y_voff + ro : y_voff, 0, 0));
                 }
             }
+            float vmax = -INFINITY, vmin = INFINITY;
+            int imax = 0, imin = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 const float v = acc[b][r] + bias;
                 const float vs = (cok && (full_rows || row < g.M)) ? v : 0.f;
+                if (PMAX) {  // rows ascend with r inside a lane: strict comparisons keep the first occurrence
+                    const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const bool rok = full_rows || row < g.M;
+                    if (rok && v > vmax) { vmax = v; imax = ri; }
+                    if (rok && v < vmin) { vmin = v; imin = ri; }
+                }
                 if (RED) {
                     const float gm = fmaf(kf[r], rs, rt) > 0.f ? vs : 0.f;
                     csum[b] += gm;
@@ -771,6 +783,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const int ro = ((r & 3) + 8 * (r >> 2)) * ldc4;
                 if (full_rows) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, ro, 0);
                 else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, cok ? c_voff + ro : c_voff, 0, 0);
+            }
+            if (PMAX) {
+                // the other half of the block's rows lives in lane ^ 32; ties go to the lower row
+                const float ov = __shfl_xor(vmax, 32, 64), on = __shfl_xor(vmin, 32, 64);
+                const int oi = __shfl_xor(imax, 32, 64), oj = __shfl_xor(imin, 32, 64);
+                if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }
+                if (on < vmin || (on == vmin && oj < imin)) { vmin = on; imin = oj; }
+                const int blk_row = m0 + wm0;
+                if (lh == 0 && cok && blk_row < g.M) {
+                    float *cd = g.cand + (long long)(blk_row >> 5) * 4 * g.N + col;
+                    cd[0] = vmax; cd[g.N] = __int_as_float(imax); cd[2 * g.N] = vmin; cd[3 * g.N] = __int_as_float(imin);
+                }
             }
         }
         if (g.stats) {
@@ -1000,7 +1024,7 @@ static bool g_persistent_enabled()
 
 // the persistent kernel's cases: NT / NN, one z slice, plain store, (bias + statistics) or EPI_BNRED, 16-byte rows,
 // 32-bit byte offsets everywhere, more tiles than resident workgroups
-static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st)
+static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st, float *want_cand = nullptr, bool dry = false)
 {
     GemmArgs g = g_;
     if (!g_persistent_enabled() || lay == LAY_TN || g.batch != 1 || g.splitk != 1 || g.accumulate || g.a_rowsum || g.kswitch ||
@@ -1013,12 +1037,18 @@ static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st)
     g.ntiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int slots = 512;   // two 8-wave workgroups per CU (73 KB of LDS, <= 128 VGPRs)
     if (g.ntiles <= slots) return false;
+    if (dry) return lay == LAY_NT && g.epi == EPI_NONE && g.a_scale;   // (prifit_gemm_pool_supported)
     const dim3 grid(slots), block(512);
     if (lay == LAY_NT) {
         if (g.epi != EPI_NONE) return false;
-        if (g.a_scale) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false>), grid, block, 0, st, g);
+        if (want_cand) {
+            if (!g.a_scale) return false;
+            g.cand = want_cand;
+            hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false, true>), grid, block, 0, st, g);
+        } else if (g.a_scale) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, false, false>), grid, block, 0, st, g);
     } else {
+        if (want_cand) return false;
         if (g.a_scale) return false;
         if (g.epi == EPI_BNRED) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NN, false, true>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NN, false, false>), grid, block, 0, st, g);
@@ -1308,6 +1338,42 @@ int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float
     const int T = n / 128;
     hipLaunchKernelGGL(chord_sym_kernel, dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0, as_stream(stream), A, lda, strideA, C, ldc,
                        strideC, n, K);
+    return prifit_check_launch();
+}
+
+static void pool_gemm_args(GemmArgs &g, int M, int N, int K, const float *A, long long lda, const float *W, long long ldb,
+                           float *Y, long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *stats)
+{
+    g.A = A; g.B = W; g.C = Y; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA = g.sB = g.sC = 0; g.batch = 1; g.splitk = 1;
+    g.a_scale = a_scale; g.a_shift = a_shift; g.b_scale = g.b_shift = nullptr;
+    g.bias = bias; g.bias_stride = 0; g.stats = stats; g.epi = EPI_NONE; g.epi_batch_scalar = nullptr;
+    g.aux = nullptr; g.row_add = nullptr; g.a_rowsum = nullptr; g.ldaux = 0; g.sAux = 0;
+    g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr;
+    g.dA2 = g.dB2 = 0; g.kswitch = 0; g.accumulate = 0;
+    g.vecA = aligned16(A) && (lda % 4 == 0) && (K % 4 == 0);
+    g.vecB = aligned16(W) && (ldb % 4 == 0) && (K % 4 == 0);
+}
+
+/* 1 when prifit_gemm_pool_f32 takes this shape (the persistent 128 x 128 kernel: more tiles than resident workgroups) */
+int prifit_gemm_pool_supported(int M, int N, int K)
+{
+    if (M <= 0 || N <= 96 || K <= 0 || (M & 31)) return 0;
+    GemmArgs g;
+    static float dummy[4] __attribute__((aligned(16)));
+    pool_gemm_args(g, M, N, K, dummy, K, dummy, K, dummy, N, dummy, dummy, nullptr, nullptr);
+    return launch_persistent(g, LAY_NT, nullptr, nullptr, true) ? 1 : 0;
+}
+
+int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, const float *W, long long ldb, float *Y,
+                         long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
+                         float *cand, void *stream)
+{
+    if (!A || !W || !Y || !a_scale || !a_shift || !cand || !prifit_gemm_pool_supported(M, N, K) || lda < K || ldb < K || ldc < N)
+        return PRIFIT_EINVAL;
+    GemmArgs g;
+    pool_gemm_args(g, M, N, K, A, lda, W, ldb, Y, ldc, a_scale, a_shift, bias, col_stats);
+    if (!launch_persistent(g, LAY_NT, as_stream(stream), cand)) return PRIFIT_EINVAL;
     return prifit_check_launch();
 }
 

@@ -171,6 +171,13 @@ class SharedMLPFn(torch.autograd.Function):
                     with profiler.span(profiler.tag("gemm_stream_nt", P, Cout, Kin, 1), 4.0 * (P * Kin + P * Cout + Cout * Kin)):
                         call("prifit_gemm_stream_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin),
                              ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), cur_stream())
+                elif (l == L - 1 and cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and _FUSE_POOL_FWD and aligned and
+                        prev_aff is not None and not _stream_ok(NT, P, Cout, Kin) and dll().prifit_gemm_pool_supported(P, Cout, Kin)):
+                    # the same on the tiled (persistent) kernel: SA2's 256-wide last layers
+                    cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
+                    with profiler.span(profiler.tag("gemm_nt_bn128", P, Cout, Kin, "pool"), 2.0 * P * Cout * Kin):
+                        call("prifit_gemm_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin), ptr(Y),
+                             _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), cur_stream())
                 else:
                     gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
                 call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
