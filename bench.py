@@ -370,8 +370,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 10 warm-up steps bring the clocks and the caching allocator to steady state (with 3 the first timed
-    # steps still run ~10 % slow); 50 timed steps = ~2 s
-    ap.add_argument("--steps", type=int, default=50)
+    # steps still run ~10 % slow); 200 timed steps = ~5 s of GPU work (a sampled GPU-busy monitor sees it beside the ~15 s
+    # CPU-baseline leg; 50 steps measure the same rate to 0.3 %)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("PRIFIT_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
