@@ -179,6 +179,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     const float *Xb = X + (size_t)b * N * D;
     const float bwv = bw[b];
     const float rcp_b2 = 1.0f / (bwv * bwv);
+    const float c_e2 = rcp_b2 * 1.44269504088896341f;   // log2(e) / b^2
     const float kmin = __expf(-13.0f);
 
     const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(Qb, (long long)N * D * 4), x_rs = make_rsrc(Xb, (long long)N * D * 4);
@@ -284,11 +285,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             const bool ok = FAST || (key < N && q_ok);
             float p;
             if (MODE == 0) {
-                // src/mean_shift.py:65-68 with src/guard.py:6-11
-                const float dist = 2.0f - 2.0f * sacc[r];
-                float e = (-dist * rcp_b2) * 0.5f;
-                e = fminf(fmaxf(e, -13.0f), 75.0f);
-                p = ok ? __expf(e) : 0.f;
+                // src/mean_shift.py:65-68 with src/guard.py:6-11: K = exp(clamp(-(2 - 2 s) / b^2 / 2, -13, 75)), evaluated as
+                // exp2(clamp((s - 1) * log2(e) / b^2, -13 log2(e), 75 log2(e))): one fma, one med3, one v_exp_f32 per element
+                // instead of seven VALU instructions -- on this chip every VALU instruction of an fp32-MFMA loop costs its
+                // four issue cycles in full (tools/micro/mfma_shape_clock.hip: the matrix and the vector pipe do not overlap)
+                const float t = fminf(fmaxf(fmaf(sacc[r], c_e2, -c_e2), -13.0f * 1.44269504088896341f), 75.0f * 1.44269504088896341f);
+                p = ok ? __builtin_amdgcn_exp2f(t) : 0.f;
                 rsum += p;
                 pprev[r] = p;
             } else {
