@@ -74,7 +74,6 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     static_assert(NV * 256 * 4 == SBM * K, "tile divides evenly");
     __shared__ __attribute__((aligned(16))) float s_a[2][SBM * LD];
     __shared__ __attribute__((aligned(16))) float s_aff[2][K];   // POOL: [0] = b
-    __shared__ __attribute__((aligned(16))) float s_pool[2][2][POOL ? K : 4];  // [stage][arg | T][channel]
     __shared__ float s_red[WM][2][32 * WN];
     __shared__ __attribute__((aligned(16))) float s_bna[BNA ? 5 : 1][BNA ? K : 4];   // s, t, a, b, d
 
@@ -115,7 +114,8 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     const int tiles = (g.M + SBM - 1) / SBM;
     float4 st[NV];
     float4 stg[BNA ? NV : 1];   // BNA: the gradient tile beside the pre-activation tile
-    float st_pool = 0.f;
+    int4 st_arg = make_int4(0, 0, 0, 0);
+    float4 st_T = make_float4(0.f, 0.f, 0.f, 0.f);
     // Addressing: one buffer resource per tile (base = the tile's first row, exact extent: rows beyond M read as zeros and
     // stores to them are dropped by the bounds check); a thread's part of an address is a loop-invariant VGPR, the rest
     // is scalar -- no 64-bit VALU address chain per access (the launcher checks SBM * ld * 4 < 2^31).
@@ -126,11 +126,9 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
         const int row = id / (K / 4), c4 = id - row * (K / 4);
         aoff[p] = (row * (int)g.lda + 4 * c4) * 4;
     }
-    const float *pool_src = nullptr;
-    if (POOL) {
-        const int which = (threadIdx.x / K) & 1, k = threadIdx.x % K;
-        pool_src = (which ? g.pool_T : reinterpret_cast<const float *>(g.pool_arg)) + k;
-    }
+    // POOL: the (arg, T) entries of a thread's four channels (the same four for all its NV rows of a tile: K / 4 divides 256)
+    static_assert(!POOL || (256 % (K / 4)) == 0, "POOL: one channel group per thread");
+    const int pool_c4 = threadIdx.x % (K / 4);
     auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
         const int rows = g.M - m0 < SBM ? g.M - m0 : SBM;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0,
@@ -138,11 +136,14 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     };
     auto load_tile = [&](int tile) {
         const int m0 = tile * SBM;
-        // the (arg, T) rows of this tile's pooling group: 2 x K values, ONE dword per thread, loaded by every thread (no
-        // branch).  (As a float4 of the first 2 * K / 4 threads the value was copied to other registers right after the
-        // load -- a split live range, or the join of the branch -- and that copy waited for the load and, vmcnt being one
-        // in-order counter, for all of the previous tile's stores: a full memory round trip per tile.)
-        if (POOL) st_pool = pool_src[(long long)(m0 / g.pool_K) * K];
+        // the (arg, T) entries of this tile's pooling group for the thread's four channels, loaded by every thread (no
+        // branch) and used when the tile is staged: the operand is formed ONCE per element there instead of once per
+        // fragment read (every element is read by all WN waves; on this chip VALU instructions cost matrix time one for one)
+        if (POOL) {
+            const long long po = (long long)(m0 / g.pool_K) * K + 4 * pool_c4;
+            st_arg = *reinterpret_cast<const int4 *>(g.pool_arg + po);
+            st_T = ld4(g.pool_T + po);
+        }
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g.A, g.lda, m0, K);
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     };
     auto store_tile = [&](int tile, float *dst, int stage) {
         const int m0 = tile * SBM;
-        if (POOL && threadIdx.x < 2 * K) s_pool[stage][threadIdx.x / K][threadIdx.x % K] = st_pool;
         const bool full = m0 + SBM <= g.M;   // block-uniform: only the tail tile pays for the row checks
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -173,6 +173,15 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
                 x.x = fmaxf(fmaf(x.x, s.x, t.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, t.y), 0.f);
                 x.z = fmaxf(fmaf(x.z, s.z, t.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, t.w), 0.f);
                 if (!full && m0 + row >= g.M) x = make_float4(0.f, 0.f, 0.f, 0.f);   // (without AFF the load returned zeros)
+            }
+            if (POOL) {   // dY = b * Y + one-hot * T (d is folded into the bias by the caller); a pooling group is a whole number of tiles
+                const float4 b4 = *reinterpret_cast<const float4 *>(&s_aff[0][4 * c4]);
+                const int kr = m0 % g.pool_K + row;   // sample index of this row in its group
+                x.x = fmaf(b4.x, x.x, st_arg.x == kr ? st_T.x : 0.f);
+                x.y = fmaf(b4.y, x.y, st_arg.y == kr ? st_T.y : 0.f);
+                x.z = fmaf(b4.z, x.z, st_arg.z == kr ? st_T.z : 0.f);
+                x.w = fmaf(b4.w, x.w, st_arg.w == kr ? st_T.w : 0.f);
+                if (!full && m0 + row >= g.M) x = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (BNA) {   // bn_relu_bwd_apply's expression, term by term
                 const float4 cs = *reinterpret_cast<const float4 *>(&s_bna[0][4 * c4]);
@@ -237,20 +246,6 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
             float4 fa[TM];
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LD + 8 * q);
-            if (POOL) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(&s_aff[0][8 * q + 4 * lh]);
-                const int4 w4 = *reinterpret_cast<const int4 *>(&s_pool[it & 1][0][8 * q + 4 * lh]);
-                const float4 t4 = *reinterpret_cast<const float4 *>(&s_pool[it & 1][1][8 * q + 4 * lh]);
-                const int kr0 = (tile * SBM) % g.pool_K + wm * 32 * TM + li;  // sample index of this lane's row in its group
-#pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const int kr = kr0 + 32 * a;
-                    fa[a].x = fmaf(b4.x, fa[a].x, w4.x == kr ? t4.x : 0.f);
-                    fa[a].y = fmaf(b4.y, fa[a].y, w4.y == kr ? t4.y : 0.f);
-                    fa[a].z = fmaf(b4.z, fa[a].z, w4.z == kr ? t4.z : 0.f);
-                    fa[a].w = fmaf(b4.w, fa[a].w, w4.w == kr ? t4.w : 0.f);
-                }
-            }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
@@ -640,8 +635,13 @@ void launch_aff(const StreamArgs &g_, int nslab, hipStream_t st)
     const int occ = KG <= 8 ? (heavy ? 3 : 4) : (KG <= 12 ? (heavy ? 2 : 3) : 2);
     const int grid = nslab < 256 * occ ? nslab : 256 * occ;
     if (!BKC && g.bna_G && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
-    else if (!BKC && g.pool_arg && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
-    else if (!BKC && g.pool_arg) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && g.pool_arg) {
+        // (K = 96 pooled layers do not exist: a thread's rows of a tile would not share their four channels; launch_k refuses them)
+        if constexpr (256 % (2 * KG) == 0) {
+            if (g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
+        }
+    }
     else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
     else if (BKC && g.cand && g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, true, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
     else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false, false, false>), dim3(grid), dim3(256), 0, st, g);
@@ -653,7 +653,10 @@ int launch_k(const StreamArgs &g, int grid, hipStream_t st)
 {
     switch (g.K) {
         case 64: launch_aff<WN, 8, BKC>(g, grid, st); break;
-        case 96: launch_aff<WN, 12, BKC>(g, grid, st); break;
+        case 96:
+            if (g.pool_arg) return PRIFIT_EINVAL;
+            launch_aff<WN, 12, BKC>(g, grid, st);
+            break;
         case 128: launch_aff<WN, 16, BKC>(g, grid, st); break;
         default: return PRIFIT_EINVAL;
     }

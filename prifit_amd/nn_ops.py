@@ -254,7 +254,7 @@ class SharedMLPFn(torch.autograd.Function):
             pooled = (l == L - 1) and cfg["pool_K"]
             # the pooled last layer: dY = T*[k == arg] + b*Y + d is formed inside the streaming dA / dW kernels from Y
             # itself (no pool_bwd_apply pass writing dY, no reads of it) when both consumers are streaming shapes
-            fuse_pool = bool(pooled and _FUSE_POOL and training and l > 0 and W is not None and cfg["pool_K"] % 64 == 0 and
+            fuse_pool = bool(pooled and _FUSE_POOL and training and l > 0 and W is not None and cfg["pool_K"] % 64 == 0 and Cout != 96 and
                              ctx.needs_input_grad[2 + 6 * l] and _stream_ok(NN, P, Kin, Cout) and
                              dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
             direct0 = l == 0 and ctx.preact_direct is not None
