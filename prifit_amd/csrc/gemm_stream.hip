@@ -498,12 +498,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_stream_tn_kernel(const StreamTN
 #pragma unroll
             for (int a = 0; a < AM; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xg[a][j] = fmaf(pb[a], xg[a][j], pd[a]) + (xw[a] == kb + j ? xt[a] : 0.f);
+                for (int j = 0; j < 4; ++j) xg[a][j] = fmaf(pb[a], xg[a][j], pd[a]) + (xw[a] == kb + j ? xt[a] : 0.f);   // (pool_bwd_apply's order of additions)
         }
+        if (!live) {   // (a scalar branch: nothing of it in the steady state -- VALU instructions cost matrix time here)
 #pragma unroll
-        for (int a = 0; a < AM; ++a)
+            for (int a = 0; a < AM; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xg[a][j] = live ? xg[a][j] : 0.f;
+                for (int j = 0; j < 4; ++j) xg[a][j] = 0.f;
+        }
         if (AFF) {
 #pragma unroll
             for (int b = 0; b < AN; ++b)
