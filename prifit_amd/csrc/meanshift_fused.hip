@@ -63,6 +63,15 @@ struct Tile64T {
             v[p] = make_float4(t.x, t.y, t.z, t.w);
         }
     }
+    template <bool EXACT>
+    __device__ __forceinline__ void load_one(int p, __amdgpu_buffer_rsrc_t rs, int voff, int row0, int nrows)
+    {
+        const int row = row0 + RP * p;
+        const f32x4 t = __builtin_bit_cast(f32x4, EXACT
+            ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff, row * D * 4, 0)
+            : __builtin_amdgcn_raw_buffer_load_b128(rs, row + (int)(threadIdx.x >> 5) < nrows ? voff + row * D * 4 : OOB, 0, 0));
+        v[p] = make_float4(t.x, t.y, t.z, t.w);
+    }
     __device__ __forceinline__ void store(float *__restrict__ lds) const
     {
 #pragma unroll
@@ -73,6 +82,21 @@ struct Tile64T {
     }
 };
 typedef Tile64T<256> Tile64;
+
+// DIAGNOSIS build (PRIFIT_BUILD_DEFS=-DMSF_STAMPS, tools/msf_stamps.py): wave 0 of a few workgroups of the standard forward
+// kernel leaves s_memtime stamps at the phase boundaries of its first key steps.  No stamp executes in the product build.
+#ifdef MSF_STAMPS
+__device__ unsigned long long g_msf_stamps[8 * 16 * 8];   // [workgroup slot][step][phase]
+#define MSF_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (st_slot >= 0 && st_step < 16) {                                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+            if (threadIdx.x == 0) g_msf_stamps[(st_slot * 16 + st_step) * 8 + (i)] = t_;                    \
+        }                                                                                                    \
+    } while (0)
+#else
+#define MSF_STAMP(i) do { } while (0)
+#endif
 
 // the key tile of a step: ROWS = 64 or 128 rows loaded by NTH threads (one or two 64-row passes)
 template <int NTH, int ROWS>
@@ -175,6 +199,13 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         kbeg = 0; kend = N;
     }
     const bool whole = !SK || (kend - kbeg >= N);
+#ifdef MSF_STAMPS
+    int st_slot = -1, st_step = 0;
+    if (MODE == 0 && !SK && NW == 4 && NQG == 2 && threadIdx.x < 64) {
+        const int Lb = blockIdx.y * gridDim.x + blockIdx.x;
+        st_slot = (Lb == 3) ? 0 : (Lb == 130) ? 1 : (Lb == 301) ? 2 : (Lb == 470) ? 3 : (Lb == 515) ? 4 : (Lb == 600) ? 5 : (Lb == 700) ? 6 : (Lb == 767) ? 7 : -1;
+    }
+#endif
     const float *Qb = Q + (size_t)b * q_stride;
     const float *Xb = X + (size_t)b * N * D;
     const float bwv = bw[b];
@@ -236,18 +267,29 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += KB) {
+        MSF_STAMP(0);
         __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
+        MSF_STAMP(1);
         t.store(s_x);
+        MSF_STAMP(2);
         __syncthreads();
+        MSF_STAMP(3);
         const int kb_bytes = __builtin_amdgcn_readfirstlane(k0 * ldk4);          // this step's key block
-        if ((MODE == 0 ? KTb : GSb) && k0 > kbeg) {   // the previous step's stream values (K^T / gS^T)
+        // MODE 0 (standard form): the step's 24 vector-memory instructions -- 8 loads of the next tile, 16 stores of the
+        // previous step's K^T values -- are issued one per group of four S MFMAs below instead of in a block here: their
+        // issue (~40 cycles each, in-kernel stamps: 970-1290 cycles per step with the matrix pipe idle) then runs beside
+        // the matrix instructions.
+        constexpr bool SPREAD = MODE == 0 && NW == 4 && NQG == 2;
+        const bool st_prev = SPREAD && KTb && k0 > kbeg, ld_next = SPREAD && k0 + KB < kend;
+        const int pb_bytes_s = __builtin_amdgcn_readfirstlane((k0 - KB) * ldk4);
+        if (!SPREAD && (MODE == 0 ? KTb : GSb) && k0 > kbeg) {   // the previous step's stream values (K^T / gS^T)
             const int pb_bytes = __builtin_amdgcn_readfirstlane((k0 - KB) * ldk4);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[r]), MODE == 0 ? kt_rs : gs_rs,
                                                       st_voff(k0 - KB, r), st_soff(pb_bytes, r), MODE == 0 ? 2 : 0);
         }
-        if (k0 + KB < kend) t.template load<FAST>(x_rs, t_voff, k0 + KB, N);
+        if (!SPREAD && k0 + KB < kend) t.template load<FAST>(x_rs, t_voff, k0 + KB, N);
 
         // MODE 1: the saved kernel values under this wave's sub-tile, requested before the S MFMAs so that their
         // latency hides behind the 64 matrix instructions (they were the exposed part of this mode)
@@ -260,6 +302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             // (fewer live registers), and every step then waits out the full memory latency
             __builtin_amdgcn_sched_barrier(0);
         }
+        MSF_STAMP(4);
         // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
         const float *xa = s_x + (kh * 32 + li) * LDSW + lh * 4;
         const float *qb = s_q + qrow * LDSW + lh * 4;
@@ -274,9 +317,19 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, sacc, 0, 0, 0);
+            if (SPREAD) {
+                if (ld_next && g < 8) t.t[0].template load_one<FAST>(g, x_rs, t_voff, k0 + KB, N);
+                if (st_prev)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[g]), kt_rs, st_voff(k0 - KB, g),
+                                                          st_soff(pb_bytes_s, g), 2);
+            }
         }
         // (MODE 1: nothing of the transform -- e.g. the compares on the just-requested K values -- may move above the S MFMAs)
         if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
+#ifdef MSF_STAMPS
+        asm volatile("" ::"v"(sacc[15]));   // the S product is complete in the register file before the stamp
+#endif
+        MSF_STAMP(5);
         // ---- elementwise transform; accumulator register r of lane (query li, half lh) is key (r&3)+8(r>>2)+4lh
         const int key_base = k0 + kh * 32 + 4 * lh;
 #pragma unroll
@@ -300,15 +353,36 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             }
             sacc[r] = p;
         }
+#ifdef MSF_STAMPS
+        asm volatile("" ::"v"(sacc[15]));
+#endif
+        MSF_STAMP(6);
         // ---- O_q += P . X_sub : A = P from the accumulator registers (k = key), B = X_sub[key][d]
         const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + li;
+        // the B operands of key row r + 1 are requested before the four MFMAs of row r (left to itself the compiler reads
+        // each pair right in front of its two MFMAs and waits lgkmcnt(0): an LDS round trip per pair -- in-kernel stamps:
+        // 5200-6400 cycles for these 64 MFMAs, 4096 of them matrix time)
+        float bo[2][4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bo[0][d] = xs[32 * d];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float *row = xs + ((r & 3) + 8 * (r >> 2)) * LDSW;
+            if (r + 1 < 16) {
+                const float *row = xs + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LDSW;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bo[(r + 1) & 1][d] = row[32 * d];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of the MFMAs they do not feed)
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], row[32 * d], oacc[d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1][d], oacc[d], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef MSF_STAMPS
+        asm volatile("" ::"v"(oacc[3][15]));   // the O product is complete
+        MSF_STAMP(7);
+        ++st_step;
+#endif
     }
 
     if (MODE == 0 ? KTb != nullptr : GSb != nullptr) {  // the last step's stream values
@@ -708,6 +782,13 @@ static int sk_slots()
 }
 
 extern "C" {
+
+#ifdef MSF_STAMPS
+int prifit_debug_msf_stamps(unsigned long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_msf_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D_, float *KT,
                                long long ld_kt, long long stride_kt, float *Znext, float *O, float *rowsum,
