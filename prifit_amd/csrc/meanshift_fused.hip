@@ -161,6 +161,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     constexpr int NKH = NW / NQG;        // key sub-tiles per step
     constexpr int KB = 32 * NKH;         // keys per step
     constexpr bool SQ = NQG == 2;        // the query tile lives in LDS
+    constexpr bool ILV = MODE == 0;      // output column of accumulator block d, lane li: 4 li + d instead of 32 d + li
     __shared__ __attribute__((aligned(16))) float s_q[SQ ? QB * LDSW : 4];
     __shared__ __attribute__((aligned(16))) float s_x[KB * LDSW];
     __shared__ float s_rs[NKH * QB];
@@ -358,25 +359,45 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
 #endif
         MSF_STAMP(6);
         // ---- O_q += P . X_sub : A = P from the accumulator registers (k = key), B = X_sub[key][d]
-        const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + li;
-        // the B operands of key row r + 1 are requested before the four MFMAs of row r (left to itself the compiler reads
-        // each pair right in front of its two MFMAs and waits lgkmcnt(0): an LDS round trip per pair -- in-kernel stamps:
-        // 5200-6400 cycles for these 64 MFMAs, 4096 of them matrix time)
-        float bo[2][4];
+        // Output column of accumulator block d, lane li: 4 li + d (NOT 32 d + li): the four B operands of a key row are then
+        // four consecutive floats of the LDS row -- ONE ds_read_b128 per row instead of two ds_read2_b32 (in-kernel stamps:
+        // the S product, fed by ds_read_b128, runs its 64 MFMAs in 4240 cycles, this one, fed by 32 ds_read2_b32, took
+        // 5200-6400) -- and an output row of a lane is one 128-bit store.  The operands of key row r + 1 are requested before
+        // the four MFMAs of row r (left to itself the compiler reads them right in front of their MFMAs with lgkmcnt(0)).
+        // (ILV is the forward only: the dZ mode's split blocks add their accumulators with float atomics, and an atomic
+        // instruction over columns 4 li + d touches four times as many cache lines as one over 32 d + li: 387 -> 408 us)
+        if constexpr (ILV) {
+            const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + 4 * li;
+            float4 bo[2];
+            bo[0] = *reinterpret_cast<const float4 *>(xs);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) bo[0][d] = xs[32 * d];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (r + 1 < 16) {
-                const float *row = xs + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LDSW;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) bo[(r + 1) & 1][d] = row[32 * d];
+            for (int r = 0; r < 16; ++r) {
+                if (r + 1 < 16) bo[(r + 1) & 1] = *reinterpret_cast<const float4 *>(xs + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LDSW);
+                __builtin_amdgcn_sched_barrier(0);   // (the read stays ahead of the MFMAs it does not feed)
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].x, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].y, oacc[1], 0, 0, 0);
+                oacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].z, oacc[2], 0, 0, 0);
+                oacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].w, oacc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of the MFMAs they do not feed)
+        } else {
+            const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + li;
+            float bo[2][4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1][d], oacc[d], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int d = 0; d < 4; ++d) bo[0][d] = xs[32 * d];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r + 1 < 16) {
+                    const float *row = xs + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LDSW;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) bo[(r + 1) & 1][d] = row[32 * d];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (the reads stay ahead of the MFMAs they do not feed)
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1][d], oacc[d], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #ifdef MSF_STAMPS
         asm volatile("" ::"v"(oacc[3][15]));   // the O product is complete
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             const int qr = qg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int gr = q0 + qr;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) unsafeAtomicAdd(O_out + ((size_t)b * N + gr) * D + 32 * d + li, oacc[d][r]);
+            for (int d = 0; d < 4; ++d) unsafeAtomicAdd(O_out + ((size_t)b * N + gr) * D + 4 * li + d, oacc[d][r]);
             if (li == 0) unsafeAtomicAdd(rsum_out + (size_t)b * N + gr, s_rs[qr] + s_rs[QB + qr]);
         }
     } else {
@@ -464,21 +485,20 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         float ss = 0.f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const float z = SQ ? s_q[qr * LDSW + 32 * d + li] : (gr < N ? Zin[((size_t)b * N + gr) * D + 32 * d + li] : 0.f);
+            const float z = SQ ? s_q[qr * LDSW + 4 * li + d] : (gr < N ? Zin[((size_t)b * N + gr) * D + 4 * li + d] : 0.f);
             const float m = oacc[d][r] * dinv - z;
             nv[d] = z + m;
             ss += nv[d] * nv[d];
         }
-        // sum over the 32 lanes of this half (d = 32 per tile x 4 tiles already added locally)
+        // sum over the 32 lanes of this half (the lane's four columns already added locally)
 #pragma unroll
         for (int off = 16; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
         const float nrm = sqrtf(ss);
         if (gr < N) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                outb[(size_t)gr * D + 32 * d + li] = nv[d] / nrm;
-                if (O_out) O_out[((size_t)b * N + gr) * D + 32 * d + li] = oacc[d][r];
-            }
+            *reinterpret_cast<float4 *>(outb + (size_t)gr * D + 4 * li) = make_float4(nv[0] / nrm, nv[1] / nrm, nv[2] / nrm, nv[3] / nrm);
+            if (O_out)
+                *reinterpret_cast<float4 *>(O_out + ((size_t)b * N + gr) * D + 4 * li) =
+                    make_float4(oacc[0][r], oacc[1][r], oacc[2][r], oacc[3][r]);
             if (li == 0) {
                 nrm_out[(size_t)b * N + gr] = nrm;
                 rsum_out[(size_t)b * N + gr] = rs;
