@@ -222,19 +222,30 @@ def run_rank(args):
     fit_kw = dict(chamfer_points=data.get("chamfer"), include_convex_loss=True, quantile=0.05, msc_iterations=10,
                   max_num_clusters=25)
 
+    # Farthest-point sampling of the NEXT batch on a side stream while this step runs (ops.sample_ahead: the samples
+    # depend on the coordinates alone, and the search keeps 24 of 256 CUs busy).  Every step launches the sampling of
+    # one batch -- the synthetic batch is the same every step, its samples are recomputed every step all the same --
+    # and consumes the one launched a step earlier.  PRIFIT_SAMPLE_AHEAD=0: in line, on the step's own stream.
+    ahead_on = args.workload != "c5" and os.environ.get("PRIFIT_SAMPLE_AHEAD", "1") != "0"
+    starts = (data.get("s1"), data.get("s2"))
+    sampled = {"cur": starts, "next": None}
+
     def selfsup_fwd_bwd():
         if args.workload == "c5":
             out = net(data["xyz"], None, **fit_kw)
         else:
-            out = net(data["xyz"], data["cls"], fps_start=(data["s1"], data["s2"]), **fit_kw)
+            out = net(data["xyz"], data["cls"], fps_start=sampled["cur"], **fit_kw)
         loss = out[3].mean()
         loss.backward()
         return loss
 
     def step():
+        if ahead_on:
+            sampled["cur"] = sampled["next"] if sampled["next"] is not None else starts
+            sampled["next"] = net.sample_ahead(data["xyz"], starts)   # the next step's batch
         bucket.zero()
         if args.workload == "c2":
-            seg = net(data["xyz"], data["cls"], fps_start=(data["s1"], data["s2"]))[0]
+            seg = net(data["xyz"], data["cls"], fps_start=sampled["cur"])[0]
             loss = crit(seg.reshape(-1, NUM_PARTS), data["target"].view(-1), None)
             loss.backward()
         elif os.environ.get("PRIFIT_SPECULATE", "1") != "0":
@@ -352,7 +363,9 @@ def run_rank(args):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload],
                        "global_batch": world * B_PER_GPU, "points": NPTS, "parallelism": "dp%d" % world,
-                       "loss": float(loss.item())},
+                       "loss": float(loss.item()),
+                       "fps": ("side stream, one batch ahead (every step launches one batch's sampling and consumes the "
+                               "previous launch)" if ahead_on else "in line")},
             "roofline": roof, "roofline_grouping": grouping, "kernels": detail,
             "speculation_fallbacks": runner.fallbacks,
             "host_enqueue_ms_per_step": 1e3 * t_host,

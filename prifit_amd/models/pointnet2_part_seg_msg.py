@@ -55,6 +55,14 @@ class get_model(nn.Module):
         with batched_bn_counters():
             return self._embed_features(xyz, cls_label, fps_start)
 
+    def sample_ahead(self, xyz, fps_start=None):
+        """The two farthest-point-sampling levels of a batch `xyz` [B,C,N] on a side stream (ops.sample_ahead): call it
+        for the NEXT batch before running the current one and pass the result as that step's `fps_start`."""
+        from .. import ops
+        pts = xyz.permute(0, 2, 1)
+        l0_xyz = (pts[:, :, :3] if self.normal_channel else pts).contiguous()
+        return tuple(ops.sample_ahead(l0_xyz, (self.sa1.npoint, self.sa2.npoint), fps_start))
+
     def _embed_features(self, xyz, cls_label, fps_start=None):
         B, C, N = xyz.shape
         pts = xyz.permute(0, 2, 1).contiguous()           # l0_points (= xyz, also without normals: :69-75)

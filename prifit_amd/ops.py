@@ -13,10 +13,62 @@ from . import arena as zero_pool
 from ._lib import call, cf, cur_stream, ptr, require_cuda
 
 
+class SampledAhead:
+    """Farthest-point samples of one set-abstraction level computed ahead of the step that uses them (`sample_ahead`):
+    pass it where a module takes `fps_start`.  `farthest_point_sample` then only makes the consuming stream wait for the
+    event and hands the stored (indices, coordinates) out -- the same numbers the in-line launch would produce."""
+    __slots__ = ("idx", "new_xyz", "event", "npoint", "keep")
+
+    def __init__(self, idx, new_xyz, event, keep=()):
+        self.idx, self.new_xyz, self.event, self.npoint = idx, new_xyz, event, idx.shape[1]
+        self.keep = keep   # the side stream's inputs: not back to the allocator before the consumer has waited for the event
+
+
+_ahead_streams = {}
+
+
+def sample_ahead(xyz, npoints, starts=None):
+    """The farthest-point-sampling CHAIN of a batch (level l samples npoints[l] of level l - 1's samples; it depends on
+    the coordinates alone) on a side stream, for the NEXT step's batch while the current step runs: the search is a
+    serial loop of `npoint` rounds on one workgroup per shape (24 of 256 CUs busy for 0.32 ms of a 24 ms step), so on
+    the step's own stream the rest of the chip waits for it.  xyz [B,N,3] channels-last; returns one SampledAhead per
+    level.  The side stream first waits for everything already enqueued on the current stream (the batch's producers)."""
+    require_cuda(xyz)
+    dev = xyz.device
+    side = _ahead_streams.get(dev)
+    if side is None:
+        side = _ahead_streams[dev] = torch.cuda.Stream(dev)
+    xyz = cf(xyz)
+    B = xyz.shape[0]
+    starts = list(starts) if starts is not None else [None] * len(npoints)
+    n_in = [xyz.shape[1]] + [int(n) for n in npoints[:-1]]
+    starts = [torch.randint(0, n, (B,), dtype=torch.long, device=dev) if s is None
+              else s.to(device=dev, dtype=torch.int64).contiguous() for s, n in zip(starts, n_in)]
+    # outputs are allocated on the CONSUMING stream's pool: they are freed there, after the wait for the event
+    outs = [(torch.empty(B, int(n), dtype=torch.int64, device=dev), torch.empty(B, int(n), 3, dtype=torch.float32, device=dev))
+            for n in npoints]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        cur = xyz
+        for (idx, nx), st, n in zip(outs, starts, npoints):
+            call("prifit_fps", ptr(cur), B, cur.shape[1], int(n), ptr(st), ptr(idx), ptr(nx), cur_stream())
+            cur = nx
+        ev = torch.cuda.Event()
+        ev.record(side)
+    return [SampledAhead(idx, nx, ev, keep=(xyz, starts)) for idx, nx in outs]
+
+
 def farthest_point_sample(xyz, npoint, start_idx=None, return_xyz=False):
     """models/pointnet_util.py:63-84.  xyz [B,N,3] -> int64 [B,npoint] (bit-exact for a given
-    start_idx; when None a random start is drawn like the reference's torch.randint at :75)."""
+    start_idx; when None a random start is drawn like the reference's torch.randint at :75).
+    `start_idx` may be a SampledAhead (the samples of this level, launched earlier by `sample_ahead`)."""
     require_cuda(xyz)
+    if isinstance(start_idx, SampledAhead):
+        if start_idx.npoint != npoint or start_idx.idx.shape[0] != xyz.shape[0]:
+            raise ValueError("SampledAhead holds %s samples, the module asks for [%d, %d]"
+                             % (tuple(start_idx.idx.shape), xyz.shape[0], npoint))
+        torch.cuda.current_stream(xyz.device).wait_event(start_idx.event)
+        return (start_idx.idx, start_idx.new_xyz) if return_xyz else start_idx.idx
     xyz = cf(xyz)
     B, N, _ = xyz.shape
     if start_idx is None:
