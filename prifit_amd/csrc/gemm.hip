@@ -204,6 +204,7 @@ struct TileLoader {
 // vector arithmetic, no predicates, no selects per k-tile (what the generic loader spends ~10 VALU per float4 on).
 // The matrix (one batch item) must span < 2 GiB.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 template <int ROWS, bool KC, bool AFF, int NTH>
 struct ExactLoader {
     static constexpr int NV = ROWS * BK / 4 / NTH;
@@ -654,14 +655,44 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
 // PMAX (forward of a max-pooled last layer): per 32-row block and column, the largest and the smallest stored C and the
 // row (0..31) of their first occurrence: cand[M / 32][4][N] = (max, argmax, min, argmin; indices as int bits), read by
 // prifit_pool_from_candidates instead of C (as the streaming kernel does, csrc/gemm_stream.hip).
+// DIAGNOSIS build (PRIFIT_BUILD_DEFS=-DPERS_STAMPS, tools/pers_stamps.py): wave 0 of eight workgroups stamps s_memtime at
+// six phase boundaries of its first eight tiles.
+#ifdef PERS_STAMPS
+__device__ unsigned long long g_pers_stamps[8 * 8 * 8];   // [workgroup slot][tile][phase]
+__device__ int g_pers_ktail = 1;                           // A/B inside one process: skip the empty k groups of the last k-tile
+#define PERS_STAMP(i)                                                                                       \
+    do {                                                                                                     \
+        if (st_slot >= 0 && st_tile < 8) {                                                                   \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                      \
+            if (threadIdx.x == 0) g_pers_stamps[(st_slot * 8 + st_tile) * 8 + (i)] = t_;                    \
+        }                                                                                                    \
+    } while (0)
+#else
+#define PERS_STAMP(i) do { } while (0)
+#endif
+
 template <int LAY, bool FA, bool RED, bool PMAX = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_pers_kernel(const GemmArgs g)
 {
+#ifdef PERS_STAMPS
+    const int st_slot = (blockIdx.x % 61 == 0 && blockIdx.x / 61 < 8) ? (int)blockIdx.x / 61 : -1;
+    int st_tile = 0;
+#endif
     constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
     constexpr bool B_KC = (LAY == LAY_NT);
     constexpr int SZA = BM * (BK + PAD);
     constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
     __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];  // two stages
+#ifndef PERS_EPV
+#define PERS_EPV 0
+#endif
+    // A/B build switch (PRIFIT_BUILD_DEFS=-DPERS_EPV=1): C leaves as 128-bit row stores, transposed through LDS, and the
+    // BatchNorm-backward partials are formed in that row layout from 128-bit pieces of Yp.  Stand-alone (tools/pers_stamps.py)
+    // the epilogue drops from ~8 K to ~4 K cycles per tile and the launches gain 3-4 %; inside the training step the same
+    // launches and the step itself are unchanged (same box, alternating builds: 24.21 / 24.12 against 24.09 / 24.16 ms).
+    constexpr bool EPV = PERS_EPV;
+    constexpr int EPLD = WN;             // (32-bit writes go 32 lanes a cycle, 128-bit reads 16: a row of 64 floats is one pass over the banks either way)
+    static_assert(8 * 32 * EPLD + (BM / WM) * 2 * BN <= 2 * (SZA + SZB), "epilogue regions + statistics fit the stages");
 
     const int tilesN = (g.N + BN - 1) / BN;
     const int nwg = g.ntiles;
@@ -676,6 +707,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+#ifdef PERS_STAMPS
+    const int ngk_last = g_pers_ktail ? (g.K - (ktiles - 1) * BK + 7) >> 3 : BK / 8;
+#else
+    const int ngk_last = (g.K - (ktiles - 1) * BK + 7) >> 3;   // 8-wide k groups of the last k-tile that hold data
+#endif
 
     BufLoader<BM, true, FA, NTH> la;
     BufLoader<BN, B_KC, false, NTH> lb;
@@ -692,6 +728,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int ldc4 = (int)g.ldc * 4, ldy4 = RED ? (int)g.ldaux * 4 : 0;
 
     for (;;) {
+        PERS_STAMP(0);
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         const int ntix = tix + (int)gridDim.x;
         const bool has_next = ntix < nwg;
@@ -715,6 +752,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
 #pragma unroll
             for (int gk = 0; gk < BK / 8; ++gk) {
+                if (gk > 0 && !more && gk >= ngk_last) break;   // (scalar) 8-wide k groups beyond K hold zeros: K = 196 has 1 of 4
                 const float4 fa = read_frag<BM, true>(As, wm0 + li, gk, lh);
                 float4 fb[TN];
 #pragma unroll
@@ -733,11 +771,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 la.store(An); lb.store(An + SZA);
             }
             __syncthreads();
+#ifdef PERS_STAMPS
+            if (kt == ktiles - 2) PERS_STAMP(1);   // all but the last k-tile
+#endif
         }
+        PERS_STAMP(2);
 
         // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const bool full_rows = m0 + BM <= g.M;   // block-uniform
         const int rbase = m0 + wm0 + 4 * lh;
+        float *ep = lds + wave * (32 * EPLD);
         float csum[TN], csq[TN];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -746,12 +789,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool cok = col < g.N;
             const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
             float rs = 0.f, rt = 0.f, rmu = 0.f, ris = 0.f;
-            if (RED && cok) { rs = g.red_scale[col]; rt = g.red_shift[col]; rmu = g.red_mean[col]; ris = g.red_invstd[col]; }
+            if (RED && !EPV && cok) { rs = g.red_scale[col]; rt = g.red_shift[col]; rmu = g.red_mean[col]; ris = g.red_invstd[col]; }
             // lane part of the address (the first of this lane's rows, its column); not an existing column: fails the bounds check
             const int c_voff = cok ? (int)(((long long)rbase * g.ldc + col) * 4) : 0x7fffffff;
             const int y_voff = (RED && cok) ? (int)(((long long)rbase * g.ldaux + col) * 4) : 0x7fffffff;
             float kf[16];
-            if (RED) {
+            if (RED && !EPV) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = ((r & 3) + 8 * (r >> 2)) * ldy4;
@@ -773,16 +816,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     if (rok && v < vmin) { vmin = v; imin = ri; }
                 }
                 if (RED) {
-                    const float gm = fmaf(kf[r], rs, rt) > 0.f ? vs : 0.f;
-                    csum[b] += gm;
-                    csq[b] += gm * ((kf[r] - rmu) * ris);
+                    if (!EPV) {
+                        const float gm = fmaf(kf[r], rs, rt) > 0.f ? vs : 0.f;
+                        csum[b] += gm;
+                        csq[b] += gm * ((kf[r] - rmu) * ris);
+                    }
                 } else {
                     csum[b] += vs;
                     csq[b] += vs * vs;
                 }
-                const int ro = ((r & 3) + 8 * (r >> 2)) * ldc4;
-                if (full_rows) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, ro, 0);
-                else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, cok ? c_voff + ro : c_voff, 0, 0);
+                if (EPV) {
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPLD + 32 * b + li] = v;
+                } else {
+                    const int ro = ((r & 3) + 8 * (r >> 2)) * ldc4;
+                    if (full_rows) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, ro, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, cok ? c_voff + ro : c_voff, 0, 0);
+                }
             }
             if (PMAX) {
                 // the other half of the block's rows lives in lane ^ 32; ties go to the lower row
@@ -797,15 +846,73 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
-        if (g.stats) {
-            float *red = lds;   // both stages are dead: everybody passed the barrier that ended the k-loop
+        if (EPV) {
+            // the wave's 32 x 64 block of C, transposed through its own LDS region: rows as 128-bit stores (the vector-memory
+            // path takes a wave instruction four lanes a cycle whatever their width: 8 instead of 32 per wave and tile)
+            const int c4 = (lane & 15) * 4, gcol = n0 + wn0 + c4;
+            const bool cok4 = gcol < g.N;
+            float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f), cq4 = cs4;
+            float4 rs4 = cs4, rt4 = cs4, rmu4 = cs4, ris4 = cs4;
+            f32x4v yv[8];
+            if (RED) {
+                // BatchNorm-backward partials of the layer below, in the row layout: its pre-activations Yp arrive as the same
+                // 128-bit row pieces, requested now that the accumulators are in LDS (their registers are free) and in
+                // flight under the stores of C (rows beyond M / columns beyond N: zeros, and so is C there)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
-                const float q = csq[b] + __shfl_xor(csq[b], 32, 64);
-                if (lh == 0) {
-                    red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
-                    red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
+                for (int i = 0; i < 8; ++i) {
+                    const int vo = cok4 ? ((m0 + wm0 + 4 * i + (lane >> 4)) * (int)g.ldaux + gcol) * 4 : 0x7fffffff;
+                    yv[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(yrs, vo, 0, 0));
+                }
+                if (cok4) { rs4 = ld4(g.red_scale + gcol); rt4 = ld4(g.red_shift + gcol); rmu4 = ld4(g.red_mean + gcol); ris4 = ld4(g.red_invstd + gcol); }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rowl = 4 * i + (lane >> 4);
+                const float4 t = *reinterpret_cast<const float4 *>(ep + rowl * EPLD + c4);
+                // (a column group beyond N fails the bounds check; so does a row beyond M: the resource ends at M * ldc)
+                const int vo = cok4 ? ((m0 + wm0 + rowl) * (int)g.ldc + gcol) * 4 : 0x7fffffff;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4v{__builtin_bit_cast(unsigned, t.x), __builtin_bit_cast(unsigned, t.y),
+                                                              __builtin_bit_cast(unsigned, t.z), __builtin_bit_cast(unsigned, t.w)},
+                                                       crs, vo, 0, 0);
+            }
+            if (RED) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 t = *reinterpret_cast<const float4 *>(ep + (4 * i + (lane >> 4)) * EPLD + c4);
+                    const f32x4v y = yv[i];
+                    float gm;
+                    gm = fmaf(y.x, rs4.x, rt4.x) > 0.f ? t.x : 0.f; cs4.x += gm; cq4.x += gm * ((y.x - rmu4.x) * ris4.x);
+                    gm = fmaf(y.y, rs4.y, rt4.y) > 0.f ? t.y : 0.f; cs4.y += gm; cq4.y += gm * ((y.y - rmu4.y) * ris4.y);
+                    gm = fmaf(y.z, rs4.z, rt4.z) > 0.f ? t.z : 0.f; cs4.z += gm; cq4.z += gm * ((y.z - rmu4.z) * ris4.z);
+                    gm = fmaf(y.w, rs4.w, rt4.w) > 0.f ? t.w : 0.f; cs4.w += gm; cq4.w += gm * ((y.w - rmu4.w) * ris4.w);
+                }
+            }
+            if (RED && g.stats) {   // the four row groups of a column live in lanes l, l ^ 16, l ^ 32, l ^ 48
+                float *red = lds + 8 * 32 * EPLD;
+                float v8[8] = {cs4.x, cs4.y, cs4.z, cs4.w, cq4.x, cq4.y, cq4.z, cq4.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v8[j] += __shfl_xor(v8[j], 16, 64);
+                    v8[j] += __shfl_xor(v8[j], 32, 64);
+                }
+                if (lane < 16) {
+                    *reinterpret_cast<float4 *>(red + ((wave / WAVES_N) * 2 + 0) * BN + wn0 + c4) = make_float4(v8[0], v8[1], v8[2], v8[3]);
+                    *reinterpret_cast<float4 *>(red + ((wave / WAVES_N) * 2 + 1) * BN + wn0 + c4) = make_float4(v8[4], v8[5], v8[6], v8[7]);
+                }
+            }
+        }
+        PERS_STAMP(3);
+        if (g.stats) {
+            float *red = lds + 8 * 32 * EPLD;   // behind the waves' transposition regions (both stages are dead: everybody passed the barrier that ended the k-loop)
+            if (!(RED && EPV)) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
+                    const float q = csq[b] + __shfl_xor(csq[b], 32, 64);
+                    if (lh == 0) {
+                        red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
+                        red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
+                    }
                 }
             }
             __syncthreads();
@@ -817,12 +924,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (n0 + c < g.N) g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
             }
             if (has_next) __syncthreads();   // `red` is read before the next tile is staged over it
+        } else if (EPV && has_next) {
+            __syncthreads();                 // every wave has read its transposition region before the next tile is staged
         }
+        PERS_STAMP(4);
         if (!has_next) break;
         tix = ntix; tile_m = ntile_m; tile_n = ntile_n;
         la.finish(g.a_scale, g.a_shift);
         la.store(lds); lb.store(lds + SZA);
         __syncthreads();
+        PERS_STAMP(5);
+#ifdef PERS_STAMPS
+        ++st_tile;
+#endif
     }
 }
 
@@ -1030,6 +1144,12 @@ static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st, float
     if (!g_persistent_enabled() || lay == LAY_TN || g.batch != 1 || g.splitk != 1 || g.accumulate || g.a_rowsum || g.kswitch ||
         g.b_scale || !(g.epi == EPI_NONE || g.epi == EPI_BNRED) || !(g.vecA && g.vecB) || (g.K & 3) || (lay == LAY_NN && (g.N & 3)))
         return false;
+#if PERS_EPV
+    if ((g.N & 3) || (g.ldc & 3) || ((uintptr_t)g.C & 15)) return false;   // (rows of C leave as 128-bit stores)
+    if (g.epi == EPI_BNRED && ((g.ldaux & 3) || (((uintptr_t)g.aux | (uintptr_t)g.red_scale | (uintptr_t)g.red_shift |
+                                                   (uintptr_t)g.red_mean | (uintptr_t)g.red_invstd) & 15)))
+        return false;              // (Yp arrives as 128-bit row pieces, its column constants as float4)
+#endif
     const long long lim = 0x7ff00000LL;
     if ((long long)g.M * g.lda * 4 >= lim || (long long)(lay == LAY_NT ? g.N : g.K) * g.ldb * 4 >= lim ||
         (long long)g.M * g.ldc * 4 >= lim || (g.epi == EPI_BNRED && (long long)g.M * g.ldaux * 4 >= lim))
@@ -1225,6 +1345,17 @@ static int dispatch(GemmArgs &g, int layout, void *stream)
 }
 
 extern "C" {
+
+#ifdef PERS_STAMPS
+int prifit_debug_pers_ktail(int on)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pers_ktail), &on, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+int prifit_debug_pers_stamps(unsigned long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pers_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int prifit_gemm_tile_m(int N)
 {
