@@ -310,10 +310,20 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        // the fragments of k group g + 1 are requested before the four MFMAs of group g (left to itself the compiler reads
+        // each group right in front of its MFMAs and waits out the LDS latency with lgkmcnt(0), sixteen times per step)
+        float4 a2[2], b2[2];
+        a2[0] = *reinterpret_cast<const float4 *>(xa);
+        if (MODE != 0) b2[0] = *reinterpret_cast<const float4 *>(qb);
 #pragma unroll
         for (int g = 0; g < D / 8; ++g) {
-            const float4 a = *reinterpret_cast<const float4 *>(xa + g * 8);
-            const float4 bq = MODE == 0 ? qf[g] : *reinterpret_cast<const float4 *>(qb + g * 8);
+            if (g + 1 < D / 8) {
+                a2[(g + 1) & 1] = *reinterpret_cast<const float4 *>(xa + (g + 1) * 8);
+                if (MODE != 0) b2[(g + 1) & 1] = *reinterpret_cast<const float4 *>(qb + (g + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 a = a2[g & 1];
+            const float4 bq = MODE == 0 ? qf[g] : b2[g & 1];
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, sacc, 0, 0, 0);
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pprev[g]), kt_rs, st_voff(k0 - KB, g),
                                                           st_soff(pb_bytes_s, g), 2);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // (MODE 1: nothing of the transform -- e.g. the compares on the just-requested K values -- may move above the S MFMAs)
         if (MODE == 1) __builtin_amdgcn_sched_barrier(0);

@@ -42,6 +42,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int j = 0; j < 12; ++j) op[j] = *reinterpret_cast<const float4 *>(mine + (it & 1) * 1024 + (j * 64 + lane) * 4);
         }
+        if (MODE == 5 || MODE == 6) {   // dependent chains: all 32 MFMAs into ONE accumulator / alternating between two
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 a = op[j % 4], b = op[4 + j];
+                constexpr int W = MODE == 5 ? 0 : 1;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0], 0, 0, 0);
+                acc[W] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[W], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[0], 0, 0, 0);
+                acc[W] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[W], 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float4 a = op[j % 4];
@@ -100,5 +111,7 @@ int main()
     run<2>("2: + 12 ds_read_b128 + 4 buffer_load_dwordx4 -> VGPR", src, window);
     run<3>("3: + 12 ds_read_b128 + 4 loads -> VGPR + 4 ds_write_b128", src, window);
     run<4>("4: + 12 ds_read_b128 + 4 buffer_load_dwordx4 ... lds", src, window);
+    run<5>("5: as 0, all MFMAs into ONE accumulator (dependent chain)", src, window);
+    run<6>("6: as 0, two accumulators alternating", src, window);
     return 0;
 }
