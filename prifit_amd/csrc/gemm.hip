@@ -382,6 +382,40 @@ __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int r
     return make_float4(p[0], p[ROWS + PAD], p[2 * (ROWS + PAD)], p[3 * (ROWS + PAD)]);
 }
 
+// The MFMAs of one staged k-tile for a wave with a 32 x (32 TN) block: the fragments of k group g + 1 are requested before
+// the 2 TN x 4 matrix instructions of group g and pinned there (left to itself the compiler reads each operand two MFMAs
+// ahead of its use -- 128 cycles of cover for an LDS round trip under load).  ngk < BK / 8: a ragged last k-tile.
+// Same products in the same order as the plain loop: bit-identical sums.
+template <int RA, bool AKC, int RB, bool BKC, int TN>
+__device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int arow, int bcol, int lh,
+                                          f32x16 (&acc)[TN], int ngk = BK / 8)
+{
+    float4 fa[2], fb[2][TN];
+    fa[0] = read_frag<RA, AKC>(As, arow, 0, lh);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb[0][b] = read_frag<RB, BKC>(Bs, bcol + 32 * b, 0, lh);
+#pragma unroll
+    for (int gk = 0; gk < BK / 8; ++gk) {
+        if (gk > 0 && gk >= ngk) break;   // (scalar)
+        if (gk + 1 < BK / 8) {
+            fa[(gk + 1) & 1] = read_frag<RA, AKC>(As, arow, gk + 1, lh);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[(gk + 1) & 1][b] = read_frag<RB, BKC>(Bs, bcol + 32 * b, gk + 1, lh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 a = fa[gk & 1];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const float4 w = fb[gk & 1][b];
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc[b], 0, 0, 0);
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc[b], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <bool C, class A, class B> struct pick { typedef A type; };
 template <class A, class B> struct pick<false, A, B> { typedef B type; };
 
@@ -750,21 +784,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 lb.init(g.B, g.ldb, ntile_n * BN, g.N, g.K);
                 la.load(0); lb.load(0);
             }
-#pragma unroll
-            for (int gk = 0; gk < BK / 8; ++gk) {
-                if (gk > 0 && !more && gk >= ngk_last) break;   // (scalar) 8-wide k groups beyond K hold zeros: K = 196 has 1 of 4
-                const float4 fa = read_frag<BM, true>(As, wm0 + li, gk, lh);
-                float4 fb[TN];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, B_KC>(Bs, wn0 + 32 * b + li, gk, lh);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
-                }
-            }
+            // (8-wide k groups beyond K hold zeros: K = 196 fills one of the last k-tile's four)
+            mma_ktile<BM, true, BN, B_KC, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc, more ? BK / 8 : ngk_last);
             if (more) {
                 float *An = lds + (stage ^ 1) * (SZA + SZB);
                 la.finish(g.a_scale, g.a_shift);
@@ -1070,20 +1091,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float *As = lds + S * (SZA + SZB), *Bs = As + SZA;
         if (kt + 2 < kt1) { la[S].load((kt + 2) * BK); lb[S].load((kt + 2) * BK); }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gk = 0; gk < BK / 8; ++gk) {
-            const float4 fa = read_frag<BM, false>(As, wm0 + li, gk, lh);
-            float4 fb[TN];
-#pragma unroll
-            for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, false>(Bs, wn0 + 32 * b + li, gk, lh);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
-            }
-        }
+        mma_ktile<BM, false, BN, false, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc);
         if (kt + 1 < kt1) {
             float *An = lds + (S ^ 1) * (SZA + SZB);
             lb[S ^ 1].finish(g.b_scale, g.b_shift);
@@ -1238,20 +1246,7 @@ __global__ __launch_bounds__(512, 4) void gemm_dual_sk_kernel(const GemmArgs g)
                 la.load((kt + 1) * BK, nullptr, nullptr);
                 lb.load((kt + 1) * BK, nullptr, nullptr);
             }
-#pragma unroll
-            for (int gk = 0; gk < BK / 8; ++gk) {
-                const float4 fa = read_frag<BM, true>(As, wm0 + li, gk, lh);
-                float4 fb[TN];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) fb[b] = read_frag<BN, false>(Bs, wn0 + 32 * b + li, gk, lh);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[b].x, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[b].y, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[b].z, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[b].w, acc[b], 0, 0, 0);
-                }
-            }
+            mma_ktile<BM, true, BN, false, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc);
             if (more) {
                 float *An = lds + (stage ^ 1) * (SZA + SZB);
                 la.store(An);
