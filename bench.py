@@ -222,13 +222,22 @@ def run_rank(args):
     fit_kw = dict(chamfer_points=data.get("chamfer"), include_convex_loss=True, quantile=0.05, msc_iterations=10,
                   max_num_clusters=25)
 
-    # Farthest-point sampling of the NEXT batch on a side stream while this step runs (ops.sample_ahead: the samples
-    # depend on the coordinates alone, and the search keeps 24 of 256 CUs busy).  Every step launches the sampling of
-    # one batch -- the synthetic batch is the same every step, its samples are recomputed every step all the same --
-    # and consumes the one launched a step earlier.  PRIFIT_SAMPLE_AHEAD=0: in line, on the step's own stream.
-    ahead_on = args.workload != "c5" and os.environ.get("PRIFIT_SAMPLE_AHEAD", "1") != "0"
+    # PRIFIT_SAMPLE_AHEAD=1 (default 0: in line, on the step's own stream): farthest-point sampling of the NEXT batch on
+    # a side stream while this step runs (ops.sample_ahead: the samples depend on the coordinates alone, and the search
+    # keeps 24 of 256 CUs busy).  Every step then launches the sampling of one batch -- the synthetic batch is the same
+    # every step, its samples are recomputed every step all the same -- and consumes the one launched a step earlier.
+    # Measured: launched at the top of the step 24.33 -> 24.2 ms, but the grouping launches it runs beside
+    # lose 7 %; launched between forward and backward nothing either way -- so the headline runs in line.
+    ahead_on = args.workload != "c5" and os.environ.get("PRIFIT_SAMPLE_AHEAD", "0") == "1"
     starts = (data.get("s1"), data.get("s2"))
     sampled = {"cur": starts, "next": None}
+
+    def sample_next():
+        # launched between the forward and the backward pass: the chain then runs beside the first backward kernels (at
+        # the top of the step it ran beside the set-abstraction grouping launches, which are HBM-bound and lost 7 %:
+        # roofline_grouping.frac 0.52 -> 0.48)
+        if ahead_on:
+            sampled["next"] = net.sample_ahead(data["xyz"], starts)   # the next step's batch
 
     def selfsup_fwd_bwd():
         if args.workload == "c5":
@@ -236,16 +245,17 @@ def run_rank(args):
         else:
             out = net(data["xyz"], data["cls"], fps_start=sampled["cur"], **fit_kw)
         loss = out[3].mean()
+        sample_next()
         loss.backward()
         return loss
 
     def step():
         if ahead_on:
             sampled["cur"] = sampled["next"] if sampled["next"] is not None else starts
-            sampled["next"] = net.sample_ahead(data["xyz"], starts)   # the next step's batch
         bucket.zero()
         if args.workload == "c2":
             seg = net(data["xyz"], data["cls"], fps_start=sampled["cur"])[0]
+            sample_next()
             loss = crit(seg.reshape(-1, NUM_PARTS), data["target"].view(-1), None)
             loss.backward()
         elif os.environ.get("PRIFIT_SPECULATE", "1") != "0":
