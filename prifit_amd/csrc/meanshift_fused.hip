@@ -160,10 +160,20 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     constexpr int QB = 32 * NQG;         // queries per workgroup (shadows the standard form's constant)
     constexpr int NKH = NW / NQG;        // key sub-tiles per step
     constexpr int KB = 32 * NKH;         // keys per step
-    constexpr bool SQ = NQG == 2;        // the query tile lives in LDS
+#ifndef MSF_DB
+#define MSF_DB 0
+#endif
+    // DB (A/B build switch -DMSF_DB=1, standard forward): the key tile double-buffered in the LDS the query tile would take
+    // (the forward keeps its query fragments in registers; its epilogue then reads Z from global, as the narrow form does)
+    // -- the next tile is written into the other buffer beside the second half of the O product and ONE barrier per step
+    // separates its writers from its readers (the single buffer needs two: readers done -> write -> written).  Measured
+    // SLOWER on one box, alternating builds: 419.7 against 408.5 us per launch (written at the end of the step: 424.7
+    // against 416.2), the step 24.21 against 24.1 ms; 228 instead of 209 VGPRs.  Off.
+    constexpr bool DB = MSF_DB && MODE == 0 && NW == 4 && NQG == 2;
+    constexpr bool SQ = NQG == 2 && !DB; // the query tile lives in LDS
     constexpr bool ILV = MODE == 0;      // output column of accumulator block d, lane li: 4 li + d instead of 32 d + li
     __shared__ __attribute__((aligned(16))) float s_q[SQ ? QB * LDSW : 4];
-    __shared__ __attribute__((aligned(16))) float s_x[KB * LDSW];
+    __shared__ __attribute__((aligned(16))) float s_x[(DB ? 2 : 1) * KB * LDSW];
     __shared__ float s_rs[NKH * QB];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -267,13 +277,16 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     float pprev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
-    for (int k0 = kbeg; k0 < kend; k0 += KB) {
+    if (DB) t.store(s_x);                // the first tile (a previous segment's readers passed the barrier that ends a segment)
+    int it = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += KB, ++it) {
+        float *sx = DB ? s_x + (it & 1) * (KB * LDSW) : s_x;   // this step's key tile
         MSF_STAMP(0);
-        __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
+        __syncthreads();                 // previous tile's readers are done (also orders the s_q store); DB: this tile is written
         MSF_STAMP(1);
-        t.store(s_x);
+        if (!DB) t.store(s_x);
         MSF_STAMP(2);
-        __syncthreads();
+        if (!DB) __syncthreads();
         MSF_STAMP(3);
         const int kb_bytes = __builtin_amdgcn_readfirstlane(k0 * ldk4);          // this step's key block
         // MODE 0 (standard form): the step's 24 vector-memory instructions -- 8 loads of the next tile, 16 stores of the
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         }
         MSF_STAMP(4);
         // ---- S^T sub-tile (32 keys x 32 queries), K = 128: A = X_sub rows, B = query rows
-        const float *xa = s_x + (kh * 32 + li) * LDSW + lh * 4;
+        const float *xa = sx + (kh * 32 + li) * LDSW + lh * 4;
         const float *qb = s_q + qrow * LDSW + lh * 4;
         f32x16 sacc;
 #pragma unroll
@@ -378,12 +391,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         // (ILV is the forward only: the dZ mode's split blocks add their accumulators with float atomics, and an atomic
         // instruction over columns 4 li + d touches four times as many cache lines as one over 32 d + li: 387 -> 408 us)
         if constexpr (ILV) {
-            const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + 4 * li;
+            const float *xs = sx + (kh * 32 + 4 * lh) * LDSW + 4 * li;
             float4 bo[2];
             bo[0] = *reinterpret_cast<const float4 *>(xs);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r + 1 < 16) bo[(r + 1) & 1] = *reinterpret_cast<const float4 *>(xs + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LDSW);
+                // DB: the next tile (requested during the S product) goes into the other buffer beside the second half of
+                // this product's MFMAs; that buffer's last readers passed this step's barrier
+                if (DB && r == 6 && k0 + KB < kend) t.store(s_x + ((it + 1) & 1) * (KB * LDSW));
                 __builtin_amdgcn_sched_barrier(0);   // (the read stays ahead of the MFMAs it does not feed)
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].x, oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].y, oacc[1], 0, 0, 0);
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            const float *xs = s_x + (kh * 32 + 4 * lh) * LDSW + li;
+            const float *xs = sx + (kh * 32 + 4 * lh) * LDSW + li;
             float bo[2][4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) bo[0][d] = xs[32 * d];
