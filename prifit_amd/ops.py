@@ -23,6 +23,15 @@ class SampledAhead:
         self.idx, self.new_xyz, self.event, self.npoint = idx, new_xyz, event, idx.shape[1]
         self.keep = keep   # the side stream's inputs: not back to the allocator before the consumer has waited for the event
 
+    def __del__(self):
+        # dropped without having been consumed: the side stream may still be writing idx / new_xyz, whose memory goes back
+        # to the CONSUMING stream's allocator pool right now -- let the chain finish first
+        try:
+            if not self.event.query():
+                self.event.synchronize()
+        except Exception:   # interpreter shutdown
+            pass
+
 
 _ahead_streams = {}
 
