@@ -325,18 +325,25 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
         // the fragments of k group g + 1 are requested before the four MFMAs of group g (left to itself the compiler reads
         // each group right in front of its MFMAs and waits out the LDS latency with lgkmcnt(0), sixteen times per step)
-        float4 a2[2], b2[2];
-        a2[0] = *reinterpret_cast<const float4 *>(xa);
-        if (MODE != 0) b2[0] = *reinterpret_cast<const float4 *>(qb);
+#ifndef MSF_PFD
+#define MSF_PFD 1   // (2 measured the same: 420.5 / 420.4 against 419.2 / 422.4 us per forward launch, alternating builds on one box)
+#endif
+        constexpr int PFD = MSF_PFD;          // groups requested ahead (ring of PFD + 1 fragments)
+        float4 a2[PFD + 1], b2[PFD + 1];
+#pragma unroll
+        for (int g = 0; g < PFD; ++g) {
+            a2[g] = *reinterpret_cast<const float4 *>(xa + g * 8);
+            if (MODE != 0) b2[g] = *reinterpret_cast<const float4 *>(qb + g * 8);
+        }
 #pragma unroll
         for (int g = 0; g < D / 8; ++g) {
-            if (g + 1 < D / 8) {
-                a2[(g + 1) & 1] = *reinterpret_cast<const float4 *>(xa + (g + 1) * 8);
-                if (MODE != 0) b2[(g + 1) & 1] = *reinterpret_cast<const float4 *>(qb + (g + 1) * 8);
+            if (g + PFD < D / 8) {
+                a2[(g + PFD) % (PFD + 1)] = *reinterpret_cast<const float4 *>(xa + (g + PFD) * 8);
+                if (MODE != 0) b2[(g + PFD) % (PFD + 1)] = *reinterpret_cast<const float4 *>(qb + (g + PFD) * 8);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float4 a = a2[g & 1];
-            const float4 bq = MODE == 0 ? qf[g] : b2[g & 1];
+            const float4 a = a2[g % (PFD + 1)];
+            const float4 bq = MODE == 0 ? qf[g] : b2[g % (PFD + 1)];
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, sacc, 0, 0, 0);
@@ -392,19 +399,21 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         // instruction over columns 4 li + d touches four times as many cache lines as one over 32 d + li: 387 -> 408 us)
         if constexpr (ILV) {
             const float *xs = sx + (kh * 32 + 4 * lh) * LDSW + 4 * li;
-            float4 bo[2];
-            bo[0] = *reinterpret_cast<const float4 *>(xs);
+            float4 bo[PFD + 1];
+#pragma unroll
+            for (int r = 0; r < PFD; ++r) bo[r] = *reinterpret_cast<const float4 *>(xs + ((r & 3) + 8 * (r >> 2)) * LDSW);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (r + 1 < 16) bo[(r + 1) & 1] = *reinterpret_cast<const float4 *>(xs + (((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LDSW);
+                if (r + PFD < 16)
+                    bo[(r + PFD) % (PFD + 1)] = *reinterpret_cast<const float4 *>(xs + (((r + PFD) & 3) + 8 * ((r + PFD) >> 2)) * LDSW);
                 // DB: the next tile (requested during the S product) goes into the other buffer beside the second half of
                 // this product's MFMAs; that buffer's last readers passed this step's barrier
                 if (DB && r == 6 && k0 + KB < kend) t.store(s_x + ((it + 1) & 1) * (KB * LDSW));
                 __builtin_amdgcn_sched_barrier(0);   // (the read stays ahead of the MFMAs it does not feed)
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].x, oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].y, oacc[1], 0, 0, 0);
-                oacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].z, oacc[2], 0, 0, 0);
-                oacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r & 1].w, oacc[3], 0, 0, 0);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r % (PFD + 1)].x, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r % (PFD + 1)].y, oacc[1], 0, 0, 0);
+                oacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r % (PFD + 1)].z, oacc[2], 0, 0, 0);
+                oacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r % (PFD + 1)].w, oacc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
