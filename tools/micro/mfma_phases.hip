@@ -8,7 +8,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int PHASE, bool OFFSET>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k(float *out, int iters, int second_from)
+#ifndef WPE
+#define WPE 2      // waves per SIMD the kernel is compiled for (hipcc -DWPE=4: the 3- and 4-wave rows)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k(float *out, int iters, int second_from)
 {
     __shared__ __attribute__((aligned(16))) float lds[4 * 1024];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -22,6 +25,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i < 8; ++i) va[i] = 0.5f + i;
     if (OFFSET && (int)blockIdx.x >= second_from)
         for (int i = 0; i < 26; ++i) __builtin_amdgcn_s_sleep(2);   // ~3300 cycles: half a period
+#ifdef PRIO
+    // the FIRST workgroup of a CU (dispatch order) runs at a higher wave priority for its whole life: the two waves of a
+    // SIMD then cannot fall into step (equal priorities share the pipe, finish their MFMA phases together and idle together)
+    if ((int)blockIdx.x < second_from) __builtin_amdgcn_s_setprio(3);
+#endif
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 64; ++j) acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j & 3], 0, 0, 0);
@@ -58,7 +66,7 @@ template <int PHASE, bool OFFSET>
 static void run(const char *name, int wgs)
 {
     float *out;
-    hipMalloc(&out, 512 * 256 * sizeof(float));
+    hipMalloc(&out, 1024 * 256 * sizeof(float));
     const int iters = 4000, launches = 10;
     hipEvent_t s, e;
     hipEventCreate(&s); hipEventCreate(&e);
@@ -78,6 +86,14 @@ static void run(const char *name, int wgs)
 
 int main()
 {
+#if WPE > 2
+    for (int w = 1; w <= WPE; ++w) {
+        run<1, false>("+ 2560 cycles of s_sleep", 256 * w);
+        run<3, false>("+ 20 dependent LDS round trips", 256 * w);
+        run<2, false>("+ 600 VALU instructions", 256 * w);
+    }
+    return 0;
+#endif
     run<0, false>("MFMAs only", 256);
     run<0, false>("MFMAs only", 512);
     run<1, false>("+ 2560 cycles of s_sleep", 256);
