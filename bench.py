@@ -170,16 +170,16 @@ def _traffic_per_launch(dom):
 
 
 def run_rank(args):
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     trace = os.environ.get("PRIFIT_BENCH_TRACE")     # tests: each rank leaves a line saying who it is
-    if trace:
+    if trace:   # written BEFORE torch is imported (seconds on a cold box): a rank the launcher ends early has left it
         with open("%s.%d" % (trace, rank), "w") as f:
             f.write("rank %d of %d local %d" % (rank, world, local))
+    import torch
+    import torch.distributed as dist
+
     if "RANK" in os.environ and args.gpus != world and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; the environment wins" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():

@@ -430,6 +430,25 @@ int prifit_meanshift_fused_bwd_dx(const float *gO, const float *Z, const float *
                                   const float *g_rowsum, const float *KT, long long ld_kt,
                                   long long stride_kt, int B, int N, int D, float *dX, void *stream);
 
+/* Row-sparse backward of `iterations` mean-shift updates, for a loss that reads the shifted points through
+ * `center = new_X[indices]` only (src/mean_shift.py:44-46; autograd of :61-82).  Row i of an iterate depends on row i of
+ * the previous iterate alone (the dictionary is the fixed input X, :65), so d loss / d new_X is non-zero on the R kept
+ * rows in EVERY iteration; the dense backward's other N - R query rows multiply exact zeros.  This entry point does the
+ * R x N x D products only and re-forms the K values under the kept rows from the saved iterate rows -- the forward need
+ * not keep K^T (call prifit_meanshift_fused_fwd with KT = NULL).
+ * X [B,N,D], bw [B]; Zin / Zout / O / rowsum / nrm: HOST arrays of T device pointers, the tensors iteration t consumed
+ * (Zin[t] [B,N,D]) and produced (Zout[t] [B,N,D], O[t] [B,N,D], rowsum[t] [B,N], nrm[t] [B,N]; Zin[t+1] == Zout[t]);
+ * ids [B,R] int64 row indices (clamped to [0,N)), nrows [B] live slots per shape (NULL: all R), R <= 32;
+ * g_rows [B,R,D] = dL/d(Zout[T-1][b, ids[b,r]]); dX [B,N,D] is ACCUMULATED into (both uses of the dictionary and the
+ * Z_0 = X.clone() of :60).  workspace: prifit_meanshift_rows_bwd_workspace floats, 16-byte aligned.
+ * D in {32, 64, 128} (prifit_meanshift_rows_supported).  Deterministic except where two live slots name one point. */
+int prifit_meanshift_rows_supported(int N, int D, int R);
+long long prifit_meanshift_rows_bwd_workspace(int B, int N, int D, int R);
+int prifit_meanshift_rows_bwd(const float *X, const float *bw, int B, int N, int D, int T, const float *const *Zin,
+                              const float *const *Zout, const float *const *O, const float *const *rowsum,
+                              const float *const *nrm, const long long *ids, const int *nrows, int R,
+                              const float *g_rows, float *workspace, float *dX, void *stream);
+
 /* Non-maximum suppression, src/mean_shift.py:162-202 called as nms(Z, Z, b) (:44).
  * dist [B,N,N] = 2 - 2 Z Z^T, Z [B,N,D], bw [B].  Outputs: owner [B,N] (nearest centre of each point),
  * counts [B,N], flags [B,N] (scratch), ids [B,cap] ascending kept centre ids, count [B] = number of kept
@@ -562,6 +581,10 @@ int prifit_edge_scatter(const float *gout, int ld_gout, const int32_t *idx, int 
  * prifit_comm_unique_id_bytes() bytes to every rank (any side channel); every rank calls prifit_comm_init with its
  * device current; then prifit_allreduce_flat(buf, count, comm, stream) in place; prifit_comm_destroy at the end. */
 int prifit_comm_unique_id_bytes(void);
+/* 1 when the entry points are bound to an RCCL that was ALREADY loaded in the process (e.g. by torch.distributed's nccl
+ * backend), 0 when the library had to load the system copy itself (or found none): a caller that also uses another
+ * RCCL client in the same process must see 1 -- two RCCL instances in one process are undefined. */
+int prifit_comm_in_process(void);
 int prifit_comm_unique_id(void *out);
 int prifit_comm_init(void **comm, int nranks, int rank, const void *unique_id);
 int prifit_allreduce_flat(float *buf, long long count, void *comm, void *stream);

@@ -735,4 +735,7 @@ if __name__ == "__main__":
     if "fit" in which:
         import make_golden_fit
         make_golden_fit.run(save, eq, close)
+    if "bw_over" in which or "fit" in which:
+        import make_golden_fit
+        make_golden_fit.run_bandwidth_over(save, close)
     print("all oracle-vs-reference checks passed; fixtures under", GOLD)

@@ -60,6 +60,24 @@ def patched(obj, name, value):
         setattr(obj, name, old)
 
 
+def run_bandwidth_over(save, close):
+    """num_samples > N (src/mean_shift.py:151-155: `X[L[0:num_samples]]` keeps all N rows, K = int(quantile *
+    num_samples)): clustering(X)'s default num_samples = 1000 on a 512-point cloud.  Own fixture, own entry
+    (`make_golden.py bw_over`), so that the other fitting fixtures are not rewritten."""
+    ms = refshim.ref("src.mean_shift").MeanShift()
+    seed, B, N, D, q = 2, 2, 512, 128, 0.05
+    _, _, emb = fit_inputs(B, N, D, seed)
+    out = {"seed": seed, "N": N, "num_samples": 1000, "quantile": q}
+    for b in range(B):
+        with torch.no_grad():
+            bw_r = ms.compute_bandwidth(emb[b], 1000, q)
+        bw_o = orc.compute_bandwidth(emb[b], q, num_samples=1000)
+        close(bw_o, bw_r, f"bandwidth with num_samples > N b={b}", rtol=1e-6)
+        assert abs(float(orc.compute_bandwidth(emb[b], q)) - float(bw_r)) > 1e-3 * float(bw_r)   # k = 25 is another statistic
+        out[f"bw_{b}"] = bw_r
+    save("fit_bandwidth_over", **out)
+
+
 def run(save, eq, close):
     print("[fit]")
     MS = refshim.ref("src.mean_shift")

@@ -527,15 +527,16 @@ def guard_exp(x):
     return torch.exp(torch.clamp(x, min=-13.0, max=75.0))
 
 
-def compute_bandwidth(X, quantile, rows=None):
+def compute_bandwidth(X, quantile, rows=None, num_samples=None):
     """src/mean_shift.py:138-160.  With num_samples == N (convex_loss.py:68) the reference's row shuffle only
     permutes the per-row values that are averaged; with num_samples < N (`clustering(X)`'s default 1000, fitting.py:43)
-    `rows` = the shuffled prefix `L[0:num_samples]` of :149-151, passed in explicitly."""
+    `rows` = the shuffled prefix `L[0:num_samples]` of :149-151, passed in explicitly.  num_samples > N (the same default
+    on a small cloud): the slice keeps all N rows but K = int(quantile * num_samples) (:155) -- `num_samples` given."""
     if rows is not None:
         X = X[torch.as_tensor(rows, dtype=torch.long)]
     n = X.shape[0]
     dist = 2 - 2 * X @ X.t()
-    k = int(quantile * n)
+    k = int(quantile * (n if num_samples is None else num_samples))
     kth = torch.topk(dist, k=k, dim=1, largest=False)[0][:, -1]
     return torch.sqrt(torch.clamp(kth, min=1e-6)).mean()
 
@@ -567,7 +568,7 @@ def nms(centers, X, b):
     return kept, ids, labels
 
 
-def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None):
+def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None, num_samples=None):
     """src/mean_shift.py:18-48 (eff=False).
 
     `center_ids` (harness hook): WHICH point represents a collapsed mode is decided by last-bit noise in the
@@ -576,7 +577,7 @@ def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None):
     oracle/make_golden.py).  A harness that compares gradients passes the reference's ids; the partition is checked
     to be the one nms found."""
     with torch.no_grad():
-        bw = compute_bandwidth(X, quantile, bandwidth_rows)
+        bw = compute_bandwidth(X, quantile, bandwidth_rows, num_samples)
     Z = mean_shift_iterations(X, bw, iterations)
     with torch.no_grad():
         _, ids, labels = nms(Z, Z, bw)
@@ -589,10 +590,10 @@ def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None):
     return Z[ids], bw, labels, ids, Z
 
 
-def guard_mean_shift(X, quantile, iterations, max_num_clusters, center_ids=None, bandwidth_rows=None):
+def guard_mean_shift(X, quantile, iterations, max_num_clusters, center_ids=None, bandwidth_rows=None, num_samples=None):
     """src/ellipsoid_utils.py:9-27: double the quantile until <= max_num_clusters distinct labels."""
     while True:
-        centers, bw, labels, ids, Z = mean_shift(X, quantile, iterations, center_ids, bandwidth_rows)
+        centers, bw, labels, ids, Z = mean_shift(X, quantile, iterations, center_ids, bandwidth_rows, num_samples)
         if torch.unique(labels).shape[0] > max_num_clusters:
             quantile *= 2
         else:
@@ -607,13 +608,14 @@ def membership(centers, X, bw):
     return e / e.sum(0, keepdim=True)
 
 
-def clustering(X, quantile, iterations, max_num_clusters, center_ids=None, bandwidth_rows=None):
+def clustering(X, quantile, iterations, max_num_clusters, center_ids=None, bandwidth_rows=None, num_samples=None):
     """src/ellipsoid_utils.py:31-73 (visualize=False).  X [B,N,D] -> (list of W_b [N,K_b], list of labels)."""
     Ws, labs, info = [], [], []
     for b in range(X.shape[0]):
         centers, bw, labels, ids, Z, q = guard_mean_shift(X[b], quantile, iterations, max_num_clusters,
                                                           None if center_ids is None else center_ids[b],
-                                                          None if bandwidth_rows is None else bandwidth_rows[b])
+                                                          None if bandwidth_rows is None else bandwidth_rows[b],
+                                                          num_samples)
         Ws.append(membership(centers, X[b], bw).t())
         labs.append(labels)
         info.append({"bw": bw, "ids": ids, "Z": Z, "quantile": q})

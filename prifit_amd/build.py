@@ -27,6 +27,7 @@ SOURCES = {
     "bn.hip": [],
     "meanshift.hip": [],
     "meanshift_fused.hip": [],
+    "meanshift_rows.hip": [],
     "fit.hip": [],
     "dgcnn.hip": ["-ffp-contract=off"],
     "comm.hip": [],        # host-only: the RCCL export (RCCL itself is resolved with dlopen at run time)

@@ -20,6 +20,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     bool ok;
+    bool in_process;   // bound to an RCCL that was already loaded in the process (RTLD_NOLOAD found it)
 };
 
 const Rccl &rccl()
@@ -31,6 +32,7 @@ const Rccl &rccl()
         void *h = nullptr;
         for (const char *n : names)   // already loaded in this process?
             if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+        t.in_process = h != nullptr;
         for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
         if (!h) return t;
         t.GetUniqueId = (decltype(t.GetUniqueId))dlsym(h, "ncclGetUniqueId");
@@ -48,6 +50,8 @@ const Rccl &rccl()
 extern "C" {
 
 int prifit_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+int prifit_comm_in_process(void) { return rccl().ok && rccl().in_process ? 1 : 0; }
 
 int prifit_comm_unique_id(void *out)
 {

@@ -717,16 +717,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int SZA = BM * (BK + PAD);
     constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
     __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];  // two stages
-#ifndef PERS_EPV
-#define PERS_EPV 0
-#endif
-    // A/B build switch (PRIFIT_BUILD_DEFS=-DPERS_EPV=1): C leaves as 128-bit row stores, transposed through LDS, and the
-    // BatchNorm-backward partials are formed in that row layout from 128-bit pieces of Yp.  Stand-alone (tools/pers_stamps.py)
-    // the epilogue drops from ~8 K to ~4 K cycles per tile and the launches gain 3-4 %; inside the training step the same
-    // launches and the step itself are unchanged (same box, alternating builds: 24.21 / 24.12 against 24.09 / 24.16 ms).
-    constexpr bool EPV = PERS_EPV;
-    constexpr int EPLD = WN;             // (32-bit writes go 32 lanes a cycle, 128-bit reads 16: a row of 64 floats is one pass over the banks either way)
-    static_assert(8 * 32 * EPLD + (BM / WM) * 2 * BN <= 2 * (SZA + SZB), "epilogue regions + statistics fit the stages");
+    // (an epilogue that transposes C through LDS for 128-bit row stores and forms the BatchNorm-backward partials in that
+    // layout measured +3-4 % stand-alone and nothing inside the training step -- DESIGN 5c -- and is not kept)
+    static_assert((BM / WM) * 2 * BN <= 2 * (SZA + SZB), "the statistics slab fits the stages");
 
     const int tilesN = (g.N + BN - 1) / BN;
     const int nwg = g.ntiles;
@@ -801,7 +794,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
         const bool full_rows = m0 + BM <= g.M;   // block-uniform
         const int rbase = m0 + wm0 + 4 * lh;
-        float *ep = lds + wave * (32 * EPLD);
         float csum[TN], csq[TN];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -810,12 +802,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool cok = col < g.N;
             const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
             float rs = 0.f, rt = 0.f, rmu = 0.f, ris = 0.f;
-            if (RED && !EPV && cok) { rs = g.red_scale[col]; rt = g.red_shift[col]; rmu = g.red_mean[col]; ris = g.red_invstd[col]; }
+            if (RED && cok) { rs = g.red_scale[col]; rt = g.red_shift[col]; rmu = g.red_mean[col]; ris = g.red_invstd[col]; }
             // lane part of the address (the first of this lane's rows, its column); not an existing column: fails the bounds check
             const int c_voff = cok ? (int)(((long long)rbase * g.ldc + col) * 4) : 0x7fffffff;
             const int y_voff = (RED && cok) ? (int)(((long long)rbase * g.ldaux + col) * 4) : 0x7fffffff;
             float kf[16];
-            if (RED && !EPV) {
+            if (RED) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = ((r & 3) + 8 * (r >> 2)) * ldy4;
@@ -837,18 +829,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     if (rok && v < vmin) { vmin = v; imin = ri; }
                 }
                 if (RED) {
-                    if (!EPV) {
-                        const float gm = fmaf(kf[r], rs, rt) > 0.f ? vs : 0.f;
-                        csum[b] += gm;
-                        csq[b] += gm * ((kf[r] - rmu) * ris);
-                    }
+                    const float gm = fmaf(kf[r], rs, rt) > 0.f ? vs : 0.f;
+                    csum[b] += gm;
+                    csq[b] += gm * ((kf[r] - rmu) * ris);
                 } else {
                     csum[b] += vs;
                     csq[b] += vs * vs;
                 }
-                if (EPV) {
-                    ep[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPLD + 32 * b + li] = v;
-                } else {
+                {
                     const int ro = ((r & 3) + 8 * (r >> 2)) * ldc4;
                     if (full_rows) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, ro, 0);
                     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, cok ? c_voff + ro : c_voff, 0, 0);
@@ -867,73 +855,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
-        if (EPV) {
-            // the wave's 32 x 64 block of C, transposed through its own LDS region: rows as 128-bit stores (the vector-memory
-            // path takes a wave instruction four lanes a cycle whatever their width: 8 instead of 32 per wave and tile)
-            const int c4 = (lane & 15) * 4, gcol = n0 + wn0 + c4;
-            const bool cok4 = gcol < g.N;
-            float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f), cq4 = cs4;
-            float4 rs4 = cs4, rt4 = cs4, rmu4 = cs4, ris4 = cs4;
-            f32x4v yv[8];
-            if (RED) {
-                // BatchNorm-backward partials of the layer below, in the row layout: its pre-activations Yp arrive as the same
-                // 128-bit row pieces, requested now that the accumulators are in LDS (their registers are free) and in
-                // flight under the stores of C (rows beyond M / columns beyond N: zeros, and so is C there)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int vo = cok4 ? ((m0 + wm0 + 4 * i + (lane >> 4)) * (int)g.ldaux + gcol) * 4 : 0x7fffffff;
-                    yv[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(yrs, vo, 0, 0));
-                }
-                if (cok4) { rs4 = ld4(g.red_scale + gcol); rt4 = ld4(g.red_shift + gcol); rmu4 = ld4(g.red_mean + gcol); ris4 = ld4(g.red_invstd + gcol); }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int rowl = 4 * i + (lane >> 4);
-                const float4 t = *reinterpret_cast<const float4 *>(ep + rowl * EPLD + c4);
-                // (a column group beyond N fails the bounds check; so does a row beyond M: the resource ends at M * ldc)
-                const int vo = cok4 ? ((m0 + wm0 + rowl) * (int)g.ldc + gcol) * 4 : 0x7fffffff;
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4v{__builtin_bit_cast(unsigned, t.x), __builtin_bit_cast(unsigned, t.y),
-                                                              __builtin_bit_cast(unsigned, t.z), __builtin_bit_cast(unsigned, t.w)},
-                                                       crs, vo, 0, 0);
-            }
-            if (RED) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 t = *reinterpret_cast<const float4 *>(ep + (4 * i + (lane >> 4)) * EPLD + c4);
-                    const f32x4v y = yv[i];
-                    float gm;
-                    gm = fmaf(y.x, rs4.x, rt4.x) > 0.f ? t.x : 0.f; cs4.x += gm; cq4.x += gm * ((y.x - rmu4.x) * ris4.x);
-                    gm = fmaf(y.y, rs4.y, rt4.y) > 0.f ? t.y : 0.f; cs4.y += gm; cq4.y += gm * ((y.y - rmu4.y) * ris4.y);
-                    gm = fmaf(y.z, rs4.z, rt4.z) > 0.f ? t.z : 0.f; cs4.z += gm; cq4.z += gm * ((y.z - rmu4.z) * ris4.z);
-                    gm = fmaf(y.w, rs4.w, rt4.w) > 0.f ? t.w : 0.f; cs4.w += gm; cq4.w += gm * ((y.w - rmu4.w) * ris4.w);
-                }
-            }
-            if (RED && g.stats) {   // the four row groups of a column live in lanes l, l ^ 16, l ^ 32, l ^ 48
-                float *red = lds + 8 * 32 * EPLD;
-                float v8[8] = {cs4.x, cs4.y, cs4.z, cs4.w, cq4.x, cq4.y, cq4.z, cq4.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    v8[j] += __shfl_xor(v8[j], 16, 64);
-                    v8[j] += __shfl_xor(v8[j], 32, 64);
-                }
-                if (lane < 16) {
-                    *reinterpret_cast<float4 *>(red + ((wave / WAVES_N) * 2 + 0) * BN + wn0 + c4) = make_float4(v8[0], v8[1], v8[2], v8[3]);
-                    *reinterpret_cast<float4 *>(red + ((wave / WAVES_N) * 2 + 1) * BN + wn0 + c4) = make_float4(v8[4], v8[5], v8[6], v8[7]);
-                }
-            }
-        }
         PERS_STAMP(3);
         if (g.stats) {
-            float *red = lds + 8 * 32 * EPLD;   // behind the waves' transposition regions (both stages are dead: everybody passed the barrier that ended the k-loop)
-            if (!(RED && EPV)) {
+            float *red = lds;   // both stages are dead: everybody passed the barrier that ended the k-loop
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
-                    const float q = csq[b] + __shfl_xor(csq[b], 32, 64);
-                    if (lh == 0) {
-                        red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
-                        red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
-                    }
+            for (int b = 0; b < TN; ++b) {
+                const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
+                const float q = csq[b] + __shfl_xor(csq[b], 32, 64);
+                if (lh == 0) {
+                    red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
+                    red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
                 }
             }
             __syncthreads();
@@ -945,8 +876,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (n0 + c < g.N) g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
             }
             if (has_next) __syncthreads();   // `red` is read before the next tile is staged over it
-        } else if (EPV && has_next) {
-            __syncthreads();                 // every wave has read its transposition region before the next tile is staged
         }
         PERS_STAMP(4);
         if (!has_next) break;
@@ -1126,8 +1055,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // the split-K kernel's cases: TN, one batch item, no epilogue / statistics / bias / A prologue, 16-byte rows, spans < 2 GiB
 static bool launch_tnsk(const GemmArgs &g, hipStream_t st)
 {
-    static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_TNSK"); return !(e && e[0] == '0'); }();  // A/B switch
-    if (!on || g.batch != 1 || g.a_scale || g.bias || g.stats || g.epi != EPI_NONE || g.a_rowsum || g.kswitch ||
+    if (g.batch != 1 || g.a_scale || g.bias || g.stats || g.epi != EPI_NONE || g.a_rowsum || g.kswitch ||
         !(g.vecA && g.vecB) || (g.M & 3) || (g.N & 3) || (g.splitk > 1 && !g.accumulate) || g.splitk > 65535)
         return false;
     const long long lim = 0x7ff00000LL;
@@ -1138,26 +1066,14 @@ static bool launch_tnsk(const GemmArgs &g, hipStream_t st)
     return true;
 }
 
-static bool g_persistent_enabled()
-{
-    static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_PERSISTENT"); return !(e && e[0] == '0'); }();  // A/B switch
-    return on;
-}
-
 // the persistent kernel's cases: NT / NN, one z slice, plain store, (bias + statistics) or EPI_BNRED, 16-byte rows,
 // 32-bit byte offsets everywhere, more tiles than resident workgroups
 static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st, float *want_cand = nullptr, bool dry = false)
 {
     GemmArgs g = g_;
-    if (!g_persistent_enabled() || lay == LAY_TN || g.batch != 1 || g.splitk != 1 || g.accumulate || g.a_rowsum || g.kswitch ||
+    if (lay == LAY_TN || g.batch != 1 || g.splitk != 1 || g.accumulate || g.a_rowsum || g.kswitch ||
         g.b_scale || !(g.epi == EPI_NONE || g.epi == EPI_BNRED) || !(g.vecA && g.vecB) || (g.K & 3) || (lay == LAY_NN && (g.N & 3)))
         return false;
-#if PERS_EPV
-    if ((g.N & 3) || (g.ldc & 3) || ((uintptr_t)g.C & 15)) return false;   // (rows of C leave as 128-bit stores)
-    if (g.epi == EPI_BNRED && ((g.ldaux & 3) || (((uintptr_t)g.aux | (uintptr_t)g.red_scale | (uintptr_t)g.red_shift |
-                                                   (uintptr_t)g.red_mean | (uintptr_t)g.red_invstd) & 15)))
-        return false;              // (Yp arrives as 128-bit row pieces, its column constants as float4)
-#endif
     const long long lim = 0x7ff00000LL;
     if ((long long)g.M * g.lda * 4 >= lim || (long long)(lay == LAY_NT ? g.N : g.K) * g.ldb * 4 >= lim ||
         (long long)g.M * g.ldc * 4 >= lim || (g.epi == EPI_BNRED && (long long)g.M * g.ldaux * 4 >= lim))
@@ -1182,12 +1098,6 @@ static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st, float
         else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NN, false, false>), grid, block, 0, st, g);
     }
     return true;
-}
-
-static bool g_exact_enabled()
-{
-    static const bool on = [] { const char *e = getenv("PRIFIT_GEMM_EXACT"); return !(e && e[0] == '0'); }();  // A/B switch
-    return on;
 }
 
 // Stream-K form of the dual-source NN product of the mean-shift backward (dX += gS^T Z + K^T gO; M = N_points, N = 128,
@@ -1275,7 +1185,7 @@ static void launch_aff(const GemmArgs &g, dim3 grid, hipStream_t st)
     // 16-byte rows, each operand (one batch item) below 2 GiB, no A row sums: the buffer loaders
     const long long spanA = (LAY == LAY_TN ? (long long)g.K * g.lda : (long long)g.M * g.lda) * 4;
     const long long spanB = (LAY == LAY_NT ? (long long)g.N * g.ldb : (long long)g.K * g.ldb) * 4;
-    const bool exact = VEC && g_exact_enabled() && !g.a_rowsum && spanA < 0x7ff00000LL && spanB < 0x7ff00000LL;
+    const bool exact = VEC && !g.a_rowsum && spanA < 0x7ff00000LL && spanB < 0x7ff00000LL;
     if (exact) {
         if (g.a_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, true, false, true>), grid, block, 0, st, g);
         else if (g.b_scale) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, LAY, true, true, false, true, true>), grid, block, 0, st, g);
@@ -1416,8 +1326,7 @@ int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const
     g.dB2 = (B2 - B1) - (long long)K1 * ldb;
     g.kswitch = K1 / BK;
     // stream-K over persistent workgroups when the shape is whole tiles (the mean-shift backward: M = K1 = K2 = N_points)
-    static const bool streamk = [] { const char *e = getenv("PRIFIT_GEMM_STREAMK"); return !(e && e[0] == '0'); }();
-    if (streamk && accumulate && N == 128 && M % 128 == 0 && K1 == K2 && aligned16(A1) && aligned16(B1) && (lda % 4 == 0) &&
+    if (accumulate && N == 128 && M % 128 == 0 && K1 == K2 && aligned16(A1) && aligned16(B1) && (lda % 4 == 0) &&
         (ldb % 4 == 0) && (strideA % 4 == 0) && (strideB % 4 == 0) && (long long)M * lda * 4 < 0x7ff00000LL &&
         (long long)(K1 + K2) * ldb * 4 < 0x7ff00000LL) {
         static const int slots = [] {

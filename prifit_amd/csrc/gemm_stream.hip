@@ -673,15 +673,14 @@ struct TNPlan { int am, an, pf, occ, ragged; };
 static TNPlan stream_tn_plan(int Mo, int No)
 {
     const int mt = Mo >> 5, nt = No >> 5;
-    static const int env_pf = [] { const char *e = getenv("PRIFIT_TN_PF"); return e ? atoi(e) : 0; }();
     TNPlan p;
     p.ragged = 0;
     if (mt == 3 && nt == 3) { p.am = 2; p.an = 2; p.ragged = 1; }
     else if (mt == 3) { p.am = 3; p.an = 1; }
     else if (nt == 3) { p.am = 1; p.an = 3; }
     else { p.am = mt >= 2 ? 2 : 1; p.an = nt >= 2 ? 2 : 1; }
-    p.pf = env_pf >= 2 && env_pf <= 4 ? env_pf : 3;
-    p.occ = (p.am * p.an == 4 && p.pf == 4) ? 2 : 3;
+    p.pf = 3;   // register stages in flight (2 and 4 measured slower)
+    p.occ = 3;
     return p;
 }
 
@@ -716,8 +715,7 @@ template <int AM, int AN, bool RAG = false>
 static void stream_tn_launch_pf(const StreamTNArgs &g, const TNPlan &p, dim3 grid, hipStream_t st)
 {
     // (the BatchNorm-apply variant of the 2 x 2 plan spills two registers at depth 3)
-    if (p.pf == 2 || (g.bn_G && AM * AN == 4 && p.pf == 3)) stream_tn_launch_t<AM, AN, 2, 3, RAG>(g, grid, st);
-    else if (p.pf == 4) stream_tn_launch_t<AM, AN, 4, (AM * AN == 4 ? 2 : 3), RAG>(g, grid, st);
+    if (g.bn_G && AM * AN == 4) stream_tn_launch_t<AM, AN, 2, 3, RAG>(g, grid, st);
     else stream_tn_launch_t<AM, AN, 3, 3, RAG>(g, grid, st);
 }
 
@@ -725,8 +723,7 @@ static int stream_tn_launch(StreamTNArgs &g, float *out, long long ldo, void *st
 {
     const long long nwg = stream_tn_split(g.Mo, g.No, g.P, &g.rows_per_wg);
     const TNPlan p = stream_tn_plan(g.Mo, g.No);
-    static const int env_il = [] { const char *e = getenv("PRIFIT_TN_INTERLEAVE"); return e ? atoi(e) : 1; }();
-    g.interleave = env_il;
+    g.interleave = 1;
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)nwg);
     if (p.ragged) stream_tn_launch_pf<2, 2, true>(g, p, grid, st);

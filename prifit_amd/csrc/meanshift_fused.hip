@@ -160,20 +160,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     constexpr int QB = 32 * NQG;         // queries per workgroup (shadows the standard form's constant)
     constexpr int NKH = NW / NQG;        // key sub-tiles per step
     constexpr int KB = 32 * NKH;         // keys per step
-#ifndef MSF_DB
-#define MSF_DB 0
-#endif
-    // DB (A/B build switch -DMSF_DB=1, standard forward): the key tile double-buffered in the LDS the query tile would take
-    // (the forward keeps its query fragments in registers; its epilogue then reads Z from global, as the narrow form does)
-    // -- the next tile is written into the other buffer beside the second half of the O product and ONE barrier per step
-    // separates its writers from its readers (the single buffer needs two: readers done -> write -> written).  Measured
-    // SLOWER on one box, alternating builds: 419.7 against 408.5 us per launch (written at the end of the step: 424.7
-    // against 416.2), the step 24.21 against 24.1 ms; 228 instead of 209 VGPRs.  Off.
-    constexpr bool DB = MSF_DB && MODE == 0 && NW == 4 && NQG == 2;
-    constexpr bool SQ = NQG == 2 && !DB; // the query tile lives in LDS
+    // (a double-buffered key tile with ONE barrier per step -- in the LDS the query tile leaves free -- measured SLOWER,
+    // 419.7 against 408.5 us per launch, alternating builds on one box (228 instead of 209 VGPRs): not kept)
+    constexpr bool SQ = NQG == 2;        // the query tile lives in LDS
     constexpr bool ILV = MODE == 0;      // output column of accumulator block d, lane li: 4 li + d instead of 32 d + li
     __shared__ __attribute__((aligned(16))) float s_q[SQ ? QB * LDSW : 4];
-    __shared__ __attribute__((aligned(16))) float s_x[(DB ? 2 : 1) * KB * LDSW];
+    __shared__ __attribute__((aligned(16))) float s_x[KB * LDSW];
     __shared__ float s_rs[NKH * QB];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -277,16 +269,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     float pprev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
-    if (DB) t.store(s_x);                // the first tile (a previous segment's readers passed the barrier that ends a segment)
     int it = 0;
     for (int k0 = kbeg; k0 < kend; k0 += KB, ++it) {
-        float *sx = DB ? s_x + (it & 1) * (KB * LDSW) : s_x;   // this step's key tile
+        float *sx = s_x;                 // this step's key tile
         MSF_STAMP(0);
-        __syncthreads();                 // previous tile's readers are done (also orders the s_q store); DB: this tile is written
+        __syncthreads();                 // previous tile's readers are done (also orders the s_q store)
         MSF_STAMP(1);
-        if (!DB) t.store(s_x);
+        t.store(s_x);
         MSF_STAMP(2);
-        if (!DB) __syncthreads();
+        __syncthreads();
         MSF_STAMP(3);
         const int kb_bytes = __builtin_amdgcn_readfirstlane(k0 * ldk4);          // this step's key block
         // MODE 0 (standard form): the step's 24 vector-memory instructions -- 8 loads of the next tile, 16 stores of the
@@ -325,10 +316,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
         // the fragments of k group g + 1 are requested before the four MFMAs of group g (left to itself the compiler reads
         // each group right in front of its MFMAs and waits out the LDS latency with lgkmcnt(0), sixteen times per step)
-#ifndef MSF_PFD
-#define MSF_PFD 1   // (2 measured the same: 420.5 / 420.4 against 419.2 / 422.4 us per forward launch, alternating builds on one box)
-#endif
-        constexpr int PFD = MSF_PFD;          // groups requested ahead (ring of PFD + 1 fragments)
+        constexpr int PFD = 1;                // groups requested ahead (ring of PFD + 1 fragments); 2 measured the same
         float4 a2[PFD + 1], b2[PFD + 1];
 #pragma unroll
         for (int g = 0; g < PFD; ++g) {
@@ -406,9 +394,6 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             for (int r = 0; r < 16; ++r) {
                 if (r + PFD < 16)
                     bo[(r + PFD) % (PFD + 1)] = *reinterpret_cast<const float4 *>(xs + (((r + PFD) & 3) + 8 * ((r + PFD) >> 2)) * LDSW);
-                // DB: the next tile (requested during the S product) goes into the other buffer beside the second half of
-                // this product's MFMAs; that buffer's last readers passed this step's barrier
-                if (DB && r == 6 && k0 + KB < kend) t.store(s_x + ((it + 1) & 1) * (KB * LDSW));
                 __builtin_amdgcn_sched_barrier(0);   // (the read stays ahead of the MFMAs it does not feed)
                 oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r % (PFD + 1)].x, oacc[0], 0, 0, 0);
                 oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[r], bo[r % (PFD + 1)].y, oacc[1], 0, 0, 0);
@@ -820,11 +805,9 @@ __global__ __launch_bounds__(256) void ms_sk_epilogue_kernel(const float *__rest
     if (lane == 0) nrm_o[row] = n;
 }
 
-static int xcd_map()
-{
-    static const int on = [] { const char *e = getenv("PRIFIT_MS_XCD"); return e ? atoi(e) : 1; }();   // A/B switch
-    return on;
-}
+// whole shapes placed on one XCD (the dictionary in one L2, the rows of the K^T / gS^T streams written by neighbours on
+// the same L2); measured 436 against 437 us without it: kept on, not a switch
+static int xcd_map() { return 1; }
 
 static int sk_slots()
 {
@@ -863,27 +846,9 @@ int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, 
                            rowsum, Z, N, B, slots, Znext, nrm);
         return prifit_check_launch();
     }
-    // Left-over blocks after the full rounds (B x N / 64 = 768 blocks on 512 slots: the last 256 would run one workgroup
-    // per CU, a lone wave per SIMD): PRIFIT_MS_TAIL = 2 runs them as twice as many NARROW workgroups (32 queries, two per CU
-    // again), 1 as 8-wave workgroups (one per CU), 0 (default) as they are: measured, the forward kernel's time is
-    // linear in the number of blocks (B = 16 / 24 / 32: 345 / 504 / 655 us) -- it has no tail to win back -- and both
-    // forms lose 3-4 % to the second launch.
-    static const int tail_mode = [] { const char *e = getenv("PRIFIT_MS_TAIL"); return e ? atoi(e) : 0; }();
-    const long long blocks = (long long)B * (N / QB), tail = blocks % slots;
-    if (tail_mode && N % 128 == 0 && blocks > slots && tail != 0 && tail <= slots / 2) {
-        hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3((unsigned)(blocks - tail)), dim3(256), 0, as_stream(stream), Z,
-                           (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm, B, 0, 0);
-        if (tail_mode == 1)
-            hipLaunchKernelGGL((ms_fused_kernel<0, true, false, 8, 2>), dim3((unsigned)tail), dim3(512), 0, as_stream(stream), Z,
-                               (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                               Znext, O, rowsum, nrm, B, (int)(blocks - tail), 0);
-        else
-            hipLaunchKernelGGL((ms_fused_kernel<0, true, false, 4, 1>), dim3((unsigned)(2 * tail)), dim3(256), 0, as_stream(stream), Z,
-                               (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                               Znext, O, rowsum, nrm, B, (int)(2 * (blocks - tail)), 0);
-        return prifit_check_launch();
-    }
+    // (Left-over blocks after the full rounds -- B x N / 64 = 768 blocks on 512 slots -- run as they are: the forward's time
+    // is linear in the number of blocks (B = 16 / 24 / 32: 345 / 504 / 655 us), it has no tail to win back; an 8-wave and a
+    // 32-query "narrow" form for the last 256 blocks both lost 3-4 % to their second launch, DESIGN 5c, and are gone.)
     if (N % QB == 0)
         hipLaunchKernelGGL((ms_fused_kernel<0, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
@@ -925,13 +890,9 @@ int prifit_meanshift_dx_streams(const float *gO, const float *Z, const float *gS
     if (!gO || !Z || !gST || !KT || !dX || B <= 0 || N <= 0 || (N % QB) || (ld_kt & 3) || ld_kt < N || D_ != D || B > 65535 ||
         (((uintptr_t)gST | (uintptr_t)KT) & 15) || (stride_kt & 3))
         return PRIFIT_EINVAL;
-    static const int nkg = [] { const char *e = getenv("PRIFIT_MS_DX_NKG"); return e ? atoi(e) : 2; }();   // 4 (128 keys, 512 threads) measured slower: 566 vs 456 us
-    if (nkg == 4 && N % 128 == 0)
-        hipLaunchKernelGGL(ms_dx_streams_kernel<4>, dim3(N / 128, B), dim3(512), 0, as_stream(stream), gO, Z, gST, KT, ld_kt,
-                           stride_kt, N, dX);
-    else
-        hipLaunchKernelGGL(ms_dx_streams_kernel<2>, dim3(N / KB, B), dim3(256), 0, as_stream(stream), gO, Z, gST, KT, ld_kt,
-                           stride_kt, N, dX);
+    // (128 keys per 512-thread workgroup measured slower: 566 vs 456 us)
+    hipLaunchKernelGGL(ms_dx_streams_kernel<2>, dim3(N / KB, B), dim3(256), 0, as_stream(stream), gO, Z, gST, KT, ld_kt,
+                       stride_kt, N, dX);
     return prifit_check_launch();
 }
 

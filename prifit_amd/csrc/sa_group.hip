@@ -32,7 +32,6 @@ constexpr int SG_UNR = 4;       // independent row chains in flight per lane
 struct SAGroupArgs {
     const float *xyz, *new_xyz, *feat;
     int B, N, S, feat_first;
-    int nt;                // non-temporal row stores (default; PRIFIT_SA_NT=0 for A/B): the rows do not evict U from L2
     int feat_xyz;          // MODE 0: the first 3 feature channels ARE the coordinates (taken from the LDS cloud)
     float r2[4];
     int K[4], C[4];
@@ -455,7 +454,6 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
     SAGroupArgs a;
     a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.B = B; a.N = N; a.S = S; a.feat_first = feat_first;
     a.feat_xyz = feat_xyz;
-    { const char *e = getenv("PRIFIT_SA_NT"); a.nt = e ? atoi(e) : 1; }
     int ksum = 0;
     for (int r = 0; r < 4; ++r) {
         const bool in = r < R;

@@ -27,19 +27,27 @@ class FlatGradBucket:
     its weight decay and stale moments there; a parameter that never had one stays `None` and is
     skipped.  The same rule holds with 1 and with N ranks, so the trajectories agree."""
 
-    def __init__(self, module, process_group=None, native=None):
+    def __init__(self, module, process_group=None, native=None, strict_seen=False):
         self.module = module
         self.group = process_group
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # the bucket ends with one has-gradient flag per parameter: summed by the same all-reduce, they make "has this
+        # parameter ever had a gradient" (self.seen) a GLOBAL fact -- with rank-local flags a rank whose shard produced
+        # no gradient for a parameter (a shape batch with no cluster, a data-dependent branch) would skip it in Adam
+        # while the others apply weight decay and moments to the averaged gradient: silent divergence of the replicas
+        self.nflat = n
+        self.flat = torch.zeros(n + len(self.params), dtype=torch.float32, device=dev)
+        self.flags = self.flat[n:]
         self.views = []
         off = 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.seen = [False] * len(self.params)   # has this parameter ever had a gradient (see the class docstring)
+        self.seen = [False] * len(self.params)   # has this parameter ever had a gradient ON ANY RANK (see the class docstring)
+        self.strict_seen = strict_seen
+        self._pending, self._flag_host = None, None
         self.dist = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist else 1
         # native=True / PRIFIT_NATIVE_RCCL=1: the all-reduce goes through the library's own RCCL communicator
@@ -61,17 +69,62 @@ class FlatGradBucket:
             if p.grad is not None:
                 self.seen[i] = True
 
-    def pack(self):
-        """Copy the per-parameter gradients into the bucket (zeros for parameters that got none) and point every
-        `p.grad` of a parameter that has ever had a gradient at its slice."""
-        self._mark_seen()
+    def pack(self, adopt=True):
+        """Copy the per-parameter gradients into the bucket (zeros for parameters that got none) and set the
+        has-gradient flags behind them; adopt: point `p.grad` of every parameter that has ever had a gradient at its
+        slice (allreduce() does that after the exchange instead, with the other ranks' flags)."""
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         if len(have) != len(self.params):
             self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        local = [p.grad is not None for p in self.params]
+        if all(local):
+            self.flags.fill_(1.0)
+        else:
+            self.flags.copy_(torch.tensor(local, dtype=torch.float32), non_blocking=True)
+        if adopt:
+            self.seen = [s or l for s, l in zip(self.seen, local)]
+            for v, p, s in zip(self.views, self.params, self.seen):
+                p.grad = v if s else None
+        return local
+
+    def _adopt(self, local):
+        """After the exchange: a parameter that had a gradient on ANY rank, now or earlier, gets its bucket slice.
+        Whether another rank had a gradient this rank lacks is in the reduced flags.  They are read on the host only when
+        it can matter -- some parameter here has no gradient now and never had one -- and then either synchronously
+        (`strict_seen`, and always for host buckets: exact) or, on the device path, asynchronously: the step carries on
+        with the rank-local answer and the NEXT exchange raises if the flags say that answer was wrong, so a divergence
+        of the replicas is never silent and the steady state has no host read-back."""
+        self._check_pending()
+        open_ = [i for i, (s, l) in enumerate(zip(self.seen, local)) if not (s or l)]
+        self.seen = [s or l for s, l in zip(self.seen, local)]
+        if open_ and (self.strict_seen or not self.flat.is_cuda):
+            got = (self.flags > 0).tolist()
+            self.seen = [s or g for s, g in zip(self.seen, got)]
+        elif open_:
+            if self._flag_host is None:
+                self._flag_host = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
+            self._flag_host.copy_(self.flags, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (ev, open_)
         for v, p, s in zip(self.views, self.params, self.seen):
             p.grad = v if s else None
+
+    def _check_pending(self):
+        if self._pending is None:
+            return
+        ev, open_ = self._pending
+        self._pending = None
+        ev.synchronize()
+        bad = [i for i in open_ if float(self._flag_host[i]) > 0]
+        if bad:
+            names = {id(p): n for n, p in self.module.named_parameters()}
+            raise RuntimeError("gradient exchange: %s received a gradient on another rank only; this rank skipped it in "
+                               "the optimizer step and the replicas have diverged.  Construct FlatGradBucket(..., "
+                               "strict_seen=True) when ranks can disagree on which parameters get gradients."
+                               % ", ".join(names.get(id(self.params[i]), "#%d" % i) for i in bad))
 
     def allreduce(self):
         """Average gradients over ranks: one sum all-reduce of the flat bucket, then scale by 1/world.
@@ -86,12 +139,13 @@ class FlatGradBucket:
                     if s and p.grad is None:
                         p.grad = v
             return
-        self.pack()
+        local = self.pack(adopt=False)
         if self.native is not None:
             self.native.allreduce_(self.flat)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.mul_(1.0 / self.world)
+        self._adopt(local)
+        self.flat[:self.nflat].mul_(1.0 / self.world)
 
     def broadcast_parameters(self, src=0):
         if self.dist:

@@ -32,6 +32,10 @@ MS_BALANCED = __import__("os").environ.get("PRIFIT_MS_BALANCED", "1") != "0"
 MS_BALANCED_FWD = __import__("os").environ.get("PRIFIT_MS_BALANCED_FWD", "0") != "0"
 CHORD_SYM = __import__("os").environ.get("PRIFIT_CHORD_SYM", "1") != "0"   # symmetric kernel for chord_matrix(X, X)
 DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
+# cluster(): the loss reads the shifted points through `center = new_X[indices]` only, so the mean-shift backward runs
+# on those rows alone (MeanShiftRowsFn); 0 = the dense backward of MeanShiftFn + a gather (same numbers; the A/B arm
+# and the path of callers that differentiate through the whole of new_X)
+ROWS_BWD = __import__("os").environ.get("PRIFIT_MS_ROWS", "1") != "0"
 
 
 def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
@@ -70,20 +74,25 @@ def compute_bandwidth(X, quantile, num_samples=None, rows=None):
 
     num_samples < N (upstream :148-151: a random row subset, the default of `clustering(X)`, num_samples=1000): the
     statistic is taken over `rows` [B, num_samples] (int64 row indices; hidden randomness made an explicit input like
-    the other ones) or, when omitted, over a fresh random subset per shape, as upstream."""
+    the other ones) or, when omitted, over a fresh random subset per shape, as upstream.  num_samples > N: upstream's
+    slice keeps all N rows and K = int(quantile * num_samples) (:155) all the same -- and so here (topk raises when
+    K exceeds the row length; so does this)."""
     Bt, N, D = X.shape
-    if num_samples is not None and num_samples < N:
+    ns = N if num_samples is None else int(num_samples)
+    if ns < N:
         if rows is None:
-            rows = torch.stack([torch.randperm(N, device=X.device)[:num_samples] for _ in range(Bt)])
+            rows = torch.stack([torch.randperm(N, device=X.device)[:ns] for _ in range(Bt)])
         rows = rows.to(X.device).long()
-        if rows.shape != (Bt, num_samples):
+        if rows.shape != (Bt, ns):
             raise ValueError("bandwidth rows must be [B, num_samples]")
         X = torch.gather(X, 1, rows.unsqueeze(-1).expand(-1, -1, D)).contiguous()
-        N = num_samples
+        N = ns
     dist = chord_matrix(X, X)
-    k = int(quantile * N)
+    k = int(quantile * ns)
     if k < 1:
         raise ValueError("quantile * num_samples < 1: torch.topk(k=0) upstream")
+    if k > N:
+        raise ValueError("k = int(quantile * num_samples) = %d exceeds the %d rows (torch.topk raises upstream)" % (k, N))
     kth = torch.empty(Bt * N, dtype=torch.float32, device=X.device)
     call("prifit_kth_smallest_rows", ptr(dist), _LL(Bt * N), N, k, ptr(kth), cur_stream())
     return torch.sqrt(torch.clamp(kth, min=1e-6)).view(Bt, N).mean(dim=1)
@@ -111,6 +120,91 @@ class Normalize2Fn(torch.autograd.Function):
         return gx
 
 
+def mean_shift_trajectory(X, bw, iterations, keep_kernel):
+    """`iterations` updates of src/mean_shift.py:61-82 (gaussian kernel, delta = 1) for all shapes at once, no autograd.
+    X [B,N,D] unit rows (contiguous), bw [B].  Returns (Z_final, per iteration [Z_in, K or None, O, rowsum, Z_out, nrm]);
+    keep_kernel=False: the N x N kernel matrix is not kept (D = 128: never written -- prifit_meanshift_fused_fwd with
+    KT = NULL; other widths: one scratch matrix for the GEMM chain)."""
+    Bt, N, D = X.shape
+    dev = X.device
+    fused = D == 128  # flash-style kernel (csrc/meanshift_fused.hip); other widths take the GEMM chain
+    Z = X.clone()
+    saved = []
+    scratch = None
+    for _ in range(iterations):
+        Kmat = None
+        if keep_kernel:
+            Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)  # fused: K^T [key][query]; else K
+        elif not fused:
+            scratch = Kmat = scratch if scratch is not None else torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
+        if fused and MS_BALANCED_FWD:   # stream-K schedule: split query blocks accumulate O / rowsum with atomics
+            O = zero_pool.zeros(Bt, N, D, device=dev)
+            rsum = zero_pool.zeros(Bt, N, device=dev)
+        else:
+            O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
+            rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+        Zn = torch.empty_like(Z)
+        nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+        if fused:
+            with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
+                call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
+                     _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), int(MS_BALANCED_FWD), cur_stream())
+        else:
+            _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
+            _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X, rowsum(K)
+            call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
+                 cur_stream())
+        saved.append([Z, Kmat if keep_kernel else None, O, rsum, Zn, nrm])
+        Z = Zn
+    return Z, saved
+
+
+def rows_supported(N, D, R):
+    return bool(dll().prifit_meanshift_rows_supported(N, D, R))
+
+
+class MeanShiftRowsFn(torch.autograd.Function):
+    """centres = new_X[ids] of src/mean_shift.py:44-46 as a function of the embedding X, given the trajectory
+    `mean_shift_trajectory(X, bw, T, keep_kernel=False)` already computed (nms needed its end point to choose ids).
+
+    Row i of an iterate depends on row i of the previous one alone (the dictionary is the fixed X, :65), so the gradient
+    that enters through the gathered rows stays on those rows in every iteration: the backward is R x N x D products per
+    iteration (prifit_meanshift_rows_bwd) instead of the dense N x N x D ones -- the same numbers, the dense form's other
+    rows multiply exact zeros.  apply(X, bw, ids [B,R] int64, nrows [B] int32 or None, traj) -> [B,R,D]."""
+
+    @staticmethod
+    def forward(ctx, X, bw, ids, nrows, traj):
+        X = X.contiguous()
+        Bt, N, D = X.shape
+        R = ids.shape[1]
+        if not rows_supported(N, D, R):
+            raise ValueError("row-sparse mean-shift backward: D in {32, 64, 128}, R <= 32 (got D=%d, R=%d)" % (D, R))
+        ids = ids.to(device=X.device, dtype=torch.int64).clamp(0, N - 1).contiguous()
+        Zf = traj[-1][4] if traj else X
+        out = torch.gather(Zf, 1, ids.unsqueeze(-1).expand(-1, -1, D))
+        # (attributes, not save_for_backward: nothing saved here is an output of this function, so no reference cycle)
+        ctx.traj, ctx.X, ctx.bw, ctx.ids = traj, X, bw, ids
+        ctx.nrows = None if nrows is None else nrows.to(device=X.device, dtype=torch.int32).contiguous()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, bw, ids, nrows, traj = ctx.X, ctx.bw, ctx.ids, ctx.nrows, ctx.traj
+        ctx.traj = None
+        Bt, N, D = X.shape
+        R = ids.shape[1]
+        g = g.contiguous()
+        gX = zero_pool.zeros(Bt, N, D, device=X.device)
+        ws = torch.empty(dll().prifit_meanshift_rows_bwd_workspace(Bt, N, D, R), dtype=torch.float32, device=X.device)
+        T = len(traj)
+        arr = lambda k: (ctypes.c_void_p * max(T, 1))(*[it[k].data_ptr() for it in traj])
+        # work: R of N query rows of the dense backward's four products per iteration
+        with profiler.span("ms_rows_bwd", 8.0 * Bt * R * N * D * T):
+            call("prifit_meanshift_rows_bwd", ptr(X), ptr(bw), Bt, N, D, T, arr(0), arr(4), arr(2), arr(3), arr(5), ptr(ids),
+                 ptr(nrows), R, ptr(g), ptr(ws), ptr(gX), cur_stream())
+        return gX, None, None, None, None
+
+
 class MeanShiftFn(torch.autograd.Function):
     """src/mean_shift.py:50-84 (gaussian kernel, delta = 1), all shapes at once.
 
@@ -122,36 +216,11 @@ class MeanShiftFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, bw, iterations):
         X = X.contiguous()
-        Bt, N, D = X.shape
-        dev = X.device
-        fused = D == 128  # flash-style kernel (csrc/meanshift_fused.hip); other widths take the GEMM chain
-        Z = X.clone()
-        saved = []
-        for _ in range(iterations):
-            Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)  # fused: K^T [key][query]; else K
-            if fused and MS_BALANCED_FWD:   # stream-K schedule: split query blocks accumulate O / rowsum with atomics
-                O = zero_pool.zeros(Bt, N, D, device=dev)
-                rsum = zero_pool.zeros(Bt, N, device=dev)
-            else:
-                O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
-                rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
-            Zn = torch.empty_like(Z)
-            nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
-            if fused:
-                with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
-                    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
-                         _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), int(MS_BALANCED_FWD), cur_stream())
-            else:
-                _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
-                _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X, rowsum(K)
-                call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
-                     cur_stream())
-            saved += [Z, Kmat, O, rsum, Zn, nrm]
-            Z = Zn
+        Z, saved = mean_shift_trajectory(X, bw, iterations, keep_kernel=True)
         # save_for_backward (not a python attribute): the last Zn IS the output, and an attribute would close a
         # reference cycle output -> grad_fn -> ctx -> output that only the cyclic GC frees (4 GB of K per step)
-        ctx.save_for_backward(X, bw, *saved)
-        ctx.fused = fused
+        ctx.save_for_backward(X, bw, *[t for it in saved for t in it])
+        ctx.fused = X.shape[2] == 128
         return Z
 
     @staticmethod
@@ -433,13 +502,32 @@ def speculative():
         _spec = prev
 
 
+def _shift(X, bw, iterations):
+    """The shifted points for nms + what the centre gather needs afterwards: (Z detached, handle).  Row-sparse engine:
+    handle = the trajectory (no autograd graph yet); dense engine: handle = the differentiable Z of MeanShiftFn."""
+    Bt, N, D = X.shape
+    if ROWS_BWD and rows_supported(N, D, KM):
+        with torch.no_grad():
+            Z, traj = mean_shift_trajectory(X.detach().contiguous(), bw, iterations, keep_kernel=False)
+        return Z, traj
+    Z = MeanShiftFn.apply(X, bw, iterations)
+    return Z.detach(), Z
+
+
+def _centres(X, bw, handle, ids, count):
+    """center = new_X[indices] (src/mean_shift.py:46), [B,KM,D], differentiable w.r.t. X."""
+    if isinstance(handle, list):
+        return MeanShiftRowsFn.apply(X, bw, ids, count.clamp(max=KM), handle)
+    return torch.gather(handle, 1, ids.unsqueeze(-1).expand(-1, -1, X.shape[2]))
+
+
 def _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples=None, bandwidth_rows=None):
     Bt, N, D = X.shape
     with torch.no_grad():
         bw = compute_bandwidth(X, quantile, num_samples, bandwidth_rows)
-    Z = MeanShiftFn.apply(X, bw, iterations)
+    Z, handle = _shift(X, bw, iterations)
     with torch.no_grad():
-        ids, count, labels, used = nms(Z.detach(), bw)
+        ids, count, labels, used = nms(Z, bw)
         nuniq = torch.where(count > NMS_CAP, count, used.sum(dim=1).to(torch.int32))
         bad = ((nuniq > max_num_clusters) | (count > KM)).any().to(torch.int32).reshape(1)
         flag = _pinned_flag()
@@ -448,7 +536,7 @@ def _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples=
         ev.record()
         _spec.checks.append((ev, flag))
     return {"bw": bw, "ids": ids[:, :KM].long(), "count": count, "labels": labels.long(),
-            "quantile": [quantile] * Bt, "Z": Z}
+            "quantile": [quantile] * Bt, "Z": Z, "_handle": handle}
 
 
 def _pin_representatives(res, center_ids):
@@ -489,7 +577,7 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
         res = _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples, bandwidth_rows)
         if center_ids is not None:
             _pin_representatives(res, center_ids)
-        res["centres"] = torch.gather(res["Z"], 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))
+        res["centres"] = _centres(X, res["bw"], res.pop("_handle"), res["ids"], res["count"])
         res["W"] = MembershipFn.apply(res["centres"], X, res["bw"], res["count"])
         return res
     res = {"bw": torch.empty(Bt, device=dev), "ids": torch.zeros(Bt, KM, dtype=torch.int64, device=dev),
@@ -497,7 +585,7 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
            "labels": torch.zeros(Bt, N, dtype=torch.int64, device=dev), "quantile": [quantile] * Bt}
     pending = torch.arange(Bt, device=dev)
     q = quantile
-    Zs, idx_sets = [], []
+    rounds = []   # (shapes of the round, accepted mask, X of the round, bw, Z detached, handle)
     while pending.numel():
         Xp = X if pending.numel() == Bt else X.index_select(0, pending)
         with torch.no_grad():
@@ -505,9 +593,9 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
             if rows_p is not None and pending.numel() != Bt:
                 rows_p = rows_p.to(dev).index_select(0, pending)
             bw = compute_bandwidth(Xp, q, num_samples, rows_p)
-        Z = MeanShiftFn.apply(Xp, bw, iterations)
+        Z, handle = _shift(Xp, bw, iterations)
         with torch.no_grad():
-            ids, count, labels, used = nms(Z.detach(), bw)
+            ids, count, labels, used = nms(Z, bw)
             nuniq = torch.where(count > NMS_CAP, count, used.sum(dim=1).to(torch.int32))
             host = torch.stack([count, nuniq]).cpu()  # the one host sync of the round (guard_mean_shift's check)
         ok = host[1] <= max_num_clusters
@@ -520,20 +608,29 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
             res["ids"][sel] = ids[okd][:, :KM].long()
             res["count"][sel] = count[okd]
             res["labels"][sel] = labels[okd].long()
-            Zs.append(Z[okd] if not bool(ok.all()) else Z)
-            idx_sets.append(sel)
+            rounds.append((pending, okd, Xp, bw, Z, handle))
             for i in sel.tolist():
                 res["quantile"][i] = q
         pending = pending[~okd]
         q *= 2
-    if len(Zs) == 1 and idx_sets[0].numel() == Bt:
-        Zfull = Zs[0]
+    if len(rounds) == 1 and bool(rounds[0][1].all()):
+        Zfull = rounds[0][4]
     else:
-        Zfull = torch.zeros(Bt, N, D, device=dev).index_copy(0, torch.cat(idx_sets), torch.cat(Zs))
+        Zfull = torch.zeros(Bt, N, D, device=dev).index_copy(0, torch.cat([p[o] for p, o, *_ in rounds]),
+                                                             torch.cat([z[o] for _, o, _, _, z, _ in rounds]))
     res["Z"] = Zfull
     if center_ids is not None:
         _pin_representatives(res, center_ids)
-    centres = torch.gather(Zfull, 1, res["ids"].unsqueeze(-1).expand(-1, -1, D))  # center = new_X[indices] (:46)
+    # center = new_X[indices] (:46), per round: a shape's centres come from the trajectory of the round that accepted it
+    if len(rounds) == 1 and bool(rounds[0][1].all()):
+        _, _, Xp, bw, _, handle = rounds[0]
+        centres = _centres(Xp, bw, handle, res["ids"], res["count"])
+    else:
+        centres = torch.zeros(Bt, KM, D, device=dev)
+        for shapes, okd, Xp, bw, _, handle in rounds:
+            live = torch.where(okd, res["count"].index_select(0, shapes), torch.zeros_like(res["count"].index_select(0, shapes)))
+            cen = _centres(Xp, bw, handle, res["ids"].index_select(0, shapes), live)
+            centres = centres.index_copy(0, shapes[okd], cen[okd])
     res["centres"] = centres
     res["W"] = MembershipFn.apply(centres, X, res["bw"], res["count"])
     return res

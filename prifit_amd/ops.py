@@ -17,18 +17,22 @@ class SampledAhead:
     """Farthest-point samples of one set-abstraction level computed ahead of the step that uses them (`sample_ahead`):
     pass it where a module takes `fps_start`.  `farthest_point_sample` then only makes the consuming stream wait for the
     event and hands the stored (indices, coordinates) out -- the same numbers the in-line launch would produce."""
-    __slots__ = ("idx", "new_xyz", "event", "npoint", "keep")
+    __slots__ = ("idx", "new_xyz", "event", "npoint", "keep", "consumed")
 
     def __init__(self, idx, new_xyz, event, keep=()):
         self.idx, self.new_xyz, self.event, self.npoint = idx, new_xyz, event, idx.shape[1]
         self.keep = keep   # the side stream's inputs: not back to the allocator before the consumer has waited for the event
+        self.consumed = False   # set by farthest_point_sample once the consuming stream waits for the event
 
     def __del__(self):
-        # dropped without having been consumed: the side stream may still be writing idx / new_xyz, whose memory goes back
-        # to the CONSUMING stream's allocator pool right now -- let the chain finish first
+        # dropped WITHOUT having been consumed: the side stream may still be writing idx / new_xyz, whose memory goes back to
+        # the consuming stream's allocator pool right now -- make that stream wait for the chain (a device-side wait: no
+        # host sync in a finaliser).  Once consumed, the consumer's wait_event already orders every later reuse.
+        if self.consumed:
+            return
         try:
             if not self.event.query():
-                self.event.synchronize()
+                torch.cuda.current_stream(self.idx.device).wait_event(self.event)
         except Exception:   # interpreter shutdown
             pass
 
@@ -77,6 +81,7 @@ def farthest_point_sample(xyz, npoint, start_idx=None, return_xyz=False):
             raise ValueError("SampledAhead holds %s samples, the module asks for [%d, %d]"
                              % (tuple(start_idx.idx.shape), xyz.shape[0], npoint))
         torch.cuda.current_stream(xyz.device).wait_event(start_idx.event)
+        start_idx.consumed = True
         return (start_idx.idx, start_idx.new_xyz) if return_xyz else start_idx.idx
     xyz = cf(xyz)
     B, N, _ = xyz.shape

@@ -7,7 +7,9 @@
 process group is then only the side channel that carries the 128-byte unique id and the parameter broadcast.  The
 default stays `torch.distributed` (backend "nccl" IS RCCL on ROCm): same collective, one code path fewer to set up.
 """
+import atexit
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -23,7 +25,13 @@ class NativeComm:
         self.nranks, self.rank = nranks, rank
         self._comm = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(unique_id, n)
+        # torch.distributed's nccl backend has its RCCL loaded in this process; the library must bind THAT copy (a second
+        # RCCL instance in one process is undefined): prifit_comm_in_process() says whether it did
+        if dist.is_initialized() and dist.get_backend() == "nccl" and not dll().prifit_comm_in_process():
+            raise RuntimeError("libprifit_hip.so did not find the RCCL already loaded by torch.distributed (nccl backend) and "
+                               "would load a second copy; use FlatGradBucket(native=False)")
         call("prifit_comm_init", ctypes.byref(self._comm), nranks, rank, buf)
+        _live.add(self)
 
     @staticmethod
     def new_unique_id() -> bytes:
@@ -48,5 +56,23 @@ class NativeComm:
 
     def destroy(self):
         if self._comm:
-            call("prifit_comm_destroy", self._comm)
-            self._comm = ctypes.c_void_p()
+            comm, self._comm = self._comm, ctypes.c_void_p()
+            call("prifit_comm_destroy", comm)
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:   # interpreter shutdown / the library already unloaded
+            pass
+
+
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _destroy_all():
+    for c in list(_live):
+        try:
+            c.destroy()
+        except Exception:
+            pass

@@ -29,7 +29,7 @@ def clustering(X, num_samples=1000, quantile=0.01, iterations=5, visualize=False
     `num_samples` < N: the bandwidth is estimated on a row subset (upstream src/mean_shift.py:148-151) -- random per
     shape, or `bandwidth_rows` [B, num_samples] when the caller wants it reproducible."""
     cl = fit_ops.cluster(X.contiguous(), quantile, iterations, max_num_clusters, center_ids=center_ids,
-                         num_samples=min(num_samples, X.shape[1]), bandwidth_rows=bandwidth_rows)
+                         num_samples=num_samples, bandwidth_rows=bandwidth_rows)
     counts = cl["count"].cpu().tolist()
     return [cl["W"][b, :, :counts[b]] for b in range(X.shape[0])], list(cl["labels"].unbind(0))
 

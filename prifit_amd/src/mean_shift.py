@@ -14,14 +14,26 @@ class MeanShift:
         if bw is None:
             with torch.no_grad():
                 bw = self.compute_bandwidth(X, num_samples, quantile)
-        bwb = bw.reshape(1).to(X.device, torch.float32)
-        Z = fit_ops.MeanShiftFn.apply(Xb, bwb, iterations)
+        bwb = torch.as_tensor(bw, dtype=torch.float32, device=X.device).reshape(1)
+        N, D = X.shape
+        rows = fit_ops.ROWS_BWD and fit_ops.rows_supported(N, D, fit_ops.KM)
+        if rows:   # the gradient enters through `new_X[indices]` (:46) alone: trajectory now, row-sparse backward later
+            with torch.no_grad():
+                Z, traj = fit_ops.mean_shift_trajectory(Xb.detach(), bwb, iterations, keep_kernel=False)
+        else:
+            Zg = fit_ops.MeanShiftFn.apply(Xb, bwb, iterations)
+            Z = Zg.detach()
         with torch.no_grad():
-            ids, count, labels, _ = fit_ops.nms(Z.detach(), bwb)
+            ids, count, labels, _ = fit_ops.nms(Z, bwb)
         K = int(count.item())
         if K > fit_ops.NMS_CAP:
             raise RuntimeError("more than %d clusters" % fit_ops.NMS_CAP)
-        return Z[0][ids[0, :K].long()], bw, labels[0].long()
+        ids = ids[:, :K].long()
+        if rows and K <= fit_ops.KM:
+            return fit_ops.MeanShiftRowsFn.apply(Xb, bwb, ids, None, traj)[0], bw, labels[0].long()
+        if rows:   # more kept centres than row slots: the dense engine
+            Zg = fit_ops.MeanShiftFn.apply(Xb, bwb, iterations)
+        return Zg[0][ids[0]], bw, labels[0].long()
 
     def mean_shift_(self, X, b, iterations=10, kernel_type="gaussian"):
         """upstream :50-84 -> (new_X, X)."""
@@ -32,10 +44,13 @@ class MeanShift:
         """upstream :138-160; num_samples < N takes the statistic over a random row subset (`rows` [num_samples]
         makes it reproducible)."""
         rows = None if rows is None else torch.as_tensor(rows).reshape(1, -1)
-        return fit_ops.compute_bandwidth(X.unsqueeze(0).contiguous(), quantile, min(num_samples, X.shape[0]), rows)[0]
+        return fit_ops.compute_bandwidth(X.unsqueeze(0).contiguous(), quantile, num_samples, rows)[0]
 
     def nms(self, centers, X, b):
         """upstream :162-202 for centers is X (the only way it is called, :44)."""
+        if centers is not X and not (centers.shape == X.shape and centers.data_ptr() == X.data_ptr()):
+            raise NotImplementedError("nms(centers, X, b) is implemented for centers is X only (upstream calls it as "
+                                      "nms(new_X, new_X, b), src/mean_shift.py:44)")
         bwb = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(1)
         ids, count, labels, _ = fit_ops.nms(X.unsqueeze(0).contiguous(), bwb)
         K = int(count.item())

@@ -157,15 +157,24 @@ class Trainer:
         return ss_loss.detach()
 
     # ------------------------------------------------------------------ checkpoints (upstream :467-475, :263-274)
-    def save(self, path):
-        """Collective under torch.distributed: every rank calls it, rank 0's BatchNorm statistics win
-        ("replica 0" of DataParallel) and only rank 0 writes the file."""
-        import torch.distributed as dist
+    def sync_buffers(self):
+        """COLLECTIVE: rank 0's BatchNorm statistics win on every rank ("replica 0" of DataParallel)."""
         self.bucket.sync_buffers(0)
-        if dist.is_initialized() and dist.get_rank() != 0:
-            return
+
+    def write_checkpoint(self, path):
+        """Local, no communication: the checkpoint dict of upstream :467-475 -- safe under `if rank == 0:`."""
         torch.save({"epoch": self.epoch, "train_acc": self.train_acc, "model_state_dict": self.model.state_dict(),
                     "optimizer_state_dict": self.optimizer.state_dict()}, path)
+
+    def save(self, path):
+        """sync_buffers() + write_checkpoint() on rank 0.  COLLECTIVE under torch.distributed: EVERY rank must call it
+        (a caller that guards it with `if rank == 0:` would leave rank 0 alone in the broadcast -- such a caller uses
+        write_checkpoint, after a sync_buffers() that all ranks entered)."""
+        import torch.distributed as dist
+        self.sync_buffers()
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return
+        self.write_checkpoint(path)
 
     def load(self, path):
         ck = torch.load(path, map_location="cpu")

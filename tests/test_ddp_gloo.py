@@ -73,6 +73,51 @@ def test_flat_bucket_allreduce_two_ranks():
     assert torch.isfinite(grad).all() and grad.abs().sum() > 0
 
 
+def _asym_worker(rank, world, port, out):
+    """Rank 0's loss reaches both heads, rank 1's only head_a (a data-dependent branch): head_b has a gradient on rank 0
+    alone.  Both ranks must treat head_b the same way in Adam -- the averaged gradient (rank 1 contributes zeros)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prifit_amd.ddp import FlatGradBucket
+
+    class TwoHeads(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = torch.nn.Linear(6, 8)
+            self.head_a = torch.nn.Linear(8, 3)
+            self.head_b = torch.nn.Linear(8, 2)
+
+    torch.manual_seed(3)
+    net = TwoHeads()
+    bucket = FlatGradBucket(net)
+    bucket.broadcast_parameters(0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=1e-2)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(11 + rank))
+    had = []
+    for step in range(3):
+        bucket.zero()
+        h = torch.relu(net.trunk(x))
+        loss = net.head_a(h).pow(2).mean()
+        if rank == 0 and step >= 1:          # from step 1 on, on rank 0 only
+            loss = loss + net.head_b(h).pow(2).mean()
+        loss.backward()
+        bucket.allreduce()
+        had.append(net.head_b.weight.grad is not None)
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    out.put((rank, flat.numpy().copy(), had))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gradient_on_one_rank_only_is_adopted_by_all():
+    (_, f0, had0), (_, f1, had1) = _run_two(_asym_worker)
+    assert had0 == had1 == [False, True, True]          # never-seen -> skipped by both; seen on one rank -> seen by both
+    assert (f0 == f1).all(), "replicas diverged"
+
+
 def test_single_process_bucket_matches_plain_autograd():
     sys.path.insert(0, ROOT)
     from prifit_amd.ddp import FlatGradBucket

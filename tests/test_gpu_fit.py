@@ -448,6 +448,79 @@ def test_subsampled_bandwidth_matches_reference_golden(hiplib, golden):
         fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000, rows=rows[:, :10].cuda())
 
 
+def test_bandwidth_with_more_samples_than_rows(hiplib, golden):
+    """num_samples > N keeps all rows and takes K = int(quantile * num_samples) (src/mean_shift.py:151-155), against the
+    value captured from the reference; K beyond the row length raises like upstream's topk."""
+    from prifit_amd import fit_ops
+    from prifit_amd.src.mean_shift import MeanShift
+    g = golden("fit_bandwidth_over")
+    _, _, emb = fit_inputs(2, int(g["N"]), 128, int(g["seed"]))
+    bw = fit_ops.compute_bandwidth(emb.cuda(), float(g["quantile"]), num_samples=int(g["num_samples"])).cpu()
+    ref = torch.tensor([float(g["bw_0"]), float(g["bw_1"])])
+    torch.testing.assert_close(bw, ref, rtol=1e-5, atol=1e-7)
+    one = MeanShift().compute_bandwidth(emb[0].cuda(), int(g["num_samples"]), float(g["quantile"]))
+    torch.testing.assert_close(one.cpu(), ref[0], rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        fit_ops.compute_bandwidth(emb.cuda(), 0.9, num_samples=1000)      # K = 900 > 512 rows
+
+
+@pytest.mark.parametrize("N,D,T,nrows", [(2048, 128, 10, (8, 1, 32)), (300, 128, 3, (5, 0, 2)), (1500, 32, 5, (3, 32, 7)),
+                                         (256, 64, 2, (32, 32, 32)), (2048, 128, 0, (4, 4, 4))])
+def test_mean_shift_row_sparse_backward_equals_dense(F, N, D, T, nrows):
+    """MeanShiftRowsFn (the loss reads new_X[ids] only: backward on those rows alone) against the dense engine --
+    MeanShiftFn + gather, whose other rows multiply exact zeros: same centres bit for bit, same dX to fp32 rounding.
+    Ragged N, all three widths, per-shape live counts incl. 0 and the full 32 slots, zero iterations."""
+    B, R = 3, F.KM
+    gen = torch.Generator().manual_seed(N + D + T)
+    # clustered rows so that kernel values span the clamp: prototypes + noise
+    proto = torch.nn.functional.normalize(torch.randn(6, D, generator=gen), dim=1)
+    X = torch.nn.functional.normalize(proto[torch.randint(0, 6, (B, N), generator=gen)] + 0.15 * torch.randn(B, N, D, generator=gen), dim=2)
+    bw = torch.tensor([0.35, 0.5, 0.8])
+    ids = torch.stack([torch.randperm(N, generator=gen)[:R] for _ in range(B)])
+    nr = torch.tensor(nrows, dtype=torch.int32)
+    G = torch.randn(B, R, D, generator=gen)
+    live = (torch.arange(R).view(1, R) < nr.view(B, 1)).view(B, R, 1).float()
+
+    Xd = X.cuda().requires_grad_(True)
+    Zd = F.MeanShiftFn.apply(Xd, bw.cuda(), T) if T else Xd.clone()
+    cd = torch.gather(Zd, 1, ids.cuda().unsqueeze(-1).expand(-1, -1, D))
+    (cd * (G * live).cuda()).sum().backward()
+
+    Xr = X.cuda().requires_grad_(True)
+    with torch.no_grad():
+        Zf, traj = F.mean_shift_trajectory(Xr.detach(), bw.cuda(), T, keep_kernel=False)
+    assert all(it[1] is None for it in traj)
+    cr = F.MeanShiftRowsFn.apply(Xr, bw.cuda(), ids.cuda(), nr.cuda(), traj)
+    (cr * G.cuda()).sum().backward()          # slots beyond nrows: their gradient must be ignored
+
+    assert torch.equal(Zf, Zd.detach())
+    assert torch.equal(cr.detach(), cd.detach())
+    ref = Xd.grad
+    assert torch.isfinite(Xr.grad).all()
+    torch.testing.assert_close(Xr.grad, ref, rtol=2e-4, atol=2e-5 * ref.abs().max().item())
+    assert abs(Xr.grad.norm().item() - ref.norm().item()) <= 1e-4 * ref.norm().item()
+
+
+def test_cluster_gradient_same_with_both_mean_shift_engines(F, monkeypatch):
+    """cluster() -> centres / membership -> a scalar: d/dX with the row-sparse engine (default) and with the dense one."""
+    _, _, emb = fit_inputs(2, 2048, 128, 7)
+    Gc = torch.randn(2, F.KM, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    Gw = torch.randn(2, 2048, F.KM, generator=torch.Generator().manual_seed(2)).cuda()
+    grads, outs = [], []
+    for rows in (True, False):
+        monkeypatch.setattr(F, "ROWS_BWD", rows)
+        X = emb.cuda().requires_grad_(True)
+        cl = F.cluster(X, 0.05, 10, 25)
+        live = (torch.arange(F.KM, device="cuda").view(1, -1) < cl["count"].view(-1, 1)).unsqueeze(-1)
+        ((cl["centres"] * Gc * live).sum() + (cl["W"] * Gw).sum()).backward()
+        grads.append(X.grad.clone())
+        outs.append(cl)
+    for k in ("bw", "ids", "count", "labels", "Z", "centres", "W"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert int(outs[0]["count"].min()) >= 2
+    torch.testing.assert_close(grads[0], grads[1], rtol=2e-4, atol=2e-5 * grads[1].abs().max().item())
+
+
 def test_dx_streams_kernel_matches_dual_gemm(hiplib):
     """prifit_meanshift_dx_streams (opt-in, atomics-free dX of a mean-shift backward iteration) against the dual-source
     GEMM on the same streams, and its run-to-run bit-reproducibility."""

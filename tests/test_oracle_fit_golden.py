@@ -116,3 +116,14 @@ def test_subsampled_bandwidth_matches_reference(golden):
     for b in range(2):
         bw = orc.compute_bandwidth(emb[b], 0.05, rows=g["rows_%d" % b].astype(np.int64))
         assert abs(float(bw) - float(g["bw_%d" % b])) <= 1e-6 * float(g["bw_%d" % b])
+
+
+def test_bandwidth_with_more_samples_than_rows_matches_reference(golden):
+    """src/mean_shift.py:151-155 with num_samples = 1000 > N = 512 (clustering(X)'s default on a small cloud): all N rows,
+    K = int(quantile * num_samples) = 50 -- not int(quantile * N) = 25."""
+    from tests_helpers import fit_inputs
+    g = golden("fit_bandwidth_over")
+    _, _, emb = fit_inputs(2, int(g["N"]), 128, int(g["seed"]))
+    for b in range(2):
+        bw = orc.compute_bandwidth(emb[b], float(g["quantile"]), num_samples=int(g["num_samples"]))
+        assert abs(float(bw) - float(g["bw_%d" % b])) <= 1e-6 * float(g["bw_%d" % b])
