@@ -11,7 +11,9 @@ Explicit inputs that replace hidden randomness / absent third-party code (SURVEY
   * `canonical`   pin the SVD column signs (largest component positive);
   * the surface sampler is the build's deterministic Fibonacci (U,V) table (trimesh is not used);
   * `center_ids`  (gradient-parity harness only) which point represents each mode -- last-bit noise in upstream's nms,
-                  yet the gradient enters through that point (fit_ops._pin_representatives).
+                  yet the gradient enters through that point (fit_ops._pin_representatives, SURVEY q14);
+  * `embedding_offset` (benchmark harness only) a per-point tensor added to the embedding: stands in for training, which
+                  is what separates the parts of a shape in embedding space (synth.part_embedding_offset).
 Optional terms (off in the README configuration): `include_entropy_loss` (upstream :59-62,209-225),
 `include_intersect_loss` (:96-99,374-413 -- upstream's scatter_mean import is commented out, so this term is
 parity-unpinned and restates the documented intent), `include_pruning` (:78-82: upstream computes the pruned
@@ -136,9 +138,13 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
                 visualize=False, max_num_clusters=25, class_list=[], include_intersect_loss=False, alpha=1, beta=1,
                 if_cuboid=False, include_pruning=False, include_entropy_loss=False, evaluation=False,
                 rand_table=None, canonical=True, return_info=False, entropy_indices=None, intersect_jitter=None,
-                center_ids=None):
-    """points [B,3,N], chamfer_points [B,3,M], X [B,D,N] (per-point embedding)."""
+                center_ids=None, embedding_offset=None):
+    """points [B,3,N], chamfer_points [B,3,M], X [B,D,N] (per-point embedding).
+    embedding_offset [B,N,D] (benchmark harness only, synth.part_embedding_offset): added to the embedding before the
+    normalisation."""
     emb = X.permute(0, 2, 1)
+    if embedding_offset is not None:
+        emb = emb + embedding_offset
     if emb.shape[2] <= 256 and emb.dtype == torch.float32:
         emb = fit_ops.Normalize2Fn.apply(emb)                # normalised twice upstream (:41,57), one kernel here
     else:

@@ -94,7 +94,8 @@ def compute_bandwidth(X, quantile, num_samples=None, rows=None):
     if k > N:
         raise ValueError("k = int(quantile * num_samples) = %d exceeds the %d rows (torch.topk raises upstream)" % (k, N))
     kth = torch.empty(Bt * N, dtype=torch.float32, device=X.device)
-    call("prifit_kth_smallest_rows", ptr(dist), _LL(Bt * N), N, k, ptr(kth), cur_stream())
+    with profiler.span("kth_smallest", 4.0 * Bt * N * N):
+        call("prifit_kth_smallest_rows", ptr(dist), _LL(Bt * N), N, k, ptr(kth), cur_stream())
     return torch.sqrt(torch.clamp(kth, min=1e-6)).view(Bt, N).mean(dim=1)
 
 
@@ -313,8 +314,9 @@ def nms(Z, bw):
     count = torch.empty(Bt, **i32)
     labels = torch.empty(Bt, N, **i32)
     used = torch.empty(Bt, NMS_CAP, **i32)
-    call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(owner), ptr(counts), ptr(flags), ptr(ids),
-         ptr(count), ptr(labels), ptr(used), cur_stream())
+    with profiler.span("nms", 8.0 * Bt * N * N):   # the chord matrix is read twice (owner, neighbour pick)
+        call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(owner), ptr(counts), ptr(flags), ptr(ids),
+             ptr(count), ptr(labels), ptr(used), cur_stream())
     return ids, count, labels, used
 
 
@@ -332,7 +334,8 @@ class MembershipFn(torch.autograd.Function):
         live = torch.arange(K, device=dev).view(1, 1, K) < count.view(Bt, 1, 1)
         gmax = dots.masked_fill(~live, float("-inf")).amax(dim=(1, 2)) / (bw * bw)  # global max, detached (:242)
         W = torch.empty_like(dots)
-        call("prifit_membership_fwd", ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(W), cur_stream())
+        with profiler.span("membership", 8.0 * Bt * N * K):
+            call("prifit_membership_fwd", ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(W), cur_stream())
         ctx.save_for_backward(centres, X, bw, count, dots, gmax, W)
         return W
 
@@ -343,8 +346,9 @@ class MembershipFn(torch.autograd.Function):
         K = centres.shape[1]
         gW = gW.contiguous()
         gd = torch.empty_like(dots)
-        call("prifit_membership_bwd", ptr(gW), ptr(W), ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(gd),
-             cur_stream())
+        with profiler.span("membership", 16.0 * Bt * N * K):
+            call("prifit_membership_bwd", ptr(gW), ptr(W), ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(gd),
+                 cur_stream())
         # dcentres = gd^T X: one 32 x 128 output tile per shape over N = 2048 rows -- split the reduction so that
         # more than 24 workgroups run (242 us -> tens of us at B = 24)
         sk = _skinny_splitk(K, D, N, Bt)
@@ -371,8 +375,9 @@ class EllipsoidFitFn(torch.autograd.Function):
         c = torch.empty(Bt, K, 3, dtype=torch.float32, device=dev)
         valid = torch.empty(Bt, K, dtype=torch.int32, device=dev)
         state = zero_pool.zeros(Bt, K, dll().prifit_fit_state_floats(), device=dev)
-        call("prifit_ellipsoid_fit_fwd", ptr(points), ptr(W), ptr(count), ptr(rnd), _LL(sb), _LL(sk), int(canonical),
-             Bt, N, K, ptr(r), ptr(V), ptr(c), ptr(valid), ptr(state), cur_stream())
+        with profiler.span("ellipsoid_fit", 3.0 * 16.0 * Bt * N * K):   # (12 + 4) N bytes, three passes, per cluster slot
+            call("prifit_ellipsoid_fit_fwd", ptr(points), ptr(W), ptr(count), ptr(rnd), _LL(sb), _LL(sk), int(canonical),
+                 Bt, N, K, ptr(r), ptr(V), ptr(c), ptr(valid), ptr(state), cur_stream())
         ctx.save_for_backward(points, W, count, rnd, state, valid)
         ctx.strides = (sb, sk)
         ctx.mark_non_differentiable(valid)
@@ -385,9 +390,10 @@ class EllipsoidFitFn(torch.autograd.Function):
         K = W.shape[2]
         sb, sk = ctx.strides
         gW = torch.empty_like(W)
-        call("prifit_ellipsoid_fit_bwd", ptr(points), ptr(W), ptr(count), ptr(valid), ptr(rnd), _LL(sb), _LL(sk),
-             ptr(state), ptr(g_r.contiguous()), ptr(g_V.contiguous()), ptr(g_c.contiguous()), Bt, N, K, ptr(gW),
-             cur_stream())
+        with profiler.span("ellipsoid_fit", 20.0 * Bt * N * K):
+            call("prifit_ellipsoid_fit_bwd", ptr(points), ptr(W), ptr(count), ptr(valid), ptr(rnd), _LL(sb), _LL(sk),
+                 ptr(state), ptr(g_r.contiguous()), ptr(g_V.contiguous()), ptr(g_c.contiguous()), Bt, N, K, ptr(gW),
+                 cur_stream())
         return None, gW, None, None, None
 
 
@@ -404,8 +410,9 @@ class SdfLossFn(torch.autograd.Function):
         fval = torch.empty(Bt, M, dtype=torch.float32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
         ctx.prim = "cuboid" if cuboid else "ellipsoid"   # convex_loss.py:473-502 vs :313-328
-        call("prifit_%s_sdf_fwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(arg),
-             ptr(fval), ptr(s), cur_stream())
+        with profiler.span("sdf", 20.0 * Bt * M):
+            call("prifit_%s_sdf_fwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(valid), K, ptr(arg),
+                 ptr(fval), ptr(s), cur_stream())
         ctx.save_for_backward(targets, r, V, c, arg)
         return s
 
@@ -415,8 +422,9 @@ class SdfLossFn(torch.autograd.Function):
         Bt, M, _ = targets.shape
         K = r.shape[1]
         g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
-        call("prifit_%s_sdf_bwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(arg), ptr(gs.contiguous()),
-             K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
+        with profiler.span("sdf", 16.0 * Bt * M):
+            call("prifit_%s_sdf_bwd" % ctx.prim, ptr(targets), Bt, M, ptr(r), ptr(V), ptr(c), ptr(arg), ptr(gs.contiguous()),
+                 K, ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return None, g_r, g_V, g_c, None, None
 
 
@@ -453,8 +461,9 @@ class SampleNNLossFn(torch.autograd.Function):
         Bt, M, _ = targets.shape
         K = r.shape[1]
         g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
-        call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
-             ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
+        with profiler.span("sample_nn", 0.0):
+            call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
+                 ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return g_r, g_V, g_c, None, None, None
 
 

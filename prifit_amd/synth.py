@@ -125,3 +125,27 @@ def ellipsoid_scene(B, seed, n_per=500, D=32):
             X[b, k * n_per:(k + 1) * n_per, k] = 1.0
             abc[b, k], ctr[b, k] = axes, c
     return pts, X, abc, ctr
+
+
+def part_labels(points, K=8, seed=0):
+    """A spatial partition of every cloud into K parts (what a trained part embedding encodes): the Voronoi cells of K
+    of its own points, chosen with a seeded permutation.  points [B,N,3] -> int64 [B,N]."""
+    rng = np.random.default_rng(seed + 32452843)
+    B, N, _ = points.shape
+    out = np.empty((B, N), dtype=np.int64)
+    for b in range(B):
+        anchors = points[b][rng.permutation(N)[:K]]
+        out[b] = ((points[b][:, None, :] - anchors[None]) ** 2).sum(-1).argmin(1)
+    return out
+
+
+def part_embedding_offset(labels, D=128, seed=0, K=8, noise=0.03, scale=30.0):
+    """What a TRAINED embedding head adds to an untrained one, as an explicit input: `scale` x (a random unit prototype
+    per part label + `noise` x N(0,1), normalised).  A seeded untrained PointNet++ maps every point of a shape to nearly
+    the same embedding direction: mean-shift finds ONE cluster per shape and the fit path downstream of it (nms, membership,
+    ellipsoid fit, SDF, sampler) runs at 1/8 .. 1/25 of its training-time work (the reference's regime is up to 25
+    clusters, README.md:62).  `convex_loss(..., embedding_offset=...)` adds this tensor to the network's embedding before
+    the normalisation -- the head's own output (norm ~8, one common direction) then only tilts the K prototypes, the
+    clusters are the parts, memberships are soft (noise 0.03), and the gradient still flows through head and backbone.
+    labels int64 [B,N] -> float32 [B,N,D]."""
+    return (scale * prototype_embedding(np.asarray(labels), D, seed + 2, K=K, noise=noise)).astype(np.float32)
