@@ -199,8 +199,8 @@ class MeanShiftRowsFn(torch.autograd.Function):
         ws = torch.empty(dll().prifit_meanshift_rows_bwd_workspace(Bt, N, D, R), dtype=torch.float32, device=X.device)
         T = len(traj)
         arr = lambda k: (ctypes.c_void_p * max(T, 1))(*[it[k].data_ptr() for it in traj])
-        # work: R of N query rows of the dense backward's four products per iteration
-        with profiler.span("ms_rows_bwd", 8.0 * Bt * R * N * D * T):
+        # HBM-bound: per iteration the dictionary is read once and dX read-modified-written once (12 B per element)
+        with profiler.span("ms_rows_bwd", 12.0 * Bt * N * D * T):
             call("prifit_meanshift_rows_bwd", ptr(X), ptr(bw), Bt, N, D, T, arr(0), arr(4), arr(2), arr(3), arr(5), ptr(ids),
                  ptr(nrows), R, ptr(g), ptr(ws), ptr(gX), cur_stream())
         return gX, None, None, None, None

@@ -118,6 +118,60 @@ def test_gradient_on_one_rank_only_is_adopted_by_all():
     assert (f0 == f1).all(), "replicas diverged"
 
 
+def _fallback_worker(rank, world, port, out):
+    """Only rank 1's clustering verdict asks for the quantile-doubling retry: it discards its step and re-runs it
+    synchronously (train_step.SpeculativeRunner) while rank 0 goes straight to the exchange.  Forward and backward contain
+    no collective, so both ranks still enter exactly one all-reduce per step: no deadlock, same averaged gradient."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prifit_amd import fit_ops
+    from prifit_amd.ddp import FlatGradBucket
+    from prifit_amd.train_step import SpeculativeRunner
+
+    class Verdict:                      # what fit_ops._cluster_speculative leaves behind: (event, pinned flag)
+        def synchronize(self):
+            pass
+
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Linear(8, 3))
+    bucket = FlatGradBucket(net)
+    bucket.broadcast_parameters(0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    runner = SpeculativeRunner(net)
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(20 + rank))
+    attempts = []
+    for step in range(3):
+        bucket.zero()
+
+        def fwd_bwd():
+            spec = fit_ops._spec
+            attempts.append((step, spec is not None))
+            if spec is not None:    # speculative attempt: rank 1's verdict at step 1 says "retry"
+                spec.checks.append((Verdict(), [1 if (rank == 1 and step == 1) else 0]))
+            loss = net(x).pow(2).mean()
+            loss.backward()
+            return loss
+
+        runner.run(fwd_bwd, bucket.zero)
+        bucket.allreduce()
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    out.put((rank, flat.numpy().copy(), runner.fallbacks, attempts, int(net[1].num_batches_tracked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_speculation_fallback_on_one_rank_does_not_stall_the_others():
+    (_, f0, fb0, att0, nb0), (_, f1, fb1, att1, nb1) = _run_two(_fallback_worker)
+    assert fb0 == 0 and fb1 == 1
+    assert att0 == [(0, True), (1, True), (2, True)]
+    assert att1 == [(0, True), (1, True), (1, False), (2, True)]      # the discarded attempt re-ran the synchronous way
+    assert nb0 == nb1 == 3                                            # ... and left no trace in the BatchNorm buffers
+    assert (f0 == f1).all(), "replicas diverged"
+
+
 def test_single_process_bucket_matches_plain_autograd():
     sys.path.insert(0, ROOT)
     from prifit_amd.ddp import FlatGradBucket
