@@ -304,6 +304,16 @@ int prifit_gather_linear_fwd(const float *U, const float *Vc, const float *bias,
 /* autograd: dU [B,N,C] (initialised by the caller) += scatter of dY; dVc [B,S,C] = -sum_k dY. */
 int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, int S, int K, int C,
                              float *dU, float *dVc, void *stream);
+/* The same autograd with the train-mode BatchNorm + ReLU backward of the gathered layer folded in (what
+ * prifit_bn_relu_bwd_apply would have written first): dY = a (Y s + t > 0 ? G : 0) + (b Y + d) is formed on load from G
+ * (gradient w.r.t. the layer's ReLU output) and Y (its pre-activation), [B*S*K, C] each; per-channel scale / shift and
+ * the coefficients a, b, d of prifit_bn_bwd_finalize.  dU [B,N,C] AND dVc [B,S,C] arrive ZERO-INITIALISED and are
+ * accumulated into (scatter staged in LDS per shape and range of 128 points; C <= 128, even --
+ * prifit_gather_linear_bwd_bn_supported).  Replaces autograd of models/pointnet_util.py:243-252 through the first conv + BatchNorm. */
+int prifit_gather_linear_bwd_bn_supported(int N, int C);
+int prifit_gather_linear_bwd_bn(const float *G, const float *Y, const float *scale, const float *shift, const float *coef_a,
+                                const float *coef_b, const float *coef_d, const int32_t *idx, int B, int N, int S, int K,
+                                int C, float *dU, float *dVc, void *stream);
 
 /* Set-abstraction front end in ONE launch per layer: multi-radius ball query (models/pointnet_util.py:87-107 with
  * :19-40 fused, bit-exact like prifit_ball_query) + grouping (:43-60, :127-133 / :243-249) + the first 1x1 conv of

@@ -278,6 +278,99 @@ __global__ __launch_bounds__(256) void gather_linear_bwd_kernel(const float *__r
     }
 }
 
+// The same autograd with the BatchNorm + ReLU backward of the gathered layer folded in and the scatter staged in LDS:
+//     dY = a (Y s + t > 0 ? G : 0) + (b Y + d)         (bn_relu_bwd_apply_kernel's expression, term by term)
+//     dU[b, idx, :] += dY,   dVc[g, :] -= sum_k dY[(g,k), :]
+// One workgroup = (shape, a range of GLB_PTS points, a range of centres): it keeps dU of its points in LDS ([GLB_PTS][C]
+// floats), walks the index lists of its centres, loads the rows whose index falls into its range -- whole rows: one wave
+// instruction = the 4 C contiguous bytes of a row, lane = 2 channels -- forms dY and adds it there (each wave owns a quarter
+// of the points: plain read-modify-write); at the end the non-zero entries go to global memory with float atomics.  Every row is loaded by exactly one workgroup, the global
+// atomics drop from one per element of dY (B S K C: 75 M at SA2) to at most one per element of dU and centre range, and
+// the pass that wrote dY (read G, read Y, write dY) is gone.  (Splitting the CHANNELS over workgroups instead -- 128-byte
+// pieces of every row read by four different workgroups -- measured slower than the pass it replaces.)
+constexpr int GLB_PTS = 128, GLB_CMAX = 128;
+__global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
+    const float *__restrict__ G, const float *__restrict__ Y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ ca, const float *__restrict__ cb,
+    const float *__restrict__ cd, const int32_t *__restrict__ idx, int N, int S, int K, int C, int splits,
+    float *__restrict__ dU, float *__restrict__ dVc)
+{
+    __shared__ float s_acc[GLB_PTS * GLB_CMAX];
+    __shared__ int s_rows[4][128];          // per wave: the rows of the current batch of the index list that are ours
+    const int n0 = blockIdx.x * GLB_PTS, split = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = 2 * lane;                 // this lane's channel pair
+    const bool cok = c < C;
+    for (int i = threadIdx.x; i < GLB_PTS * C; i += 256) s_acc[i] = 0.f;
+    float2 sc = {0.f, 0.f}, sh = sc, a = sc, bb = sc, d = sc;
+    if (cok) {
+        sc = *reinterpret_cast<const float2 *>(scale + c); sh = *reinterpret_cast<const float2 *>(shift + c);
+        a = *reinterpret_cast<const float2 *>(ca + c); bb = *reinterpret_cast<const float2 *>(cb + c);
+        d = *reinterpret_cast<const float2 *>(cd + c);
+    }
+    __syncthreads();
+    const int per = (S + splits - 1) / splits;
+    const int s_begin = split * per, s_end = min(S, s_begin + per);
+    int *rows = s_rows[wave];
+    // every wave walks ALL index lists of the workgroup's centres and takes the rows of ITS points (point & 3 == wave): a point's
+    // accumulator is then touched by one wave only and the LDS update needs no atomic (LDS float atomics measured ~2 cycles
+    // per LANE: 75 M of them were 3 x the time of the loads)
+    for (int sidx = s_begin; sidx < s_end; ++sidx) {
+        const long long g = (long long)b * S + sidx;
+        const float *gp = G + (size_t)g * K * C + c, *yp = Y + (size_t)g * K * C + c;
+        const int32_t *ix = idx + (size_t)g * K;
+        float2 acc = {0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            // the rows of this batch whose point is this wave's: compacted in slot order (ballot + prefix count)
+            const int r = k0 + lane;
+            const int n = r < K ? ix[r] : -1;
+            const bool mine = n >= n0 && n < n0 + GLB_PTS && n < N && (n & 3) == wave;
+            const unsigned long long m = __ballot(mine);
+            if (mine) rows[__popcll(m & ((1ull << lane) - 1ull))] = (r << 8) | (n - n0);
+            const int cnt = __popcll(m);
+            // (wave-private LDS: the writes above are visible to the wave's own later reads without a barrier)
+            __builtin_amdgcn_wave_barrier();
+            constexpr int UNR = 4;
+            for (int t = 0; t < cnt; t += UNR) {
+                float2 gv[UNR], yv[UNR];
+                int pk[UNR];
+#pragma unroll
+                for (int j = 0; j < UNR; ++j) {
+                    pk[j] = rows[min(t + j, cnt - 1)];
+                    const size_t off = (size_t)(pk[j] >> 8) * C;
+                    gv[j] = cok ? *reinterpret_cast<const float2 *>(gp + off) : make_float2(0.f, 0.f);
+                    yv[j] = cok ? *reinterpret_cast<const float2 *>(yp + off) : make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < UNR; ++j) {
+                    if (t + j < cnt && cok) {
+                        const float dx = fmaf(a.x, fmaf(yv[j].x, sc.x, sh.x) > 0.f ? gv[j].x : 0.f, fmaf(bb.x, yv[j].x, d.x));
+                        const float dyy = fmaf(a.y, fmaf(yv[j].y, sc.y, sh.y) > 0.f ? gv[j].y : 0.f, fmaf(bb.y, yv[j].y, d.y));
+                        // plain read-modify-write: the point is this wave's alone, and a wave's LDS accesses execute in order
+                        float2 *dst = reinterpret_cast<float2 *>(s_acc + (pk[j] & 255) * C + c);
+                        float2 v = *dst;
+                        v.x += dx; v.y += dyy;
+                        *dst = v;
+                        acc.x += dx; acc.y += dyy;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (cok && (acc.x != 0.f || acc.y != 0.f)) {
+            unsafeAtomicAdd(dVc + (size_t)g * C + c, -acc.x);
+            unsafeAtomicAdd(dVc + (size_t)g * C + c + 1, -acc.y);
+        }
+    }
+    __syncthreads();
+    const int npts = min(GLB_PTS, N - n0);
+    float *dst = dU + ((size_t)b * N + n0) * C;
+    for (int i = threadIdx.x; i < npts * C; i += 256) {
+        const float v = s_acc[i];
+        if (v != 0.f) unsafeAtomicAdd(dst + i, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
@@ -569,6 +662,24 @@ int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, 
     const long long total = (long long)B * S * C;
     hipLaunchKernelGGL(gather_linear_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), dY, idx, N, S,
                        K, C, total, dU, dVc);
+    return prifit_check_launch();
+}
+
+int prifit_gather_linear_bwd_bn_supported(int N, int C) { return (N > 0 && C > 0 && C <= GLB_CMAX && C % 2 == 0) ? 1 : 0; }
+
+int prifit_gather_linear_bwd_bn(const float *G, const float *Y, const float *scale, const float *shift, const float *coef_a,
+                                const float *coef_b, const float *coef_d, const int32_t *idx, int B, int N, int S, int K,
+                                int C, float *dU, float *dVc, void *stream)
+{
+    if (!G || !Y || !scale || !shift || !coef_a || !coef_b || !coef_d || !idx || !dU || !dVc || B <= 0 || B > 65535 ||
+        S <= 0 || K <= 0 || !prifit_gather_linear_bwd_bn_supported(N, C))
+        return PRIFIT_EINVAL;
+    // centre ranges per (shape, chunk): enough workgroups for two per CU, at least 16 centres each
+    const int ranges = (N + GLB_PTS - 1) / GLB_PTS;
+    int splits = (2 * 256) / (B * ranges);                 // one round of resident workgroups (two per CU), no tail
+    splits = splits < 1 ? 1 : (splits > (S + 7) / 8 ? (S + 7) / 8 : splits);
+    hipLaunchKernelGGL(gather_linear_bwd_bn_kernel, dim3(ranges, splits, B), dim3(256), 0, as_stream(stream), G, Y, scale,
+                       shift, coef_a, coef_b, coef_d, idx, N, S, K, C, splits, dU, dVc);
     return prifit_check_launch();
 }
 

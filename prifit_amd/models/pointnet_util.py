@@ -135,7 +135,8 @@ def _fused_mode(first_convs, feats, N, nsamples, kp):
     return None
 
 
-def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii, nsamples, kp, feat_first):
+def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii, nsamples, kp, feat_first,
+                        fused_gather_bwd=False):
     """-> per radius (Y1 [B*S*K, C1], column-statistics slab, info): `info` is None, or -- direct mode in training --
     the dict SharedMLPFn needs to take over the first conv's weight gradient (cfg["preact_direct"]): Y1 is then plain
     data for autograd and the BatchNorm backward of that layer is fused into the weight-gradient kernel."""
@@ -149,6 +150,20 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
                                                [w.shape[0] for w in Ws], Ws, None, None, bs, feat_xyz=fx)
         return [(Ys[i], slabs[i], {"idx": idxs[i], "xyz": xyz, "new_xyz": new_xyz, "feat": feats, "feat_first": feat_first,
                                    "K": nsamples[i], "D": D}) for i in range(len(first_convs))]
+    if mode == "gather" and training and fused_gather_bwd:
+        # first layer by linearity, training: U / Vc stay differentiable, the launch itself is data for autograd, and the
+        # SharedMLPFn that consumes Y1 returns dU / dVc with its first BatchNorm backward folded in (cfg["preact_gather"])
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        ops_ = [_linearity_operands(c, feats, xyz, new_xyz, kp, feat_first) for c in first_convs]
+        with torch.no_grad():
+            Us = [u.detach().contiguous() for u, _ in ops_]
+            Vcs = [v.detach().contiguous() for _, v in ops_]
+            bs = [None if c.bias is None else c.bias.detach().contiguous() for c in first_convs]
+            Ys, slabs, idxs = _sa_group_launch(1, xyz, new_xyz, None, True, list(radii), list(nsamples),
+                                               [u.shape[-1] for u in Us], None, Us, Vcs, bs)
+        return [(Ys[i], slabs[i], {"gather": True, "idx": idxs[i], "U": ops_[i][0], "Vc": ops_[i][1], "B": B, "N": N, "S": S,
+                                   "K": nsamples[i]}) for i in range(len(first_convs))]
     if mode == "direct":
         ts = []
         for c in first_convs:
@@ -163,13 +178,38 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
     return [(out[2 * i], out[2 * i + 1], None) for i in range(len(first_convs))]
 
 
-def _mlp_tensors_preact(convs, bns, direct=False):
-    """Layer 0 is already computed: its W / bias slots are None -- unless SharedMLPFn owns their gradient (direct mode)."""
-    if direct:
+def _mlp_tensors_preact(convs, bns, info=None):
+    """Layer 0 is already computed: its W / bias slots are None -- unless SharedMLPFn owns the gradients of the fused
+    front end's inputs: direct mode (`info` without "gather") the first conv's weight in the W slot; gather mode U in the
+    W slot, the conv's bias in the bias slot and Vc behind the layer tensors."""
+    if info is not None and info.get("gather"):
+        ts = _mlp_tensors(convs, bns, info["U"])
+        return ts + [info["Vc"]]
+    if info is not None:
         return _mlp_tensors(convs, bns, convs[0].weight.reshape(convs[0].weight.shape[0], -1))
     ts = _mlp_tensors(convs, bns, None)
     ts[1] = None
     return ts
+
+
+def _preact_cfg(cfg, slab, info):
+    cfg["preact_slab"] = slab
+    if info is not None and info.get("gather"):
+        cfg["preact_gather"] = info
+    else:
+        cfg["preact_direct"] = info
+    return cfg
+
+
+# gather mode in training: dU / dVc of the first layer come out of ONE kernel with that layer's BatchNorm + ReLU backward
+# folded in and the scatter staged in LDS (0: bn_relu_bwd_apply pass + SAGroupGatherFn autograd with global atomics, A/B)
+_GATHER_FUSED_BWD = os.environ.get("PRIFIT_SA_GATHER_FUSED_BWD", "1") != "0"
+
+
+def _gather_bwd_ok(mode, convs_per_scale, N):
+    from .._lib import dll
+    return (mode == "gather" and _GATHER_FUSED_BWD and all(len(c) >= 2 for c in convs_per_scale) and
+            all(dll().prifit_gather_linear_bwd_bn_supported(N, c[0].weight.shape[0]) for c in convs_per_scale))
 
 
 _pending_counters = None   # list while a model forward batches the BatchNorm step counters, else None
@@ -260,11 +300,10 @@ class PointNetSetAbstraction(nn.Module):
             mode = _fused_mode([self.mlp_convs[0]], feats, N, [K], kp)
             if mode is not None:
                 (y1, slab, info), = _fused_first_layers(mode, [self.mlp_convs[0]], self.training, feats, xyz, new_xyz,
-                                                        [self.radius], [K], kp, feat_first=False)
-                cfg = _mlp_cfg(self.mlp_bns, K, self.training)
-                cfg["preact_slab"] = slab
-                cfg["preact_direct"] = info
-                out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns, info is not None))
+                                                        [self.radius], [K], kp, feat_first=False,
+                                                        fused_gather_bwd=_gather_bwd_ok(mode, [self.mlp_convs], N))
+                cfg = _preact_cfg(_mlp_cfg(self.mlp_bns, K, self.training), slab, info)
+                out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns, info))
                 return new_xyz, out.reshape(B, S, -1)
             idx = ops.ball_query_multi([self.radius], [K], xyz, new_xyz)[0]
             # rows = [features, rel_xyz, pad]; upstream order is [rel_xyz, features] (:131)
@@ -317,13 +356,12 @@ class PointNetSetAbstractionMsg(nn.Module):
         mode = _fused_mode(firsts, feats, N, self.nsample_list, kp) if len(firsts) <= 4 else None
         if mode is not None:
             ys = _fused_first_layers(mode, firsts, self.training, feats, xyz, new_xyz, self.radius_list,
-                                     self.nsample_list, kp, feat_first=True)
+                                     self.nsample_list, kp, feat_first=True,
+                                     fused_gather_bwd=_gather_bwd_ok(mode, self.conv_blocks, N))
             for i, K in enumerate(self.nsample_list):
-                cfg = _mlp_cfg(self.bn_blocks[i], K, self.training)
-                cfg["preact_slab"] = ys[i][1]
-                cfg["preact_direct"] = ys[i][2]
+                cfg = _preact_cfg(_mlp_cfg(self.bn_blocks[i], K, self.training), ys[i][1], ys[i][2])
                 pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i],
-                                                                                    ys[i][2] is not None)))
+                                                                                    ys[i][2])))
             return new_xyz, torch.cat(pooled, dim=-1).reshape(B, S, -1)
         idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
         for i, K in enumerate(self.nsample_list):

@@ -121,7 +121,12 @@ class SharedMLPFn(torch.autograd.Function):
 
     cfg["preact_slab"] (a [nslab, 2, C] column-statistics slab, or True in eval mode) marks x as the
     already-computed pre-activation of layer 0 (GatherLinearFn): layer 0 then has no GEMM and its W/bias slots
-    are None; the gradient returned for x is the one w.r.t. that pre-activation."""
+    are None; the gradient returned for x is the one w.r.t. that pre-activation.
+    cfg["preact_direct"] / cfg["preact_gather"] (training, fused set-abstraction front end): x is plain data and this
+    function owns the gradients of the front end's inputs -- direct: the first conv's weight sits in layer 0's W slot;
+    gather (first layer by linearity): U sits in layer 0's W slot, the conv's bias in its bias slot and Vc is appended
+    behind the 6 L layer tensors; their gradients come out of prifit_gather_linear_bwd_bn with the BatchNorm + ReLU
+    backward of layer 0 folded in (no dY of that layer is ever written)."""
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
@@ -129,6 +134,7 @@ class SharedMLPFn(torch.autograd.Function):
         P, K0 = x.shape
         dev = x.device
         training = cfg["training"]
+        gather = cfg.get("preact_gather") if cfg.get("preact_slab") is not None else None
         tile_m = 128
         Ys, affines, stats_saved, Ws = [], [], [], []
         prev, prev_aff = x, None
@@ -211,7 +217,8 @@ class SharedMLPFn(torch.autograd.Function):
             out = torch.empty(P, CL, dtype=torch.float32, device=dev)
             call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, 0, _F(0.0),
                  ptr(out), _LL(CL), cur_stream())
-        ctx.cfg = {k: v for k, v in cfg.items() if k not in ("preact_slab", "preact_direct")}
+        ctx.cfg = {k: v for k, v in cfg.items() if k not in ("preact_slab", "preact_direct", "preact_gather")}
+        ctx.preact_gather = gather
         ctx.preact = cfg.get("preact_slab") is not None
         # direct-mode set-abstraction front end: this function owns the gradient of the first conv's weight (tensors[0],
         # upstream layout [C1, D+3]) and computes it with the BatchNorm backward fused in (prifit_sa_first_layer_dw_bn)
@@ -230,6 +237,7 @@ class SharedMLPFn(torch.autograd.Function):
         gout = gout.contiguous()
         rps = _rows_per_slab()
         grads = [None] * (6 * L)
+        extra_grads = (None,) if ctx.preact_gather is not None else ()
         # one zero-filled arena for every weight gradient (split-K adds into it) and, in training, the (exactly
         # zero) bias gradients of this stack
         wslots, total = {}, 0
@@ -258,12 +266,13 @@ class SharedMLPFn(torch.autograd.Function):
                              ctx.needs_input_grad[2 + 6 * l] and _stream_ok(NN, P, Kin, Cout) and
                              dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
             direct0 = l == 0 and ctx.preact_direct is not None
+            gather0 = l == 0 and ctx.preact_gather is not None
             # a middle layer on streaming shapes: dY = a*(relu mask)*G + b*Y + d is formed inside its two consumers (the dW and
             # the dA kernel read G and Y instead of dY: no bn_relu_bwd_apply pass writing dY, one read of it less)
             fuse_bn = bool(_FUSE_BN_APPLY and _FUSE_RED and not pooled and not direct0 and training and l > 0 and W is not None and
                            ctx.needs_input_grad[2 + 6 * l] and G_in.stride(0) == Cout and G_in.data_ptr() % 16 == 0 and
                            _stream_ok(NN, P, Kin, Cout) and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
-            dY = None if (fuse_pool or direct0 or fuse_bn) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            dY = None if (fuse_pool or direct0 or gather0 or fuse_bn) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
@@ -330,6 +339,24 @@ class SharedMLPFn(torch.autograd.Function):
                     grads[0] = part.sum(dim=0)
                 if ctx.needs_input_grad[3]:
                     grads[1] = zero_pool.zeros(Cout, device=dev)  # bias in front of a batch-stat BatchNorm
+                G_in = None
+                break
+            if gather0:
+                # first layer by linearity: dU / dVc straight from (G, Y) -- BatchNorm + ReLU backward formed on load, the
+                # scatter staged in LDS (prifit_gather_linear_bwd_bn)
+                info = ctx.preact_gather
+                Bq, Nq, Sq, Kq = info["B"], info["N"], info["S"], info["K"]
+                grads[2] = dgamma
+                grads[3] = dbeta
+                dU = zero_pool.zeros(Bq, Nq, Cout, device=dev)
+                dVc = zero_pool.zeros(Bq, Sq, Cout, device=dev)
+                with profiler.span("gather_linear_bwd", 4.0 * (2.0 * P * Cout + P + (Bq * Nq + Bq * Sq) * Cout)):
+                    call("prifit_gather_linear_bwd_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
+                         ptr(info["idx"]), Bq, Nq, Sq, Kq, Cout, ptr(dU), ptr(dVc), cur_stream())
+                grads[0] = dU
+                if ctx.needs_input_grad[3]:
+                    grads[1] = zero_pool.zeros(Cout, device=dev)   # bias in front of a batch-stat BatchNorm
+                extra_grads = (dVc,)
                 G_in = None
                 break
             if fuse_bn:
@@ -409,7 +436,7 @@ class SharedMLPFn(torch.autograd.Function):
             else:
                 G_in = None
             del dY
-        return (G_in, None) + tuple(grads)
+        return (G_in, None) + tuple(grads) + extra_grads
 
 
 class GatherLinearFn(torch.autograd.Function):

@@ -182,3 +182,37 @@ def test_modules_fused_vs_separate_launches(mods, case):
     for n in st_s:
         if st_s[n].dtype.is_floating_point:
             _close(st_f[n], st_s[n], 1e-4)
+
+
+def test_gather_mode_fused_first_layer_backward(mods):
+    """Gather mode in training: dU / dVc from prifit_gather_linear_bwd_bn (first BatchNorm + ReLU backward formed on load, scatter
+    staged in LDS) against the bn_relu_bwd_apply pass + prifit_gather_linear_bwd (global atomics).  Same forward launch,
+    so every parameter gradient and the input-feature gradient agree to float-atomic rounding; padded groups (surface
+    cloud: first-index repeats) and an SSG module (one scale, [rel, feat] order) included."""
+    ops, nn_ops, pu = mods
+    B = 3
+    cases = []
+    xyz = _t(synth.cloud("surface", B, 512, 2)).cuda()
+    cases.append((lambda: pu.PointNetSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 320, [[128, 128, 256], [128, 196, 256]]),
+                  (xyz, torch.randn(B, 512, 320, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)),
+                   torch.zeros(B, dtype=torch.long, device="cuda"))))
+    xyz2 = _t(synth.cloud("cube", B, 300, 5)).cuda()      # ragged N, sparse balls: mostly padding
+    cases.append((lambda: pu.PointNetSetAbstraction(64, 0.3, 32, 96 + 3, [64, 64, 128], False),
+                  (xyz2, torch.randn(B, 300, 96, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)),
+                   torch.zeros(B, dtype=torch.long, device="cuda"))))
+    for make, args in cases:
+        res = []
+        for fused_bwd in (True, False):
+            old = pu._GATHER_FUSED_BWD
+            pu._GATHER_FUSED_BWD = fused_bwd
+            try:
+                res.append(_run_module(pu, True, make, args, 11, True))
+            finally:
+                pu._GATHER_FUSED_BWD = old
+        (out_a, gr_a, gin_a, st_a), (out_b, gr_b, gin_b, st_b) = res
+        assert torch.equal(out_a, out_b)
+        for n in gr_b:
+            _close(gr_a[n], gr_b[n], 2e-5)
+        _close(gin_a, gin_b, 2e-5)
+        for n in st_b:
+            assert torch.equal(st_a[n], st_b[n]), n
