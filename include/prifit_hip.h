@@ -410,13 +410,12 @@ int prifit_meanshift_update_bwd(const float *g, const float *out, const float *n
  * points streams the dictionary X through LDS; S = Z X^T, K = exp(clamp((S-1)/b^2)) and O = K X are
  * chained on the matrix cores without leaving registers, followed by the normalisation epilogue.
  * Z, X [B,N,128]; bw [B].  Outputs: Znext [B,N,128]; saved for autograd: KT = K^T, element (b, key, query)
- * at KT[b*stride_kt + key*ld_kt + query] (may be NULL), O [B,N,128] (may be NULL), rowsum [B,N], nrm [B,N].
- * balanced != 0 (needs O): O and rowsum arrive ZERO-INITIALISED and the stream-K schedule may be used (grid = resident
- * workgroup slots; query blocks split over two workgroups accumulate O / rowsum with float atomics and a second small
- * launch normalises them) -- taken when the plain grid would leave a partial last round and N % 64 == 0. */
+ * at KT[b*stride_kt + key*ld_kt + query] (may be NULL: the row-sparse backward does not need it), O [B,N,128] (may be
+ * NULL), rowsum [B,N], nrm [B,N].  (A stream-K schedule of this kernel measured slower than the plain grid -- its time is
+ * linear in the number of query blocks -- and is not kept; the dZ mode below keeps its own.) */
 int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D,
                                float *KT, long long ld_kt, long long stride_kt, float *Znext, float *O,
-                               float *rowsum, float *nrm, int balanced, void *stream);
+                               float *rowsum, float *nrm, void *stream);
 /* dZ = gS X with gS = (gO X^T + g_rowsum 1^T) * K / b^2 (clamp-masked), same fused data flow;
  * gST (may be NULL) receives gS^T in the layout of KT (for the dX GEMM).
  * balanced != 0: the caller hands in a ZERO-INITIALISED dZ and allows the stream-K schedule (a grid of exactly the

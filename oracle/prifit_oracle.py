@@ -734,6 +734,7 @@ def fibonacci_uv(n):
 def sample_ellipsoid(a, b, c, center, V, n):
     """src/sample_ellipsoid.py:50-63 evaluated on the (detached) Fibonacci parameter table."""
     U, Vang = fibonacci_uv(int(n))
+    U, Vang = U.to(a.dtype), Vang.to(a.dtype)       # (a float64 evaluation of the oracle keeps the fp32 table values)
     pts = torch.stack([a * torch.cos(U) * torch.sin(Vang), b * torch.sin(U) * torch.sin(Vang), c * torch.cos(Vang)], 1)
     return pts @ V.t() + center
 

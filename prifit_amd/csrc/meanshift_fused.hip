@@ -763,48 +763,6 @@ __global__ __launch_bounds__(NKG * 128, 2) void ms_dx_streams_kernel(
     }
 }
 
-// Normalisation epilogue (src/mean_shift.py:70-82) of the query blocks that the stream-K schedule of the forward kernel
-// split over two workgroups: their O rows and row sums were accumulated with atomics, nobody has the totals in
-// registers.  One wave per point; a workgroup whose block was NOT split (its whole range lies inside one workgroup's
-// units) returns at once.  `grid` = the grid size of the forward launch.
-__global__ __launch_bounds__(256) void ms_sk_epilogue_kernel(const float *__restrict__ O, const float *__restrict__ rsum,
-                                                             const float *__restrict__ Z, int N, int nbatch, int grid,
-                                                             float *__restrict__ out, float *__restrict__ nrm_o)
-{
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // 4 rows of the same query block
-    const int nsteps = N / KB, nqb = N / QB;
-    const long long total = (long long)nbatch * nqb * nsteps;
-    const long long blk = row / QB;
-    const long long lo = blk * nsteps, hi = lo + nsteps;
-    // a boundary total * w / grid strictly inside (lo, hi) <=> the block was split
-    const long long w = lo * grid / total + 1;
-    bool split = false;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const long long bnd = total * (w + i) / grid;
-        split = split || (bnd > lo && bnd < hi);
-    }
-    if (!split) return;
-    const int lane = threadIdx.x & 63;
-    const float *o = O + row * D;
-    const float *z = Z + row * D;
-    const float dinv = 1.0f / rsum[row];
-    float nv[2], ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float zz = z[lane + 64 * j];
-        const float m = o[lane + 64 * j] * dinv - zz;
-        nv[j] = zz + m;
-        ss += nv[j] * nv[j];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    const float n = sqrtf(ss);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) out[row * D + lane + 64 * j] = nv[j] / n;
-    if (lane == 0) nrm_o[row] = n;
-}
-
 // whole shapes placed on one XCD (the dictionary in one L2, the rows of the K^T / gS^T streams written by neighbours on
 // the same L2); measured 436 against 437 us without it: kept on, not a switch
 static int xcd_map() { return 1; }
@@ -831,21 +789,11 @@ int prifit_debug_msf_stamps(unsigned long long *host, int n)
 
 int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D_, float *KT,
                                long long ld_kt, long long stride_kt, float *Znext, float *O, float *rowsum,
-                               float *nrm, int balanced, void *stream)
+                               float *nrm, void *stream)
 {
     if (!Z || !X || !bw || !Znext || !rowsum || !nrm || B <= 0 || N <= 0 || D_ != D || B > 65535 ||
         (KT && ld_kt < N))
         return PRIFIT_EINVAL;
-    const int slots = sk_slots();
-    if (balanced && O && N % QB == 0 && (long long)B * (N / QB) > slots && ((long long)B * (N / QB)) % slots != 0) {
-        // stream-K: O and rowsum arrive ZERO-INITIALISED; split query blocks get their epilogue from the second launch
-        hipLaunchKernelGGL((ms_fused_kernel<0, true, true>), dim3(slots), dim3(256), 0, as_stream(stream), Z,
-                           (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
-                           Znext, O, rowsum, nrm, B, 0, xcd_map());
-        hipLaunchKernelGGL(ms_sk_epilogue_kernel, dim3((unsigned)((long long)B * N / 4)), dim3(256), 0, as_stream(stream), O,
-                           rowsum, Z, N, B, slots, Znext, nrm);
-        return prifit_check_launch();
-    }
     // (Left-over blocks after the full rounds -- B x N / 64 = 768 blocks on 512 slots -- run as they are: the forward's time
     // is linear in the number of blocks (B = 16 / 24 / 32: 345 / 504 / 655 us), it has no tail to win back; an 8-wave and a
     // 32-query "narrow" form for the last 256 blocks both lost 3-4 % to their second launch, DESIGN 5c, and are gone.)

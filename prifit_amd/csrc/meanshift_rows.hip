@@ -44,28 +44,40 @@ __device__ __forceinline__ int live_rows(const RowsArgs &a, int b)
     return n < 0 ? 0 : (n > a.R ? a.R : n);
 }
 
-// grid (R, B), one wave per (row, shape)
+// grid (R, B), 256 threads per (row, shape): thread = (column c, tile lane q of 256 / D): the per-tile partials are summed by
+// 256 / D lanes per column and combined through LDS in a fixed order (deterministic), then one wave finishes the row
 template <int D>
-__global__ __launch_bounds__(64) void ms_rows_prep_kernel(RowsArgs a)
+__global__ __launch_bounds__(256) void ms_rows_prep_kernel(RowsArgs a)
 {
-    constexpr int PL = D / 64 > 0 ? D / 64 : 1;   // columns per lane
-    const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    constexpr int TL = 256 / D;                   // tile lanes per column (2 at D = 128, 8 at D = 32)
+    constexpr int PL = D / 64 > 0 ? D / 64 : 1;   // columns per lane of the finishing wave
+    __shared__ float s_g[TL][D];
+    const int r = blockIdx.x, b = blockIdx.y;
     if (r >= live_rows(a, b)) return;
     long long id = a.ids[(size_t)b * a.R + r];
     id = id < 0 ? 0 : (id >= a.N ? a.N - 1 : id);
     const size_t row = (size_t)b * a.N + id;
     const size_t slot = (size_t)b * a.R + r;
+    {
+        const int c = threadIdx.x % D, q = threadIdx.x / D;
+        float v = 0.f;
+        if (a.g_rows) v = q == 0 ? a.g_rows[slot * D + c] : 0.f;
+        else
+            for (int t = q; t < a.ntile; t += TL) v += a.part[(((size_t)b * a.ntile + t) * a.R + r) * D + c];
+        s_g[q][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     float g[PL], o[PL];
     float dot = 0.f;
 #pragma unroll
     for (int p = 0; p < PL; ++p) {
         const int c = lane + 64 * p;
         float v = 0.f;
-        if (c < D) {
-            if (a.g_rows) v = a.g_rows[slot * D + c];
-            else
-                for (int t = 0; t < a.ntile; ++t) v += a.part[(((size_t)b * a.ntile + t) * a.R + r) * D + c];
-        }
+        if (c < D)
+#pragma unroll
+            for (int q = 0; q < TL; ++q) v += s_g[q][c];
         g[p] = v;
         o[p] = c < D ? a.Zout[row * D + c] : 0.f;
         dot += g[p] * o[p];
@@ -254,7 +266,7 @@ int rows_bwd(const float *X, const float *bw, int B, int N, int T, const float *
     for (int t = T - 1; t >= 0; --t) {
         a.Zin = Zin[t]; a.Zout = Zout[t]; a.O = O[t]; a.rsum = rsum[t]; a.nrm = nrm[t];
         if (!a.Zin || !a.Zout || !a.O || !a.rsum || !a.nrm) return PRIFIT_EINVAL;
-        hipLaunchKernelGGL(ms_rows_prep_kernel<D>, dim3(R, B), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(ms_rows_prep_kernel<D>, dim3(R, B), dim3(256), 0, st, a);
         hipLaunchKernelGGL(ms_rows_main_kernel<D>, dim3(a.ntile, B), dim3(256), 0, st, a);
         a.g_rows = nullptr;
     }

@@ -25,13 +25,10 @@ BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "hybrid")
 # 1: dX from the stream-fed flash-style kernel (prifit_meanshift_dx_streams: no split-K atomics, so dX is bit-reproducible
 # from run to run) instead of the dual-source GEMM; measured 456 vs ~440 us per call at B = 24, N = 2048 -> default off
 DX_STREAMS = __import__("os").environ.get("PRIFIT_MS_DX_STREAMS", "0") != "0"
-# stream-K schedule of the fused mean-shift kernels (grid = resident slots, split query blocks combine through atomics):
-# the dZ mode gains 7 % (488 -> 452 us at B = 24, N = 2048); the forward does not (484 -> 497 us with its zero-fills,
-# atomics and second-launch epilogue), so it stays on the plain grid unless asked for
-MS_BALANCED = __import__("os").environ.get("PRIFIT_MS_BALANCED", "1") != "0"
-MS_BALANCED_FWD = __import__("os").environ.get("PRIFIT_MS_BALANCED_FWD", "0") != "0"
+# stream-K schedule of the dense backward's dZ kernel (grid = resident slots, split query blocks combine through atomics):
+# +7 % (488 -> 452 us at B = 24, N = 2048).  (The forward's time is linear in its block count: no such schedule there.)
+MS_BALANCED = True
 CHORD_SYM = __import__("os").environ.get("PRIFIT_CHORD_SYM", "1") != "0"   # symmetric kernel for chord_matrix(X, X)
-DUAL_DX = __import__("os").environ.get("PRIFIT_MS_DUAL_DX", "1") != "0"  # both dX terms of an iteration in one product
 # cluster(): the loss reads the shifted points through `center = new_X[indices]` only, so the mean-shift backward runs
 # on those rows alone (MeanShiftRowsFn); 0 = the dense backward of MeanShiftFn + a gather (same numbers; the A/B arm
 # and the path of callers that differentiate through the whole of new_X)
@@ -49,7 +46,7 @@ def _skinny_splitk(M, N, K, batch):
     232 (sk 2), 243 (sk 4), 270 us (sk 8); TN 286 / 237 / 249 / 278 -> aim at ~768 workgroups (sk = 2)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     sk = 1
-    while tiles * sk < int(__import__("os").environ.get("PRIFIT_SKINNY_WGS", "768")) and (K // 32) // (2 * sk) >= 8:
+    while tiles * sk < 768 and (K // 32) // (2 * sk) >= 8:
         sk *= 2
     return sk
 
@@ -138,18 +135,14 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
             Kmat = torch.empty(Bt, N, N, dtype=torch.float32, device=dev)  # fused: K^T [key][query]; else K
         elif not fused:
             scratch = Kmat = scratch if scratch is not None else torch.empty(Bt, N, N, dtype=torch.float32, device=dev)
-        if fused and MS_BALANCED_FWD:   # stream-K schedule: split query blocks accumulate O / rowsum with atomics
-            O = zero_pool.zeros(Bt, N, D, device=dev)
-            rsum = zero_pool.zeros(Bt, N, device=dev)
-        else:
-            O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
-            rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
+        O = torch.empty(Bt, N, D, dtype=torch.float32, device=dev)
+        rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
         Zn = torch.empty_like(Z)
         nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
         if fused:
             with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
                 call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
-                     _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), int(MS_BALANCED_FWD), cur_stream())
+                     _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), cur_stream())
         else:
             _bgemm(NT, N, N, D, Z, D, X, D, Kmat, N, Bt, N * D, N * D, N * N, epi=EPI_MSKERNEL, epi_scalar=bw)
             _bgemm(NN, N, D, N, Kmat, N, X, D, O, D, Bt, N * N, N * D, N * D, a_rowsum=rsum)  # K X, rowsum(K)
@@ -280,7 +273,7 @@ class MeanShiftFn(torch.autograd.Function):
                 _bgemm(NT, N, N, D, X, D, gO, D, gS, N, Bt, sV, sV, sM, epi=EPI_MSBWD, epi_scalar=bw, aux=Kmat,
                        ld_aux=N, s_aux=sM, bias=grs, bias_stride=N)
                 _bgemm(TN, N, D, N, gS, N, X, D, gZ, D, Bt, sM, sV, sV, splitk=sk)                       # dZ  = gS X
-                if DUAL_DX and N % 32 == 0:
+                if N % 32 == 0:
                     # dX += gS^T Z + K^T gO as one product over 2N (one epilogue of float atomics instead of two)
                     with profiler.span("gemm_nn_bn128", 4.0 * Bt * N * D * N):
                         call("prifit_gemm_dual_nn_f32", N, D, N, N, ptr(gS), ptr(Kmat), _LL(N), _LL(sM), ptr(Z), ptr(gO),

@@ -79,7 +79,7 @@ def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, spl
 
 # split-K of the tiled dW products: one round of resident workgroups (512: two 8-wave workgroups per CU) measured best
 # ([256 x 196 x 393 K]: 549 / 455 / 466 / 494 us at 256 / 512 / 1024 / 2048 workgroups)
-_SPLITK_WGS = int(os.environ.get("PRIFIT_SPLITK_WGS", "512"))
+_SPLITK_WGS = 512
 
 
 def _splitk_for(P, tiles):

@@ -550,9 +550,9 @@ def test_dx_streams_kernel_matches_dual_gemm(hiplib):
 
 
 def test_stream_k_schedules_of_the_fused_mean_shift_kernels(hiplib):
-    """The stream-K (balanced) forms of the fused forward / dZ kernels against their plain-grid forms on a size where the
-    plain grid leaves a partial round (B x N/64 > resident slots, not a multiple of them): same Z / O / row sums / dZ to
-    rounding (split query blocks add two partial sums), identical K^T / gS^T streams."""
+    """The stream-K (balanced) form of the dense backward's dZ kernel against its plain-grid form on a size where the plain
+    grid leaves a partial round (B x N/64 > resident slots, not a multiple of them): same dZ to rounding (split query
+    blocks add two partial sums), identical gS^T stream.  (The forward has no such schedule.)"""
     import ctypes
     from prifit_amd._lib import call, ptr, cur_stream
     LL = ctypes.c_longlong
@@ -567,7 +567,7 @@ def test_stream_k_schedules_of_the_fused_mean_shift_kernels(hiplib):
         Zn, O = torch.empty_like(Z), torch.zeros_like(Z)
         rs, nrm = torch.zeros(B, N, device="cuda"), torch.empty(B, N, device="cuda")
         call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), LL(N), LL(N * N), ptr(Zn), ptr(O), ptr(rs),
-             ptr(nrm), bal, cur_stream())
+             ptr(nrm), cur_stream())
         gO = torch.randn(B, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
         grs = torch.randn(B, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
         gS, dZ = torch.empty(B, N, N, device="cuda"), torch.zeros(B, N, D, device="cuda")

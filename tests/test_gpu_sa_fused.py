@@ -216,3 +216,35 @@ def test_gather_mode_fused_first_layer_backward(mods):
         _close(gin_a, gin_b, 2e-5)
         for n in st_b:
             assert torch.equal(st_a[n], st_b[n]), n
+
+
+@pytest.mark.parametrize("switch,case", [("_SA_LINEARITY", "msg_sa2"), ("_DIRECT_FUSED_BWD", "msg_sa1")])
+def test_ab_arms_of_the_front_end(mods, switch, case):
+    """The two remaining A/B arms of the set-abstraction front end against the default: PRIFIT_SA_LINEARITY=0 (materialised
+    grouped rows + GEMM: the bytes of the SURVEY 8d grouping formula) and PRIFIT_SA_DIRECT_FUSED_BWD=0 (separate
+    bn_relu_bwd_apply pass + SAGroupDirectFn autograd)."""
+    ops, nn_ops, pu = mods
+    B = 3
+    if case == "msg_sa1":
+        xyz = _t(synth.cloud("surface", B, 2048, 1)).cuda()
+        make = lambda: pu.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], 3, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        args = (xyz, xyz, torch.zeros(B, dtype=torch.long, device="cuda"))
+    else:
+        xyz = _t(synth.cloud("surface", B, 512, 2)).cuda()
+        make = lambda: pu.PointNetSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 320, [[128, 128, 256], [128, 196, 256]])
+        args = (xyz, torch.randn(B, 512, 320, device="cuda"), torch.zeros(B, dtype=torch.long, device="cuda"))
+    feat_grad = case == "msg_sa2"
+    res = []
+    for on in (True, False):
+        old = getattr(pu, switch)
+        setattr(pu, switch, on)
+        try:
+            res.append(_run_module(pu, True, make, args, 7, feat_grad))
+        finally:
+            setattr(pu, switch, old)
+    (out_a, gr_a, gin_a, st_a), (out_b, gr_b, gin_b, st_b) = res
+    _close(out_a, out_b, 2e-4)
+    for n in gr_b:
+        _close(gr_a[n], gr_b[n], 1e-2)      # (BatchNorm sums in another order: a few ReLU / pool winners flip, see above)
+    if gin_b is not None:
+        _close(gin_a, gin_b, 1e-2)

@@ -20,7 +20,7 @@ bw = torch.full((B,), 0.6, device="cuda")
 KT = torch.empty(B, N, N, device="cuda"); Zn = torch.empty_like(Z); O = torch.empty_like(Z)
 rs = torch.empty(B, N, device="cuda"); nrm = torch.empty(B, N, device="cuda")
 for _ in range(5):
-    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), 0, cur_stream())
+    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), cur_stream())
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 16 * 8))()
 assert dll().prifit_debug_msf_stamps(buf, 8 * 16 * 8) == 0

@@ -12,11 +12,11 @@ KT = torch.empty(B, N, N, device="cuda"); Zn = torch.empty_like(Z); O = torch.em
 rs = torch.empty(B, N, device="cuda"); nrm = torch.empty(B, N, device="cuda")
 gS = torch.empty(B, N, N, device="cuda"); gO = torch.randn(B, N, D, device="cuda"); grs = torch.randn(B, N, device="cuda"); gZ = torch.empty_like(Z)
 def fwd():
-    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), int(os.environ.get("MSBAL", "1")), cur_stream())
+    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, ptr(KT), _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), cur_stream())
 def dz():
     call("prifit_meanshift_fused_bwd_dz", ptr(gO), _LL(N * D), ptr(X), ptr(bw), ptr(grs), ptr(KT), _LL(N), _LL(N * N), ptr(gS), B, N, D, ptr(gZ), int(os.environ.get("MSBAL", "1")), cur_stream())
 def fwd_nokt():
-    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, None, _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), 0, cur_stream())
+    call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), B, N, D, None, _LL(N), _LL(N * N), ptr(Zn), ptr(O), ptr(rs), ptr(nrm), cur_stream())
 for name, fn in (("fused fwd", fwd), ("fwd, no K^T stream", fwd_nokt), ("fused dz", dz)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
