@@ -439,6 +439,26 @@ int prifit_meanshift_fused_bwd_dx(const float *gO, const float *Z, const float *
                                   const float *g_rowsum, const float *KT, long long ld_kt,
                                   long long stride_kt, int B, int N, int D, float *dX, void *stream);
 
+/* Backward of one (conv1x1 + train-mode BatchNorm + ReLU) layer of a shared MLP on the tall-and-skinny shapes, BOTH
+ * products in one pass over the rows (autograd of models/pointnet_util.py:195-199, :252-256; replaces a
+ * prifit_gemm_stream_dgrad_{bn,pool}_f32 + prifit_gemm_stream_tn_{bn,pool}_f32 pair, which each stream the same tensors):
+ *     dY = a (Y s + t > 0 ? G : 0) + (b Y + d)       middle layer (pool_arg == NULL)
+ *        = b Y + d + (k == arg ? T : 0)              max-pooled last layer (pool_arg / pool_T [P / pool_K, Cout], pool_K % 64 == 0)
+ *     Gp [P, Cin] = dY W;  red_slab [slabs][2][Cin] = the (m1, m2) column sums of the BatchNorm backward of the layer below
+ *     (pre-activation Yp [P, Cin], its scale / shift / mean / invstd);  dW [Cout, Cin] = dY^T relu(p_scale Yp + p_shift).
+ * G, Y [P, Cout] contiguous; W [Cout, Cin] (ldw); (Cout, Cin) in {(128,128), (128,96), (128,64), (96,64), (64,64)}
+ * (prifit_gemm_stream_bwd_supported); slabs = prifit_gemm_stream_bwd_slabs; workspace: prifit_gemm_stream_bwd_workspace
+ * floats.  Deterministic (per-workgroup slabs, fixed summation order). */
+int prifit_gemm_stream_bwd_supported(long long P, int Cout, int Cin, int pool_K);
+int prifit_gemm_stream_bwd_slabs(long long P, int Cout, int Cin);
+long long prifit_gemm_stream_bwd_workspace(long long P, int Cout, int Cin);
+int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, const float *Y, const float *scale,
+                               const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                               const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
+                               const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
+                               const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
+                               float *dW, long long lddw, float *workspace, void *stream);
+
 /* Row-sparse backward of `iterations` mean-shift updates, for a loss that reads the shifted points through
  * `center = new_X[indices]` only (src/mean_shift.py:44-46; autograd of :61-82).  Row i of an iterate depends on row i of
  * the previous iterate alone (the dictionary is the fixed input X, :65), so d loss / d new_X is non-zero on the R kept

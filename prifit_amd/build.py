@@ -24,6 +24,7 @@ SOURCES = {
     "sa_group.hip": ["-ffp-contract=off"],
     "gemm.hip": [],
     "gemm_stream.hip": [],
+    "gemm_stream_bwd.hip": [],
     "bn.hip": [],
     "meanshift.hip": [],
     "meanshift_fused.hip": [],

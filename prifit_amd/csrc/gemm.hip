@@ -1228,7 +1228,9 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static inline bool small_tiles(int M, int N, int batch, int splitk)
 {
     const long long wgs = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
-    return wgs < 160 && M > 64 && N > 32;
+    // (fewer than ~two 128 x 128 tiles per CU: measured over the step's 28 SA3 / feature-propagation / head products,
+    // tools/small_gemm_bench.py: 838 us with the threshold at 160 workgroups, 796 at 320, 786 at 520)
+    return wgs < 520 && M > 64 && N > 32;
 }
 
 static int dispatch(GemmArgs &g, int layout, void *stream)

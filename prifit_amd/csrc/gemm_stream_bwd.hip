@@ -1,0 +1,363 @@
+// Backward of one (conv1x1 + train-mode BatchNorm + ReLU) layer of a shared per-position MLP on the tall-and-skinny shapes
+// (models/pointnet_util.py:195-199, :252-256 through autograd), BOTH products in one pass over the rows:
+//     dY  = a (Y s + t > 0 ? G : 0) + (b Y + d)            middle layer   (bn_relu_bwd_apply's expression, term by term)
+//         = b Y + d + (k == arg ? T : 0)                   max-pooled last layer (pool_bwd_apply's expression)
+//     Gp  = dY W                  [P, Cin]   gradient w.r.t. relu(bn(Yp)) of the layer below, + the (m1, m2) column sums of
+//                                            that layer's BatchNorm backward
+//     dW  = dY^T relu(bn(Yp))     [Cout, Cin]
+// The separate dA and dW kernels (gemm_stream_kernel NN, gemm_stream_tn_kernel) each stream dY's sources (G, Y) and Yp from
+// HBM: 3.6 GB for SA1's widest middle layer where the tensors themselves are 2.0 GB.  Here a persistent workgroup stages
+// every 64-row tile ONCE (dY formed while staging, Yp raw) and two groups of waves work on the same LDS tiles:
+//   * A-waves (one per 32 columns of Cin) keep their Cout x 32 slice of W as MFMA fragments in registers and compute Gp
+//     (k = Cout, fragments read along the rows of the dY tile), store it, and accumulate (m1, m2) from the Yp tile;
+//   * W-waves (one per 32 rows of Cout) accumulate dW over ALL tiles of the workgroup in registers (k = the tile's rows:
+//     the A operand is a column of the dY tile, the B operand a row of relu(s Yp + t), formed on read).
+// One barrier per tile, the next tile in flight (global -> registers) during the MFMAs, two LDS stages.  Per-workgroup
+// slabs for (m1, m2) and for dW, summed by the finalize kernel / a second small launch: deterministic, no atomics.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SBM = 64;   // rows per tile
+
+struct BwdArgs {
+    long long P;
+    const float *G, *Y;                       // [P, Cout] (G: NULL in POOL mode)
+    const float *cs, *ct, *ca, *cb, *cd;      // per-channel [Cout]: mask scale / shift, a, b, d (cs, ct, ca: BN mode)
+    const int32_t *pool_arg;                  // [P / pool_K, Cout]
+    const float *pool_T;                      // [P / pool_K, Cout]
+    int pool_K;
+    const float *W;                           // [Cout, Cin] row-major, leading dimension ldw
+    long long ldw;
+    const float *Yp;                          // [P, Cin], leading dimension ldyp
+    long long ldyp;
+    const float *ps, *pt, *pmu, *pis;         // previous layer: scale, shift, mean, invstd [Cin]
+    float *Gp;                                // [P, Cin], leading dimension ldgp
+    long long ldgp;
+    float *red_slab;                          // [grid][2][Cin]
+    float *dw_part;                           // [grid][Cout][Cin]
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int COUT, int CIN, bool POOL>
+__global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bwd_kernel(const BwdArgs g)
+{
+    constexpr int NA = CIN / 32, NWV = COUT / 32, NTH = 64 * (NA + NWV);
+    constexpr int LDY = COUT + 4, LDP = CIN + 4;     // padded rows: conflict-free ds_read_b128 fragments / b32 columns
+    constexpr int KG = COUT / 8;
+    constexpr int Y4 = COUT / 4, P4 = CIN / 4;       // float4 per row
+    constexpr int NY4 = SBM * Y4, NP4 = SBM * P4;
+    constexpr int NVY = (NY4 + NTH - 1) / NTH, NVP = (NP4 + NTH - 1) / NTH;
+    static_assert(!POOL || NTH % Y4 == 0, "POOL: one channel group per thread");
+    __shared__ __attribute__((aligned(16))) float s_dy[2][SBM * LDY];
+    __shared__ __attribute__((aligned(16))) float s_p[2][SBM * LDP];
+    __shared__ __attribute__((aligned(16))) float s_co[5][COUT];   // s, t, a, b, d
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool a_wave = wave < NA;
+    const int wa = a_wave ? wave : 0, ww = a_wave ? 0 : wave - NA;
+
+    for (int t = threadIdx.x; t < COUT; t += NTH) {
+        s_co[0][t] = POOL ? 0.f : g.cs[t]; s_co[1][t] = POOL ? 0.f : g.ct[t]; s_co[2][t] = POOL ? 0.f : g.ca[t];
+        s_co[3][t] = g.cb[t]; s_co[4][t] = g.cd[t];
+    }
+
+    const int tiles = (int)((g.P + SBM - 1) / SBM);
+    float4 sty[NVY], stg[POOL ? 1 : NVY], stp[NVP];
+    int4 st_arg = make_int4(0, 0, 0, 0);
+    float4 st_T = make_float4(0.f, 0.f, 0.f, 0.f);
+    int yoff[NVY], poff[NVP];
+#pragma unroll
+    for (int p = 0; p < NVY; ++p) {
+        const int id = threadIdx.x + NTH * p;
+        yoff[p] = id < NY4 ? ((id / Y4) * COUT + 4 * (id % Y4)) * 4 : 0x7fffffff;   // (beyond the tile: fails the bounds check)
+    }
+#pragma unroll
+    for (int p = 0; p < NVP; ++p) {
+        const int id = threadIdx.x + NTH * p;
+        poff[p] = id < NP4 ? ((id / P4) * (int)g.ldyp + 4 * (id % P4)) * 4 : 0x7fffffff;
+    }
+    auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
+        const long long left = g.P - m0;
+        const int rows = left < SBM ? (int)left : SBM;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0,
+                                                 ((rows - 1) * (int)ld + width) * 4, 0x00020000);
+    };
+    auto load_tile = [&](int tile) {
+        const int m0 = tile * SBM;
+        if (POOL) {
+            const long long po = (long long)(m0 / g.pool_K) * COUT + 4 * (threadIdx.x % Y4);
+            st_arg = *reinterpret_cast<const int4 *>(g.pool_arg + po);
+            st_T = ld4(g.pool_T + po);
+        }
+        const __amdgpu_buffer_rsrc_t ry = tile_rsrc(g.Y, COUT, m0, COUT);
+#pragma unroll
+        for (int p = 0; p < NVY; ++p) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yoff[p], 0, 0));
+            sty[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+        if (!POOL) {
+            const __amdgpu_buffer_rsrc_t rg = tile_rsrc(g.G, COUT, m0, COUT);
+#pragma unroll
+            for (int p = 0; p < NVY; ++p) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, yoff[p], 0, 0));
+                stg[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rp = tile_rsrc(g.Yp, g.ldyp, m0, CIN);
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, poff[p], 0, 0));
+            stp[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto store_tile = [&](int tile, int buf) {
+        const int m0 = tile * SBM;
+        const bool full = (long long)m0 + SBM <= g.P;   // block-uniform: only the tail tile pays for the row checks
+#pragma unroll
+        for (int p = 0; p < NVY; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (NVY * NTH != NY4 && id >= NY4) continue;
+            const int row = id / Y4, c4 = id - row * Y4;
+            float4 x = sty[p];
+            const float4 cb4 = *reinterpret_cast<const float4 *>(&s_co[3][4 * c4]);
+            const float4 cd4 = *reinterpret_cast<const float4 *>(&s_co[4][4 * c4]);
+            if (POOL) {
+                const int kr = m0 % g.pool_K + row;   // sample index of this row in its pooling group (a whole number of tiles)
+                x.x = fmaf(cb4.x, x.x, cd4.x) + (st_arg.x == kr ? st_T.x : 0.f);
+                x.y = fmaf(cb4.y, x.y, cd4.y) + (st_arg.y == kr ? st_T.y : 0.f);
+                x.z = fmaf(cb4.z, x.z, cd4.z) + (st_arg.z == kr ? st_T.z : 0.f);
+                x.w = fmaf(cb4.w, x.w, cd4.w) + (st_arg.w == kr ? st_T.w : 0.f);
+            } else {
+                const float4 cs = *reinterpret_cast<const float4 *>(&s_co[0][4 * c4]);
+                const float4 ct = *reinterpret_cast<const float4 *>(&s_co[1][4 * c4]);
+                const float4 ca = *reinterpret_cast<const float4 *>(&s_co[2][4 * c4]);
+                const float4 gg = stg[p];
+                x.x = fmaf(ca.x, fmaf(x.x, cs.x, ct.x) > 0.f ? gg.x : 0.f, fmaf(cb4.x, x.x, cd4.x));
+                x.y = fmaf(ca.y, fmaf(x.y, cs.y, ct.y) > 0.f ? gg.y : 0.f, fmaf(cb4.y, x.y, cd4.y));
+                x.z = fmaf(ca.z, fmaf(x.z, cs.z, ct.z) > 0.f ? gg.z : 0.f, fmaf(cb4.z, x.z, cd4.z));
+                x.w = fmaf(ca.w, fmaf(x.w, cs.w, ct.w) > 0.f ? gg.w : 0.f, fmaf(cb4.w, x.w, cd4.w));
+            }
+            if (!full && (long long)m0 + row >= g.P) x = make_float4(0.f, 0.f, 0.f, 0.f);   // (the loads returned zeros; d is not zero)
+            *reinterpret_cast<float4 *>(&s_dy[buf][row * LDY + 4 * c4]) = x;
+        }
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (NVP * NTH != NP4 && id >= NP4) continue;
+            const int row = id / P4, c4 = id - row * P4;
+            *reinterpret_cast<float4 *>(&s_p[buf][row * LDP + 4 * c4]) = stp[p];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= tiles) tile = tiles - 1;   // (the launcher never starts more workgroups than tiles)
+    load_tile(tile);
+    __syncthreads();                        // s_co visible before the first staging
+    store_tile(tile, 0);
+    __syncthreads();
+    // The two roles run the same loop skeleton (prefetch, MFMAs, stage the next tile, ONE barrier per tile) in separate
+    // branches: the branch is wave-uniform, both sides execute the same barriers, and the register allocation is the
+    // maximum of the two roles instead of their sum (W fragments 64 + dW accumulators 64 would not fit 256 VGPRs).
+    if (a_wave) {
+        // this wave's Cout x 32 slice of W as fragments: lane (li, lh) of k-group q holds W[8q + 4lh + 0..3][32 wa + li]
+        const int col = 32 * wa + li;
+        float4 bf[KG];
+#pragma unroll
+        for (int q = 0; q < KG; ++q) {
+            const int k0 = 8 * q + 4 * lh;
+            bf[q] = make_float4(g.W[(long long)k0 * g.ldw + col], g.W[(long long)(k0 + 1) * g.ldw + col],
+                                g.W[(long long)(k0 + 2) * g.ldw + col], g.W[(long long)(k0 + 3) * g.ldw + col]);
+        }
+        const float r_s = g.ps[col], r_t = g.pt[col], r_mu = g.pmu[col], r_is = g.pis[col];
+        float m1 = 0.f, m2 = 0.f;
+        const int ldgp4 = (int)g.ldgp * 4;
+        const int c_voff = ((4 * lh) * (int)g.ldgp + col) * 4;
+        for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+            const int cur = it & 1;
+            const int next = tile + gridDim.x;
+            const int ntile = next < tiles ? next : tile;
+            load_tile(ntile);
+            __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued HERE, ahead of the MFMAs
+            f32x16 acc[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+            const float *ap = &s_dy[cur][li * LDY + 4 * lh];
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                float4 fa[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LDY + 8 * q);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, bf[q].y, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, bf[q].z, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, bf[q].w, acc[a], 0, 0, 0);
+                }
+            }
+            // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Rows beyond P
+            // hold exact zeros (their dY rows are zero) and their stores are dropped by the bounds check.
+            const __amdgpu_buffer_rsrc_t crs = tile_rsrc(g.Gp, g.ldgp, tile * SBM, CIN);
+            const float *yp = &s_p[cur][(4 * lh) * LDP + col];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 32 * a + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[a][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, rl * ldgp4, 0);
+                    const float y = yp[rl * LDP];
+                    const float gm = fmaf(y, r_s, r_t) > 0.f ? v : 0.f;
+                    m1 += gm;
+                    m2 += gm * ((y - r_mu) * r_is);
+                }
+            store_tile(ntile, cur ^ 1);
+            __syncthreads();
+        }
+        m1 += __shfl_xor(m1, 32, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (lh == 0) {
+            g.red_slab[((long long)blockIdx.x * 2 + 0) * CIN + col] = m1;
+            g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
+        }
+    } else {
+        // dW accumulators (32 rows of Cout x all of Cin) for the life of the workgroup; the previous layer's affine of this
+        // lane's columns
+        f32x16 accw[NA];
+        float w_s[NA], w_t[NA];
+#pragma unroll
+        for (int cb = 0; cb < NA; ++cb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw[cb][r] = 0.f;
+            w_s[cb] = g.ps[32 * cb + li];
+            w_t[cb] = g.pt[32 * cb + li];
+        }
+        for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+            const int cur = it & 1;
+            const int next = tile + gridDim.x;
+            const int ntile = next < tiles ? next : tile;
+            load_tile(ntile);
+            __builtin_amdgcn_sched_barrier(0);
+            const float *dcol = &s_dy[cur][lh * LDY + 32 * ww + li];
+            const float *prow = &s_p[cur][lh * LDP + li];
+#pragma unroll 4
+            for (int st = 0; st < SBM / 2; ++st) {
+                const float aop = dcol[2 * st * LDY];
+                float bv[NA];
+#pragma unroll
+                for (int cb = 0; cb < NA; ++cb) bv[cb] = fmaxf(fmaf(prow[2 * st * LDP + 32 * cb], w_s[cb], w_t[cb]), 0.f);
+#pragma unroll
+                for (int cb = 0; cb < NA; ++cb) accw[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bv[cb], accw[cb], 0, 0, 0);
+            }
+            store_tile(ntile, cur ^ 1);
+            __syncthreads();
+        }
+        float *dst = g.dw_part + (long long)blockIdx.x * COUT * CIN;
+#pragma unroll
+        for (int cb = 0; cb < NA; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                dst[row * CIN + 32 * cb + li] = accw[cb][r];
+            }
+    }
+}
+
+// dW[c] = sum over workgroups of their partial slabs (fixed order)
+__global__ __launch_bounds__(256) void stream_bwd_dw_reduce_kernel(const float *__restrict__ part, int nwg, int n, int cin,
+                                                                  long long lddw, float *__restrict__ dW)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += part[(long long)w * n + i];
+    dW[(long long)(i / cin) * lddw + (i % cin)] = s;
+}
+
+int bwd_grid(long long P, int Cout, int Cin)
+{
+    const long long tiles = (P + SBM - 1) / SBM;
+    // LDS per workgroup: two stages of both tiles; two workgroups per CU where they fit in 160 KB
+    const long long lds = 2LL * SBM * (Cout + 4 + Cin + 4) * 4 + 5 * Cout * 4 + 4 * Cin * 4;
+    const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+    const long long want = 256LL * per_cu;
+    return (int)(tiles < want ? tiles : want);
+}
+
+bool bwd_shape_ok(int Cout, int Cin)
+{
+    return (Cout == 128 && (Cin == 128 || Cin == 96 || Cin == 64)) || (Cout == 96 && Cin == 64) || (Cout == 64 && Cin == 64);
+}
+
+template <int COUT, int CIN>
+void bwd_launch(const BwdArgs &g, bool pool, int grid, hipStream_t st)
+{
+    constexpr int NTH = 64 * (CIN / 32 + COUT / 32);
+    if (pool) {
+        if constexpr (NTH % (COUT / 4) == 0) hipLaunchKernelGGL((gemm_stream_bwd_kernel<COUT, CIN, true>), dim3(grid), dim3(NTH), 0, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_stream_bwd_kernel<COUT, CIN, false>), dim3(grid), dim3(NTH), 0, st, g);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int prifit_gemm_stream_bwd_supported(long long P, int Cout, int Cin, int pool_K)
+{
+    if (P < SBM || P > 0x7fffffffLL * 32 || !bwd_shape_ok(Cout, Cin)) return 0;
+    if (pool_K > 0) {
+        const int nth = 64 * (Cin / 32 + Cout / 32);
+        if (pool_K % SBM != 0 || P % pool_K != 0 || nth % (Cout / 4) != 0) return 0;
+    }
+    return 1;
+}
+
+int prifit_gemm_stream_bwd_slabs(long long P, int Cout, int Cin) { return bwd_shape_ok(Cout, Cin) ? bwd_grid(P, Cout, Cin) : 0; }
+
+long long prifit_gemm_stream_bwd_workspace(long long P, int Cout, int Cin)
+{
+    return bwd_shape_ok(Cout, Cin) ? (long long)bwd_grid(P, Cout, Cin) * Cout * Cin : 0;
+}
+
+int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, const float *Y, const float *scale,
+                               const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                               const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
+                               const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
+                               const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
+                               float *dW, long long lddw, float *workspace, void *stream)
+{
+    const bool pool = pool_arg != nullptr;
+    if (!Y || !coef_b || !coef_d || !W || !Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !Gp || !red_slab || !dW ||
+        !workspace || !prifit_gemm_stream_bwd_supported(P, Cout, Cin, pool ? pool_K : 0) || ldw < Cin || ldyp < Cin || ldgp < Cin ||
+        lddw < Cin || (ldyp & 3) || (pool ? (!pool_T) : (!G || !scale || !shift || !coef_a)) ||
+        (((uintptr_t)Y | (uintptr_t)G | (uintptr_t)Yp | (uintptr_t)pool_arg | (uintptr_t)pool_T) & 15) ||
+        (long long)SBM * ldyp * 4 >= 0x7ff00000LL || (long long)SBM * ldgp * 4 >= 0x7ff00000LL)
+        return PRIFIT_EINVAL;
+    BwdArgs g;
+    g.P = P; g.G = G; g.Y = Y; g.cs = scale; g.ct = shift; g.ca = coef_a; g.cb = coef_b; g.cd = coef_d;
+    g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_K = pool ? pool_K : 1;
+    g.W = W; g.ldw = ldw; g.Yp = Yp; g.ldyp = ldyp; g.ps = p_scale; g.pt = p_shift; g.pmu = p_mean; g.pis = p_invstd;
+    g.Gp = Gp; g.ldgp = ldgp; g.red_slab = red_slab; g.dw_part = workspace;
+    const int grid = bwd_grid(P, Cout, Cin);
+    hipStream_t st = as_stream(stream);
+    if (Cout == 128 && Cin == 128) bwd_launch<128, 128>(g, pool, grid, st);
+    else if (Cout == 128 && Cin == 96) bwd_launch<128, 96>(g, pool, grid, st);
+    else if (Cout == 128 && Cin == 64) bwd_launch<128, 64>(g, pool, grid, st);
+    else if (Cout == 96 && Cin == 64) bwd_launch<96, 64>(g, pool, grid, st);
+    else bwd_launch<64, 64>(g, pool, grid, st);
+    const int n = Cout * Cin;
+    hipLaunchKernelGGL(stream_bwd_dw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, grid, n, Cin, lddw, dW);
+    return prifit_check_launch();
+}
+
+}  // extern "C"

@@ -32,6 +32,12 @@ _FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate b
 _FUSE_POOL_FWD = os.environ.get("PRIFIT_FUSE_POOL_FWD", "1") != "0"  # 0: pool_fwd re-reads the last layer's Y (A/B runs)
 _FUSE_BN_APPLY = os.environ.get("PRIFIT_FUSE_BN_APPLY", "1") != "0"  # 0: bn_relu_bwd_apply writes a middle layer's dY (A/B runs)
 _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
+# 1: dA and dW of a streaming-shape layer from ONE pass over its rows (csrc/gemm_stream_bwd.hip) instead of the separate
+# streaming dA (NN) and dW (TN) kernels, which each read G, Y and the previous layer's pre-activation.  Measured (round 3,
+# DESIGN 5d): the one-pass kernel halves the HBM bytes but its first form -- one 7..8-wave workgroup per CU, A-waves and
+# W-waves on the same LDS tiles -- runs at 0.3-0.5 of the matrix peak: [1.57 M x 128 x 96 pooled] 933 us against 502 + 365,
+# [1.57 M x 96 x 64] 771 against 363 + 358, the step 16.70 against 16.23 ms.  OFF; correct and covered by GPU tests.
+_FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "0") != "0"
 
 
 def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, a_rowsum=None, accumulate=False,
@@ -111,6 +117,24 @@ def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
         dW = zero_pool.zeros(Cout, Kin, device=dY.device)
     gemm(TN, Cout, Kin, P, dY, dY.stride(0), Ain, Ain.stride(0), dW, Kin, splitk=sk, b_affine=a_affine)
     return dW
+
+
+def _fused_bwd(P, Cout, Kin, G, Y, scale, shift, ca, cb, cd, arg, Ttab, pool_K, W, Yp, aff_p, stats_p, dW, dev):
+    """Gp, (m1, m2) slab of the layer below and dW of one layer in one pass (prifit_gemm_stream_bwd_f32)."""
+    ns = dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin)
+    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+    ws = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
+    Gp = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+    (sc1, sh1), (mu1, is1) = aff_p, stats_p
+    pooled = arg is not None
+    # HBM-bound on the narrow layers: every tensor once (G and Y or Y alone, Yp in, Gp out)
+    work = 4.0 * P * ((1 if pooled else 2) * Cout + 2 * Kin)
+    with profiler.span(profiler.tag("gemm_stream_bwd", P, Cout, Kin, "pool" if pooled else "bn"), work):
+        call("prifit_gemm_stream_bwd_f32", _LL(P), Cout, Kin, ptr(None if pooled else G), ptr(Y), ptr(None if pooled else scale),
+             ptr(None if pooled else shift), ptr(None if pooled else ca), ptr(cb), ptr(cd), ptr(arg), ptr(Ttab), int(pool_K or 0),
+             ptr(W), _LL(Kin), ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(rslab),
+             ptr(dW), _LL(Kin), ptr(ws), cur_stream())
+    return Gp, rslab, ns
 
 
 class SharedMLPFn(torch.autograd.Function):
@@ -297,6 +321,17 @@ class SharedMLPFn(torch.autograd.Function):
                      ptr(shift), ptr(ca), G, K, Cout, _F(0.0), ptr(Ttab), cur_stream())
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
+                if _FUSE_BWD and _FUSE_RED and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, K) and Ys[l - 1].stride(0) % 4 == 0:
+                    G_prev, rslab, ns = _fused_bwd(P, Cout, Kin, None, Y, None, None, None, cb, cd, arg, Ttab, K, W, Ys[l - 1],
+                                                   affines[l - 1], stats_saved[l - 1], dW, dev)
+                    grads[6 * l] = dW
+                    if ctx.needs_input_grad[2 + 6 * l + 1]:
+                        grads[6 * l + 1] = arena[bo:bo + bn_]
+                    grads[6 * l + 2] = dgamma
+                    grads[6 * l + 3] = dbeta
+                    fused_red = (rslab, ns)
+                    G_in = G_prev
+                    continue
                 ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
                 a_aff = affines[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P, 1), 4.0 * P * (Cout + Kin)):
@@ -362,6 +397,17 @@ class SharedMLPFn(torch.autograd.Function):
             if fuse_bn:
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
+                if _FUSE_BWD and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, 0) and Ys[l - 1].stride(0) % 4 == 0:
+                    G_prev, rslab, ns = _fused_bwd(P, Cout, Kin, G_in, Y, scale, shift, ca, cb, cd, None, None, 0, W, Ys[l - 1],
+                                                   affines[l - 1], stats_saved[l - 1], dW, dev)
+                    grads[6 * l] = dW
+                    if ctx.needs_input_grad[2 + 6 * l + 1]:
+                        grads[6 * l + 1] = arena[bo:bo + bn_]   # bias in front of a batch-stat BatchNorm: zero gradient
+                    grads[6 * l + 2] = dgamma
+                    grads[6 * l + 3] = dbeta
+                    fused_red = (rslab, ns)
+                    G_in = G_prev
+                    continue
                 ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
                 a_aff = affines[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P, "bn"), 4.0 * P * (2 * Cout + Kin)):

@@ -213,6 +213,40 @@ def test_shared_mlp_fused_bn_reduce_matches_separate_launches(nn_ops, P, K, dims
         assert (a - b).norm() <= 5e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
 
 
+@pytest.mark.parametrize("P,K,dims", [(98304, 128, ((64, 64), (64, 96), (96, 128))), (65536, 64, ((64, 64), (64, 64), (64, 128))),
+                                      (32768, 64, ((64, 128), (128, 128), (128, 128)))])
+def test_shared_mlp_fused_da_dw_matches_separate_kernels(nn_ops, P, K, dims):
+    """SharedMLPFn with the one-pass dA + dW kernel (default) against the separate streaming dA / dW kernels: same forward,
+    every gradient to fp32 rounding."""
+    x = _rand((P, dims[0][0]), 31).cuda()
+    g = torch.Generator().manual_seed(32)
+    tens = []
+    for cin, cout in dims:
+        tens += [(torch.randn(cout, cin, generator=g) * (2.0 / cin ** 0.5)).cuda().requires_grad_(True),
+                 torch.zeros(cout, device="cuda", requires_grad=True),
+                 (torch.rand(cout, generator=g) + 0.5).cuda().requires_grad_(True), (torch.randn(cout, generator=g) * 0.1).cuda().requires_grad_(True),
+                 torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")]
+    gout = _rand((P // K, dims[-1][1]), 33).cuda()
+    res = {}
+    for fuse in (True, False):
+        old = nn_ops._FUSE_BWD
+        nn_ops._FUSE_BWD = fuse
+        try:
+            xi = x.clone().requires_grad_(True)
+            cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
+            out = nn_ops.SharedMLPFn.apply(xi, cfg, *[t.clone() if not t.requires_grad else t for t in tens])
+            grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
+            res[fuse] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
+        finally:
+            nn_ops._FUSE_BWD = old
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        if b is None:
+            assert a is None
+            continue
+        assert (a - b).norm() <= 2e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
+
+
 @pytest.mark.parametrize("P,Cout,Kin", [(40008, 96, 64), (65536, 64, 64), (33000, 128, 128), (50000, 128, 96)])
 def test_bn_apply_on_load_matches_apply_pass(nn_ops, P, Cout, Kin):
     """prifit_gemm_stream_tn_bn_f32 / prifit_gemm_stream_dgrad_bn_f32 (a middle layer's dY formed from G and Y inside the
@@ -244,6 +278,55 @@ def test_bn_apply_on_load_matches_apply_pass(nn_ops, P, Cout, Kin):
          ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), cur_stream())
     assert torch.equal(Gp, Gp_ref)
     torch.testing.assert_close(sl.double().sum(0), sl_ref.double().sum(0), rtol=1e-6, atol=1e-3)
+
+
+@pytest.mark.parametrize("P,Cout,Kin,pool_K", [(40008, 96, 64, 0), (65536, 64, 64, 0), (33000, 128, 128, 0), (50000, 128, 96, 0),
+                                              (36936, 128, 64, 0), (49152, 128, 96, 128), (65536, 128, 64, 64), (40960, 64, 64, 64),
+                                              (36864, 128, 128, 192)])
+def test_fused_da_dw_kernel_matches_separate_streaming_kernels(nn_ops, P, Cout, Kin, pool_K):
+    """prifit_gemm_stream_bwd_f32 (dA, the BatchNorm-backward partials of the layer below and dW from ONE pass over the rows)
+    against the separate streaming kernels on the same operands: Gp, dW and the (m1, m2) sums to fp32 rounding (the
+    products are summed in another order); middle-layer and max-pooled forms, ragged P, every supported (Cout, Cin)."""
+    from prifit_amd.nn_ops import call, ptr, cur_stream, _LL, _F, dll
+    assert dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, pool_K)
+    Y, A = _rand((P, Cout), 62).cuda(), _rand((P, Kin), 63).cuda()
+    W = _rand((Cout, Kin), 64).cuda()
+    s, t, ca, cb, cd = [_rand((Cout,), 65 + i).cuda() for i in range(5)]
+    s1, t1, mu1, is1 = [_rand((Kin,), 71 + i).cuda() for i in range(4)]
+    ns_ref = dll().prifit_gemm_stream_slabs(P, Cout)
+    Gp_ref = torch.empty(P, Kin, device="cuda")
+    sl_ref = torch.empty(ns_ref, 2, Kin, device="cuda")
+    dW_ref = torch.zeros(Cout, Kin, device="cuda")
+    ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), device="cuda")
+    if pool_K:
+        Gn = P // pool_K
+        arg = torch.randint(0, pool_K, (Gn, Cout), generator=torch.Generator().manual_seed(5), dtype=torch.int32).cuda()
+        T = _rand((Gn, Cout), 81).cuda()
+        bias_dw = torch.mv(W.t(), cd)
+        call("prifit_gemm_stream_tn_pool_f32", Cout, Kin, _LL(P), ptr(Y), _LL(Cout), ptr(A), _LL(Kin), ptr(dW_ref), _LL(Kin), ptr(s1),
+             ptr(t1), ptr(arg), ptr(T), ptr(cb), ptr(cd), pool_K, ptr(ws), cur_stream())
+        call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp_ref), _LL(Kin), ptr(bias_dw),
+             ptr(arg), ptr(T), ptr(cb), pool_K, ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), cur_stream())
+        G = None
+    else:
+        G = _rand((P, Cout), 61).cuda()
+        arg = T = None
+        call("prifit_gemm_stream_tn_bn_f32", Cout, Kin, _LL(P), ptr(G), ptr(Y), _LL(Cout), ptr(A), _LL(Kin), ptr(dW_ref), _LL(Kin), ptr(s1),
+             ptr(t1), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), ptr(ws), cur_stream())
+        call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G), ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp_ref), _LL(Kin), ptr(s), ptr(t),
+             ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), cur_stream())
+    ns = dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin)
+    Gp = torch.full((P, Kin), float("nan"), device="cuda")
+    sl = torch.full((ns, 2, Kin), float("nan"), device="cuda")
+    dW = torch.full((Cout, Kin), float("nan"), device="cuda")
+    ws2 = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), device="cuda")
+    call("prifit_gemm_stream_bwd_f32", _LL(P), Cout, Kin, ptr(G), ptr(Y), ptr(None if pool_K else s), ptr(None if pool_K else t),
+         ptr(None if pool_K else ca), ptr(cb), ptr(cd), ptr(arg), ptr(T), pool_K, ptr(W), _LL(Kin), ptr(A), _LL(Kin), ptr(s1), ptr(t1),
+         ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(sl), ptr(dW), _LL(Kin), ptr(ws2), cur_stream())
+    assert torch.isfinite(Gp).all() and torch.isfinite(dW).all() and torch.isfinite(sl).all()
+    assert (Gp - Gp_ref).abs().max() <= 2e-5 * Gp_ref.abs().max()
+    assert (dW - dW_ref).norm() <= 2e-6 * dW_ref.norm()
+    torch.testing.assert_close(sl.double().sum(0), sl_ref.double().sum(0), rtol=2e-5, atol=2e-5 * sl_ref.double().sum(0).abs().max().item())
 
 
 @pytest.mark.parametrize("P,K,N,Kin", [(65536, 64, 128, 64), (49152, 96, 64, 96), (32768, 32, 96, 128)])
