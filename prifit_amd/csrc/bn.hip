@@ -319,14 +319,25 @@ __global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
         const long long g = (long long)b * S + sidx;
         const float *gp = G + (size_t)g * K * C + c, *yp = Y + (size_t)g * K * C + c;
         const int32_t *ix = idx + (size_t)g * K;
-        float2 acc = {0.f, 0.f};
+        float2 acc = {0.f, 0.f}, pacc = {0.f, 0.f};
+        // Padding: a ball with fewer than K points repeats its FIRST index (models/pointnet_util.py:104-106), on sparse clouds
+        // in most of the slots -- all of them rows of one point, i.e. of one wave.  The workgroup that owns that point deals
+        // the padded slots round-robin over its four waves instead; their sum stays in registers and goes to dU with one
+        // global atomic per channel and group.
+        const int first = ix[0];
+        const bool pads_here = first >= n0 && first < n0 + GLB_PTS && first < N;
+        int pad_seen = 0;
         for (int k0 = 0; k0 < K; k0 += 64) {
-            // the rows of this batch whose point is this wave's: compacted in slot order (ballot + prefix count)
+            // the rows of this batch that are this wave's: compacted in slot order (ballot + prefix count)
             const int r = k0 + lane;
             const int n = r < K ? ix[r] : -1;
-            const bool mine = n >= n0 && n < n0 + GLB_PTS && n < N && (n & 3) == wave;
+            const bool pad = pads_here && r > 0 && n == first;
+            const unsigned long long pm = __ballot(pad);
+            const bool my_pad = pad && ((pad_seen + __popcll(pm & ((1ull << lane) - 1ull))) & 3) == wave;
+            pad_seen += __popcll(pm);
+            const bool mine = my_pad || (!pad && n >= n0 && n < n0 + GLB_PTS && n < N && (n & 3) == wave);
             const unsigned long long m = __ballot(mine);
-            if (mine) rows[__popcll(m & ((1ull << lane) - 1ull))] = (r << 8) | (n - n0);
+            if (mine) rows[__popcll(m & ((1ull << lane) - 1ull))] = (r << 8) | (my_pad ? 0x80 : 0) | ((n - n0) & 0x7f);
             const int cnt = __popcll(m);
             // (wave-private LDS: the writes above are visible to the wave's own later reads without a barrier)
             __builtin_amdgcn_wave_barrier();
@@ -346,11 +357,15 @@ __global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
                     if (t + j < cnt && cok) {
                         const float dx = fmaf(a.x, fmaf(yv[j].x, sc.x, sh.x) > 0.f ? gv[j].x : 0.f, fmaf(bb.x, yv[j].x, d.x));
                         const float dyy = fmaf(a.y, fmaf(yv[j].y, sc.y, sh.y) > 0.f ? gv[j].y : 0.f, fmaf(bb.y, yv[j].y, d.y));
-                        // plain read-modify-write: the point is this wave's alone, and a wave's LDS accesses execute in order
-                        float2 *dst = reinterpret_cast<float2 *>(s_acc + (pk[j] & 255) * C + c);
-                        float2 v = *dst;
-                        v.x += dx; v.y += dyy;
-                        *dst = v;
+                        if (pk[j] & 0x80) {   // (wave-uniform) a padded slot: summed in registers
+                            pacc.x += dx; pacc.y += dyy;
+                        } else {
+                            // plain read-modify-write: the point is this wave's alone, and a wave's LDS accesses execute in order
+                            float2 *dst = reinterpret_cast<float2 *>(s_acc + (pk[j] & 0x7f) * C + c);
+                            float2 v = *dst;
+                            v.x += dx; v.y += dyy;
+                            *dst = v;
+                        }
                         acc.x += dx; acc.y += dyy;
                     }
                 }
@@ -360,6 +375,10 @@ __global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
         if (cok && (acc.x != 0.f || acc.y != 0.f)) {
             unsafeAtomicAdd(dVc + (size_t)g * C + c, -acc.x);
             unsafeAtomicAdd(dVc + (size_t)g * C + c + 1, -acc.y);
+        }
+        if (cok && (pacc.x != 0.f || pacc.y != 0.f)) {
+            unsafeAtomicAdd(dU + ((size_t)b * N + first) * C + c, pacc.x);
+            unsafeAtomicAdd(dU + ((size_t)b * N + first) * C + c + 1, pacc.y);
         }
     }
     __syncthreads();

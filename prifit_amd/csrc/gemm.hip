@@ -1230,7 +1230,8 @@ static inline bool small_tiles(int M, int N, int batch, int splitk)
     const long long wgs = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * splitk;
     // (fewer than ~two 128 x 128 tiles per CU: measured over the step's 28 SA3 / feature-propagation / head products,
     // tools/small_gemm_bench.py: 838 us with the threshold at 160 workgroups, 796 at 320, 786 at 520)
-    return wgs < 520 && M > 64 && N > 32;
+    // (split-K launches -- the tall weight-gradient reductions -- keep the 128 x 128 split-K kernel down to 160 workgroups)
+    return wgs < (splitk > 1 ? 160 : 520) && M > 64 && N > 32;
 }
 
 static int dispatch(GemmArgs &g, int layout, void *stream)

@@ -14,6 +14,9 @@ for K in (64, 128):
     G = torch.randn(P, C, device=dev, generator=g)
     Y = torch.randn(P, C, device=dev, generator=g)
     idx = torch.randint(0, N, (B, S, K), device=dev, generator=g, dtype=torch.int32)
+    if os.environ.get("PAD", "0") == "1":   # sparse cloud: ~60 % of the slots repeat the first index
+        cnt = torch.randint(1, K, (B, S, 1), device=dev, generator=g)
+        idx = torch.where(torch.arange(K, device=dev).view(1, 1, K) < cnt, idx, idx[:, :, :1])
     vec = [torch.randn(C, device=dev, generator=g) for _ in range(5)]
     dY = torch.empty(P, C, device=dev)
     def old():
