@@ -34,7 +34,7 @@ _FUSE_BN_APPLY = os.environ.get("PRIFIT_FUSE_BN_APPLY", "1") != "0"  # 0: bn_rel
 _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
 # 1: dA and dW of a streaming-shape layer from ONE pass over its rows (csrc/gemm_stream_bwd.hip) instead of the separate
 # streaming dA (NN) and dW (TN) kernels, which each read G, Y and the previous layer's pre-activation.  Measured (round 3,
-# DESIGN 5d): the one-pass kernel halves the HBM bytes but its first form -- one 7..8-wave workgroup per CU, A-waves and
+# DESIGN 5e): the one-pass kernel halves the HBM bytes but its first form -- one 7..8-wave workgroup per CU, A-waves and
 # W-waves on the same LDS tiles -- runs at 0.3-0.5 of the matrix peak: [1.57 M x 128 x 96 pooled] 933 us against 502 + 365,
 # [1.57 M x 96 x 64] 771 against 363 + 358, the step 16.70 against 16.23 ms.  OFF; correct and covered by GPU tests.
 _FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "0") != "0"
