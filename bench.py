@@ -349,6 +349,17 @@ def measure(args, ctx, cloud, embedding, steps, warmup, full):
     dominant = max(cal.items(), key=lambda kv: kv[1][1])[0] if cal else None
     profiler.disable()
     profiler.reset()
+    graph_note = None
+    if args.graph:
+        if args.workload == "c5":
+            raise SystemExit("--graph: the PointNet++ backbone (c2 / c3)")
+        from prifit_amd.train_step import graph_backbone
+        graph_backbone(net, data["xyz"], data["cls"], starts)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        graph_note = ("backbone forward + backward replayed as two HIP graphs (train_step.graph_backbone); the grouping "
+                      "launches are inside them: roofline_grouping from the last eager warm-up step")
     if os.environ.get("PRIFIT_BENCH_EVENTS", "1") == "all":   # diagnosis: every family bracketed (slows the step down)
         profiler.enable("*")
     elif os.environ.get("PRIFIT_BENCH_EVENTS", "1") != "0":  # 0: diagnosis only (no roofline objects in the line)
@@ -373,7 +384,13 @@ def measure(args, ctx, cloud, embedding, steps, warmup, full):
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    res = {"elapsed": el.item(), "steps": steps, "warmup": warmup, "fams": profiler.collect(), "loss": float(loss.item()),
+    fams = profiler.collect()
+    if graph_note:   # the launches inside the graphs carry no events: their rows come from the calibration step (one eager step)
+        for k in GROUPING_FAMILIES:
+            if k in cal and k not in fams:
+                n, ms, work = cal[k]
+                fams[k] = (n * steps, ms * steps, work * steps)
+    res = {"elapsed": el.item(), "steps": steps, "warmup": warmup, "fams": fams, "loss": float(loss.item()), "graph": graph_note,
            "fallbacks": runner.fallbacks - fallbacks0, "ahead_on": ahead_on,
            "clusters": last["count"].tolist() if "count" in last else None}
     if full:
@@ -493,6 +510,7 @@ def headline(args, ctx, r, cloud):
                    "cloud": cloud, "embedding": args.embedding if args.workload != "c2" else None,
                    "clusters_per_shape": (sum(ks) / len(ks)) if ks else None,
                    "loss": r["loss"],
+                   "launch": r.get("graph") or "eager",
                    "fps": ("side stream, one batch ahead (every step launches one batch's sampling and consumes the "
                            "previous launch)" if r["ahead_on"] else "in line")},
         "roofline": roof, "roofline_grouping": grouping_roofline(detail), "kernels": detail,
@@ -517,6 +535,7 @@ def main():
     ap.add_argument("--cloud", default=None, choices=("cube", "blobs", "surface"))
     ap.add_argument("--embedding", default="untrained", choices=("untrained", "clustered"))
     ap.add_argument("--no-extra", action="store_true", help="skip the training-like conditions reported under `extra`")
+    ap.add_argument("--graph", action="store_true", help="replay the backbone forward + backward as HIP graphs (static shapes)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:

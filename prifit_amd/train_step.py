@@ -72,6 +72,50 @@ class SpeculativeRunner:
         return fn()
 
 
+class _Backbone(torch.nn.Module):
+    """`net.embed_features` as a module of its own (what make_graphed_callables captures): parameters = the network's."""
+
+    def __init__(self, net, fps_start):
+        super().__init__()
+        self.net, self.fps_start = net, fps_start
+
+    def forward(self, xyz, cls_label):
+        return self.net._embed_features_eager(xyz, cls_label, self.fps_start)
+
+
+def graph_backbone(net, xyz, cls_label, fps_start):
+    """Capture the backbone of `net` (everything up to `feat`: set abstraction, feature propagation, conv1 + bn1 --
+    upstream models/pointnet2_part_seg_msg.py:64-88 -- forward AND backward) into two HIP graphs and install it as
+    `net.embed_features`: ~300 of a step's ~440 launches then cost the host one graph launch each way.  The shapes are
+    static and nothing in there reads back to the host, the kernels only enqueue on the current stream (include/
+    prifit_hip.h), so the capture is `torch.cuda.make_graphed_callables` as is; the fit path stays eager (its
+    cluster-count verdict is read on the host, SpeculativeRunner).  Static inputs: `xyz` / `cls_label` of these shapes
+    (other tensors are copied in), `fps_start` = these very tensors.  BatchNorm buffers are put back after the warm-up
+    iterations of the capture.  Returns the graphed callable (also `net.embed_features`); `net.embed_features_eager`
+    keeps the original."""
+    from . import arena
+    if not hasattr(net, "_embed_features_eager"):
+        net._embed_features_eager = net.embed_features
+    bufs = [b for b in net.buffers()]
+    snap = [b.clone() for b in bufs]
+    was_enabled = arena._ENABLED
+    arena._ENABLED = False          # zero-filled tensors inside the graphs are the graphs' own (re-zeroed at every replay)
+    try:
+        graphed = torch.cuda.make_graphed_callables(_Backbone(net, fps_start), (xyz, cls_label), num_warmup_iters=2,
+                                                    allow_unused_input=True)
+    finally:
+        arena._ENABLED = was_enabled
+        with torch.no_grad():
+            for b, s_ in zip(bufs, snap):
+                b.copy_(s_)
+
+    def embed_features(xyz_, cls_, fps_start_=None):
+        return graphed(xyz_, cls_)
+
+    net.embed_features = embed_features
+    return graphed
+
+
 class Trainer:
     def __init__(self, model, num_part=50, learning_rate=0.001, decay_rate=1e-4, lr_decay=0.5, step_size=20, lmbda=1.0,
                  fused_adam=True):

@@ -163,3 +163,55 @@ def test_speculative_retry_restores_python_state(hiplib):
     assert torch.equal(calls[0][1], calls[1][1])                          # same random draw in the retried step
     expect = rm0 * 0.9 + 0.1 * 2.0                                        # one momentum update, from the second call's input
     torch.testing.assert_close(m.bn.running_mean, expect)
+
+
+def test_graphed_backbone_matches_eager(hiplib):
+    """train_step.graph_backbone: the backbone's forward and backward replayed as two HIP graphs give the eager step's loss
+    and parameter gradients (supervised step, models/pointnet2_part_seg_msg.py:64-88 + autograd), BatchNorm buffers are
+    left as the eager step leaves them, and a second replay with other input VALUES (same shapes) follows the eager path."""
+    import numpy as np
+    from prifit_amd import synth
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    from prifit_amd.train_step import graph_backbone
+    dev = torch.device("cuda", 0)
+    B, N = 2, 1024
+
+    def batch(seed):
+        xyz = torch.from_numpy(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous().to(dev)
+        tgt = torch.from_numpy(synth.labels(B, N, 50, seed)).to(dev)
+        return xyz, tgt
+
+    starts = (torch.from_numpy(synth.fps_start(B, N, 3)).to(dev), torch.from_numpy(synth.fps_start(B, 512, 4)).to(dev))
+    cls = torch.zeros(B, 1, 16, device=dev)
+
+    def make():
+        torch.manual_seed(0)
+        net = M.get_model(50)
+        synth.xavier_like_trainer(net)
+        net = net.to(dev).train()
+        net.drop1.eval()
+        return net
+
+    def run(net, xyz, tgt):
+        for p in net.parameters():
+            p.grad = None
+        seg = net(xyz, cls, fps_start=starts)[0]
+        loss = torch.nn.functional.cross_entropy(seg.reshape(-1, 50), tgt.view(-1))
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    eager, graphed = make(), make()
+    graph_backbone(graphed, *batch(5)[:1], cls, starts)
+    for n, b in eager.named_buffers():                      # the capture's warm-up iterations left no trace
+        assert torch.equal(b, dict(graphed.named_buffers())[n]), n
+    for seed in (5, 6):
+        xyz, tgt = batch(seed)
+        le, ge = run(eager, xyz, tgt)
+        lg, gg = run(graphed, xyz, tgt)
+        assert abs(le - lg) <= 1e-6 * abs(le)
+        assert set(ge) == set(gg)
+        for n in ge:
+            if ge[n].norm() > 1e-6:                          # (bias gradients in front of a BatchNorm are rounding noise)
+                assert (ge[n] - gg[n]).norm() <= 2e-3 * ge[n].norm(), (n, (ge[n] - gg[n]).norm().item(), ge[n].norm().item())
+    for n, b in eager.named_buffers():
+        torch.testing.assert_close(b, dict(graphed.named_buffers())[n], rtol=1e-5, atol=1e-6)
