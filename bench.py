@@ -289,20 +289,27 @@ def measure(args, ctx, cloud, embedding, steps, warmup, full):
         off = torch.from_numpy(synth.part_embedding_offset(data["parts"].cpu().numpy(), 128, 1000 * rank)).to(device)
         fit_kw["fit_inputs"] = dict(embedding_offset=off)
 
-    # PRIFIT_SAMPLE_AHEAD=1 (default 0: in line, on the step's own stream): farthest-point sampling of the NEXT batch on
-    # a side stream while this step runs (ops.sample_ahead: the samples depend on the coordinates alone, and the search
-    # keeps 24 of 256 CUs busy).  Every step then launches the sampling of one batch -- the synthetic batch is the same
-    # every step, its samples are recomputed every step all the same -- and consumes the one launched a step earlier.
-    # Measured: launched at the top of the step 24.33 -> 24.2 ms, but the grouping launches it runs beside
-    # lose 7 %; launched between forward and backward nothing either way -- so the headline runs in line.
-    ahead_on = args.workload != "c5" and os.environ.get("PRIFIT_SAMPLE_AHEAD", "0") == "1"
+    # Farthest-point sampling of the NEXT batch on a side stream while this step runs (ops.sample_ahead: the samples depend
+    # on the coordinates alone, and the search is 640 serial rounds on one workgroup per shape: 24 of 256 CUs busy for
+    # 0.28 ms at the head of every step).  Every step launches the sampling of one batch -- the synthetic batch is the same
+    # every step, its samples are recomputed every step all the same -- and consumes the one launched a step earlier: the
+    # work inside the timed region is unchanged, only its place in the step.  PRIFIT_SAMPLE_AHEAD = 2 (default): launched
+    # right behind the backbone forward (`net.after_backbone`), where it runs beside the matrix-bound mean-shift kernels
+    # (c3 16.27 -> 16.08 ms, same box, alternating runs; grouping launches unaffected: 0.51 both ways); 1: between
+    # forward and backward (16.10); 0: in line on the step's own stream.  Round 2 had it in line: launched at the top of the
+    # step it ran beside the HBM-bound grouping launches, which lost 7 %.
+    ahead_mode = os.environ.get("PRIFIT_SAMPLE_AHEAD", "2")
+    ahead_on = args.workload != "c5" and ahead_mode in ("1", "2")
     starts = (data.get("s1"), data.get("s2"))
     sampled = {"cur": starts, "next": None}
     last = {}
 
-    def sample_next():
-        if ahead_on:
+    def sample_next(force=False):
+        if ahead_on and (force or ahead_mode == "1"):
             sampled["next"] = net.sample_ahead(data["xyz"], starts)   # the next step's batch
+
+    if ahead_on and ahead_mode == "2":
+        net.after_backbone = lambda: sample_next(True)
 
     def selfsup_fwd_bwd():
         if args.workload == "c5":
@@ -511,8 +518,8 @@ def headline(args, ctx, r, cloud):
                    "clusters_per_shape": (sum(ks) / len(ks)) if ks else None,
                    "loss": r["loss"],
                    "launch": r.get("graph") or "eager",
-                   "fps": ("side stream, one batch ahead (every step launches one batch's sampling and consumes the "
-                           "previous launch)" if r["ahead_on"] else "in line")},
+                   "fps": ("side stream, one batch ahead: every step launches one batch's sampling (behind its backbone forward) "
+                           "and consumes the previous launch; PRIFIT_SAMPLE_AHEAD=0 runs it in line" if r["ahead_on"] else "in line")},
         "roofline": roof, "roofline_grouping": grouping_roofline(detail), "kernels": detail,
         "speculation_fallbacks": r["fallbacks"],
         "host_enqueue_ms_per_step": 1e3 * r["t_host"],

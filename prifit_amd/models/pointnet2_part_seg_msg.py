@@ -89,6 +89,11 @@ class get_model(nn.Module):
         if xyz.is_cuda:
             zero_pool.begin_step(xyz.device)   # one zero-fill per step for all zero-initialised fp32 buffers
         l1, l2, l3, feat = self.embed_features(xyz, cls_label, fps_start)
+        if getattr(self, "after_backbone", None) is not None:
+            # data-path hook (like a DataLoader worker): e.g. `net.after_backbone = lambda: net.sample_ahead(next_xyz)` starts
+            # the NEXT batch's farthest-point sampling here, so that its 640 serial rounds on 24 CUs run beside the
+            # matrix-bound mean-shift kernels of this step instead of at the head of the next one
+            self.after_backbone()
         total_loss = torch.zeros(1, device=xyz.device)
         chamfer_loss = torch.zeros(1, device=xyz.device)
         extra = ()
