@@ -141,9 +141,12 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
 /* Chord-distance matrix of a point set with itself (src/mean_shift.py:154 bandwidth statistic, :185 non-maximum
  * suppression): C[z] = 2 - 2 A[z] A[z]^T for unit rows, [n, n] per batch item; n % 128 == 0, K % 32 == 0, 16-byte rows.
  * Only the tiles on and above the diagonal are computed, the others written as their transposes: the same bits as
- * prifit_gemm_f32(NT, A, A, epilogue = chord). */
+ * prifit_gemm_f32(NT, A, A, epilogue = chord).
+ * owner_key (may be NULL): [batch, n] 64-bit keys, ALL BITS SET on entry; on return the low word of key j is
+ * argmin_i C[i][j] (first minimum) and the high word the order-preserving image of that distance -- nms's owner pass
+ * (src/mean_shift.py:168-170) without a second read of the matrix; hand it to prifit_nms. */
 int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
-                         int n, int K, int batch, void *stream);
+                         int n, int K, int batch, unsigned long long *owner_key, void *stream);
 
 /* Forward of a max-pooled last layer on the tiled (persistent 128 x 128) kernel, as prifit_gemm_stream_pool_f32 does on
  * the streaming shapes (models/pointnet_util.py:252-257): Y = relu(bn(A)) W^T + bias with the column statistics AND the
@@ -482,10 +485,11 @@ int prifit_meanshift_rows_bwd(const float *X, const float *bw, int B, int N, int
  * dist [B,N,N] = 2 - 2 Z Z^T, Z [B,N,D], bw [B].  Outputs: owner [B,N] (nearest centre of each point),
  * counts [B,N], flags [B,N] (scratch), ids [B,cap] ascending kept centre ids, count [B] = number of kept
  * centres (may exceed cap: only the first cap ids are stored), labels [B,N] = argmax_k <Z[ids[k]], z_j>
- * over the stored centres, used [B,cap] = 1 where label k occurs. */
+ * over the stored centres, used [B,cap] = 1 where label k occurs.  owner_key (may be NULL): the keys
+ * prifit_chord_sym_f32 left while it wrote `dist`; then the owner pass does not read the matrix again. */
 int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap,
-               int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count,
-               int32_t *labels, int32_t *used, void *stream);
+               const unsigned long long *owner_key, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids,
+               int32_t *count, int32_t *labels, int32_t *used, void *stream);
 
 /* Soft membership, src/mean_shift.py:230-247.  dots [B,N,KM] = <x_j, centre_k> (raw), bw [B], gmax [B] =
  * max over live (k, j) of dots / bw^2 (detached): W [B,N,KM] = softmax-like weights, 0 for k >= count[b]. */

@@ -897,7 +897,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // k order -- so only the tiles on and above the diagonal are computed (136 of 256 at n = 2048); an off-diagonal tile
 // is also written transposed, through LDS, as whole coalesced rows.  Bit-identical to the full product.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chord_sym_kernel(
-    const float *__restrict__ A, long long lda, long long sA, float *__restrict__ C, long long ldc, long long sC, int n, int K)
+    const float *__restrict__ A, long long lda, long long sA, float *__restrict__ C, long long ldc, long long sC, int n, int K,
+    unsigned long long *__restrict__ okey)
 {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int SZ = BM * (BK + PAD);
@@ -955,15 +956,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const bool mirror = tile_m != tile_n;   // block-uniform
+    // okey (optional): nms's owner pass fused in (src/mean_shift.py:168-170: owner[j] = argmin_i dist[i][j], first minimum).
+    // Every point keeps a 64-bit key (order-preserving image of the distance << 32 | candidate index) whose minimum over
+    // the launch IS (smallest distance, lowest index among equals); this tile contributes, for the points of its column
+    // block, the candidates of its row block (a column minimum, from the accumulator registers) and -- off the diagonal --
+    // for the points of its row block the candidates of its column block (from the transposed copy in LDS).  The matrix is
+    // bitwise symmetric, so a column's minimum over rows is that point's row minimum over columns.
+    unsigned long long *okz = okey ? okey + (long long)blockIdx.z * n : nullptr;
+    auto fkey = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = wn0 + 32 * b + li;
+        float cmin = INFINITY;
+        int cidx = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float v = 2.0f - 2.0f * acc[b][r];   // src/mean_shift.py:154 / :168
             Cz[(long long)(m0 + row) * ldc + n0 + col] = v;
             if (mirror) lds[col * TLD + row] = v;
+            if (v < cmin) { cmin = v; cidx = row; }     // rows ascend with r inside a lane: strict keeps the first
+        }
+        if (okz) {
+            const float ov = __shfl_xor(cmin, 32, 64);
+            const int oi = __shfl_xor(cidx, 32, 64);
+            if (ov < cmin || (ov == cmin && oi < cidx)) { cmin = ov; cidx = oi; }
+            if (lh == 0) atomicMin(okz + n0 + col, ((unsigned long long)fkey(cmin) << 32) | (unsigned)(m0 + cidx));
         }
     }
     if (mirror) {
@@ -972,6 +990,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int trow = i / (BM / 4), c4 = i - trow * (BM / 4);
             *reinterpret_cast<float4 *>(Cz + (long long)(n0 + trow) * ldc + m0 + 4 * c4) =
                 *reinterpret_cast<const float4 *>(lds + trow * TLD + 4 * c4);
+        }
+        if (okz) {
+            // lds[c][r] = dist[m0 + r][n0 + c]: thread (r, quarter q) scans the columns 32 q .. 32 q + 31 of row r
+            const int r = threadIdx.x & (BM - 1), q = threadIdx.x >> 7;
+            float rmin = INFINITY;
+            int ridx = 0;
+#pragma unroll 8
+            for (int c = 32 * q; c < 32 * q + 32; ++c) {
+                const float v = lds[c * TLD + r];
+                if (v < rmin) { rmin = v; ridx = c; }
+            }
+            atomicMin(okz + m0 + r, ((unsigned long long)fkey(rmin) << 32) | (unsigned)(n0 + ridx));
         }
     }
 }
@@ -1367,7 +1397,7 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
 }
 
 int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
-                         int n, int K, int batch, void *stream)
+                         int n, int K, int batch, unsigned long long *owner_key, void *stream)
 {
     if (!A || !C || n <= 0 || (n % 128) || K <= 0 || (K % BK) || batch <= 0 || batch > 65535 || lda < K || ldc < n || (lda & 3) ||
         (ldc & 3) || (strideA & 3) || (strideC & 3) || ((uintptr_t)A & 15) || ((uintptr_t)C & 15) ||
@@ -1375,7 +1405,7 @@ int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float
         return PRIFIT_EINVAL;
     const int T = n / 128;
     hipLaunchKernelGGL(chord_sym_kernel, dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0, as_stream(stream), A, lda, strideA, C, ldc,
-                       strideC, n, K);
+                       strideC, n, K, owner_key);
     return prifit_check_launch();
 }
 

@@ -457,9 +457,22 @@ int prifit_meanshift_update_bwd(const float *g, const float *out, const float *n
     return prifit_check_launch();
 }
 
-int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap, int32_t *owner,
-               int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count, int32_t *labels, int32_t *used,
-               void *stream)
+// owner / counts from the keys the chord kernel left (prifit_chord_sym_f32 with owner_key): low word = the owner
+__global__ __launch_bounds__(256) void nms_owner_from_keys_kernel(const unsigned long long *__restrict__ okey, int N,
+                                                                  long long rows, int32_t *__restrict__ owner,
+                                                                  int32_t *__restrict__ counts)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    int bi = (int)(unsigned)(okey[row] & 0xffffffffull);
+    bi = bi < 0 ? 0 : (bi >= N ? N - 1 : bi);
+    owner[row] = bi;
+    atomicAdd(counts + (row / N) * N + bi, 1);
+}
+
+int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap,
+               const unsigned long long *owner_key, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids,
+               int32_t *count, int32_t *labels, int32_t *used, void *stream)
 {
     if (!dist || !Z || !bw || !owner || !counts || !flags || !ids || !count || !labels || !used || B <= 0 ||
         N <= 0 || D <= 0 || D > 256 || cap <= 0)
@@ -470,7 +483,11 @@ int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N,
     if (hipMemsetAsync(counts, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
     if (hipMemsetAsync(flags, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
     if (hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)B * cap, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist, N, rows, owner, counts);
+    if (owner_key)
+        hipLaunchKernelGGL(nms_owner_from_keys_kernel, dim3((unsigned)((rows + 255) / 256)), block, 0, st, owner_key, N, rows,
+                           owner, counts);
+    else
+        hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist, N, rows, owner, counts);
     hipLaunchKernelGGL(nms_pick_kernel, grid, block, 0, st, dist, counts, bw, N, rows, flags);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(B), block, 0, st, flags, N, cap, ids, count);
     hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, Z, N, D, ids, count, cap, rows, labels, used);

@@ -29,6 +29,7 @@ DX_STREAMS = __import__("os").environ.get("PRIFIT_MS_DX_STREAMS", "0") != "0"
 # +7 % (488 -> 452 us at B = 24, N = 2048).  (The forward's time is linear in its block count: no such schedule there.)
 MS_BALANCED = True
 CHORD_SYM = __import__("os").environ.get("PRIFIT_CHORD_SYM", "1") != "0"   # symmetric kernel for chord_matrix(X, X)
+FUSE_NMS_OWNER = True   # nms: the owner pass (column argmin) in the chord kernel's epilogue (False: a second read of the matrix)
 # cluster(): the loss reads the shifted points through `center = new_X[indices]` only, so the mean-shift backward runs
 # on those rows alone (MeanShiftRowsFn); 0 = the dense backward of MeanShiftFn + a gather (same numbers; the A/B arm
 # and the path of callers that differentiate through the whole of new_X)
@@ -51,16 +52,22 @@ def _skinny_splitk(M, N, K, batch):
     return sk
 
 
-def chord_matrix(A, B_):
-    """2 - 2 A B^T for unit rows (src/mean_shift.py:154,168,185).  A [B,N,D], B_ [B,M,D] -> [B,N,M]."""
+def chord_matrix(A, B_, owner_key=None):
+    """2 - 2 A B^T for unit rows (src/mean_shift.py:154,168,185).  A [B,N,D], B_ [B,M,D] -> [B,N,M].
+    owner_key: a one-element list; when the symmetric kernel runs it receives the [B,N] int64 keys of nms's owner pass
+    (argmin over each column in the low word), computed in the kernel's epilogue."""
     Bt, N, D = A.shape
     M = B_.shape[1]
     out = torch.empty(Bt, N, M, dtype=torch.float32, device=A.device)
     if (CHORD_SYM and A.data_ptr() == B_.data_ptr() and N == M and N % 128 == 0 and D % 32 == 0 and A.is_contiguous() and
             A.data_ptr() % 16 == 0):
         # a set against itself: the symmetric kernel computes the upper triangle of tiles only (same bits)
+        keys = None
+        if owner_key is not None:
+            keys = torch.full((Bt, N), -1, dtype=torch.int64, device=A.device)   # all bits set: the atomic-min identity
+            owner_key.append(keys)
         with profiler.span(profiler.tag("chord_sym", N, D, Bt), 2.0 * Bt * N * N * D):
-            call("prifit_chord_sym_f32", ptr(A), _LL(D), _LL(N * D), ptr(out), _LL(N), _LL(N * N), N, D, Bt, cur_stream())
+            call("prifit_chord_sym_f32", ptr(A), _LL(D), _LL(N * D), ptr(out), _LL(N), _LL(N * N), N, D, Bt, ptr(keys), cur_stream())
         return out
     _bgemm(NT, N, M, D, A, D, B_, D, out, M, Bt, N * D, M * D, N * M, epi=EPI_CHORD)
     return out
@@ -298,7 +305,9 @@ def nms(Z, bw):
     Returns ids [B,NMS_CAP] (ascending kept centre ids), count [B], labels [B,N], used [B,NMS_CAP]."""
     Bt, N, D = Z.shape
     dev = Z.device
-    dist = chord_matrix(Z, Z)
+    keys = [] if FUSE_NMS_OWNER else None
+    dist = chord_matrix(Z, Z, keys)
+    okey = keys[0] if keys else None
     i32 = dict(dtype=torch.int32, device=dev)
     owner = torch.empty(Bt, N, **i32)
     counts = torch.empty(Bt, N, **i32)
@@ -308,7 +317,7 @@ def nms(Z, bw):
     labels = torch.empty(Bt, N, **i32)
     used = torch.empty(Bt, NMS_CAP, **i32)
     with profiler.span("nms", 8.0 * Bt * N * N):   # the chord matrix is read twice (owner, neighbour pick)
-        call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(owner), ptr(counts), ptr(flags), ptr(ids),
+        call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(okey), ptr(owner), ptr(counts), ptr(flags), ptr(ids),
              ptr(count), ptr(labels), ptr(used), cur_stream())
     return ids, count, labels, used
 

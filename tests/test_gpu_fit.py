@@ -448,6 +448,31 @@ def test_subsampled_bandwidth_matches_reference_golden(hiplib, golden):
         fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000, rows=rows[:, :10].cuda())
 
 
+def test_nms_owner_pass_fused_into_the_chord_kernel(F, monkeypatch):
+    """nms with the owner pass (argmin over every column of 2 - 2 Z Z^T, first minimum) taken in the chord kernel's epilogue
+    through 64-bit atomic-min keys against the separate pass that re-reads the matrix: the very same owners, kept ids,
+    labels -- on clustered points, on a collapsed cloud (all points within 1e-7: ties and negative distances everywhere)
+    and with exact duplicate rows in different tiles."""
+    gen = torch.Generator().manual_seed(9)
+    _, _, emb = fit_inputs(3, 2048, 128, 4)
+    Zs = [emb]
+    base = torch.nn.functional.normalize(torch.randn(1, 1, 128, generator=gen), dim=2)
+    Zs.append(torch.nn.functional.normalize(base + 1e-7 * torch.randn(2, 1024, 128, generator=gen), dim=2))
+    dup = torch.nn.functional.normalize(torch.randn(2, 512, 64, generator=gen), dim=2)
+    dup[:, 300:340] = dup[:, 7:47]            # duplicates 293 rows apart: other tiles
+    dup[:, 129] = dup[:, 0]
+    Zs.append(dup)
+    for Z in Zs:
+        Zc = Z.cuda().contiguous()
+        bw = torch.full((Z.shape[0],), 0.3, device="cuda")
+        res = []
+        for fused in (True, False):
+            monkeypatch.setattr(F, "FUSE_NMS_OWNER", fused)
+            res.append(F.nms(Zc, bw))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+
+
 def test_bandwidth_with_more_samples_than_rows(hiplib, golden):
     """num_samples > N keeps all rows and takes K = int(quantile * num_samples) (src/mean_shift.py:151-155), against the
     value captured from the reference; K beyond the row length raises like upstream's topk."""
