@@ -735,6 +735,9 @@ if __name__ == "__main__":
     if "fit" in which:
         import make_golden_fit
         make_golden_fit.run(save, eq, close)
+    if "ms_variants" in which or "fit" in which:
+        import make_golden_fit
+        make_golden_fit.run_mean_shift_variants(save, close)
     if "bw_over" in which or "fit" in which:
         import make_golden_fit
         make_golden_fit.run_bandwidth_over(save, close)

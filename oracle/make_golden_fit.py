@@ -78,6 +78,37 @@ def run_bandwidth_over(save, close):
     save("fit_bandwidth_over", **out)
 
 
+def run_mean_shift_variants(save, close):
+    """The two variants of MeanShift the loss never takes (src/mean_shift.py:70-74 epanechnikov kernel, :86-136
+    mean_shift_eff_): oracle vs reference, forward and d/dX.  Own fixture (`make_golden.py ms_variants`)."""
+    ms = refshim.ref("src.mean_shift").MeanShift()
+    seed, N, D = 6, 512, 32
+    _, _, emb = fit_inputs(1, N, D, seed, M=1000, noise=0.1)
+    X0 = emb[0]
+    G = torch.from_numpy(synth.features(1, N, D, seed + 1))[0]
+    seeds = torch.from_numpy(np.random.default_rng(seed).choice(N, N // 2, replace=False))
+    out = {"seed": seed, "rows": seeds.numpy().astype(np.int16)}
+    b = torch.tensor(0.9)
+    for name, fr, fo, g in (
+            ("epa", lambda X: ms.mean_shift_(X, b, 3, kernel_type="epa")[0], lambda X: orc.mean_shift_iterations(X, b, 3, "epa"), G),
+            ("eff", lambda X: ms.mean_shift_eff_(X, X[seeds], b, 3)[0], lambda X: orc.mean_shift_eff(X, X[seeds], b, 3), G[: N // 2]),
+            ("eff_epa", lambda X: ms.mean_shift_eff_(X, X[seeds], b, 3, kernel_type="epa")[0],
+             lambda X: orc.mean_shift_eff(X, X[seeds], b, 3, "epa"), G[: N // 2])):
+        Xr = X0.clone().requires_grad_(True)
+        Zr = fr(Xr)
+        (Zr * g).sum().backward()
+        Xo = X0.clone().requires_grad_(True)
+        Zo = fo(Xo)
+        (Zo * g).sum().backward()
+        close(Zo.detach(), Zr.detach(), "mean-shift variant %s: Z" % name, rtol=1e-5, atol=1e-6)
+        close(Xo.grad, Xr.grad, "mean-shift variant %s: dX" % name, rtol=1e-4, atol=1e-6 * Xr.grad.abs().max().item())
+        out["Z_" + name] = Zr.detach()[:64]
+        out["Zsum_" + name] = Zr.detach().sum(0)
+        out["dX_" + name] = Xr.grad[:64]
+        out["dXnorm_" + name] = Xr.grad.norm()
+    save("fit_meanshift_variants", **out)
+
+
 def run(save, eq, close):
     print("[fit]")
     MS = refshim.ref("src.mean_shift")

@@ -541,11 +541,32 @@ def compute_bandwidth(X, quantile, rows=None, num_samples=None):
     return torch.sqrt(torch.clamp(kth, min=1e-6)).mean()
 
 
-def mean_shift_iterations(X, b, iterations):
-    """src/mean_shift.py:50-84 (gaussian kernel, delta = 1)."""
+def mean_shift_eff(X, X_seed, b, iterations, kernel_type="gaussian"):
+    """src/mean_shift.py:86-136 (unused by the loss: eff=False): a subset of seed points shifted over the full dictionary;
+    note the gaussian branch's exponent `X_seed X^T / b^2` (no `2 - 2 s`, no / 2)."""
+    for _ in range(iterations):
+        if kernel_type == "gaussian":
+            Kmat = guard_exp((X_seed @ X.t()) / (b ** 2))
+        else:
+            Kmat = torch.relu(3 / 4 * (1 - (2.0 - 2.0 * X_seed @ X.t()) / (b ** 2)))
+        D = 1 / Kmat.sum(1, keepdim=True)
+        X_seed = (Kmat @ X) * D
+        X_seed = X_seed / torch.norm(X_seed, dim=1, p=2, keepdim=True)
+    return X_seed
+
+
+def mean_shift_iterations(X, b, iterations, kernel_type="gaussian"):
+    """src/mean_shift.py:50-84 (delta = 1); kernel_type other than "gaussian": the epanechnikov branch :70-74."""
     Z = X.clone()
     for _ in range(iterations):
         dist = 2.0 - 2.0 * Z @ X.t()
+        if kernel_type != "gaussian":
+            Kmat = torch.relu(3 / 4 * (1 - dist / (b ** 2)))
+            D = 1 / Kmat.sum(1, keepdim=True)
+            step = (Kmat @ X) * D - Z
+            Z = Z + step
+            Z = Z / torch.norm(Z, dim=1, p=2, keepdim=True)
+            continue
         Kmat = guard_exp(-dist / (b ** 2) / 2)
         D = 1 / Kmat.sum(1, keepdim=True)
         step = (Kmat @ X) * D - Z

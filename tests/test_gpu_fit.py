@@ -448,6 +448,33 @@ def test_subsampled_bandwidth_matches_reference_golden(hiplib, golden):
         fit_ops.compute_bandwidth(emb.cuda(), 0.05, num_samples=1000, rows=rows[:, :10].cuda())
 
 
+def test_mean_shift_variants_the_loss_never_takes(hiplib, golden):
+    """MeanShift.mean_shift_ with the epanechnikov kernel (src/mean_shift.py:70-74) and mean_shift_eff_ (:86-136), both
+    unused upstream (eff=False, gaussian), against values captured from the reference: Z and d/dX; and eff=True through
+    mean_shift() with the seed rows given."""
+    from prifit_amd.src.mean_shift import MeanShift
+    g = golden("fit_meanshift_variants")
+    seed, N, D = int(g["seed"]), 512, 32
+    _, _, emb = fit_inputs(1, N, D, seed, M=1000, noise=0.1)
+    X0 = emb[0].cuda()
+    G = _t(synth.features(1, N, D, seed + 1))[0].cuda()
+    rows = torch.from_numpy(g["rows"].astype(np.int64)).cuda()
+    ms, b = MeanShift(), torch.tensor(0.9)
+    for name, fn, gg in (("epa", lambda X: ms.mean_shift_(X, b, 3, kernel_type="epa")[0], G),
+                         ("eff", lambda X: ms.mean_shift_eff_(X, X[rows], b, 3)[0], G[: N // 2]),
+                         ("eff_epa", lambda X: ms.mean_shift_eff_(X, X[rows], b, 3, kernel_type="epa")[0], G[: N // 2])):
+        X = X0.clone().requires_grad_(True)
+        Z = fn(X)
+        (Z * gg).sum().backward()
+        torch.testing.assert_close(Z[:64].detach().cpu(), _t(g["Z_" + name]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(Z.detach().sum(0).cpu(), _t(g["Zsum_" + name]), rtol=1e-4, atol=1e-3)
+        ref = _t(g["dX_" + name])
+        torch.testing.assert_close(X.grad[:64].cpu(), ref, rtol=2e-3, atol=2e-4 * ref.abs().max().item())
+        assert abs(X.grad.norm().item() - float(g["dXnorm_" + name])) < 2e-3 * float(g["dXnorm_" + name])
+    centre, bw, labels = ms.mean_shift(X0, N, 0.1, 3, eff=True, seed_rows=rows)
+    assert centre.shape[1] == D and labels.shape[0] == N // 2 and int(labels.max()) + 1 == centre.shape[0]
+
+
 def test_nms_owner_pass_fused_into_the_chord_kernel(F, monkeypatch):
     """nms with the owner pass (argmin over every column of 2 - 2 Z Z^T, first minimum) taken in the chord kernel's epilogue
     through 64-bit atomic-min keys against the separate pass that re-reads the matrix: the very same owners, kept ids,

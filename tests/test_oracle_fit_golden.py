@@ -127,3 +127,25 @@ def test_bandwidth_with_more_samples_than_rows_matches_reference(golden):
     for b in range(2):
         bw = orc.compute_bandwidth(emb[b], float(g["quantile"]), num_samples=int(g["num_samples"]))
         assert abs(float(bw) - float(g["bw_%d" % b])) <= 1e-6 * float(g["bw_%d" % b])
+
+
+def test_mean_shift_variants_match_reference(golden):
+    """The epanechnikov kernel and mean_shift_eff_ (src/mean_shift.py:70-74, :86-136; unused by the loss) of the oracle against
+    values captured from the reference."""
+    from tests_helpers import fit_inputs
+    from prifit_amd import synth
+    g = golden("fit_meanshift_variants")
+    seed, N, D = int(g["seed"]), 512, 32
+    _, _, emb = fit_inputs(1, N, D, seed, M=1000, noise=0.1)
+    X0 = emb[0]
+    G = torch.from_numpy(synth.features(1, N, D, seed + 1))[0]
+    rows = torch.from_numpy(g["rows"].astype(np.int64))
+    b = torch.tensor(0.9)
+    for name, fn, gg in (("epa", lambda X: orc.mean_shift_iterations(X, b, 3, "epa"), G),
+                         ("eff", lambda X: orc.mean_shift_eff(X, X[rows], b, 3), G[: N // 2]),
+                         ("eff_epa", lambda X: orc.mean_shift_eff(X, X[rows], b, 3, "epa"), G[: N // 2])):
+        X = X0.clone().requires_grad_(True)
+        Z = fn(X)
+        (Z * gg).sum().backward()
+        assert torch.allclose(Z[:64].detach(), torch.from_numpy(g["Z_" + name]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(X.grad[:64], torch.from_numpy(g["dX_" + name]), rtol=1e-4, atol=1e-6 * float(X.grad.abs().max()))
