@@ -1,5 +1,5 @@
 """Timing of the streaming dW kernel (csrc/gemm_stream.hip, gemm_stream_tn_kernel) on the c3 step's shapes.
-PRIFIT_TN_PF=2|3|4 picks the prefetch depth.  Usage: python tools/stream_tn_bench.py"""
+Usage: python tools/stream_tn_bench.py"""
 import os
 import sys
 
