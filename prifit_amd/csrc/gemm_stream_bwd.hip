@@ -10,8 +10,8 @@
 // every 64-row tile ONCE (dY formed while staging, Yp raw) and two groups of waves work on the same LDS tiles:
 //   * A-waves (one per 32 columns of Cin) keep their Cout x 32 slice of W as MFMA fragments in registers and compute Gp
 //     (k = Cout, fragments read along the rows of the dY tile), store it, and accumulate (m1, m2) from the Yp tile;
-//   * W-waves (one per 32 rows of Cout) accumulate dW over ALL tiles of the workgroup in registers (k = the tile's rows:
-//     the A operand is a column of the dY tile, the B operand a row of relu(s Yp + t), formed on read).
+//   * W-waves accumulate their blocks of dW over ALL tiles of the workgroup in registers (k = the tile's rows: the A operand
+//     is a column of the dY tile, the B operand a row of relu(s Yp + t), formed on read).
 // One barrier per tile, the next tile in flight (global -> registers) during the MFMAs, two LDS stages.  Per-workgroup
 // slabs for (m1, m2) and for dW, summed by the finalize kernel / a second small launch: deterministic, no atomics.
 #include "common.h"
@@ -22,6 +22,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int SBM = 64;   // rows per tile
+#ifndef BWD_DEBUG
+#define BWD_DEBUG 0   // timing-only builds: 1 no W-role MFMAs, 2 no A-role MFMAs, 3 no Gp stores, 4 no staging arithmetic
+#endif
 
 struct BwdArgs {
     long long P;
@@ -43,10 +46,25 @@ struct BwdArgs {
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Roles per (Cout, Cin): NA A-waves (one per 32 columns of Cin; Cout MFMAs per tile each) and W-waves that own a contiguous
+// range of the (Cout / 32) x (Cin / 32) blocks of dW (32 MFMAs per block and tile), chosen so that the four SIMDs of a CU
+// (wave w runs on SIMD w % 4) carry the same number of MFMAs per tile: (128, 96): A A A | W x 6, then W x 2, W x 2, W x 2
+// beside the A-waves -- 192 per SIMD; (96, 64): A A | W x 3, W x 3; (128, 64): A A | W x 4, W x 4; (64, 64): A A | W x 2,
+// W x 2; (128, 128): A A A A | W x 4 each.
+template <int COUT, int CIN> struct Roles;
+template <> struct Roles<128, 96> { static constexpr int NW = 7; static constexpr int wb0[7] = {0, 0, 0, 0, 6, 8, 10}, wcnt[7] = {0, 0, 0, 6, 2, 2, 2}; };
+template <> struct Roles<96, 64> { static constexpr int NW = 4; static constexpr int wb0[4] = {0, 0, 0, 3}, wcnt[4] = {0, 0, 3, 3}; };
+template <> struct Roles<128, 64> { static constexpr int NW = 4; static constexpr int wb0[4] = {0, 0, 0, 4}, wcnt[4] = {0, 0, 4, 4}; };
+template <> struct Roles<64, 64> { static constexpr int NW = 4; static constexpr int wb0[4] = {0, 0, 0, 2}, wcnt[4] = {0, 0, 2, 2}; };
+template <> struct Roles<128, 128> { static constexpr int NW = 8; static constexpr int wb0[8] = {0, 0, 0, 0, 0, 4, 8, 12}, wcnt[8] = {0, 0, 0, 0, 4, 4, 4, 4}; };
+
+template <int V> struct IC { static constexpr int value = V; };
+
 template <int COUT, int CIN, bool POOL>
-__global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bwd_kernel(const BwdArgs g)
+__global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bwd_kernel(const BwdArgs g)
 {
-    constexpr int NA = CIN / 32, NWV = COUT / 32, NTH = 64 * (NA + NWV);
+    using R = Roles<COUT, CIN>;
+    constexpr int NA = CIN / 32, NTH = 64 * R::NW;
     constexpr int LDY = COUT + 4, LDP = CIN + 4;     // padded rows: conflict-free ds_read_b128 fragments / b32 columns
     constexpr int KG = COUT / 8;
     constexpr int Y4 = COUT / 4, P4 = CIN / 4;       // float4 per row
@@ -60,7 +78,7 @@ __global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bw
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const bool a_wave = wave < NA;
-    const int wa = a_wave ? wave : 0, ww = a_wave ? 0 : wave - NA;
+    const int wa = a_wave ? wave : 0;
 
     for (int t = threadIdx.x; t < COUT; t += NTH) {
         s_co[0][t] = POOL ? 0.f : g.cs[t]; s_co[1][t] = POOL ? 0.f : g.ct[t]; s_co[2][t] = POOL ? 0.f : g.ca[t];
@@ -174,7 +192,15 @@ __global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bw
             bf[q] = make_float4(g.W[(long long)k0 * g.ldw + col], g.W[(long long)(k0 + 1) * g.ldw + col],
                                 g.W[(long long)(k0 + 2) * g.ldw + col], g.W[(long long)(k0 + 3) * g.ldw + col]);
         }
-        const float r_s = g.ps[col], r_t = g.pt[col], r_mu = g.pmu[col], r_is = g.pis[col];
+        float r_s = g.ps[col], r_t = g.pt[col], r_mu = g.pmu[col], r_is = g.pis[col];
+        // The fragments must LIVE in registers: as plain loads the compiler treats them as re-loadable (the stores to Gp may
+        // alias W for all it knows) and fetched all 64 of them from global memory again in every tile, one s_waitcnt per
+        // pair of MFMAs.  An empty asm makes each value opaque.
+#pragma unroll
+        for (int q = 0; q < KG; ++q) {
+            asm volatile("" : "+v"(bf[q].x), "+v"(bf[q].y), "+v"(bf[q].z), "+v"(bf[q].w));
+        }
+        asm volatile("" : "+v"(r_s), "+v"(r_t), "+v"(r_mu), "+v"(r_is));
         float m1 = 0.f, m2 = 0.f;
         const int ldgp4 = (int)g.ldgp * 4;
         const int c_voff = ((4 * lh) * (int)g.ldgp + col) * 4;
@@ -195,6 +221,7 @@ __global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bw
                 float4 fa[2];
 #pragma unroll
                 for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LDY + 8 * q);
+#if BWD_DEBUG != 2
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
@@ -202,6 +229,10 @@ __global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bw
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, bf[q].z, acc[a], 0, 0, 0);
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, bf[q].w, acc[a], 0, 0, 0);
                 }
+#else
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[a][q & 15] += fa[a].x * bf[q].x + fa[a].w * bf[q].w;
+#endif
             }
             // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Rows beyond P
             // hold exact zeros (their dY rows are zero) and their stores are dropped by the bounds check.
@@ -213,12 +244,17 @@ __global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bw
                 for (int r = 0; r < 16; ++r) {
                     const int rl = 32 * a + (r & 3) + 8 * (r >> 2);
                     const float v = acc[a][r];
+#if BWD_DEBUG != 3
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, rl * ldgp4, 0);
+#endif
                     const float y = yp[rl * LDP];
                     const float gm = fmaf(y, r_s, r_t) > 0.f ? v : 0.f;
                     m1 += gm;
                     m2 += gm * ((y - r_mu) * r_is);
                 }
+            // (nothing of the staging -- its arithmetic needs the prefetched tile -- may be scheduled up into the MFMAs: the
+            // compiler did, and waited for the loads after the first eight matrix instructions)
+            __builtin_amdgcn_sched_barrier(0);
             store_tile(ntile, cur ^ 1);
             __syncthreads();
         }
@@ -229,45 +265,80 @@ __global__ __launch_bounds__(64 * (CIN / 32 + COUT / 32), 1) void gemm_stream_bw
             g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
         }
     } else {
-        // dW accumulators (32 rows of Cout x all of Cin) for the life of the workgroup; the previous layer's affine of this
-        // lane's columns
-        f32x16 accw[NA];
-        float w_s[NA], w_t[NA];
+        // dW accumulators of this wave's blocks for the life of the workgroup; block id = (cout block) * NA + (cin block)
+        auto w_role = [&](auto wb0c, auto wcntc) {
+            constexpr int WB0 = decltype(wb0c)::value, WCNT = decltype(wcntc)::value;
+            f32x16 accw[WCNT];
+            float w_s[WCNT], w_t[WCNT];
 #pragma unroll
-        for (int cb = 0; cb < NA; ++cb) {
+            for (int i = 0; i < WCNT; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accw[cb][r] = 0.f;
-            w_s[cb] = g.ps[32 * cb + li];
-            w_t[cb] = g.pt[32 * cb + li];
-        }
-        for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-            const int cur = it & 1;
-            const int next = tile + gridDim.x;
-            const int ntile = next < tiles ? next : tile;
-            load_tile(ntile);
+                for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+                w_s[i] = g.ps[32 * ((WB0 + i) % NA) + li];
+                w_t[i] = g.pt[32 * ((WB0 + i) % NA) + li];
+                asm volatile("" : "+v"(w_s[i]), "+v"(w_t[i]));   // (kept in registers, not re-loaded per tile: see the A role)
+            }
+            for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+                const int cur = it & 1;
+                const int next = tile + gridDim.x;
+                const int ntile = next < tiles ? next : tile;
+                load_tile(ntile);
+                __builtin_amdgcn_sched_barrier(0);
+                const float *dcol = &s_dy[cur][lh * LDY + li];
+                const float *prow = &s_p[cur][lh * LDP + li];
+                // operands of the NEXT group of k-steps are requested before the MFMAs of the current one: a W-wave may be
+                // alone on its SIMD (timing-only builds: this loop, not the A role, set the pace -- 130 cycles per MFMA with
+                // every operand read right in front of its use)
+                constexpr int GS = WCNT >= 4 ? 2 : 4, NG = SBM / 2 / GS;
+                float av[2][GS][WCNT], pv[2][GS][WCNT];
+                auto fetch = [&](int buf, int grp) {
+#pragma unroll
+                    for (int u = 0; u < GS; ++u)
+#pragma unroll
+                        for (int i = 0; i < WCNT; ++i) {
+                            av[buf][u][i] = dcol[2 * (grp * GS + u) * LDY + 32 * ((WB0 + i) / NA)];
+                            pv[buf][u][i] = prow[2 * (grp * GS + u) * LDP + 32 * ((WB0 + i) % NA)];
+                        }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp) {
+                    if (grp + 1 < NG) fetch((grp + 1) & 1, grp + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < GS; ++u) {
+#pragma unroll
+                        for (int i = 0; i < WCNT; ++i) {
+                            const float bv = fmaxf(fmaf(pv[grp & 1][u][i], w_s[i], w_t[i]), 0.f);
+#if BWD_DEBUG != 1
+                            accw[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[grp & 1][u][i], bv, accw[i], 0, 0, 0);
+#else
+                            accw[i][0] += av[grp & 1][u][i] * bv;
+#endif
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            // (nothing of the staging -- its arithmetic needs the prefetched tile -- may be scheduled up into the MFMAs: the
+            // compiler did, and waited for the loads after the first eight matrix instructions)
             __builtin_amdgcn_sched_barrier(0);
-            const float *dcol = &s_dy[cur][lh * LDY + 32 * ww + li];
-            const float *prow = &s_p[cur][lh * LDP + li];
-#pragma unroll 4
-            for (int st = 0; st < SBM / 2; ++st) {
-                const float aop = dcol[2 * st * LDY];
-                float bv[NA];
-#pragma unroll
-                for (int cb = 0; cb < NA; ++cb) bv[cb] = fmaxf(fmaf(prow[2 * st * LDP + 32 * cb], w_s[cb], w_t[cb]), 0.f);
-#pragma unroll
-                for (int cb = 0; cb < NA; ++cb) accw[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bv[cb], accw[cb], 0, 0, 0);
-            }
             store_tile(ntile, cur ^ 1);
-            __syncthreads();
-        }
-        float *dst = g.dw_part + (long long)blockIdx.x * COUT * CIN;
-#pragma unroll
-        for (int cb = 0; cb < NA; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * ww + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                dst[row * CIN + 32 * cb + li] = accw[cb][r];
+                __syncthreads();
             }
+            float *dst = g.dw_part + (long long)blockIdx.x * COUT * CIN;
+#pragma unroll
+            for (int i = 0; i < WCNT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * ((WB0 + i) / NA) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    dst[row * CIN + 32 * ((WB0 + i) % NA) + li] = accw[i][r];
+                }
+        };
+        // (one instantiation per W-wave of the role table: block indices are compile-time, the branch is wave-uniform)
+        if constexpr (R::NW > NA + 0) { if (wave == NA + 0) w_role(IC<R::wb0[NA + 0]>{}, IC<R::wcnt[NA + 0]>{}); }
+        if constexpr (R::NW > NA + 1) { if (wave == NA + 1) w_role(IC<R::wb0[NA + 1]>{}, IC<R::wcnt[NA + 1]>{}); }
+        if constexpr (R::NW > NA + 2) { if (wave == NA + 2) w_role(IC<R::wb0[NA + 2]>{}, IC<R::wcnt[NA + 2]>{}); }
+        if constexpr (R::NW > NA + 3) { if (wave == NA + 3) w_role(IC<R::wb0[NA + 3]>{}, IC<R::wcnt[NA + 3]>{}); }
     }
 }
 
@@ -300,7 +371,7 @@ bool bwd_shape_ok(int Cout, int Cin)
 template <int COUT, int CIN>
 void bwd_launch(const BwdArgs &g, bool pool, int grid, hipStream_t st)
 {
-    constexpr int NTH = 64 * (CIN / 32 + COUT / 32);
+    constexpr int NTH = 64 * Roles<COUT, CIN>::NW;
     if (pool) {
         if constexpr (NTH % (COUT / 4) == 0) hipLaunchKernelGGL((gemm_stream_bwd_kernel<COUT, CIN, true>), dim3(grid), dim3(NTH), 0, st, g);
     } else {
@@ -316,8 +387,7 @@ int prifit_gemm_stream_bwd_supported(long long P, int Cout, int Cin, int pool_K)
 {
     if (P < SBM || P > 0x7fffffffLL * 32 || !bwd_shape_ok(Cout, Cin)) return 0;
     if (pool_K > 0) {
-        const int nth = 64 * (Cin / 32 + Cout / 32);
-        if (pool_K % SBM != 0 || P % pool_K != 0 || nth % (Cout / 4) != 0) return 0;
+        if (pool_K % SBM != 0 || P % pool_K != 0 || Cout == 96) return 0;   // (Cout = 96: a thread's rows would not share their channels)
     }
     return 1;
 }

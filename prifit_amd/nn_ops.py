@@ -32,12 +32,17 @@ _FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate b
 _FUSE_POOL_FWD = os.environ.get("PRIFIT_FUSE_POOL_FWD", "1") != "0"  # 0: pool_fwd re-reads the last layer's Y (A/B runs)
 _FUSE_BN_APPLY = os.environ.get("PRIFIT_FUSE_BN_APPLY", "1") != "0"  # 0: bn_relu_bwd_apply writes a middle layer's dY (A/B runs)
 _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
-# 1: dA and dW of a streaming-shape layer from ONE pass over its rows (csrc/gemm_stream_bwd.hip) instead of the separate
-# streaming dA (NN) and dW (TN) kernels, which each read G, Y and the previous layer's pre-activation.  Measured (round 3,
-# DESIGN 5e): the one-pass kernel halves the HBM bytes but its first form -- one 7..8-wave workgroup per CU, A-waves and
-# W-waves on the same LDS tiles -- runs at 0.3-0.5 of the matrix peak: [1.57 M x 128 x 96 pooled] 933 us against 502 + 365,
-# [1.57 M x 96 x 64] 771 against 363 + 358, the step 16.70 against 16.23 ms.  OFF; correct and covered by GPU tests.
-_FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "0") != "0"
+# dA and dW of a streaming-shape layer from ONE pass over its rows (csrc/gemm_stream_bwd.hip) instead of the separate
+# streaming dA (NN) and dW (TN) kernels, which each read G, Y and the previous layer's pre-activation.  "auto" (default):
+# where it measured faster -- the 96 -> 64 middle layer of SA1's widest scale (598 against 712 us, tools/stream_bwd_bench.py);
+# "1": every supported shape (slower on the others: the kernel's dW role is latency-bound); "0": never.
+_FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "auto")
+
+
+def _fuse_bwd_on(Cout, Kin, pooled):
+    if _FUSE_BWD == "auto":
+        return (Cout, Kin) == (96, 64) and not pooled
+    return _FUSE_BWD not in ("0", "", False)
 
 
 def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, a_rowsum=None, accumulate=False,
@@ -321,7 +326,7 @@ class SharedMLPFn(torch.autograd.Function):
                      ptr(shift), ptr(ca), G, K, Cout, _F(0.0), ptr(Ttab), cur_stream())
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
-                if _FUSE_BWD and _FUSE_RED and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, K) and Ys[l - 1].stride(0) % 4 == 0:
+                if _fuse_bwd_on(Cout, Kin, True) and _FUSE_RED and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, K) and Ys[l - 1].stride(0) % 4 == 0:
                     G_prev, rslab, ns = _fused_bwd(P, Cout, Kin, None, Y, None, None, None, cb, cd, arg, Ttab, K, W, Ys[l - 1],
                                                    affines[l - 1], stats_saved[l - 1], dW, dev)
                     grads[6 * l] = dW
@@ -397,7 +402,7 @@ class SharedMLPFn(torch.autograd.Function):
             if fuse_bn:
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
-                if _FUSE_BWD and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, 0) and Ys[l - 1].stride(0) % 4 == 0:
+                if _fuse_bwd_on(Cout, Kin, False) and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, 0) and Ys[l - 1].stride(0) % 4 == 0:
                     G_prev, rslab, ns = _fused_bwd(P, Cout, Kin, G_in, Y, scale, shift, ca, cb, cd, None, None, 0, W, Ys[l - 1],
                                                    affines[l - 1], stats_saved[l - 1], dW, dev)
                     grads[6 * l] = dW

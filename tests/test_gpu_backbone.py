@@ -230,7 +230,7 @@ def test_shared_mlp_fused_da_dw_matches_separate_kernels(nn_ops, P, K, dims):
     res = {}
     for fuse in (True, False):
         old = nn_ops._FUSE_BWD
-        nn_ops._FUSE_BWD = fuse
+        nn_ops._FUSE_BWD = "1" if fuse else "0"
         try:
             xi = x.clone().requires_grad_(True)
             cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
