@@ -388,24 +388,29 @@ __device__ __forceinline__ float4 read_frag(const float *__restrict__ lds, int r
 // Same products in the same order as the plain loop: bit-identical sums.
 template <int RA, bool AKC, int RB, bool BKC, int TN>
 __device__ __forceinline__ void mma_ktile(const float *__restrict__ As, const float *__restrict__ Bs, int arow, int bcol, int lh,
-                                          f32x16 (&acc)[TN], int ngk = BK / 8)
+                                          f32x16 (&acc)[TN], int ngk = BK / 8, int nbv = TN)
 {
+    // nbv < TN (wave-uniform): the wave's column blocks from nbv on lie beyond N (a ragged last tile: 196 = 128 + 68 leaves
+    // the fourth 32-column block of the second tile empty) -- neither read nor multiplied, their accumulators stay zero
     float4 fa[2], fb[2][TN];
     fa[0] = read_frag<RA, AKC>(As, arow, 0, lh);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) fb[0][b] = read_frag<RB, BKC>(Bs, bcol + 32 * b, 0, lh);
+    for (int b = 0; b < TN; ++b)
+        if (b < nbv) fb[0][b] = read_frag<RB, BKC>(Bs, bcol + 32 * b, 0, lh);
 #pragma unroll
     for (int gk = 0; gk < BK / 8; ++gk) {
         if (gk > 0 && gk >= ngk) break;   // (scalar)
         if (gk + 1 < BK / 8) {
             fa[(gk + 1) & 1] = read_frag<RA, AKC>(As, arow, gk + 1, lh);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[(gk + 1) & 1][b] = read_frag<RB, BKC>(Bs, bcol + 32 * b, gk + 1, lh);
+            for (int b = 0; b < TN; ++b)
+                if (b < nbv) fb[(gk + 1) & 1][b] = read_frag<RB, BKC>(Bs, bcol + 32 * b, gk + 1, lh);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float4 a = fa[gk & 1];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
+            if (b >= nbv) continue;
             const float4 w = fb[gk & 1][b];
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc[b], 0, 0, 0);
             acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc[b], 0, 0, 0);
@@ -733,7 +738,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int ktiles = (g.K + BK - 1) / BK;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    // wave w holds row group w & 3 and column half w >> 2: a SIMD (waves w and w + 4) owns one wave of each column half, so
+    // the matrix work a ragged last column tile leaves out (below) is left out evenly over the four SIMDs
+    constexpr int WAVES_M = BM / WM;
+    const int wmi = wave % WAVES_M;
+    const int wm0 = wmi * WM, wn0 = (wave / WAVES_M) * WN;
 #ifdef PERS_STAMPS
     const int ngk_last = g_pers_ktail ? (g.K - (ktiles - 1) * BK + 7) >> 3 : BK / 8;
 #else
@@ -766,6 +775,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        const int nbv = min(TN, max(0, (g.N - n0 - wn0 + 31) >> 5));   // this wave's column blocks that hold columns of C
         for (int kt = 0; kt < ktiles; ++kt) {
             const int stage = kt & 1;
             const float *As = lds + stage * (SZA + SZB), *Bs = As + SZA;
@@ -778,7 +788,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 la.load(0); lb.load(0);
             }
             // (8-wide k groups beyond K hold zeros: K = 196 fills one of the last k-tile's four)
-            mma_ktile<BM, true, BN, B_KC, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc, more ? BK / 8 : ngk_last);
+            mma_ktile<BM, true, BN, B_KC, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc, more ? BK / 8 : ngk_last, nbv);
             if (more) {
                 float *An = lds + (stage ^ 1) * (SZA + SZB);
                 la.finish(g.a_scale, g.a_shift);
@@ -863,8 +873,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float s = csum[b] + __shfl_xor(csum[b], 32, 64);
                 const float q = csq[b] + __shfl_xor(csq[b], 32, 64);
                 if (lh == 0) {
-                    red[((wave / WAVES_N) * 2 + 0) * BN + wn0 + 32 * b + li] = s;
-                    red[((wave / WAVES_N) * 2 + 1) * BN + wn0 + 32 * b + li] = q;
+                    red[(wmi * 2 + 0) * BN + wn0 + 32 * b + li] = s;
+                    red[(wmi * 2 + 1) * BN + wn0 + 32 * b + li] = q;
                 }
             }
             __syncthreads();
@@ -1026,7 +1036,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (kt0 >= kt1) return;   // block-uniform
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int wm0 = (wave % (BM / WM)) * WM, wn0 = (wave / (BM / WM)) * WN;   // (one wave of each column half per SIMD)
+    // column blocks of this wave that hold elements of C: none below the last row (M = 196: the fourth row group of the
+    // second tile), not those beyond the last column (N = 196)
+    const int nbv = m0 + wm0 >= g.M ? 0 : min(TN, max(0, (g.N - n0 - wn0 + 31) >> 5));
 
     BufLoader<BM, false, false, NTH> la[2];
     BufLoader<BN, false, FB, NTH> lb[2];
@@ -1050,7 +1063,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float *As = lds + S * (SZA + SZB), *Bs = As + SZA;
         if (kt + 2 < kt1) { la[S].load((kt + 2) * BK); lb[S].load((kt + 2) * BK); }
         __builtin_amdgcn_sched_barrier(0);
-        mma_ktile<BM, false, BN, false, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc);
+        mma_ktile<BM, false, BN, false, TN>(As, Bs, wm0 + li, wn0 + li, lh, acc, BK / 8, nbv);
         if (kt + 1 < kt1) {
             float *An = lds + (S ^ 1) * (SZA + SZB);
             lb[S ^ 1].finish(g.b_scale, g.b_shift);
