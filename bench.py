@@ -43,6 +43,7 @@ B_PER_GPU = 24
 NPTS = 2048
 NUM_PARTS = 50
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # same table: dense bf16 / fp16 MFMA = 16 x the fp32 rate (only the labelled split-products experiment)
 HBM_PEAK_GBS = 8000.0           # HBM3E spec (6.29 TB/s measured by a float4 copy)
 # launches of the ball-query + grouping stage: sa_group_linear = ball query + grouping + first MLP layer of a
 # set-abstraction level in one launch (default); the others run with PRIFIT_SA_FUSED=0 / PRIFIT_SA_LINEARITY=0
@@ -237,19 +238,35 @@ def run_rank(args):
 
     ctx = {"world": world, "rank": rank, "device": device, "use_dist": use_dist}
     cloud = args.cloud or DEFAULT_CLOUD[args.workload]
-    head = measure(args, ctx, cloud, args.embedding, args.steps, args.warmup, full=True)
+    head = measure(args, ctx, cloud, args.embedding, args.steps, args.warmup, full=True, split=args.ms_split)
 
     if rank == 0:
         line = headline(args, ctx, head, cloud)
+        if args.ms_split != "0":
+            line["dtype"] = SPLIT_DTYPE % args.ms_split
+            line["experiment"] = SPLIT_NOTE
         if backend != "nccl" and use_dist:
             line["rehearsal"] = "backend=%s%s: NOT a reportable number" % (backend, ", ranks share GPUs" if share else "")
     # the same step under training-like conditions, beside the headline (single GPU, c3, default condition only)
-    if (world == 1 and args.workload == "c3" and not args.no_extra and args.cloud is None and args.embedding == "untrained"):
+    if (world == 1 and args.workload == "c3" and not args.no_extra and args.cloud is None and args.embedding == "untrained"
+            and args.ms_split == "0"):
         extra = {}
         for name, cl, emb in (("clustered_embedding", "blobs", "clustered"), ("surface_cloud", "surface", "untrained"),
                               ("surface_cloud_clustered_embedding", "surface", "clustered")):
             r = measure(args, ctx, cl, emb, max(10, min(args.steps, 30)), 5, full=False)
             extra[name] = condition_summary(r, cl, emb)
+        # LABELLED EXPERIMENT beside the headline (never the headline): the headline's own condition with the mean-shift
+        # forward's two products on the 16-bit matrix pipe, error-compensated (csrc/meanshift_split.hip)
+        exp = {"note": SPLIT_NOTE}
+        for mode in ("fp16x3", "bf16x6"):
+            r = measure(args, ctx, cloud, args.embedding, max(10, min(args.steps, 30)), 5, full=False, split=mode)
+            c = condition_summary(r, cloud, args.embedding)
+            rows = family_rows(r["fams_all"], r["fams_all_steps"])
+            exp[mode] = {"dtype": SPLIT_DTYPE % mode, "value": c["value"], "unit": "shapes/s", "ms_per_step": c["ms_per_step"],
+                         "vs_fp32_headline": c["value"] / line["value"], "loss": c["loss"],
+                         "clusters_per_shape": c["clusters_per_shape"], "speculation_fallbacks": c["speculation_fallbacks"],
+                         "kernel": {k: v for k, v in rows.items() if k.startswith("ms_split_fwd")}}
+        extra["split_mean_shift_products_experiment"] = exp
         line["extra"] = extra
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -259,13 +276,30 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_fused_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
+SPLIT_DTYPE = "f32 (mean-shift forward products %s emulated: LABELLED EXPERIMENT, not the fp32 product path)"
+SPLIT_NOTE = ("the S = Z X^T and O = K X products of the ten mean-shift updates run on the 16-bit matrix pipe with every fp32 "
+              "operand cut into 2 (bf16x3, fp16x3) or 3 (bf16x6) 16-bit planes and the significant plane products accumulated "
+              "in fp32 (csrc/meanshift_split.hip); exponent, clamp, row sums, the normalisation and the whole backward stay "
+              "fp32.  Passes test_convex_loss_end_to_end, test_selfsup_step_matches_reference_golden and the mean-shift golden "
+              "at UNCHANGED tolerances (bf16x6, fp16x3); error of ten updates against fp64 next to the fp32 kernel's: "
+              "profiles/r03_split_products.json.  Never the headline: `value` of this line is the fp32 path.")
+FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_fused_fwd", "ms_split_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
                 "ellipsoid_fit", "sdf", "sample_nn")
 
 
-def measure(args, ctx, cloud, embedding, steps, warmup, full):
+def measure(args, ctx, cloud, embedding, steps, warmup, full, split="0"):
     """Build the network and the inputs of one condition, run `warmup` untimed + `steps` timed training steps bracketed by
-    barrier + synchronize, and return the raw measurements.  full: the headline's extras (enqueue time, all ranks' MAX)."""
+    barrier + synchronize, and return the raw measurements.  full: the headline's extras (enqueue time, all ranks' MAX).
+    split: the LABELLED EXPERIMENT of csrc/meanshift_split.hip for this measurement ("0" = the fp32 product path)."""
+    from prifit_amd import fit_ops
+    fit_ops.MS_SPLIT = split
+    try:
+        return _measure(args, ctx, cloud, embedding, steps, warmup, full)
+    finally:
+        fit_ops.MS_SPLIT = "0"
+
+
+def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     import torch
     import torch.distributed as dist
     from prifit_amd import profiler, synth
@@ -421,7 +455,49 @@ def measure(args, ctx, cloud, embedding, steps, warmup, full):
         res["fams_all_steps"] = 2
         profiler.disable()
         profiler.reset()
+    if os.environ.get("PRIFIT_BENCH_CENSUS"):   # diagnosis, outside the timed region: who launches the small torch kernels
+        launch_census(step, os.environ["PRIFIT_BENCH_CENSUS"])
     return res
+
+
+def launch_census(step, path):
+    """One step under torch.profiler with Python stacks: every device kernel with its count and time, and for the torch
+    glue (fill / copy / cat / elementwise) the source line of this repo that issued it.  Written to `path` as text."""
+    import collections
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+        step()
+        torch.cuda.synchronize()
+    here = os.path.dirname(os.path.abspath(__file__))
+    by_site = collections.defaultdict(lambda: [0, 0.0, set()])
+    kernels = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        if not ev.kernels:
+            continue
+        dev_us = sum(k.duration for k in ev.kernels)
+        for k in ev.kernels:
+            kernels[k.name[:90]][0] += 1
+            kernels[k.name[:90]][1] += k.duration
+        if not ev.name.startswith("aten::"):
+            continue
+        site = "(no Python stack: autograd thread)" if not ev.stack else "?"
+        for fr in ev.stack or ():
+            if ("prifit_amd/" in fr or "bench.py" in fr) and "/torch/" not in fr:
+                site = fr[fr.find("prifit_amd/"):] if "prifit_amd/" in fr else fr[fr.find("bench.py"):]
+                break
+        rec = by_site[(site, ev.name)]
+        rec[0] += len(ev.kernels)
+        rec[1] += dev_us
+    with open(path, "w") as f:
+        f.write("== device kernels of one step\n")
+        for name, (n, us) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
+            f.write("%-92s %5d %10.1f us\n" % (name, n, us))
+        f.write("\n== torch operators that launched kernels, by the repo line that called them\n")
+        for (site, op), (n, us, _) in sorted(by_site.items(), key=lambda kv: -kv[1][1]):
+            f.write("%-70s %-28s %4d %9.1f us\n" % (site[:70], op, n, us))
 
 
 def family_rows(fams, steps):
@@ -430,7 +506,12 @@ def family_rows(fams, steps):
     for name, (n, ms, work) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
         per = {"launches_per_step": n / steps, "ms_per_step": ms / steps, "avg_us": 1e3 * ms / max(n, 1)}
         base = name.split("[")[0]
-        if (base.startswith("gemm") and not base.startswith("gemm_stream")) or base.startswith(("ms_fused", "chord_sym")):
+        if base == "ms_split_fwd":   # experiment: `work` is the fp32-equivalent product; the pipe executes 3 or 6 plane products
+            terms = 6 if "x6" in name else 3
+            per.update(bound="mfma", achieved=terms * work / (ms * 1e-3) / 1e12, peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                       flops_per_step=terms * work / steps, flops_per_launch=terms * work / max(n, 1),
+                       fp32_equivalent_tflops=work / (ms * 1e-3) / 1e12, plane_products=terms)
+        elif (base.startswith("gemm") and not base.startswith("gemm_stream")) or base.startswith(("ms_fused", "chord_sym")):
             per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=work / steps, flops_per_launch=work / max(n, 1))
         else:
@@ -543,6 +624,9 @@ def main():
     ap.add_argument("--embedding", default="untrained", choices=("untrained", "clustered"))
     ap.add_argument("--no-extra", action="store_true", help="skip the training-like conditions reported under `extra`")
     ap.add_argument("--graph", action="store_true", help="replay the backbone forward + backward as HIP graphs (static shapes)")
+    ap.add_argument("--ms-split", default="0", choices=("0", "bf16x3", "bf16x6", "fp16x3"),
+                    help="LABELLED EXPERIMENT: mean-shift forward products on the 16-bit matrix pipe, error-compensated; the line's "
+                         "dtype says so and it is never the reported fp32 number")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:

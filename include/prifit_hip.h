@@ -481,6 +481,23 @@ int prifit_meanshift_rows_bwd(const float *X, const float *bw, int B, int N, int
                               const float *const *nrm, const long long *ids, const int *nrows, int R,
                               const float *g_rows, float *workspace, float *dX, void *stream);
 
+/* LABELLED EXPERIMENT (default off; never the reported precision): the two matrix products of a mean-shift update,
+ * S = Z X^T (src/mean_shift.py:65) and O = K X (:73), on the 16-bit matrix pipe with error-compensated operands -- every
+ * fp32 operand cut into 2 or 3 16-bit planes, the significant plane products accumulated in fp32 (csrc/meanshift_split.hip).
+ * mode: PRIFIT_SPLIT_BF16X3 (2 bf16 planes, 3 products: operands to 2^-16), PRIFIT_SPLIT_BF16X6 (3 planes, 6 products:
+ * 2^-24), PRIFIT_SPLIT_FP16X3 (2 fp16 planes of power-of-two scaled operands, 3 products: ~2^-22).  D == 128, N % 256 == 0.
+ * _prep cuts the dictionary X [B,N,128] once per mean-shift call into `workspace` (_workspace BYTES, 16-byte aligned);
+ * _fwd: one update's O [B,N,128] and rowsum [B,N] from the current points Z [B,N,128] (exponent, clamp and row sums in fp32
+ * as in prifit_meanshift_fused_fwd); prifit_meanshift_update_fwd finishes the update. */
+#define PRIFIT_SPLIT_BF16X3 1
+#define PRIFIT_SPLIT_BF16X6 2
+#define PRIFIT_SPLIT_FP16X3 3
+int prifit_meanshift_split_supported(int N, int D, int mode);
+long long prifit_meanshift_split_workspace(int B, int N, int D, int mode);
+int prifit_meanshift_split_prep(const float *X, int B, int N, int D, int mode, void *workspace, void *stream);
+int prifit_meanshift_split_fwd(const float *Z, const void *workspace, const float *bw, int B, int N, int D, int mode,
+                               float *O, float *rowsum, void *stream);
+
 /* Non-maximum suppression, src/mean_shift.py:162-202 called as nms(Z, Z, b) (:44).
  * dist [B,N,N] = 2 - 2 Z Z^T, Z [B,N,D], bw [B].  Outputs: owner [B,N] (nearest centre of each point),
  * counts [B,N], flags [B,N] (scratch), ids [B,cap] ascending kept centre ids, count [B] = number of kept

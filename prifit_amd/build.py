@@ -29,6 +29,7 @@ SOURCES = {
     "meanshift.hip": [],
     "meanshift_fused.hip": [],
     "meanshift_rows.hip": [],
+    "meanshift_split.hip": [],
     "fit.hip": [],
     "dgcnn.hip": ["-ffp-contract=off"],
     "comm.hip": [],        # host-only: the RCCL export (RCCL itself is resolved with dlopen at run time)

@@ -34,6 +34,22 @@ FUSE_NMS_OWNER = True   # nms: the owner pass (column argmin) in the chord kerne
 # on those rows alone (MeanShiftRowsFn); 0 = the dense backward of MeanShiftFn + a gather (same numbers; the A/B arm
 # and the path of callers that differentiate through the whole of new_X)
 ROWS_BWD = __import__("os").environ.get("PRIFIT_MS_ROWS", "1") != "0"
+# LABELLED EXPERIMENT, default off: the two products of the mean-shift FORWARD on the 16-bit matrix pipe with
+# error-compensated operands (csrc/meanshift_split.hip): "bf16x3" | "bf16x6" | "fp16x3".  D = 128, N % 256 == 0, and only
+# where the kernel matrix is not kept (the row-sparse backward, i.e. cluster()); anything else takes the fp32 kernels.
+# A number measured with it on is not an fp32 number: bench.py labels it (`dtype`, `experiment`) and never reports it as
+# the headline.
+MS_SPLIT = __import__("os").environ.get("PRIFIT_MS_SPLIT", "0")
+_SPLIT_MODES = {"bf16x3": 1, "bf16x6": 2, "fp16x3": 3}
+split_launches = 0   # updates that took the experiment's kernel (tests assert on it; nothing reads it in the product)
+
+
+def split_mode(N, D, keep_kernel=False):
+    """The mode id of MS_SPLIT for this shape, 0 = the fp32 kernels.  An unknown name raises."""
+    if MS_SPLIT in ("0", "", None, False) or keep_kernel:
+        return 0
+    mode = _SPLIT_MODES[MS_SPLIT]
+    return mode if dll().prifit_meanshift_split_supported(N, D, mode) else 0
 
 
 def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
@@ -130,12 +146,17 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
     X [B,N,D] unit rows (contiguous), bw [B].  Returns (Z_final, per iteration [Z_in, K or None, O, rowsum, Z_out, nrm]);
     keep_kernel=False: the N x N kernel matrix is not kept (D = 128: never written -- prifit_meanshift_fused_fwd with
     KT = NULL; other widths: one scratch matrix for the GEMM chain)."""
+    global split_launches
     Bt, N, D = X.shape
     dev = X.device
     fused = D == 128  # flash-style kernel (csrc/meanshift_fused.hip); other widths take the GEMM chain
     Z = X.clone()
     saved = []
     scratch = None
+    split = split_mode(N, D, keep_kernel) if fused else 0
+    if split:   # the dictionary is the same in every iteration (:65): cut once
+        cut = torch.empty(dll().prifit_meanshift_split_workspace(Bt, N, D, split), dtype=torch.uint8, device=dev)
+        call("prifit_meanshift_split_prep", ptr(X), Bt, N, D, split, ptr(cut), cur_stream())
     for _ in range(iterations):
         Kmat = None
         if keep_kernel:
@@ -146,7 +167,13 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
         rsum = torch.empty(Bt, N, dtype=torch.float32, device=dev)
         Zn = torch.empty_like(Z)
         nrm = torch.empty(Bt, N, dtype=torch.float32, device=dev)
-        if fused:
+        if split:
+            split_launches += 1
+            with profiler.span("ms_split_fwd[%s]" % MS_SPLIT, 4.0 * Bt * N * N * D):
+                call("prifit_meanshift_split_fwd", ptr(Z), ptr(cut), ptr(bw), Bt, N, D, split, ptr(O), ptr(rsum), cur_stream())
+            call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
+                 cur_stream())
+        elif fused:
             with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
                 call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
                      _LL(N * N), ptr(Zn), ptr(O), ptr(rsum), ptr(nrm), cur_stream())

@@ -264,7 +264,14 @@ def test_cuboid_variant(F, golden):
     torch.testing.assert_close(X.grad[:, :, :32].cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
 
 
-def test_convex_loss_end_to_end(F, golden):
+@pytest.mark.parametrize("split", ["0", "bf16x6", "fp16x3"])
+def test_convex_loss_end_to_end(F, golden, split, monkeypatch):
+    """split != "0": the labelled experiment of csrc/meanshift_split.hip (mean-shift forward products on the 16-bit matrix
+    pipe, error-compensated) must pass at the SAME tolerances; "bf16x3" (operands to 2^-16) is not expected to and is
+    measured in test_split_mean_shift_products_error_against_fp64 only."""
+    monkeypatch.setattr(F, "MS_SPLIT", split)
+    assert split == "0" or F.split_mode(2048, 128) > 0
+    launches0 = F.split_launches
     g = golden("fit_convex_loss")
     seed = int(g["seed"])
     pts, cham, emb = fit_inputs(2, 2048, 128, seed)
@@ -274,6 +281,7 @@ def test_convex_loss_end_to_end(F, golden):
                                                  quantile=0.05, iterations=10, max_num_clusters=25,
                                                  rand_table=_t(g["R"]).cuda(), canonical=True, return_info=True)
     total.sum().backward()
+    assert F.split_launches - launches0 == (10 if split != "0" else 0)   # the experiment's kernel did (not) run
     assert total.shape == (1, 1) and l.shape == (1, 1)
     assert [len(p) for p in params] == list(g["K"])
     for b in range(2):
@@ -630,3 +638,42 @@ def test_stream_k_schedules_of_the_fused_mean_shift_kernels(hiplib):
     assert torch.equal(a[0], b[0]) and torch.equal(a[5], b[5])                 # the N x N streams: element for element
     for i, tol in ((1, 1e-6), (2, 1e-4), (3, 1e-4), (4, 1e-6), (6, 1e-4)):
         torch.testing.assert_close(a[i], b[i], rtol=1e-5, atol=tol)
+
+
+def test_split_mean_shift_products_error_against_fp64(F, golden, monkeypatch):
+    """The labelled experiment (fit_ops.MS_SPLIT): ten mean-shift updates on the golden's embedding with the forward
+    products as fp32 MFMA (the product path), bf16x3, bf16x6 and fp16x3, each against the same updates in fp64.  The
+    fp32-grade forms must stay within a small factor of the fp32 kernel's own error and within the golden's tolerances;
+    bf16x3 is reported only (its operands carry 16 bits)."""
+    g = golden("fit_meanshift")
+    _, _, emb = fit_inputs(2, 2048, 128, int(g["seed"]))
+    bw = torch.stack([_t(g["bw_0"]), _t(g["bw_1"])]).cuda()
+    X = emb.cuda().contiguous()
+    X64, Z64 = X.double(), X.double()
+    for _ in range(10):   # src/mean_shift.py:61-82 in fp64
+        S = Z64 @ X64.transpose(1, 2)
+        K = torch.exp(torch.clamp((S - 1.0) / (bw.double() ** 2)[:, None, None], -13.0, 75.0))
+        new = Z64 + (K @ X64 / K.sum(-1, keepdim=True) - Z64)
+        Z64 = new / new.norm(dim=-1, keepdim=True)
+    err = {}
+    for mode in ("0", "bf16x3", "bf16x6", "fp16x3"):
+        monkeypatch.setattr(F, "MS_SPLIT", mode)
+        Z, traj = F.mean_shift_trajectory(X, bw, 10, False)
+        assert len(traj) == 10
+        err[mode] = ((Z.double() - Z64).abs().max() / Z64.abs().max()).item()
+        if mode != "bf16x3":
+            for b in range(2):
+                torch.testing.assert_close(Z[b, :64].cpu(), _t(g[f"Z_head_{b}"]), rtol=1e-4, atol=1e-5)
+                torch.testing.assert_close(Z[b].sum(0).cpu(), _t(g[f"Z_colsum_{b}"]), rtol=1e-4, atol=1e-3)
+    print("max |Z - Z_fp64| / max |Z_fp64| after 10 updates:", {k: "%.2e" % v for k, v in err.items()})
+    assert err["bf16x6"] < 4 * err["0"] + 1e-7 and err["fp16x3"] < 8 * err["0"] + 1e-7
+    assert err["bf16x3"] < 1e-2
+
+
+def test_split_mode_falls_back_where_it_does_not_apply(F, monkeypatch):
+    monkeypatch.setattr(F, "MS_SPLIT", "bf16x6")
+    assert F.split_mode(2048, 128) == 2 and F.split_mode(2048, 128, keep_kernel=True) == 0
+    assert F.split_mode(300, 128) == 0 and F.split_mode(2048, 64) == 0
+    monkeypatch.setattr(F, "MS_SPLIT", "bf16x9")
+    with pytest.raises(KeyError):
+        F.split_mode(2048, 128)

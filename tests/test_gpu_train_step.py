@@ -62,14 +62,19 @@ def test_supervised_step_matches_oracle_adam(hiplib):
     assert lr == 1e-5 and mom == 0.01
 
 
-def test_selfsup_step_matches_reference_golden(hiplib, golden):
-    """SURVEY 8a row a29 step (2) on the HIP backend, through Trainer.selfsup_step itself (zero_grad, train(), forward
+@pytest.mark.parametrize("split", ["0", "bf16x6", "fp16x3"])
+def test_selfsup_step_matches_reference_golden(hiplib, golden, split, monkeypatch):
+    """(split != "0": the labelled 16-bit-products experiment of the mean-shift forward, fit_ops.MS_SPLIT, at the same bars.)
+    SURVEY 8a row a29 step (2) on the HIP backend, through Trainer.selfsup_step itself (zero_grad, train(), forward
     with the convex loss, mean(loss) * lambda, backward, Adam): total / chamfer loss, K, labels, beta, every
     parameter-gradient norm, the embedding head's gradient and its values after the Adam step against what the
     reference's own network file produced (tests/golden/step_selfsup.npz, train_partseg_shapenet.py:436-451)."""
     import step_selfsup_common as C
+    from prifit_amd import fit_ops
     from prifit_amd.models import pointnet2_part_seg_msg as M
     from prifit_amd.train_step import Trainer
+    monkeypatch.setattr(fit_ops, "MS_SPLIT", split)
+    launches0 = fit_ops.split_launches
     g = golden("step_selfsup")
     d = C.inputs(g)
     ref = C.seeded_state(g, orc.OracleMSGPartSeg)          # seeded parameters (construction order of the reference)
@@ -101,6 +106,7 @@ def test_selfsup_step_matches_reference_golden(hiplib, golden):
                            max_num_clusters=25, augment=False, subset=subset, fps_start=(d["s1"].cuda(), d["s2"].cuda()),
                            fit_inputs=dict(rand_table=d["R"].cuda(), canonical=True, center_ids=d["center_ids"]))
     after = {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
+    assert fit_ops.split_launches - launches0 == (C.ITERS if split != "0" else 0)
     assert abs(loss.item() - float(np.asarray(g["total_loss"]).reshape(-1)[0])) < 1e-4 * abs(loss.item())
     worst = C.check(g, captured["out"], captured["grads"], before, after, net.beta, loss_tol=1e-4, grad_tol=2e-2)
     print("self-supervised step vs reference: worst relative gradient deviation %.2e" % worst)
