@@ -717,7 +717,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int st_slot = (blockIdx.x % 61 == 0 && blockIdx.x / 61 < 8) ? (int)blockIdx.x / 61 : -1;
     int st_tile = 0;
 #endif
-    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32;
     constexpr bool B_KC = (LAY == LAY_NT);
     constexpr int SZA = BM * (BK + PAD);
     constexpr int SZB = B_KC ? BN * (BK + PAD) : BK * (BN + PAD);
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 template <bool FB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tnsk_kernel(const GemmArgs g)
 {
-    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32;
     constexpr int SZA = BK * (BM + PAD), SZB = BK * (BN + PAD);
     __shared__ __attribute__((aligned(16))) float lds[2 * (SZA + SZB)];  // two stages
     const int tilesN = (g.N + BN - 1) / BN;
