@@ -677,3 +677,27 @@ def test_split_mode_falls_back_where_it_does_not_apply(F, monkeypatch):
     monkeypatch.setattr(F, "MS_SPLIT", "bf16x9")
     with pytest.raises(KeyError):
         F.split_mode(2048, 128)
+
+
+@pytest.mark.parametrize("B,N", [(8, 256), (3, 512), (16, 1024)])
+def test_split_products_one_update_all_mappings(F, B, N):
+    """One update of the labelled experiment's kernels against fp64 on small shapes: B % 8 == 0 takes the XCD-aware block
+    mapping, other batch sizes the plain one; N = 256 is a single query block per shape."""
+    from prifit_amd._lib import call, cur_stream, dll, ptr
+    X = torch.nn.functional.normalize(_t(synth.features(B, N, 128, 40 + B)), dim=-1).cuda()
+    Z = torch.nn.functional.normalize(X + 0.05 * _t(synth.features(B, N, 128, 41 + B)).cuda(), dim=-1).contiguous()
+    bw = torch.linspace(0.6, 1.1, B).cuda()
+    S = Z.double() @ X.double().transpose(1, 2)
+    K = torch.exp(torch.clamp((S - 1.0) / (bw.double() ** 2)[:, None, None], -13.0, 75.0))
+    O64, r64 = K @ X.double(), K.sum(-1)
+    for mode, tol in ((1, 3e-5), (2, 3e-6), (3, 3e-6)):
+        assert dll().prifit_meanshift_split_supported(N, 128, mode) == 1
+        cut = torch.empty(dll().prifit_meanshift_split_workspace(B, N, 128, mode), dtype=torch.uint8, device="cuda")
+        call("prifit_meanshift_split_prep", ptr(X), B, N, 128, mode, ptr(cut), cur_stream())
+        O = torch.full((B, N, 128), float("nan"), device="cuda")
+        rs = torch.full((B, N), float("nan"), device="cuda")
+        call("prifit_meanshift_split_fwd", ptr(Z), ptr(cut), ptr(bw), B, N, 128, mode, ptr(O), ptr(rs), cur_stream())
+        assert ((O.double() - O64).abs().amax(dim=(1, 2)) / O64.abs().amax(dim=(1, 2))).max().item() < tol
+        assert ((rs.double() - r64).abs() / r64).max().item() < tol
+    assert dll().prifit_meanshift_split_supported(300, 128, 2) == 0 and dll().prifit_meanshift_split_supported(256, 64, 2) == 0
+    assert dll().prifit_meanshift_split_supported(256, 128, 7) == 0
