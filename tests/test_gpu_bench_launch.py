@@ -79,3 +79,20 @@ print("native rccl ok")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500)
     assert r.returncode == 0 and "native rccl ok" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.timeout(900)
+def test_labelled_experiment_line_says_what_it_is(hiplib):
+    """`bench.py --ms-split MODE` (the 16-bit-planes experiment of the mean-shift forward): the line carries the label in
+    `dtype` and `experiment`, the split kernel is the dominant family, no `extra`; without the flag `dtype` is plain f32."""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    args = ["--steps", "2", "--warmup", "2", "--workload", "c3", "--no-cpu-baseline", "--no-extra"]
+    exp = _line([sys.executable, bench] + args + ["--ms-split", "fp16x3"], base)
+    assert exp["dtype"].startswith("f32 (mean-shift forward products fp16x3 emulated") and "experiment" in exp
+    assert "extra" not in exp and any(k.startswith("ms_split_fwd[fp16x3]") for k in exp["kernels"])
+    assert not any(k.startswith("ms_fused_fwd") for k in exp["kernels"])
+    plain = _line([sys.executable, bench] + args, base)
+    assert plain["dtype"] == "f32" and "experiment" not in plain
+    assert any(k.startswith("ms_fused_fwd") for k in plain["kernels"]) and not any(k.startswith("ms_split") for k in plain["kernels"])
+    assert abs(exp["config"]["loss"] - plain["config"]["loss"]) < 1e-3 * abs(plain["config"]["loss"])
