@@ -319,10 +319,8 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            // (nothing of the staging -- its arithmetic needs the prefetched tile -- may be scheduled up into the MFMAs: the
-            // compiler did, and waited for the loads after the first eight matrix instructions)
-            __builtin_amdgcn_sched_barrier(0);
-            store_tile(ntile, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);   // (as in the A role: the staging stays behind the MFMAs)
+                store_tile(ntile, cur ^ 1);
                 __syncthreads();
             }
             float *dst = g.dw_part + (long long)blockIdx.x * COUT * CIN;
