@@ -781,17 +781,39 @@ __global__ __launch_bounds__(256) void sample_nn_fwd_kernel(
             float4 t[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) t[u] = s_t[i + u];
+            float d0[4], d1[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 // (scalar fp32 on purpose: the packed v_pk_*_f32 forms of the same six operations measured slower here)
                 const float ax = p0x - t[u].x, ay = p0y - t[u].y, az = p0z - t[u].z;
                 const float bx = p1x - t[u].x, by = p1y - t[u].y, bz = p1z - t[u].z;
-                const float d0 = fmaf(az, az, fmaf(ay, ay, ax * ax));
-                const float d1 = fmaf(bz, bz, fmaf(by, by, bx * bx));
-                if (d0 < best0) { best0 = d0; bi0 = base + i + u; }
-                if (d1 < best1) { best1 = d1; bi1 = base + i + u; }
+                d0[u] = fmaf(az, az, fmaf(ay, ay, ax * ax));
+                d1[u] = fmaf(bz, bz, fmaf(by, by, bx * bx));
             }
+            // one comparison per group of four targets: the running best keeps (distance, first target of the group); which of
+            // the four it was is found once, after the loop (three vector instructions per group instead of twelve)
+            const float m0 = fminf(fminf(d0[0], d0[1]), fminf(d0[2], d0[3]));
+            const float m1 = fminf(fminf(d1[0], d1[1]), fminf(d1[2], d1[3]));
+            if (m0 < best0) { best0 = m0; bi0 = base + i; }
+            if (m1 < best1) { best1 = m1; bi1 = base + i; }
         }
+    }
+    // the winner inside its group: the same six operations on the same operands give the same bits; the first of the four that
+    // equals the group's minimum is the first minimum of the range (strict comparisons between groups keep the earliest group).
+    // A group that straddles the end of the range repeats the last target there: a repeat never comes before the original.
+    {
+        auto pick = [&](float px, float py, float pz, float best, int g0) {
+            int w = g0;
+#pragma unroll
+            for (int u = 3; u >= 0; --u) {
+                const int ii = min(g0 + u, m_hi - 1);
+                const float ax = px - T[(size_t)ii * 3], ay = py - T[(size_t)ii * 3 + 1], az = pz - T[(size_t)ii * 3 + 2];
+                if (fmaf(az, az, fmaf(ay, ay, ax * ax)) == best) w = ii;
+            }
+            return w;
+        };
+        if (act0 && best0 < INFINITY) bi0 = pick(p0x, p0y, p0z, best0, bi0);
+        if (act1 && best1 < INFINITY) bi1 = pick(p1x, p1y, p1z, best1, bi1);
     }
     // (a padded duplicate can only tie with the real last target of the range, which came first: never taken)
     float2 *cand = reinterpret_cast<float2 *>(ws) + ((size_t)b * NN_SPLIT + blockIdx.z) * cap;
