@@ -44,14 +44,30 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
     // 0xffffffff are never below a pivot, they simply never count).  32 rounds of (VPT counts + one wave sum).
     // Early exit: c_lo / c_hi = number of keys below the current lower / upper bound of the answer; once exactly one key
     // lies between them it IS the answer (a row of distinct distances gets there after ~12 of the 32 rounds).
-    unsigned prefix = 0;
-    int c_lo = 0, c_hi = 64 * VPT;
-    for (int bit = 31; bit >= 0; --bit) {
+    // The search starts below the highest bit in which the row's smallest and largest key differ: the bits above are the
+    // answer's (a row of nearly equal distances -- an untrained embedding -- shares its top ~20 bits, 20 rounds of nothing).
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        kmin = min(kmin, key[j]);
+        kmax = max(kmax, (lane + 64 * j) < C ? key[j] : 0u);
+    }
+    kmin = ~wave_max_u32_dpp(~kmin);
+    kmax = wave_max_u32_dpp(kmax);
+    if (kmin == kmax) {   // (wave-uniform) one value in the whole row
+        if (lane == 0) out[row] = key2f(kmin);
+        return;
+    }
+    const int top = 31 - __builtin_clz(kmin ^ kmax);
+    unsigned prefix = top == 31 ? 0u : (kmin >> (top + 1)) << (top + 1);
+    int c_lo = 0, c_hi = C;   // keys below the lower / the upper end of the bracket [prefix, prefix + 2^(top+1))
+    for (int bit = top; bit >= 0; --bit) {
         const unsigned p = prefix | (1u << bit);
+        // one vector compare per key; the count of its 64-bit lane mask and the running sum are SCALAR instructions (they
+        // issue beside the vector pipe), and the sum is wave-wide as it stands: no cross-lane reduction per round
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) cnt += key[j] < p ? 1 : 0;
-        cnt = wave_sum_i32_dpp(cnt);
+        for (int j = 0; j < VPT; ++j) cnt += __builtin_popcountll(__ballot(key[j] < p));
         if (cnt < k) { prefix = p; c_lo = cnt; }   // fewer than k keys below p: the answer is >= p
         else c_hi = cnt;
         if (c_hi - c_lo == 1) {
