@@ -340,15 +340,27 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
     }
 }
 
-// dW[c] = sum over workgroups of their partial slabs (fixed order)
+// dW[c] = sum over workgroups of their partial slabs, in a fixed order: 64 outputs per workgroup, four threads per output
+// take every fourth slab (four independent loads in flight each), combined through LDS.  (One thread per output walking all
+// 256 slabs was a 61 us launch of 24 workgroups: a serial chain of dependent adds on L2 latency.)
 __global__ __launch_bounds__(256) void stream_bwd_dw_reduce_kernel(const float *__restrict__ part, int nwg, int n, int cin,
                                                                   long long lddw, float *__restrict__ dW)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int w = 0; w < nwg; ++w) s += part[(long long)w * n + i];
-    dW[(long long)(i / cin) * lddw + (i % cin)] = s;
+    __shared__ float s_p[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int w = q;
+        for (; w + 12 < nwg; w += 16) {
+            a0 += part[(long long)w * n + i]; a1 += part[(long long)(w + 4) * n + i];
+            a2 += part[(long long)(w + 8) * n + i]; a3 += part[(long long)(w + 12) * n + i];
+        }
+        for (; w < nwg; w += 4) a0 += part[(long long)w * n + i];
+    }
+    s_p[q][o] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && i < n) dW[(long long)(i / cin) * lddw + (i % cin)] = (s_p[0][o] + s_p[1][o]) + (s_p[2][o] + s_p[3][o]);
 }
 
 int bwd_grid(long long P, int Cout, int Cin)
@@ -424,7 +436,7 @@ int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, c
     else if (Cout == 96 && Cin == 64) bwd_launch<96, 64>(g, pool, grid, st);
     else bwd_launch<64, 64>(g, pool, grid, st);
     const int n = Cout * Cin;
-    hipLaunchKernelGGL(stream_bwd_dw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, workspace, grid, n, Cin, lddw, dW);
+    hipLaunchKernelGGL(stream_bwd_dw_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grid, n, Cin, lddw, dW);
     return prifit_check_launch();
 }
 
