@@ -57,14 +57,63 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+_col_index_cache = {}
+
+
+def _col_index(cols, ncols, device):
+    """(src, dst, inv) index tensors of a column map `cols` (tuple; entry j = source column of output column j, -1 = zero
+    column), cached per device: src / dst the used pairs, inv the inverse permutation when every source column is used once."""
+    key = (cols, ncols, str(device))
+    hit = _col_index_cache.get(key)
+    if hit is None:
+        pairs = [(c, j) for j, c in enumerate(cols) if c >= 0]
+        src = torch.tensor([c for c, _ in pairs], dtype=torch.long, device=device)
+        dst = torch.tensor([j for _, j in pairs], dtype=torch.long, device=device)
+        inv = None
+        if sorted(c for c, _ in pairs) == list(range(ncols)):
+            pos = {c: j for c, j in pairs}
+            inv = torch.tensor([pos[c] for c in range(ncols)], dtype=torch.long, device=device)
+        full = torch.tensor([max(c, 0) for c in cols], dtype=torch.long, device=device)      # padded columns read column 0 ...
+        mask = torch.tensor([1.0 if c >= 0 else 0.0 for c in cols], dtype=torch.float32, device=device)   # ... times zero
+        hit = _col_index_cache[key] = (src, dst, inv, full, mask)
+    return hit
+
+
+class PackColsFn(torch.autograd.Function):
+    """out[:, j] = w[:, cols[j]] (cols[j] < 0: a zero column): a column permutation / padding of a weight matrix as one gather
+    forward and one gather (or scatter) backward.  Slices + cat do the same with a zero-fill and a copy per slice in the
+    backward: ~35 tiny launches per training step over the set-abstraction / feature-propagation first layers."""
+
+    @staticmethod
+    def forward(ctx, w, cols):
+        src, dst, inv, full, mask = _col_index(cols, w.shape[1], w.device)
+        ctx.idx, ctx.ncols = (src, dst, inv), w.shape[1]
+        if len(cols) == src.numel():            # a pure permutation / selection: no padding
+            return w.index_select(1, src)
+        return w.index_select(1, full) * mask.to(w.dtype)   # (weights are finite: 0 * w = 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        src, dst, inv = ctx.idx
+        if inv is not None:                     # every source column used exactly once
+            return g.index_select(1, inv), None
+        gw = g.new_zeros(g.shape[0], ctx.ncols)
+        gw.index_copy_(1, src, g.index_select(1, dst))
+        return gw, None
+
+
+def _pack_cols(w, cols):
+    cols = tuple(cols)
+    if cols == tuple(range(w.shape[1])):
+        return w
+    return PackColsFn.apply(w, cols)
+
+
 def _pack_weight(conv, perm_slices, kp):
     """[Cout, Cin(,1,1)] -> [Cout, kp]: columns re-ordered to the internal row layout, zero padded."""
     w = conv.weight.reshape(conv.weight.shape[0], -1)
-    parts = [w[:, a:b] for a, b in perm_slices]
-    k = sum(b - a for a, b in perm_slices)
-    if kp > k:
-        parts.append(_z(w, w.shape[0], kp - k))
-    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    cols = [c for a, b in perm_slices for c in range(a, b)]
+    return _pack_cols(w, cols + [-1] * (kp - len(cols)))
 
 
 def _mlp_tensors(convs, bns, first_weight):
@@ -93,17 +142,17 @@ def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first):
     w = conv.weight.reshape(conv.weight.shape[0], -1)
     C1 = w.shape[0]
     if feat_first:   # upstream MSG order [features, rel_xyz] (:247)
-        wf, wx = w[:, :D], w[:, D:D + 3]
+        fcols, xcols = list(range(D)), list(range(D, D + 3))
     else:            # upstream single-scale order [rel_xyz, features] (:131)
-        wf, wx = w[:, 3:3 + D], w[:, :3]
+        fcols, xcols = list(range(3, 3 + D)), list(range(3))
     parts = ([feats] if feats is not None else []) + [xyz]
     if kp > D + 3:
         parts.append(_z(xyz, B, N, kp - D - 3))
     rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
-    w_pt = torch.cat([wf, wx] + ([_z(w, C1, kp - D - 3)] if kp > D + 3 else []), dim=1)
+    w_pt = _pack_cols(w, fcols + xcols + [-1] * (kp - D - 3))
     U = LinearFn.apply(rows, w_pt, None).reshape(B, N, C1)
     c4 = torch.cat([new_xyz, _z(new_xyz, B, S, 1)], dim=-1).reshape(B * S, 4)
-    Vc = LinearFn.apply(c4, torch.cat([wx, _z(w, C1, 1)], dim=1), None).reshape(B, S, C1)
+    Vc = LinearFn.apply(c4, _pack_cols(w, xcols + [-1]), None).reshape(B, S, C1)
     return U, Vc
 
 
