@@ -53,7 +53,23 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def cur_stream(device=None):
+    """hipStream_t of PyTorch's current stream on `device` (default: the current device).  Called once per kernel launch
+    (~190 times per training step): torch.cuda.current_stream() builds a Stream object through three Python layers (~10 us,
+    2 ms of host time per step); the raw accessor inductor uses costs a fraction of a microsecond."""
+    if _raw_stream is not None and _get_device is not None:
+        if device is None:
+            idx = _get_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            d = torch.device(device)
+            idx = _get_device() if d.index is None else d.index
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -139,3 +139,15 @@ def test_three_interpolate_fwd_bwd(ops):
     gb[:, 8:] = g.reshape(B * N, C).cuda()
     dp2 = ops.three_interpolate_bwd(gb, 8, idx, w, B, S, C)
     torch.testing.assert_close(dp2.cpu(), p2.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_cur_stream_is_the_current_stream(hiplib):
+    """_lib.cur_stream (the raw accessor) names the same hipStream_t as torch.cuda.current_stream(), on the default stream,
+    inside a stream context, and for an explicit device."""
+    from prifit_amd._lib import cur_stream
+    assert cur_stream().value == (torch.cuda.current_stream().cuda_stream or None)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert cur_stream().value == side.cuda_stream and cur_stream(torch.device("cuda", 0)).value == side.cuda_stream
+        assert cur_stream("cuda").value == side.cuda_stream and cur_stream(0).value == side.cuda_stream
+    assert cur_stream().value == (torch.cuda.current_stream().cuda_stream or None)
