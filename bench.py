@@ -391,15 +391,25 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     # (an event pair per launch costs host time, ~7 ms/step when all ~250 wrapped launches are bracketed).
     # (calibration on the LAST warm-up step only: the first launch of every kernel includes the lazy load of its
     # code object, which an event bracket would charge to that family)
-    for _ in range(max(warmup, 1) - 1):
+    # (a span also brackets the host code between its two event records: a cyclic-GC pause of the launch thread inside one
+    # -- 60 ms were seen in a 2-launch family -- would crown the wrong family.  So the collector is off from here on, and
+    # the calibration is the per-family MINIMUM of two bracketed steps (the first launch of a kernel also loads its code).)
+    ncal = 2   # (so at least two untimed steps run whatever --warmup says; the line reports the number that ran)
+    warmup = max(warmup, ncal)
+    for _ in range(warmup - ncal):
         step()
     torch.cuda.synchronize()
-    profiler.reset()
-    profiler.enable("*")
-    step()
-    cal = profiler.collect()
+    gc.collect()
+    gc.disable()
+    cal = None
+    for _ in range(ncal):
+        profiler.reset()
+        profiler.enable("*")
+        step()
+        one = profiler.collect()
+        profiler.disable()
+        cal = one if cal is None else {k: (v if k not in cal or v[1] < cal[k][1] else cal[k]) for k, v in one.items()}
     dominant = max(cal.items(), key=lambda kv: kv[1][1])[0] if cal else None
-    profiler.disable()
     profiler.reset()
     graph_note = None
     if args.graph:
