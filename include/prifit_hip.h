@@ -273,6 +273,19 @@ int prifit_pool_reduce_groups_per_slab(void);
 /* slab [ceil(P/rows_per_slab)][2][C] = per-block column (sum, sum of squares) of Y. */
 int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream);
 
+/* GroupNorm statistics (nn.GroupNorm of src/dgcnn.py:150-171,203-213: per sample and channel group) -> the same affine
+ * form, per-sample tables [Bs][C].  slab [Bs * slabs_per_sample][2][C]: column (sum, sum of squares) partials, consecutive
+ * slabs of one sample; count = rows per sample x channels per group; fp64 accumulation.  C / groups divides 256
+ * (prifit_gn_finalize_supported).  _bwd_: from the (sum Gm, sum Gm yhat) partials of the backward reduce kernels the apply
+ * pass's coefficients coef_b, coef_d [Bs][C] (coef_a = scale) and the per-sample channel totals S [Bs][2][C] in fp64
+ * (dgamma = sum_b S[b][1], dbeta = sum_b S[b][0]). */
+int prifit_gn_finalize_supported(int C, int groups);
+int prifit_gn_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count, const float *gamma,
+                       const float *beta, double eps, float *scale, float *shift, float *mean, float *invstd, void *stream);
+int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
+                           const float *gamma, const float *mean, const float *invstd, float *coef_b, float *coef_d,
+                           double *S, void *stream);
+
 /* Batch statistics -> affine form of BatchNorm (torch.nn.BatchNorm{1,2}d in train mode, as used at
  * models/pointnet_util.py:198,254,312): mean/var over `count` positions from the partial slabs,
  * scale = gamma*invstd, shift = beta - mean*scale; running stats (may be NULL) updated with

@@ -21,6 +21,9 @@ from ..nn_ops import NN, NT, TN, LinearFn, gemm
 
 _LL = ctypes.c_longlong
 _F = ctypes.c_float
+_D = ctypes.c_double
+# GroupNorm statistics -> coefficient tables in one launch each way (0: the torch fp64 form, ~35 tiny launches per layer; A/B)
+_GN_KERNELS = __import__("os").environ.get("PRIFIT_GN_KERNELS", "1") != "0"
 
 
 def _pad4(c):
@@ -104,16 +107,22 @@ class ConvGNActFn(torch.autograd.Function):
         nslab = (P + tile - 1) // tile
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
-        sums = slab.view(Bs, rps // tile, 2, Cout).double().sum(dim=1)           # [Bs, 2, C] per-sample column sums
         m = float(rps * (Cout // G))
-        s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
-        s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
-        var = (s2 - s1 * s1).clamp_min(0.0)
-        invstd_g = torch.rsqrt(var + eps)
-        mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()       # [Bs, C] tables
-        invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
-        scale = (gamma.unsqueeze(0) * invstd).contiguous()
-        shift = (beta.unsqueeze(0) - mean * scale).contiguous()
+        if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+            # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
+            scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
+            call("prifit_gn_finalize", ptr(slab), Bs, rps // tile, Cout, G, _D(m), ptr(gamma.contiguous()),
+                 ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), cur_stream())
+        else:
+            sums = slab.view(Bs, rps // tile, 2, Cout).double().sum(dim=1)       # [Bs, 2, C] per-sample column sums
+            s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
+            s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
+            var = (s2 - s1 * s1).clamp_min(0.0)
+            invstd_g = torch.rsqrt(var + eps)
+            mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()   # [Bs, C] tables
+            invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
+            scale = (gamma.unsqueeze(0) * invstd).contiguous()
+            shift = (beta.unsqueeze(0) - mean * scale).contiguous()
         arg = None
         if pool_K:
             Gp = P // pool_K
@@ -154,19 +163,26 @@ class ConvGNActFn(torch.autograd.Function):
             slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
             call("prifit_bn_relu_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
                  ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), cur_stream())
-        S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)              # [Bs, 2, C]: sum Gm, sum Gm*yhat
-        dgamma = S[:, 1].sum(0).float()
-        dbeta = S[:, 0].sum(0).float()
         m = float(rps * (Cout // G))
-        gd = gamma.double().unsqueeze(0)
-        m1 = (gd * S[:, 0]).view(Bs, G, -1).sum(-1) / m                          # group means of dyhat, dyhat*yhat
-        m2 = (gd * S[:, 1]).view(Bs, G, -1).sum(-1) / m
-        rep = Cout // G
-        m1c, m2c = m1.repeat_interleave(rep, dim=1), m2.repeat_interleave(rep, dim=1)
-        isd, mu = invstd.double(), mean.double()
         ca = scale.contiguous()
-        cb = (-(isd * isd) * m2c).float().contiguous()
-        cd = (-isd * m1c + mu * isd * isd * m2c).float().contiguous()
+        if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+            cb, cd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(2))
+            S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
+            call("prifit_gn_bwd_finalize", ptr(slab), Bs, nslab // Bs, Cout, G, _D(m), ptr(gamma.contiguous()), ptr(mean),
+                 ptr(invstd), ptr(cb), ptr(cd), ptr(S), cur_stream())
+            dgamma, dbeta = S[:, 1].sum(0).float(), S[:, 0].sum(0).float()
+        else:
+            S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)          # [Bs, 2, C]: sum Gm, sum Gm*yhat
+            dgamma = S[:, 1].sum(0).float()
+            dbeta = S[:, 0].sum(0).float()
+            gd = gamma.double().unsqueeze(0)
+            m1 = (gd * S[:, 0]).view(Bs, G, -1).sum(-1) / m                      # group means of dyhat, dyhat*yhat
+            m2 = (gd * S[:, 1]).view(Bs, G, -1).sum(-1) / m
+            rep = Cout // G
+            m1c, m2c = m1.repeat_interleave(rep, dim=1), m2.repeat_interleave(rep, dim=1)
+            isd, mu = invstd.double(), mean.double()
+            cb = (-(isd * isd) * m2c).float().contiguous()
+            cd = (-isd * m1c + mu * isd * isd * m2c).float().contiguous()
         dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
         if pool_K:
             call("prifit_pool_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),

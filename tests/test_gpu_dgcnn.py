@@ -47,8 +47,11 @@ def test_knn_and_graph_feature(D, golden):
     torch.testing.assert_close(xg.grad.cpu(), x.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("gn_kernels", [True, False])
 @pytest.mark.parametrize("pool", [True, False])
-def test_conv_groupnorm_block(D, pool):
+def test_conv_groupnorm_block(D, pool, gn_kernels, monkeypatch):
+    # gn_kernels: GroupNorm statistics -> coefficient tables by prifit_gn_finalize / _bwd_finalize (default) or the torch fp64 form
+    monkeypatch.setattr(D, "_GN_KERNELS", gn_kernels)
     B, N, k, Cin, Cout, G = 2, 512, 4, 24, 32, 2
     rows = B * N * (k if pool else 1)
     x = _t(synth.features(1, rows, Cin, 5))[0]
