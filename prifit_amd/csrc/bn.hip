@@ -629,8 +629,8 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float *__rest
     }
 }
 
-// The same for BatchNorm (one coefficient table) and C / 4 dividing 256: a thread keeps ITS four channels -- the five
-// coefficient vectors are loaded once, not per element -- and walks rows with 32-bit arithmetic (the generic form pays two
+// The same for C / 4 dividing 256: a thread keeps ITS four channels -- the five coefficient vectors are loaded once (BatchNorm)
+// or once per sample (GroupNorm tables), not per element -- and walks rows with 32-bit arithmetic (the generic form pays two
 // 64-bit divisions and five 16-byte table loads per 16 bytes of Y: 4.1 TB/s where the BatchNorm apply pass reaches 5.5).
 __global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float *__restrict__ gp, long long ldgp,
                                                                   const float *__restrict__ Y, long long ldy,
@@ -640,12 +640,21 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float *_
                                                                   const float *__restrict__ ca,
                                                                   const float *__restrict__ cb,
                                                                   const float *__restrict__ cd, int P, int K, int C4,
-                                                                  float slope, float *__restrict__ dY, long long ldd)
+                                                                  int rps, float slope, float *__restrict__ dY, long long ldd)
 {
     const int rpb = 256 / C4;                         // rows per block and trip
     const int c = (threadIdx.x % C4) * 4;
-    const float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
+    float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
+    int cur = 0;                                      // rps != 0 (GroupNorm): one table row per sample of rps rows
     for (int r = blockIdx.x * rpb + threadIdx.x / C4; r < P; r += gridDim.x * rpb) {
+        if (rps) {
+            const int smp = r / rps;
+            if (smp != cur) {
+                cur = smp;
+                const long long to = (long long)smp * (C4 * 4) + c;
+                s = ld4g(scale + to); t = ld4g(shift + to); a = ld4g(ca + to); b = ld4g(cb + to); d = ld4g(cd + to);
+            }
+        }
         const int gi = r / K, k = r - gi * K;
         const float4 g = ld4g(gp + (long long)gi * ldgp + c), y = ld4g(Y + (long long)r * ldy + c);
         const int4 w = *reinterpret_cast<const int4 *>(arg + (long long)gi * (C4 * 4) + c);
@@ -904,10 +913,10 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
         !coef_a || !coef_b || !coef_d || G <= 0 || K <= 0 || rows_per_sample < 0)
         return PRIFIT_EINVAL;
     const int C4 = C / 4;
-    if (rows_per_sample == 0 && C4 <= 256 && 256 % C4 == 0 && (long long)G * K < 2147483647LL)
+    if (C4 <= 256 && 256 % C4 == 0 && (long long)G * K < 2147483647LL)
         hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(ew_grid((long long)G * K * C4)), dim3(256), 0, as_stream(stream),
-                           gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, (int)((long long)G * K), K, C4, slope,
-                           dY, ldd);
+                           gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, (int)((long long)G * K), K, C4,
+                           rows_per_sample, slope, dY, ldd);
     else
         hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((long long)G * K * C4)), dim3(256), 0,
                            as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C4,
