@@ -105,6 +105,33 @@ __global__ __launch_bounds__(256) void edge_scatter_kernel(const float *__restri
     }
 }
 
+// The two halves of that autograd as two launches: the neighbour term with one atomic per float (the only part that needs
+// them), then the centre term -- k edges of a point summed in registers, plain read-modify-write of dx: half the atomics.
+__global__ __launch_bounds__(256) void edge_scatter_neigh_kernel(const float *__restrict__ g, int ld,
+                                                                 const int32_t *__restrict__ idx, int N, int C, int k,
+                                                                 long long total, float *__restrict__ dx)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long row = id / C;
+        const int c = (int)(id - row * C);
+        const long long b = row / k / N;
+        unsafeAtomicAdd(dx + (b * N + idx[row]) * C + c, g[row * ld + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_scatter_centre_kernel(const float *__restrict__ g, int ld, int C, int k,
+                                                                  long long total, float *__restrict__ dx)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long bn = id / C;
+        const int c = (int)(id - bn * C);
+        const float *p = g + bn * k * ld + c;
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j, p += ld) acc += p[C] - p[0];
+        dx[id] += acc;
+    }
+}
+
 extern "C" {
 
 int prifit_knn_topk(const float *G, const float *xx, int B, int N, int k, int32_t *idx, void *stream)
@@ -143,7 +170,16 @@ int prifit_edge_scatter(const float *gout, int ld_gout, const int32_t *idx, int 
     const long long total = (long long)B * N * k * C;
     long long gsz = (total + 255) / 256;
     if (gsz > 256 * 32) gsz = 256 * 32;
-    hipLaunchKernelGGL(edge_scatter_kernel, dim3((unsigned)gsz), dim3(256), 0, as_stream(stream), gout, ld_gout,
+    if (k >= 4) {   // (two passes over g pay once the atomics they save outweigh the second read)
+        const long long pts = (long long)B * N * C;
+        long long g2 = (pts + 255) / 256;
+        if (g2 > 256 * 32) g2 = 256 * 32;
+        hipLaunchKernelGGL(edge_scatter_neigh_kernel, dim3((unsigned)gsz), dim3(256), 0, as_stream(stream), gout, ld_gout, idx, N,
+                           C, k, total, dx);
+        hipLaunchKernelGGL(edge_scatter_centre_kernel, dim3((unsigned)g2), dim3(256), 0, as_stream(stream), gout, ld_gout, C, k,
+                           pts, dx);
+    } else
+        hipLaunchKernelGGL(edge_scatter_kernel, dim3((unsigned)gsz), dim3(256), 0, as_stream(stream), gout, ld_gout,
                            idx, N, C, k, total, dx);
     return prifit_check_launch();
 }
