@@ -124,3 +124,24 @@ def test_dgcnn_with_convex_loss_config5(D):
     out[3].mean().backward()
     gr = net.net.mlp_seg_prob2.weight.grad
     assert gr is not None and torch.isfinite(gr).all() and torch.isfinite(net.net.encoder.conv1[0].weight.grad).all()
+
+
+@pytest.mark.parametrize("N,k", [(2048, 20), (1024, 40), (300, 7), (64, 64), (70, 3)])
+def test_knn_selection_order_and_ties(hiplib, N, k):
+    """prifit_knn_topk (selection + one sort per wave) against a stable sort of the same values: descending value, exact ties
+    to the lower index -- on clouds with duplicated points (many exact ties, also across the k-th place), ragged N, k = N."""
+    import ctypes
+    from prifit_amd._lib import call, cur_stream, ptr
+    B = 3
+    rng = np.random.default_rng(N + k)
+    x = rng.normal(size=(B, N, 3)).astype(np.float32)
+    x[:, N // 2:] = x[:, :N - N // 2]                      # every point twice: equal distances everywhere
+    x[0, :10] = x[0, 0]                                    # and a ten-fold point
+    xt = torch.from_numpy(x).cuda()
+    G = torch.matmul(xt, xt.transpose(1, 2)).contiguous()  # [B, N, N] inner products
+    xx = (xt * xt).sum(-1).contiguous()
+    idx = torch.empty(B, N, k, dtype=torch.int32, device="cuda")
+    call("prifit_knn_topk", ptr(G), ptr(xx), B, N, k, ptr(idx), cur_stream())
+    v = ((-xx).unsqueeze(2) - (-2.0 * G)) - xx.unsqueeze(1)                       # the kernel's expression, same rounding
+    want = torch.argsort(-v.cpu(), dim=2, stable=True)[:, :, :k]
+    assert torch.equal(idx.cpu().long(), want)
