@@ -639,31 +639,38 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float *_
                                                                   const float *__restrict__ shift,
                                                                   const float *__restrict__ ca,
                                                                   const float *__restrict__ cb,
-                                                                  const float *__restrict__ cd, int P, int K, int C4,
+                                                                  const float *__restrict__ cd, int G, int K, int C4,
                                                                   int rps, float slope, float *__restrict__ dY, long long ldd)
 {
-    const int rpb = 256 / C4;                         // rows per block and trip
+    // a thread walks the K rows of a pooling GROUP on its four channels: the pooled gradient and the winner's index are
+    // loaded once per group, the row loop is loads, seven vector operations per float and stores -- four rows in flight
+    const int gpb = 256 / C4;                         // groups per block and trip
     const int c = (threadIdx.x % C4) * 4;
     float4 s = ld4g(scale + c), t = ld4g(shift + c), a = ld4g(ca + c), b = ld4g(cb + c), d = ld4g(cd + c);
     int cur = 0;                                      // rps != 0 (GroupNorm): one table row per sample of rps rows
-    for (int r = blockIdx.x * rpb + threadIdx.x / C4; r < P; r += gridDim.x * rpb) {
+    for (int gi = blockIdx.x * gpb + threadIdx.x / C4; gi < G; gi += gridDim.x * gpb) {
         if (rps) {
-            const int smp = r / rps;
+            const int smp = (int)(((long long)gi * K) / rps);
             if (smp != cur) {
                 cur = smp;
                 const long long to = (long long)smp * (C4 * 4) + c;
                 s = ld4g(scale + to); t = ld4g(shift + to); a = ld4g(ca + to); b = ld4g(cb + to); d = ld4g(cd + to);
             }
         }
-        const int gi = r / K, k = r - gi * K;
-        const float4 g = ld4g(gp + (long long)gi * ldgp + c), y = ld4g(Y + (long long)r * ldy + c);
+        const float4 g = ld4g(gp + (long long)gi * ldgp + c);
         const int4 w = *reinterpret_cast<const int4 *>(arg + (long long)gi * (C4 * 4) + c);
-        float4 o;
-        o.x = fmaf(a.x, k == w.x ? (fmaf(y.x, s.x, t.x) > 0.f ? g.x : g.x * slope) : 0.f, fmaf(b.x, y.x, d.x));
-        o.y = fmaf(a.y, k == w.y ? (fmaf(y.y, s.y, t.y) > 0.f ? g.y : g.y * slope) : 0.f, fmaf(b.y, y.y, d.y));
-        o.z = fmaf(a.z, k == w.z ? (fmaf(y.z, s.z, t.z) > 0.f ? g.z : g.z * slope) : 0.f, fmaf(b.z, y.z, d.z));
-        o.w = fmaf(a.w, k == w.w ? (fmaf(y.w, s.w, t.w) > 0.f ? g.w : g.w * slope) : 0.f, fmaf(b.w, y.w, d.w));
-        st4g(dY + (long long)r * ldd + c, o);
+        const float *yp = Y + (long long)gi * K * ldy + c;
+        float *dp = dY + (long long)gi * K * ldd + c;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float4 y = ld4g(yp + (long long)k * ldy);
+            float4 o;
+            o.x = fmaf(a.x, k == w.x ? (fmaf(y.x, s.x, t.x) > 0.f ? g.x : g.x * slope) : 0.f, fmaf(b.x, y.x, d.x));
+            o.y = fmaf(a.y, k == w.y ? (fmaf(y.y, s.y, t.y) > 0.f ? g.y : g.y * slope) : 0.f, fmaf(b.y, y.y, d.y));
+            o.z = fmaf(a.z, k == w.z ? (fmaf(y.z, s.z, t.z) > 0.f ? g.z : g.z * slope) : 0.f, fmaf(b.z, y.z, d.z));
+            o.w = fmaf(a.w, k == w.w ? (fmaf(y.w, s.w, t.w) > 0.f ? g.w : g.w * slope) : 0.f, fmaf(b.w, y.w, d.w));
+            st4g(dp + (long long)k * ldd, o);
+        }
     }
 }
 
@@ -914,9 +921,9 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
         return PRIFIT_EINVAL;
     const int C4 = C / 4;
     if (C4 <= 256 && 256 % C4 == 0 && (long long)G * K < 2147483647LL)
-        hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(ew_grid((long long)G * K * C4)), dim3(256), 0, as_stream(stream),
-                           gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, (int)((long long)G * K), K, C4,
-                           rows_per_sample, slope, dY, ldd);
+        hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(ew_grid((long long)G * C4)), dim3(256), 0, as_stream(stream),
+                           gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C4, rows_per_sample, slope, dY,
+                           ldd);
     else
         hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((long long)G * K * C4)), dim3(256), 0,
                            as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C4,
