@@ -116,9 +116,10 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, Bs=4):
+def cpu_baseline(workload, Bs=4, passes=5):
     """The oracle (CPU restatement of the reference, kind "port") on a bounded sample of the same
-    workload: B=4 shapes, 1 warm-up + 3 timed forward+backward passes, host cores of this box.
+    workload: B=4 shapes, 1 warm-up + 5 timed forward+backward passes (median, min and max reported), host
+    cores of this box.
     (`--cpu-baseline-shapes 24` times the full batch once: B = 24 measured 1.05x the shapes/s of B = 4)"""
     import numpy as np
     import torch
@@ -163,16 +164,19 @@ def cpu_baseline(workload, Bs=4):
 
     one()
     ts = []
-    for _ in range(3):
+    for _ in range(passes):
         t0 = time.perf_counter()
         one()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
+    # a baseline, not a target: the figure moves with the box's other tenants (1.1 .. 2.1 shapes/s were seen for the same
+    # sample on one afternoon), so the line carries the spread of its passes, not a point
     return {"value": Bs / t, "unit": "shapes/s", "cores": cores, "kind": "port", "cpu": _cpu_model(), "B": Bs,
-            "passes": 3, "seconds_per_pass": t,
+            "passes": passes, "seconds_per_pass": t, "value_min": Bs / max(ts), "value_max": Bs / min(ts),
+            "seconds_per_pass_all": [round(x, 4) for x in ts],
             "sample": "oracle/prifit_oracle.py (torch-CPU restatement of the reference, %d threads on %s), B=%d x %d "
-                      "pts, %s step fwd+bwd, median of 3 timed passes after 1 warm-up (%.2f s per pass)"
-                      % (cores, _cpu_model(), Bs, NPTS, workload, t)}
+                      "pts, %s step fwd+bwd, median of %d timed passes after 1 warm-up (%.2f s per pass, min %.2f, max %.2f)"
+                      % (cores, _cpu_model(), Bs, NPTS, workload, passes, t, min(ts), max(ts))}
 
 
 def _traffic_per_launch(dom):
@@ -181,7 +185,7 @@ def _traffic_per_launch(dom):
     # (the PMC tool names kernels, the spans name call sites)
     alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false", "ms_fused_bwd": "ms_fused_kernel<1, true, true",
              "gemm_dual_nn": "gemm_dual_sk_kernel"}
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 fams_pmc = json.load(fh)["families"]
@@ -194,6 +198,55 @@ def _traffic_per_launch(dom):
         except Exception:
             continue
     return None, None
+
+
+def device_identity(index):
+    """What tells two GPUs apart: PCI address and uuid of visible device `index` (torch's device properties; the HIP
+    runtime's hipDeviceGetPCIBusId as a fallback)."""
+    import torch
+    ident = {"device_index": int(index), "pci_bus_id": None, "uuid": None, "name": None}
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        ident["name"] = pr.name
+        if hasattr(pr, "uuid"):
+            ident["uuid"] = str(pr.uuid)
+        if hasattr(pr, "pci_bus_id"):
+            ident["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+    except Exception:   # noqa: BLE001
+        pass
+    if ident["pci_bus_id"] is None:
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                ident["pci_bus_id"] = buf.value.decode()
+        except Exception:   # noqa: BLE001
+            pass
+    return ident
+
+
+def distributed_report(mine, rehearsal=False, group=None):
+    """COLLECTIVE (every rank calls it): what makes an N > 1 line prove itself.  `mine` = this rank's record (rank,
+    local_rank, host, the device identity, its own ms_per_step, speculation_fallbacks, allreduce_ms_per_step).  Returns on
+    every rank {"world_size" (from the communicator, not from the environment), "backend", "ranks": [...all records, by
+    rank...], "distinct_gpus", "ms_per_step_min" / "_max" over ranks}; raises unless the ranks sit on `world_size`
+    distinct GPUs -- except in a labelled rehearsal (ranks sharing a GPU, PRIFIT_BENCH_SHARE_GPU=1)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    recs = [None] * world
+    dist.all_gather_object(recs, mine, group=group)
+    recs.sort(key=lambda r: r["rank"])
+    if [r["rank"] for r in recs] != list(range(world)):
+        raise RuntimeError("distributed_report: ranks %s of a world of %d" % ([r["rank"] for r in recs], world))
+    gpus = {(r.get("host"), r.get("pci_bus_id") or r.get("uuid") or ("index", r.get("device_index"))) for r in recs}
+    rep = {"world_size": world, "backend": dist.get_backend(group), "ranks": recs, "distinct_gpus": len(gpus),
+           "ms_per_step_min": min(r["ms_per_step"] for r in recs), "ms_per_step_max": max(r["ms_per_step"] for r in recs),
+           "allreduce_ms_per_step_max": max((r.get("allreduce_ms_per_step") or 0.0) for r in recs),
+           "speculation_fallbacks_per_rank": [r.get("speculation_fallbacks") for r in recs]}
+    if len(gpus) != world and not rehearsal:
+        raise RuntimeError("%d ranks on %d distinct GPUs: %s" % (world, len(gpus), sorted(map(str, gpus))))
+    return rep
 
 
 def run_rank(args):
@@ -236,12 +289,27 @@ def run_rank(args):
     if not os.path.exists(_lib.LIB_PATH):
         build.build_library()   # file-locked + atomic rename: safe when every rank gets here at once
 
-    ctx = {"world": world, "rank": rank, "device": device, "use_dist": use_dist}
+    if use_dist:
+        world = dist.get_world_size()     # the communicator's answer is the one the line reports (n_gpus), not WORLD_SIZE
+        rank = dist.get_rank()
+    ctx = {"world": world, "rank": rank, "local": local, "device": device, "use_dist": use_dist, "backend": backend,
+           "share": share}
     cloud = args.cloud or DEFAULT_CLOUD[args.workload]
     head = measure(args, ctx, cloud, args.embedding, args.steps, args.warmup, full=True, split=args.ms_split)
 
+    report = None
+    if use_dist:
+        import socket
+        mine = dict(device_identity(local_dev), rank=rank, local_rank=local, host=socket.gethostname(),
+                    ms_per_step=1e3 * head["elapsed_local"] / head["steps"], speculation_fallbacks=head["fallbacks"],
+                    allreduce_ms_per_step=head["allreduce_ms"] / head["steps"])
+        report = distributed_report(mine, rehearsal=share)
     if rank == 0:
         line = headline(args, ctx, head, cloud)
+        if report is not None:
+            line["distributed"] = report
+            line["n_gpus"] = report["world_size"]
+            line["allreduce_ms_per_step"] = report["allreduce_ms_per_step_max"]
         if args.ms_split != "0":
             line["dtype"] = SPLIT_DTYPE % args.ms_split
             line["experiment"] = SPLIT_NOTE
@@ -275,10 +343,16 @@ def run_rank(args):
                 exp[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
         extra["split_mean_shift_products_experiment"] = exp
         line["extra"] = extra
+        # the training-like conditions at the top level of the line (the driver's parsed record keeps top-level keys)
+        line["extra_summary"] = {k: {"value": v.get("value"), "unit": "shapes/s", "ms_per_step": v.get("ms_per_step"),
+                                     "clusters_per_shape_mean": (v.get("clusters_per_shape") or {}).get("mean"),
+                                     "speculation_fallbacks": v.get("speculation_fallbacks"), "error": v.get("error")}
+                                 for k, v in extra.items() if k != "split_mean_shift_products_experiment"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_shapes)
+                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_shapes,
+                                                    passes=5 if args.cpu_baseline_shapes <= 8 else 2)
             except Exception as e:   # noqa: BLE001 (the oracle is test infrastructure: its failure must not cost the measured line)
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
@@ -294,7 +368,7 @@ SPLIT_NOTE = ("the S = Z X^T and O = K X products of the ten mean-shift updates 
               "at UNCHANGED tolerances (bf16x6, fp16x3); error of ten updates against fp64 next to the fp32 kernel's: "
               "profiles/r03_split_products.json.  Never the headline: `value` of this line is the fp32 path.")
 FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_fused_fwd", "ms_split_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
-                "ellipsoid_fit", "sdf", "sample_nn")
+                "ellipsoid_fit", "sdf", "sample_nn", "sample_nn_bwd")
 
 
 def measure(args, ctx, cloud, embedding, steps, warmup, full, split="0"):
@@ -382,9 +456,18 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
             loss = runner.run(selfsup_fwd_bwd, bucket.zero)
         else:
             loss = selfsup_fwd_bwd()
-        bucket.allreduce()
+        if use_dist and ar_events is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            bucket.allreduce()
+            b.record()
+            ar_events.append((a, b))
+        else:
+            bucket.allreduce()
         opt.step()
         return loss
+
+    ar_events = None   # a list inside the timed region: the (pack + all-reduce + scale) span of every step, by HIP events
 
     # Warm-up steps also calibrate the profiler: every kernel family is bracketed with HIP events once, then
     # only the dominant family and the ball-query/grouping launches keep their events in the timed region
@@ -434,13 +517,18 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ar_events = [] if use_dist else None
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0     # this rank's own time (the reported one is the MAX behind the barrier)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) if ar_events else 0.0
+    ar_events = None
+    bucket.flush()     # the deferred has-gradient check of the last exchange (ddp.FlatGradBucket)
     gc.enable()
     profiler.disable()
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -452,7 +540,7 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
             if k in cal and k not in fams:
                 n, ms, work = cal[k]
                 fams[k] = (n * steps, ms * steps, work * steps)
-    res = {"elapsed": el.item(), "steps": steps, "warmup": warmup, "fams": fams, "loss": float(loss.item()), "graph": graph_note,
+    res = {"elapsed": el.item(), "elapsed_local": elapsed_local, "allreduce_ms": allreduce_ms, "steps": steps, "warmup": warmup, "fams": fams, "loss": float(loss.item()), "graph": graph_note,
            "fallbacks": runner.fallbacks - fallbacks0, "ahead_on": ahead_on,
            "clusters": last["count"].tolist() if "count" in last else None}
     if full:
@@ -532,6 +620,9 @@ def family_rows(fams, steps):
             per.update(bound="mfma", achieved=terms * work / (ms * 1e-3) / 1e12, peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=terms * work / steps, flops_per_launch=terms * work / max(n, 1),
                        fp32_equivalent_tflops=work / (ms * 1e-3) / 1e12, plane_products=terms)
+        elif base == "sample_nn":    # exact nearest-target search: fp32 vector ALU (its peak = the fp32 MFMA peak on gfx950)
+            per.update(bound="valu", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                       flops_per_step=work / steps, flops_per_launch=work / max(n, 1))
         elif (base.startswith("gemm") and not base.startswith("gemm_stream")) or base.startswith(("ms_fused", "chord_sym")):
             per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=work / steps, flops_per_launch=work / max(n, 1))
@@ -608,6 +699,17 @@ def headline(args, ctx, r, cloud):
         for k in ("flops_per_step", "flops_per_launch", "bytes_per_step", "bytes_per_launch"):
             if k in d:
                 roof[k] = d[k]
+    # guard against stale work models: no family may print more than its roofline (a model that still charges work a
+    # fusion removed, or full products where a triangle is computed, shows up here)
+    over = {k: round(v["frac"], 3) for k, v in detail.items() if v["frac"] > 1.0}
+    if over:
+        print("bench.py: work model above its roofline (stale model?): %s" % over, file=sys.stderr)
+    grouping = grouping_roofline(detail)
+    if grouping:
+        pmc, src = _traffic_per_launch("sa_group_linear")
+        n = sum(v["launches_per_step"] for k, v in detail.items() if k.split("[")[0] == "sa_group_linear")
+        grouping["own_bytes"]["pmc_gbytes_per_step"] = (pmc * n / 1e9) if (pmc and n) else None
+        grouping["own_bytes"]["pmc_source"] = src
     ks = r["clusters"]
     line = {
         "metric": METRIC[args.workload],
@@ -622,7 +724,7 @@ def headline(args, ctx, r, cloud):
                    "launch": r.get("graph") or "eager",
                    "fps": ("side stream, one batch ahead: every step launches one batch's sampling (behind its backbone forward) "
                            "and consumes the previous launch; PRIFIT_SAMPLE_AHEAD=0 runs it in line" if r["ahead_on"] else "in line")},
-        "roofline": roof, "roofline_grouping": grouping_roofline(detail), "kernels": detail,
+        "roofline": roof, "roofline_grouping": grouping, "kernels": detail, "roofline_model_violations": over,
         "speculation_fallbacks": r["fallbacks"],
         "host_enqueue_ms_per_step": 1e3 * r["t_host"],
     }

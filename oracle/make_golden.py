@@ -741,4 +741,10 @@ if __name__ == "__main__":
     if "bw_over" in which or "fit" in which:
         import make_golden_fit
         make_golden_fit.run_bandwidth_over(save, close)
+    if "center_grad" in which:
+        import make_golden_fit
+        make_golden_fit.run_center_grad(save, eq, close)
+    if "prune" in which:
+        import make_golden_fit
+        make_golden_fit.run_prune(save, eq, close)
     print("all oracle-vs-reference checks passed; fixtures under", GOLD)

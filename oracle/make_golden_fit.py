@@ -109,6 +109,81 @@ def run_mean_shift_variants(save, close):
     save("fit_meanshift_variants", **out)
 
 
+def run_center_grad(save, eq, close):
+    """The gradient that enters the mean-shift trajectory through `center = new_X[indices]` ALONE (src/mean_shift.py:44-46:
+    `nms` runs under no_grad, the gather is the only differentiable use of the shifted points): d/dX sum(G * new_X[ids])
+    from the reference's autograd through all ten updates.  Pins the row-sparse backward engine (prifit_amd
+    fit_ops.MeanShiftRowsFn) directly.  Own fixture (`make_golden.py center_grad`)."""
+    ms = refshim.ref("src.mean_shift").MeanShift()
+    B, N, D, seed, q, iters = 2, 2048, 128, 31, 0.05, 10
+    _, _, emb = fit_inputs(B, N, D, seed)
+    out = {"seed": seed, "quantile": q, "iterations": iters}
+    for b in range(B):
+        X = emb[b]
+        with torch.no_grad():
+            bw = ms.compute_bandwidth(X, N, q)
+        Xr = X.clone().requires_grad_(True)
+        Zr, _ = ms.mean_shift_(Xr, bw, iterations=iters)
+        with torch.no_grad():
+            _, ids, _ = ms.nms(Zr.detach(), Zr.detach(), bw)
+        Gc = torch.from_numpy(synth.features(1, ids.shape[0], D, seed + 11 + b))[0]
+        (Zr[ids] * Gc).sum().backward()                     # center = new_X[indices]; only that gather reaches the loss
+        Xo = X.clone().requires_grad_(True)
+        Zo = orc.mean_shift_iterations(Xo, bw, iters)
+        (Zo[ids] * Gc).sum().backward()
+        close(Zo[ids].detach(), Zr[ids].detach(), f"centres b={b}", rtol=1e-5, atol=1e-6)
+        close(Xo.grad, Xr.grad, f"d/dX sum(G * new_X[ids]) b={b}", rtol=1e-3, atol=1e-5 * Xr.grad.abs().max().item())
+        g = Xr.grad
+        out[f"bw_{b}"] = bw
+        out[f"ids_{b}"] = ids.to(torch.int16)
+        out[f"G_{b}"] = Gc
+        out[f"centres_{b}"] = Zr[ids].detach()
+        out[f"dX_head_{b}"] = g[:64]
+        out[f"dX_ids_{b}"] = g[ids]
+        out[f"dX_colsum_{b}"] = g.sum(0)
+        out[f"dX_rownorm_{b}"] = g.norm(dim=1)
+        out[f"dX_norm_{b}"] = g.norm()
+    save("fit_center_grad", **out)
+
+
+def run_prune(save, eq, close):
+    """prune_points (convex_loss.py:444-470) on overlapping ellipsoids: oracle vs reference, and the fixture the HIP path is
+    tested against (`make_golden.py prune`).  Surface points come from the shared Fibonacci table (oracle sampler)."""
+    CL = refshim.ref("convex_loss")
+    rng = np.random.default_rng(77)
+    params_batch = []
+    for b in range(3):
+        K = (3, 5, 1)[b]
+        params = []
+        for k in range(K):
+            r = torch.from_numpy(rng.uniform(0.15, 0.5, 3).astype(np.float32))
+            Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            if np.linalg.det(Q) < 0:
+                Q[:, 2] = -Q[:, 2]
+            c = torch.from_numpy(rng.uniform(-0.25, 0.25, 3).astype(np.float32))       # close centres: heavy overlap
+            params.append((r, torch.from_numpy(Q.astype(np.float32)), c))
+        params_batch.append(params)
+    points = orc.sample_from_params(params_batch)
+    ref = CL.prune_points(points, params_batch)
+    mine = orc.prune_points(points, params_batch)
+    out = {}
+    for b, (pr, po) in enumerate(zip(ref, mine)):
+        eq(po, pr, f"prune_points b={b}")
+        with torch.no_grad():
+            sdf = torch.stack(CL.compute_sdf_ellipsoids(points[b], params_batch[b]), 1)
+        m = sdf.min(1)[0]
+        assert 0 < pr.shape[0] <= points[b].shape[0]
+        out[f"r_{b}"] = torch.stack([p[0] for p in params_batch[b]])
+        out[f"V_{b}"] = torch.stack([p[1] for p in params_batch[b]])
+        out[f"c_{b}"] = torch.stack([p[2] for p in params_batch[b]])
+        out[f"n_{b}"] = np.int32(points[b].shape[0])
+        out[f"keep_{b}"] = (m > -1e-3).numpy()
+        out[f"minsdf_{b}"] = m
+        out[f"kept_sum_{b}"] = pr.sum(0)
+    print("    kept %s of %s" % ([int(out[f"keep_{b}"].sum()) for b in range(3)], [int(out[f"n_{b}"]) for b in range(3)]))
+    save("fit_prune", **out)
+
+
 def run(save, eq, close):
     print("[fit]")
     MS = refshim.ref("src.mean_shift")

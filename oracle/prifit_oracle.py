@@ -728,6 +728,18 @@ def sdf_ellipsoid(points, center, r, V):
     return k0 * (k0 - 1.0) / (k1 + 1e-6)
 
 
+def prune_points(points, params_batch, thres=-1e-3):
+    """convex_loss.py:444-470: per shape, the predicted points whose SDF w.r.t. the union of the shape's ellipsoids
+    (min over k, no gradient) is above `thres`.  points: list[B] of [n_b, 3]; returns list[B] of [n_b', 3]."""
+    out = []
+    for b, params in enumerate(params_batch):
+        with torch.no_grad():
+            sdf = torch.stack([sdf_ellipsoid(points[b], c, r, V) for r, V, c in params], 1)
+            keep = torch.min(sdf, 1)[0] > thres
+        out.append(points[b][keep])
+    return out
+
+
 def ellipsoid_area(a, b, c, p=1.585):
     """src/ellipsoid_utils.py:157-159 (python float)."""
     return (4 * 3.142 * ((a * b) ** p + (b * c) ** p + (c * a) ** p) ** (1 / p)).item()

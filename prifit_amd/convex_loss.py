@@ -17,7 +17,8 @@ Explicit inputs that replace hidden randomness / absent third-party code (SURVEY
 Optional terms (off in the README configuration): `include_entropy_loss` (upstream :59-62,209-225),
 `include_intersect_loss` (:96-99,374-413 -- upstream's scatter_mean import is commented out, so this term is
 parity-unpinned and restates the documented intent), `include_pruning` (:78-82: upstream computes the pruned
-set but never uses it in the loss, so it is a no-op here).  `if_cuboid` (:72-76) reads the fitted (r, V, c) as boxes
+set but never uses it in the loss, so the loss value is unchanged here too; `prune_points` itself (:444-470) is below and
+`return_info=True` hands the pruned set out).  `if_cuboid` (:72-76) reads the fitted (r, V, c) as boxes
 with half-sides r: cuboid SDF (:473-502), area-proportional budget (src/ellipsoid_utils.py:186-193) and
 src/sample_ellipsoid.py:65-96 evaluated on the build's deterministic box-surface table (fit.hip cuboid_unit).
 """
@@ -134,6 +135,92 @@ def intersection_loss_volume_3(r, V, c, valid, points, cuboid=False):
     return (per * has).sum() / has.sum().clamp(min=1.0)
 
 
+# ------------------------------------------------------------------------------------------------
+# The reference's list-based names of the SDF / intersection / pruning helpers (convex_loss.py:313-343, :374-413,
+# :444-502), thin adapters over the batched kernels above: a caller that imports them by name gets the same numbers.
+# ------------------------------------------------------------------------------------------------
+def _sdf_lists(points, params_batch, cuboid):
+    """list[B] of list[K_b] of [n_b] SDF vectors.  points: [B,M,3] tensor or list of [n_b,3] tensors (ragged, as the
+    resampled surface points are); a non-tensor entry (upstream's -1 marker, src/ellipsoid_utils.py:116) gives []."""
+    from .src.utils import pack_params
+    plist = list(points.unbind(0)) if torch.is_tensor(points) else list(points)
+    tens = [p for p in plist if torch.is_tensor(p)]
+    if not tens:
+        return [[] for _ in plist]
+    dev = tens[0].device
+    r, V, c, valid = pack_params(params_batch, dev)
+    M = max(p.shape[0] for p in tens)
+    pad = torch.zeros(len(plist), M, 3, dtype=torch.float32, device=dev)
+    for b, p in enumerate(plist):
+        if torch.is_tensor(p):
+            pad[b, :p.shape[0]] = p
+    sdf = SdfMatrixFn.apply(pad, r, V, c, valid, cuboid)                 # [B, M, KM], dead slots 0
+    live = valid.cpu()
+    out = []
+    for b, p in enumerate(plist):
+        if not torch.is_tensor(p):
+            out.append([])
+            continue
+        out.append([sdf[b, :p.shape[0], k] for k in range(live.shape[1]) if live[b, k]])
+    return out
+
+
+def compute_sdf_ellipsoid(points, center, r, V):
+    """convex_loss.py:313-328: approximate SDF of one ellipsoid at points [M,3] -> [M]."""
+    return _sdf_lists(points.unsqueeze(0), [[(r, V, center)]], False)[0][0]
+
+
+def compute_sdf_ellipsoids(points, ellipsoids_parameters):
+    """:331-336: list over the ellipsoids (r, V, center) of one shape."""
+    return _sdf_lists(points.unsqueeze(0), [ellipsoids_parameters], False)[0]
+
+
+def compute_sdf_ellipsoids_batch(points, ellipsoids_parameters_batch):
+    """:339-343: list[B] of list[K_b] of [M]."""
+    return _sdf_lists(points, ellipsoids_parameters_batch, False)
+
+
+def compute_sdf_cuboid(points, center, r, V):
+    """:473-488: SDF of a box with half-sides r."""
+    return _sdf_lists(points.unsqueeze(0), [[(r, V, center)]], True)[0][0]
+
+
+def compute_sdf_cuboids(points, ellipsoids_parameters):
+    """:491-496"""
+    return _sdf_lists(points.unsqueeze(0), [ellipsoids_parameters], True)[0]
+
+
+def compute_sdf_cuboid_batch(points, ellipsoids_parameters_batch):
+    """:499-502"""
+    return _sdf_lists(points, ellipsoids_parameters_batch, True)
+
+
+def compute_intersection_loss_volume_3(ellipsoid_params_batch, points, cuboid=False):
+    """:374-413 by its upstream name and argument order (see intersection_loss_volume_3)."""
+    from .src.utils import pack_params
+    r, V, c, valid = pack_params(ellipsoid_params_batch, points.device)
+    return intersection_loss_volume_3(r, V, c, valid, points.contiguous(), cuboid=cuboid)
+
+
+def prune_points(points, ellipsoid_param_batch, thres=-1e-3):
+    """:444-470: of the predicted surface points of every shape keep those whose SDF with respect to the UNION of the
+    shape's ellipsoids (min over k) is above `thres`, i.e. drop points well inside another primitive.  points: list[B]
+    of [n_b,3] (the resampled points) or a [B,M,3] tensor; returns list[B] of [n_b',3].  The mask is computed without
+    gradient (upstream :459-468); the kept points keep theirs."""
+    with torch.no_grad():
+        sdfs = _sdf_lists([p.detach() if torch.is_tensor(p) else p for p in points], ellipsoid_param_batch, False)
+    pruned = []
+    for b in range(len(sdfs)):
+        p = points[b]
+        if not torch.is_tensor(p) or not sdfs[b]:
+            pruned.append(p)
+            continue
+        with torch.no_grad():
+            keep = torch.stack(sdfs[b], 1).min(dim=1)[0] > thres
+        pruned.append(p[keep])
+    return pruned
+
+
 def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, quantile=0.01, iterations=5,
                 visualize=False, max_num_clusters=25, class_list=[], include_intersect_loss=False, alpha=1, beta=1,
                 if_cuboid=False, include_pruning=False, include_entropy_loss=False, evaluation=False,
@@ -175,6 +262,12 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
     params = EllipseParams(r, V, c, valid, cl["count"])
     labels = list(cl["labels"].unbind(0))
     if return_info:
-        return total.view(1, 1), l.view(1, 1), params, labels, {"cluster": cl, "parts": parts, "r": r, "V": V, "c": c,
-                                                               "valid": valid}
+        info = {"cluster": cl, "parts": parts, "r": r, "V": V, "c": c, "valid": valid}
+        if include_pruning:
+            # :78-82: upstream builds the pruned set and then feeds the UNPRUNED points to the loss (:89); the loss above
+            # does the same.  The set itself is handed out here for callers that want it (visualisation upstream).
+            from .src import ellipsoid_utils as eu
+            resampled = (eu.sample_from_pred_params_cuboid if if_cuboid else eu.sample_from_pred_params)(params, N)
+            info["pruned_points"] = prune_points(resampled, params)
+        return total.view(1, 1), l.view(1, 1), params, labels, info
     return total.view(1, 1), l.view(1, 1), params, labels

@@ -920,7 +920,8 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
         !coef_a || !coef_b || !coef_d || G <= 0 || K <= 0 || rows_per_sample < 0)
         return PRIFIT_EINVAL;
     const int C4 = C / 4;
-    if (C4 <= 256 && 256 % C4 == 0 && (long long)G * K < 2147483647LL)
+    // the row-walking form takes the per-sample coefficient row from a group's FIRST row: groups must not straddle samples
+    if (C4 <= 256 && 256 % C4 == 0 && (long long)G * K < 2147483647LL && (rows_per_sample == 0 || rows_per_sample % K == 0))
         hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(ew_grid((long long)G * C4)), dim3(256), 0, as_stream(stream),
                            gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C4, rows_per_sample, slope, dY,
                            ldd);

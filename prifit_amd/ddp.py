@@ -27,7 +27,7 @@ class FlatGradBucket:
     its weight decay and stale moments there; a parameter that never had one stays `None` and is
     skipped.  The same rule holds with 1 and with N ranks, so the trajectories agree."""
 
-    def __init__(self, module, process_group=None, native=None, strict_seen=False):
+    def __init__(self, module, process_group=None, native=None, strict_seen=False, deferred_check=None):
         self.module = module
         self.group = process_group
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -47,6 +47,9 @@ class FlatGradBucket:
             off += p.numel()
         self.seen = [False] * len(self.params)   # has this parameter ever had a gradient ON ANY RANK (see the class docstring)
         self.strict_seen = strict_seen
+        # deferred_check: the reduced flags are read one exchange late (no host read-back in the step).  Default: device
+        # buckets unless strict_seen; True forces the protocol on a host bucket (the gloo tests drive it that way)
+        self.deferred = (dev.type == "cuda" and not strict_seen) if deferred_check is None else bool(deferred_check)
         self._pending, self._flag_host = None, None
         self.dist = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.dist else 1
@@ -91,40 +94,54 @@ class FlatGradBucket:
 
     def _adopt(self, local):
         """After the exchange: a parameter that had a gradient on ANY rank, now or earlier, gets its bucket slice.
-        Whether another rank had a gradient this rank lacks is in the reduced flags.  They are read on the host only when
-        it can matter -- some parameter here has no gradient now and never had one -- and then either synchronously
-        (`strict_seen`, and always for host buckets: exact) or, on the device path, asynchronously: the step carries on
-        with the rank-local answer and the NEXT exchange raises if the flags say that answer was wrong, so a divergence
-        of the replicas is never silent and the steady state has no host read-back."""
+        Whether another rank had a gradient this rank lacks is in the reduced flags, which are THE SAME on every rank, and
+        so is `self.seen` before the exchange -- every decision below is therefore taken by all ranks alike.  The flags
+        matter only while some parameter has never had a gradient anywhere; then they are read
+        * synchronously (`strict_seen`, host buckets): a parameter with a gradient on some rank is adopted by all, exact;
+        * or one exchange late (device buckets by default: no host read-back inside the step).  The step carries on with
+          the rank-local answer, which is right whenever the ranks agree (reduced flag 0 or `world`); a flag strictly
+          between marks a parameter some ranks stepped and others skipped, and EVERY rank raises at its next exchange
+          (or in `flush()`, which the trainer and the benchmark call after their last step) -- all ranks see the same
+          flags, so no rank is left waiting in a collective and a divergence of the replicas is never silent."""
         self._check_pending()
-        open_ = [i for i, (s, l) in enumerate(zip(self.seen, local)) if not (s or l)]
+        unseen = [i for i, s in enumerate(self.seen) if not s]      # global knowledge: the same list on every rank
         self.seen = [s or l for s, l in zip(self.seen, local)]
-        if open_ and (self.strict_seen or not self.flat.is_cuda):
+        if unseen and not self.deferred:
             got = (self.flags > 0).tolist()
             self.seen = [s or g for s, g in zip(self.seen, got)]
-        elif open_:
-            if self._flag_host is None:
-                self._flag_host = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
-            self._flag_host.copy_(self.flags, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._pending = (ev, open_)
+        elif unseen:
+            if self.flat.is_cuda:
+                if self._flag_host is None:
+                    self._flag_host = torch.empty(len(self.params), dtype=torch.float32).pin_memory()
+                self._flag_host.copy_(self.flags, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending = (ev, unseen, self._flag_host)
+            else:
+                self._pending = (None, unseen, self.flags.clone())
         for v, p, s in zip(self.views, self.params, self.seen):
             p.grad = v if s else None
 
     def _check_pending(self):
         if self._pending is None:
             return
-        ev, open_ = self._pending
+        ev, unseen, host = self._pending
         self._pending = None
-        ev.synchronize()
-        bad = [i for i in open_ if float(self._flag_host[i]) > 0]
+        if ev is not None:
+            ev.synchronize()
+        bad = [i for i in unseen if 0.5 < float(host[i]) < self.world - 0.5]
         if bad:
             names = {id(p): n for n, p in self.module.named_parameters()}
-            raise RuntimeError("gradient exchange: %s received a gradient on another rank only; this rank skipped it in "
-                               "the optimizer step and the replicas have diverged.  Construct FlatGradBucket(..., "
-                               "strict_seen=True) when ranks can disagree on which parameters get gradients."
-                               % ", ".join(names.get(id(self.params[i]), "#%d" % i) for i in bad))
+            raise RuntimeError("gradient exchange: %s received a gradient on some ranks only (%s of %d); those ranks "
+                               "stepped it, the others skipped it, and the replicas have diverged.  Every rank raises "
+                               "this in the same exchange.  Construct FlatGradBucket(..., strict_seen=True) when ranks can "
+                               "disagree on which parameters get gradients."
+                               % (", ".join(names.get(id(self.params[i]), "#%d" % i) for i in bad),
+                                  "/".join("%d" % round(float(host[i])) for i in bad), self.world))
+
+    def flush(self):
+        """Check the flags of the LAST exchange (deferred protocol): call after the final optimizer step."""
+        self._check_pending()
 
     def allreduce(self):
         """Average gradients over ranks: one sum all-reduce of the flat bucket, then scale by 1/world.

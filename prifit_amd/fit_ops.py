@@ -82,7 +82,9 @@ def chord_matrix(A, B_, owner_key=None):
         if owner_key is not None:
             keys = torch.full((Bt, N), -1, dtype=torch.int64, device=A.device)   # all bits set: the atomic-min identity
             owner_key.append(keys)
-        with profiler.span(profiler.tag("chord_sym", N, D, Bt), 2.0 * Bt * N * N * D):
+        # work = the products the kernel really does: the T (T + 1) / 2 tiles (128 x 128) on and above the diagonal
+        nt = N // 128
+        with profiler.span(profiler.tag("chord_sym", N, D, Bt), 2.0 * Bt * (nt * (nt + 1) // 2) * 128 * 128 * D):
             call("prifit_chord_sym_f32", ptr(A), _LL(D), _LL(N * D), ptr(out), _LL(N), _LL(N * N), N, D, Bt, ptr(keys), cur_stream())
         return out
     _bgemm(NT, N, M, D, A, D, B_, D, out, M, Bt, N * D, M * D, N * M, epi=EPI_CHORD)
@@ -218,6 +220,9 @@ class MeanShiftRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, bw, ids, nrows, traj = ctx.X, ctx.bw, ctx.ids, ctx.nrows, ctx.traj
+        if traj is None:
+            raise RuntimeError("MeanShiftRowsFn: backward a second time -- the saved mean-shift trajectory is released by the "
+                               "first backward (retain_graph is not supported here)")
         ctx.traj = None
         Bt, N, D = X.shape
         R = ids.shape[1]
@@ -343,7 +348,8 @@ def nms(Z, bw):
     count = torch.empty(Bt, **i32)
     labels = torch.empty(Bt, N, **i32)
     used = torch.empty(Bt, NMS_CAP, **i32)
-    with profiler.span("nms", 8.0 * Bt * N * N):   # the chord matrix is read twice (owner, neighbour pick)
+    # the chord matrix is read once (neighbour pick) when the owner pass ran in the chord kernel's epilogue, else twice
+    with profiler.span("nms", (4.0 if okey is not None else 8.0) * Bt * N * N):
         call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(okey), ptr(owner), ptr(counts), ptr(flags), ptr(ids),
              ptr(count), ptr(labels), ptr(used), cur_stream())
     return ids, count, labels, used
@@ -476,7 +482,9 @@ class SampleNNLossFn(torch.autograd.Function):
         nn_idx = torch.empty(Bt, SAMPLE_CAP, dtype=torch.int32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
         ws = torch.empty(dll().prifit_sample_nn_workspace_floats(Bt, SAMPLE_CAP), dtype=torch.float32, device=dev)
-        with profiler.span("sample_nn", 0.0):
+        # VALU-bound exact search: every surface sample (budget ~10^4 per shape, src/ellipsoid_utils.py:105) against every
+        # target, 8 flop per pair (3 sub, 3 fma-equivalents, compare + select)
+        with profiler.span("sample_nn", 8.0 * Bt * 10000.0 * M):
             call(ctx.pre + "_nn_fwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M,
                  SAMPLE_CAP, ptr(nn_idx), ptr(s), ptr(ws), cur_stream())
         total = off[:, K].clone()
@@ -490,7 +498,8 @@ class SampleNNLossFn(torch.autograd.Function):
         Bt, M, _ = targets.shape
         K = r.shape[1]
         g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
-        with profiler.span("sample_nn", 0.0):
+        # HBM: per sample its (U, V) entry, its nearest target (gathered) and index; parameters from LDS
+        with profiler.span("sample_nn_bwd", Bt * 10000.0 * (8.0 + 12.0 + 4.0)):
             call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
                  ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return g_r, g_V, g_c, None, None, None

@@ -98,7 +98,7 @@ class PackColsFn(torch.autograd.Function):
         if inv is not None:                     # every source column used exactly once
             return g.index_select(1, inv), None
         gw = g.new_zeros(g.shape[0], ctx.ncols)
-        gw.index_copy_(1, src, g.index_select(1, dst))
+        gw.index_add_(1, src, g.index_select(1, dst))   # a source column may feed several output columns: sum, not overwrite
         return gw, None
 
 

@@ -17,12 +17,16 @@ class SampledAhead:
     """Farthest-point samples of one set-abstraction level computed ahead of the step that uses them (`sample_ahead`):
     pass it where a module takes `fps_start`.  `farthest_point_sample` then only makes the consuming stream wait for the
     event and hands the stored (indices, coordinates) out -- the same numbers the in-line launch would produce."""
-    __slots__ = ("idx", "new_xyz", "event", "npoint", "keep", "consumed")
+    __slots__ = ("idx", "new_xyz", "event", "npoint", "keep", "consumed", "stream")
 
-    def __init__(self, idx, new_xyz, event, keep=()):
+    def __init__(self, idx, new_xyz, event, keep=(), stream=None):
         self.idx, self.new_xyz, self.event, self.npoint = idx, new_xyz, event, idx.shape[1]
         self.keep = keep   # the side stream's inputs: not back to the allocator before the consumer has waited for the event
         self.consumed = False   # set by farthest_point_sample once the consuming stream waits for the event
+        # the stream whose allocator pool idx / new_xyz came from (the current stream when sample_ahead ran): a finaliser
+        # can run anywhere -- inside `with torch.cuda.stream(side)`, on another thread -- so "current stream" at that
+        # moment is not the pool's stream
+        self.stream = stream
 
     def __del__(self):
         # dropped WITHOUT having been consumed: the side stream may still be writing idx / new_xyz, whose memory goes back to
@@ -32,7 +36,7 @@ class SampledAhead:
             return
         try:
             if not self.event.query():
-                torch.cuda.current_stream(self.idx.device).wait_event(self.event)
+                (self.stream or torch.cuda.current_stream(self.idx.device)).wait_event(self.event)
         except Exception:   # interpreter shutdown
             pass
 
@@ -60,7 +64,8 @@ def sample_ahead(xyz, npoints, starts=None):
     # outputs are allocated on the CONSUMING stream's pool: they are freed there, after the wait for the event
     outs = [(torch.empty(B, int(n), dtype=torch.int64, device=dev), torch.empty(B, int(n), 3, dtype=torch.float32, device=dev))
             for n in npoints]
-    side.wait_stream(torch.cuda.current_stream(dev))
+    consumer = torch.cuda.current_stream(dev)
+    side.wait_stream(consumer)
     with torch.cuda.stream(side):
         cur = xyz
         for (idx, nx), st, n in zip(outs, starts, npoints):
@@ -68,7 +73,7 @@ def sample_ahead(xyz, npoints, starts=None):
             cur = nx
         ev = torch.cuda.Event()
         ev.record(side)
-    return [SampledAhead(idx, nx, ev, keep=(xyz, starts)) for idx, nx in outs]
+    return [SampledAhead(idx, nx, ev, keep=(xyz, starts), stream=consumer) for idx, nx in outs]
 
 
 def farthest_point_sample(xyz, npoint, start_idx=None, return_xyz=False):

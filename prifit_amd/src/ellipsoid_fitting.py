@@ -23,3 +23,26 @@ def weighted_ellipsoid_fitting_batch(points, weights, batch_id=0, rand_table=Non
 def weighted_ellipsoids_fitting(points, weights, batch_id=0, shape_id=0, rand_table=None, canonical=True):
     """upstream :74-102 (one shape)."""
     return weighted_ellipsoid_fitting_batch(points.unsqueeze(0), [weights], rand_table=rand_table, canonical=canonical)[0]
+
+
+def weighted_ellipsoid_fitting(points, weights, batch_id=0, shape_id=0, cluster_id=0, rand_table=None, canonical=True):
+    """upstream :19-69 for ONE cluster: points [N,3], weights [N,1] (or [N]) -> (r[3], V[3,3], center[3]), or -1 when the
+    fit is rejected (covariance condition number above 1e5, :43-47)."""
+    w = weights.reshape(points.shape[0], 1)
+    fit = weighted_ellipsoid_fitting_batch(points.unsqueeze(0), [w], rand_table=rand_table, canonical=canonical)[0]
+    return fit[0] if fit else -1
+
+
+def principal_axis_ellipsoid(points, weights, S, V, mode="slow"):
+    """upstream :119-141: axis lengths of one cluster given the SVD (S, V) of its covariance.  "fast":
+    sqrt(clamp(S, 1e-7)) * 1.732; "slow" (what the fit uses): the weight-scaled, re-centred points projected on V
+    (third column flipped when V is a reflection), half the extent per axis.  Plain device arithmetic -- inside the fit
+    kernel (csrc/fit.hip) the same steps run fused; this stand-alone form serves callers that bring their own SVD."""
+    if mode == "fast":
+        return torch.sqrt(torch.clamp(S, min=1e-7)) * 1.732, V
+    w = weights.reshape(points.shape[0], 1)
+    pts = (points - torch.sum(points * w, 0) / torch.sum(w)) * w
+    if torch.det(V.T) < 0:
+        V = torch.stack([V[:, 0], V[:, 1], -1 * V[:, 2]], 1)
+    t = pts @ V
+    return torch.abs(t.max(dim=0)[0] - t.min(dim=0)[0]) / 2.0, V

@@ -62,3 +62,25 @@ def sample_from_pred_params(ellipse_params_batch, N=500, batch_id=0, seed=0, vis
         pts = [sampleellipse.sample(p[0][0], p[0][1], p[0][2], p[2], p[1], n=int(n[b, k]))[0] for k, p in enumerate(prm)]
         out.append(torch.cat(pts, 0) if pts else -1)
     return out
+
+
+def sample_from_pred_params_cuboid(ellipse_params_batch, N=500, batch_id=0, seed=0, visualize=False, class_list=[]):
+    """upstream :162-214: the same for boxes with half-sides r -- budget proportional to the face area
+    8 (ab + bc + ca) (:186-193), every box sampled by SampleEllipsoid.sample_cuboid."""
+    from .utils import pack_params
+    first = next((p for prm in ellipse_params_batch for p in prm), None)
+    if first is None:
+        return [-1] * len(ellipse_params_batch)
+    dev = first[0].device
+    r, V, c, valid = pack_params(ellipse_params_batch, dev)
+    B, K = valid.shape
+    n = torch.empty(B, K, dtype=torch.int32, device=dev)
+    off = torch.empty(B, K + 1, dtype=torch.int32, device=dev)
+    call("prifit_cuboid_sample_budget", ptr(r.detach().contiguous()), ptr(valid), B, K, fit_ops.SAMPLE_CAP, ptr(n), ptr(off),
+         cur_stream())
+    n = n.cpu()
+    out = []
+    for b, prm in enumerate(ellipse_params_batch):
+        pts = [sampleellipse.sample_cuboid(p[0][0], p[0][1], p[0][2], p[2], p[1], n=int(n[b, k]))[0] for k, p in enumerate(prm)]
+        out.append(torch.cat(pts, 0) if pts else -1)
+    return out

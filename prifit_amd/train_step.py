@@ -91,8 +91,9 @@ def graph_backbone(net, xyz, cls_label, fps_start):
     prifit_hip.h), so the capture is `torch.cuda.make_graphed_callables` as is; the fit path stays eager (its
     cluster-count verdict is read on the host, SpeculativeRunner).  Static inputs: `xyz` / `cls_label` of these shapes
     (other tensors are copied in), `fps_start` = these very tensors.  BatchNorm buffers are put back after the warm-up
-    iterations of the capture.  Returns the graphed callable (also `net.embed_features`); `net.embed_features_eager`
-    keeps the original."""
+    iterations of the capture.  Returns the graphed callable; `net.embed_features` replays it in training mode with
+    gradients enabled and falls back to the eager backbone (`net._embed_features_eager`) otherwise -- an eval / no_grad
+    forward must not replay a training-mode graph (batch statistics, running-stat updates)."""
     from . import arena
     if not hasattr(net, "_embed_features_eager"):
         net._embed_features_eager = net.embed_features
@@ -109,7 +110,14 @@ def graph_backbone(net, xyz, cls_label, fps_start):
             for b, s_ in zip(bufs, snap):
                 b.copy_(s_)
 
+    shape = (tuple(xyz.shape), tuple(cls_label.shape))
+
     def embed_features(xyz_, cls_, fps_start_=None):
+        same_start = fps_start_ is None or fps_start_ is fps_start or (
+            len(fps_start_) == len(fps_start) and all(a is b for a, b in zip(fps_start_, fps_start)))
+        if (not net.training or not torch.is_grad_enabled() or (tuple(xyz_.shape), tuple(cls_.shape)) != shape
+                or not same_start):
+            return net._embed_features_eager(xyz_, cls_, fps_start_)
         return graphed(xyz_, cls_)
 
     net.embed_features = embed_features
@@ -118,14 +126,16 @@ def graph_backbone(net, xyz, cls_label, fps_start):
 
 class Trainer:
     def __init__(self, model, num_part=50, learning_rate=0.001, decay_rate=1e-4, lr_decay=0.5, step_size=20, lmbda=1.0,
-                 fused_adam=True):
+                 fused_adam=True, strict_seen=False):
         self.model = model
         self.num_part = num_part
         self.lr0, self.lr_decay, self.step_size, self.lmbda = learning_rate, lr_decay, step_size, lmbda
         self.optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, betas=(0.9, 0.999), eps=1e-08,
                                           weight_decay=decay_rate,
                                           fused=bool(fused_adam and next(model.parameters()).is_cuda))
-        self.bucket = FlatGradBucket(model)
+        # strict_seen: ranks may disagree on which parameters get a gradient (see ddp.FlatGradBucket._adopt)
+        self.bucket = FlatGradBucket(model, strict_seen=strict_seen)
+        self._next = None          # the batch prepared by prefetch_selfsup
         # DataParallel replicates module 0's parameters and buffers onto every GPU at each forward
         # (train_partseg_shapenet.py:248-250); with one process per GPU the ranks start from rank 0's model instead
         self.bucket.broadcast_parameters(0)
@@ -172,16 +182,50 @@ class Trainer:
         return loss.detach(), acc
 
     # ------------------------------------------------------------------ self-supervised step (upstream :436-451)
-    def selfsup_step(self, chamfer_points, npoint=2048, quantile=0.01, msc_iterations=20, max_num_clusters=25,
-                     augment=True, subset=None, **loss_kwargs):
-        """chamfer_points [B,M,3]: the model input is a random `npoint`-subset of them (upstream :441)."""
+    def _selfsup_batch(self, chamfer_points, npoint, augment, subset):
+        """Augmentation + the random `npoint`-subset that is the model input (upstream :439-441), channels-first."""
         B, M, _ = chamfer_points.shape
         if augment:
             chamfer_points = random_scale_shift(chamfer_points)
         cham = chamfer_points.transpose(2, 1).contiguous()
         if subset is None:
             subset = torch.from_numpy(np.random.choice(M, npoint, replace=False)).to(cham.device)
-        points = cham[:, :, subset].contiguous()
+        return cham, cham[:, :, subset].contiguous()
+
+    def prefetch_selfsup(self, chamfer_points, npoint=2048, augment=True, subset=None, fps_start=None):
+        """Prepare the NEXT self-supervised batch now -- augmentation and subset, what a DataLoader worker does upstream --
+        and start its farthest-point sampling behind the backbone forward of the step that runs next (`model.sample_ahead`
+        through the `after_backbone` hook: the sampling chain depends on the coordinates alone, is 640 serial rounds on one
+        workgroup per shape, and there it runs beside the matrix-bound mean-shift kernels instead of at the head of its
+        own step; same indices as in-line sampling).  The following `selfsup_step()` WITHOUT `chamfer_points` consumes it.
+        Models without `sample_ahead` (DGCNN) only get the batch prepared."""
+        cham, points = self._selfsup_batch(chamfer_points, npoint, augment, subset)
+        nxt = {"cham": cham, "points": points, "ahead": None, "fps_start": fps_start}
+        self._next = nxt
+        if points.is_cuda and hasattr(self.model, "sample_ahead"):
+            def hook():
+                self.model.after_backbone = None
+                if self._next is nxt and nxt["ahead"] is None:
+                    nxt["ahead"] = self.model.sample_ahead(points, fps_start)
+            self.model.after_backbone = hook
+
+    def selfsup_step(self, chamfer_points=None, npoint=2048, quantile=0.01, msc_iterations=20, max_num_clusters=25,
+                     augment=True, subset=None, **loss_kwargs):
+        """chamfer_points [B,M,3]: the model input is a random `npoint`-subset of them (upstream :441).
+        chamfer_points=None: the batch prepared by `prefetch_selfsup`."""
+        if chamfer_points is None:
+            if self._next is None:
+                raise RuntimeError("selfsup_step() without chamfer_points needs a prefetch_selfsup(...) before it")
+            nxt, self._next = self._next, None
+            if getattr(self.model, "after_backbone", None) is not None and nxt["ahead"] is None:
+                self.model.after_backbone = None      # no step ran in between: sample in line
+            cham, points = nxt["cham"], nxt["points"]
+            start = nxt["ahead"] if nxt["ahead"] is not None else nxt["fps_start"]
+            if start is not None:
+                loss_kwargs = dict(loss_kwargs, fps_start=start)
+        else:
+            cham, points = self._selfsup_batch(chamfer_points, npoint, augment, subset)
+        B = cham.shape[0]
         category_label = torch.zeros(B, 1, 16, device=cham.device)
         self.bucket.zero()
         self.model.train()
@@ -201,6 +245,10 @@ class Trainer:
         return ss_loss.detach()
 
     # ------------------------------------------------------------------ checkpoints (upstream :467-475, :263-274)
+    def finish(self):
+        """After the last optimizer step: the deferred has-gradient check of the final exchange (ddp.FlatGradBucket.flush)."""
+        self.bucket.flush()
+
     def sync_buffers(self):
         """COLLECTIVE: rank 0's BatchNorm statistics win on every rank ("replica 0" of DataParallel)."""
         self.bucket.sync_buffers(0)
@@ -215,6 +263,7 @@ class Trainer:
         (a caller that guards it with `if rank == 0:` would leave rank 0 alone in the broadcast -- such a caller uses
         write_checkpoint, after a sync_buffers() that all ranks entered)."""
         import torch.distributed as dist
+        self.bucket.flush()
         self.sync_buffers()
         if dist.is_initialized() and dist.get_rank() != 0:
             return

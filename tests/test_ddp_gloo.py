@@ -379,3 +379,114 @@ def test_zero_grad_semantics_match_reference_optimizer_loop():
             assert torch.equal(p, q), (step, k)
     # head_b had no gradient in step 0 and must not have moved then; from step 1 on it moves in every step
     assert bucket.seen == [True] * len(bucket.params)
+
+
+def _deferred_worker(rank, world, port, out):
+    """The device bucket's protocol (flags read one exchange late), driven on a host bucket with deferred_check=True: head_b
+    gets a gradient on rank 0 alone in step 1.  Rank 0 steps it, rank 1 skips it -- and BOTH ranks must raise at their
+    next exchange (every rank sees the same reduced flags), none may be left waiting in the collective."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from prifit_amd.ddp import FlatGradBucket
+
+    class TwoHeads(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.trunk = torch.nn.Linear(6, 8)
+            self.head_a = torch.nn.Linear(8, 3)
+            self.head_b = torch.nn.Linear(8, 2)
+
+    torch.manual_seed(3)
+    net = TwoHeads()
+    bucket = FlatGradBucket(net, deferred_check=True)
+    assert bucket.deferred
+    bucket.broadcast_parameters(0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(11 + rank))
+    raised_at, msg = None, ""
+    for step in range(3):
+        bucket.zero()
+        h = torch.relu(net.trunk(x))
+        loss = net.head_a(h).pow(2).mean()
+        if rank == 0 and step == 1:
+            loss = loss + net.head_b(h).pow(2).mean()
+        loss.backward()
+        try:
+            bucket.allreduce()
+        except RuntimeError as e:
+            raised_at, msg = step, str(e)
+            break
+        opt.step()
+    # the symmetric case: the final exchange's flags are checked by flush() and pass
+    sym = FlatGradBucket(torch.nn.Linear(3, 2), deferred_check=True)
+    sym.zero()
+    sym.module(torch.ones(1, 3)).sum().backward()
+    sym.allreduce()
+    sym.flush()
+    # the asymmetric case on the LAST step: flush() raises on both ranks
+    last = FlatGradBucket(TwoHeads(), deferred_check=True)
+    last.zero()
+    h = torch.relu(last.module.trunk(x))
+    l2 = last.module.head_a(h).pow(2).mean()
+    if rank == 1:
+        l2 = l2 + last.module.head_b(h).pow(2).mean()
+    l2.backward()
+    last.allreduce()
+    flush_raised = False
+    try:
+        last.flush()
+    except RuntimeError:
+        flush_raised = True
+    out.put((rank, raised_at, "head_b" in msg, flush_raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_deferred_flag_check_raises_on_every_rank_in_the_same_exchange():
+    (_, at0, named0, fl0), (_, at1, named1, fl1) = _run_two(_deferred_worker)
+    assert at0 == at1 == 2, (at0, at1)          # the exchange after the asymmetric step, on BOTH ranks
+    assert named0 and named1
+    assert fl0 and fl1                          # a mismatch on the final step is caught by flush(), on both ranks
+
+
+def _report_worker(rank, world, port, out):
+    """bench.distributed_report over gloo: the N > 1 bench line's self-proving fields."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="7")   # a lying environment
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+
+    def rec(pci):
+        return dict(rank=rank, local_rank=rank, host="box", device_index=rank, pci_bus_id=pci, uuid=None, name="MI355X",
+                    ms_per_step=10.0 + rank, speculation_fallbacks=rank, allreduce_ms_per_step=0.1 * (rank + 1))
+
+    good = bench.distributed_report(rec("0000:%02x:00" % (5 + rank)))
+    same_raises = False
+    try:
+        bench.distributed_report(rec("0000:05:00"))
+    except RuntimeError:
+        same_raises = True
+    rehearsal = bench.distributed_report(rec("0000:05:00"), rehearsal=True)
+    out.put((rank, good, same_raises, rehearsal["distinct_gpus"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bench_distributed_report_fields_come_from_the_communicator():
+    (_, rep0, raises0, reh0), (_, rep1, raises1, reh1) = _run_two(_report_worker)
+    assert rep0 == rep1                                                   # every rank holds the same report
+    assert rep0["world_size"] == 2 and rep0["backend"] == "gloo"          # the communicator's, not WORLD_SIZE=7
+    assert rep0["distinct_gpus"] == 2
+    assert [r["rank"] for r in rep0["ranks"]] == [0, 1]
+    for r in rep0["ranks"]:
+        for key in ("local_rank", "device_index", "pci_bus_id", "uuid", "host", "ms_per_step", "speculation_fallbacks",
+                    "allreduce_ms_per_step"):
+            assert key in r, key
+    assert rep0["ms_per_step_min"] == 10.0 and rep0["ms_per_step_max"] == 11.0
+    assert abs(rep0["allreduce_ms_per_step_max"] - 0.2) < 1e-12
+    assert rep0["speculation_fallbacks_per_rank"] == [0, 1]
+    assert raises0 and raises1                                            # two ranks on one GPU: refused ...
+    assert reh0 == reh1 == 1                                              # ... unless it is the labelled rehearsal

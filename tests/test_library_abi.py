@@ -52,7 +52,21 @@ def test_compat_aliases_resolve_to_backend(hiplib):
                   "sample_and_group_all", "PointNetSetAbstraction", "PointNetSetAbstractionMsg",
                   "PointNetFeaturePropagation"):
             assert hasattr(pu, n), n
-        assert hasattr(importlib.import_module("convex_loss"), "convex_loss")
+        cl = importlib.import_module("convex_loss")
+        for n in ("convex_loss", "entropy", "compute_sdf_ellipsoid", "compute_sdf_ellipsoids", "compute_sdf_ellipsoids_batch",
+                  "compute_sdf_cuboid", "compute_sdf_cuboids", "compute_sdf_cuboid_batch", "compute_intersection_loss_volume_3",
+                  "prune_points"):                                   # convex_loss.py:27,209,313-343,374-413,444-502
+            assert callable(getattr(cl, n)), n
+        eu = importlib.import_module("src.ellipsoid_utils")
+        for n in ("guard_mean_shift", "clustering", "sample_from_pred_params", "sample_from_pred_params_cuboid",
+                  "compute_approximate_ellipsoid_area"):             # src/ellipsoid_utils.py:9-214
+            assert callable(getattr(eu, n)), n
+        ef = importlib.import_module("src.ellipsoid_fitting")
+        for n in ("weighted_ellipsoid_fitting", "weighted_ellipsoids_fitting", "weighted_ellipsoid_fitting_batch",
+                  "principal_axis_ellipsoid"):                       # src/ellipsoid_fitting.py:19-141
+            assert callable(getattr(ef, n)), n
+        se = importlib.import_module("src.sample_ellipsoid").SampleEllipsoid
+        assert callable(se.sample) and callable(se.sample_cuboid)    # src/sample_ellipsoid.py:17-96
         assert hasattr(importlib.import_module("src.mean_shift"), "MeanShift")
         assert len(names) >= 8
         net = M.get_model(50)

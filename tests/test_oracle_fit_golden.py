@@ -149,3 +149,34 @@ def test_mean_shift_variants_match_reference(golden):
         (Z * gg).sum().backward()
         assert torch.allclose(Z[:64].detach(), torch.from_numpy(g["Z_" + name]), rtol=1e-5, atol=1e-6)
         assert torch.allclose(X.grad[:64], torch.from_numpy(g["dX_" + name]), rtol=1e-4, atol=1e-6 * float(X.grad.abs().max()))
+
+
+def test_center_gather_gradient_golden(golden):
+    """d/dX sum(G * new_X[ids]) -- the only differentiable use of the shifted points (src/mean_shift.py:44-46) -- of the
+    oracle against the reference's autograd (fit_center_grad.npz)."""
+    g = golden("fit_center_grad")
+    seed = int(g["seed"])
+    _, _, emb = fit_inputs(2, 2048, 128, seed)
+    b = 1
+    X = emb[b].clone().requires_grad_(True)
+    ids = _t(g[f"ids_{b}"]).long()
+    Z = orc.mean_shift_iterations(X, _t(g[f"bw_{b}"]), int(g["iterations"]))
+    (Z[ids] * _t(g[f"G_{b}"])).sum().backward()
+    torch.testing.assert_close(Z[ids].detach(), _t(g[f"centres_{b}"]), rtol=1e-5, atol=1e-6)
+    ref = _t(g[f"dX_ids_{b}"])
+    torch.testing.assert_close(X.grad[ids], ref, rtol=1e-3, atol=1e-4 * ref.abs().max().item())
+    assert abs(float(X.grad.norm()) - float(g[f"dX_norm_{b}"])) <= 1e-3 * float(g[f"dX_norm_{b}"])
+
+
+def test_prune_points_golden(golden):
+    """prune_points (convex_loss.py:444-470): the oracle keeps exactly the points the reference kept (fit_prune.npz)."""
+    g = golden("fit_prune")
+    params = [[(_t(g[f"r_{b}"][k]), _t(g[f"V_{b}"][k]), _t(g[f"c_{b}"][k])) for k in range(g[f"r_{b}"].shape[0])]
+              for b in range(3)]
+    pts = orc.sample_from_params(params)
+    kept = orc.prune_points(pts, params)
+    for b in range(3):
+        assert pts[b].shape[0] == int(g[f"n_{b}"])
+        assert kept[b].shape[0] == int(g[f"keep_{b}"].sum())
+        assert torch.equal(kept[b], pts[b][_t(g[f"keep_{b}"])])
+        torch.testing.assert_close(kept[b].sum(0), _t(g[f"kept_sum_{b}"]), rtol=1e-5, atol=1e-4)
