@@ -285,6 +285,14 @@ int prifit_gn_finalize(const float *slab, int Bs, int slabs_per_sample, int C, i
 int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
                            const float *gamma, const float *mean, const float *invstd, float *coef_b, float *coef_d,
                            double *S, void *stream);
+/* The same for a tensor Y + offset[b][c] whose per-sample, per-channel constant `offset` [Bs][C] the producer left out of
+ * Y (the decoder's first convolution, src/dgcnn.py:253-257: the 1024 global-feature channels of its input are the same for
+ * every point of a sample, so their product with the weight is ONE row per sample instead of N): slab = statistics of Y
+ * alone, rows_per_sample = N.  The tables are relative to Y (mean' = mean - offset, shift' = beta - mean' scale): the
+ * affine / pool / backward kernels then run on Y unchanged and the offset never has to be added to N rows. */
+int prifit_gn_finalize_offset(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
+                              const float *gamma, const float *beta, double eps, const float *offset, double rows_per_sample,
+                              float *scale, float *shift, float *mean, float *invstd, void *stream);
 
 /* Batch statistics -> affine form of BatchNorm (torch.nn.BatchNorm{1,2}d in train mode, as used at
  * models/pointnet_util.py:198,254,312): mean/var over `count` positions from the partial slabs,
@@ -529,6 +537,24 @@ int prifit_membership_bwd(const float *gW, const float *W, const float *dots, co
                           const float *gmax, const int32_t *count, int B, int N, int KM, float *gdots,
                           void *stream);
 
+/* gmax [B] of prifit_membership_fwd in one launch: (max over points j and live clusters k < count[b] of dots[b][j][k]) /
+ * bw[b]^2 -- `sim.max()` of src/mean_shift.py:237-242 after the division by b^2 (a positive scale commutes with the max).
+ * KM % 4 == 0, dots 16-byte aligned; workspace: prifit_membership_gmax_workspace(B) floats. */
+long long prifit_membership_gmax_workspace(int B);   /* floats of scratch */
+int prifit_membership_gmax(const float *dots, const float *bw, const int32_t *count, int B, int N, int KM, float *gmax,
+                           float *workspace, void *stream);
+
+/* bw [B] = mean over the N rows of sqrt(max(kth, 1e-6)) (src/mean_shift.py:158-160), kth [B*N] from
+ * prifit_kth_smallest_rows. */
+int prifit_bandwidth_from_kth(const float *kth, int B, int N, float *bw, void *stream);
+
+/* The cluster-count check of guard_mean_shift (src/ellipsoid_utils.py:19-27) for all shapes after prifit_nms:
+ * nuniq [B] (may be NULL) = distinct labels per shape (count[b] itself when more than `cap` centres were kept),
+ * bad [1] = 1 when some shape has nuniq > max_clusters (the quantile-doubling retry is due) or more than `slots` kept
+ * centres, else 0. */
+int prifit_cluster_verdict(const int32_t *count, const int32_t *used, int B, int cap, int max_clusters, int slots,
+                           int32_t *nuniq, int32_t *bad, void *stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* weighted ellipsoid fit and analytic-chamfer loss terms                                       */
 /* (fixed capacity: KM <= 64 cluster slots per shape, live when k < count[b] and valid[b][k])   */
@@ -579,6 +605,14 @@ int prifit_ellipsoid_sdf_matrix_bwd(const float *points, int B, int M, const flo
  * <=0 -> 100), off [B,KM+1] exclusive prefix (off[KM] = total, clipped to cap). */
 int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n,
                          int32_t *off, void *stream);
+
+/* The combination step of analytic_chamfer_distance (src/utils.py:417-426) in one launch: per shape
+ * (d2_sum[b] / max(total[b], 1) + sdf_sum[b] / M) / 2, averaged over the shapes with at least one valid primitive
+ * (valid [B,KM]); 0 when none has.  loss [1]; part [2][B] = the two per-shape halves; coef [2 B + 1] = what the backward
+ * needs.  _bwd: g [1] = d L / d loss -> g_d2 [B], g_sdf [B]. */
+int prifit_chamfer_combine_fwd(const float *d2_sum, const int32_t *total, const float *sdf_sum, const int32_t *valid, int B,
+                               int KM, int M, float *loss, float *part, float *coef, void *stream);
+int prifit_chamfer_combine_bwd(const float *g, const float *coef, int B, float *g_d2, float *g_sdf, void *stream);
 
 /* Surface samples on the Fibonacci (U,V) table evaluated as src/sample_ellipsoid.py:55-63, their exact
  * nearest target (src/utils.py:413-416): nn_idx [B,cap], sum_d2 [B] = sum of squared distances.

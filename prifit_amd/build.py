@@ -31,6 +31,7 @@ SOURCES = {
     "meanshift_rows.hip": [],
     "meanshift_split.hip": [],
     "fit.hip": [],
+    "fit_glue.hip": [],
     "dgcnn.hip": ["-ffp-contract=off"],
     "comm.hip": [],        # host-only: the RCCL export (RCCL itself is resolved with dlopen at run time)
 }

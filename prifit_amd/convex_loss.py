@@ -63,9 +63,8 @@ def analytic_chamfer_distance(r, V, c, valid, targets, cuboid=False):
     M = targets.shape[1]
     sdf_sum = fit_ops.SdfLossFn.apply(targets, r, V, c, valid, cuboid)
     d2_sum, total = fit_ops.SampleNNLossFn.apply(r, V, c, valid, targets, cuboid)
-    has = (valid.sum(dim=1) > 0).to(r.dtype)
-    per = (d2_sum / total.clamp(min=1).to(r.dtype) + sdf_sum / M) / 2.0
-    return (per * has).sum() / has.sum().clamp(min=1.0), (d2_sum / total.clamp(min=1), sdf_sum / M)
+    loss, part = fit_ops.ChamferCombineFn.apply(d2_sum, total, sdf_sum, valid, M)
+    return loss, (part[0], part[1])
 
 
 class EntropyFn(torch.autograd.Function):
@@ -238,7 +237,7 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
         emb = F.normalize(emb, dim=2, p=2)
         emb = F.normalize(emb, dim=2, p=2).contiguous()
     pts = points.permute(0, 2, 1).contiguous()
-    entropy_loss = torch.zeros((), device=pts.device)
+    entropy_loss = None
     if include_entropy_loss:                              # :59-62: a random quarter of the points
         if entropy_indices is None:
             entropy_indices = torch.randperm(emb.shape[1], device=emb.device)[: emb.shape[1] // 4]
@@ -252,13 +251,17 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
         l, parts = analytic_chamfer_distance(r, V, c, valid, tgt, cuboid=if_cuboid)   # :72-89
     else:
         l, parts = torch.zeros((), device=pts.device, requires_grad=True), None
-    intersection_loss = torch.zeros((), device=pts.device)
+    intersection_loss = None
     if include_intersect_loss and evaluation is False:                   # :96-99 (targets jittered by U[0, 0.2))
         if intersect_jitter is None:
             intersect_jitter = torch.rand_like(tgt) * 0.2
         intersection_loss = intersection_loss_volume_3(r, V, c, valid, tgt - intersect_jitter.to(tgt.device),
                                                        cuboid=if_cuboid)
-    total = l + (alpha * intersection_loss) + (beta * entropy_loss)      # :101
+    total = l                                                            # :101: l + alpha * intersection + beta * entropy
+    if intersection_loss is not None:
+        total = total + alpha * intersection_loss
+    if entropy_loss is not None:
+        total = total + beta * entropy_loss
     params = EllipseParams(r, V, c, valid, cl["count"])
     labels = list(cl["labels"].unbind(0))
     if return_info:

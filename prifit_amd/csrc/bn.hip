@@ -125,9 +125,14 @@ __device__ __forceinline__ double gn_group_sum(double v, int cpg, double *s_red)
     return r;
 }
 
+// offset (may be NULL) [Bs][C]: the normalised tensor is Y + offset[b][c] (a per-sample, per-channel constant that the
+// producer left out of Y, e.g. the part of a 1x1 convolution whose input is the same for every point of the sample); the
+// slabs hold the statistics of Y alone, `rows` = rows per sample.  The tables come out RELATIVE TO Y -- mean' = mean -
+// offset, shift' = beta - mean' scale -- so every consumer (affine / pool / backward kernels) works on Y unchanged.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ slab, int sps, int C, int cpg, double m,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          double eps, float *__restrict__ scale, float *__restrict__ shift,
+                                                          double eps, const float *__restrict__ offset, double rows,
+                                                          float *__restrict__ scale, float *__restrict__ shift,
                                                           float *__restrict__ mean_o, float *__restrict__ invstd_o)
 {
     __shared__ double s_part[2][256];
@@ -135,12 +140,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
     const int g = blockIdx.x, b = blockIdx.y, c0 = g * cpg;
     double t0, t1;
     gn_channel_sums(slab, b, sps, C, c0, cpg, s_part, t0, t1);
+    double off = 0.0;
+    if (offset && threadIdx.x < cpg) {
+        off = (double)offset[(size_t)b * C + c0 + threadIdx.x];
+        t1 += 2.0 * off * t0 + rows * off * off;     // sum (y + o)^2 = sum y^2 + 2 o sum y + n o^2
+        t0 += rows * off;
+    }
     const double s1 = gn_group_sum(t0, cpg, s_red) / m, s2 = gn_group_sum(t1, cpg, s_red) / m;
     double var = s2 - s1 * s1;
     var = var > 0.0 ? var : 0.0;
-    const float mean = (float)s1, invstd = (float)(1.0 / sqrt(var + eps));
+    const float invstd = (float)(1.0 / sqrt(var + eps));
     if (threadIdx.x < cpg) {
         const int c = c0 + threadIdx.x;
+        const float mean = (float)(s1 - off);
         const float sc = __fmul_rn(gamma[c], invstd);
         scale[(size_t)b * C + c] = sc;
         shift[(size_t)b * C + c] = __fsub_rn(beta[c], __fmul_rn(mean, sc));
@@ -782,7 +794,19 @@ int prifit_gn_finalize(const float *slab, int Bs, int slabs_per_sample, int C, i
         !prifit_gn_finalize_supported(C, groups))
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, Bs), dim3(256), 0, as_stream(stream), slab, slabs_per_sample, C,
-                       C / groups, count, gamma, beta, eps, scale, shift, mean, invstd);
+                       C / groups, count, gamma, beta, eps, (const float *)nullptr, 0.0, scale, shift, mean, invstd);
+    return prifit_check_launch();
+}
+
+int prifit_gn_finalize_offset(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
+                              const float *gamma, const float *beta, double eps, const float *offset, double rows_per_sample,
+                              float *scale, float *shift, float *mean, float *invstd, void *stream)
+{
+    if (!slab || !gamma || !beta || !offset || !scale || !shift || !mean || !invstd || Bs <= 0 || slabs_per_sample <= 0 ||
+        count <= 0 || rows_per_sample <= 0 || !prifit_gn_finalize_supported(C, groups))
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, Bs), dim3(256), 0, as_stream(stream), slab, slabs_per_sample, C,
+                       C / groups, count, gamma, beta, eps, offset, rows_per_sample, scale, shift, mean, invstd);
     return prifit_check_launch();
 }
 

@@ -118,7 +118,9 @@ def compute_bandwidth(X, quantile, num_samples=None, rows=None):
     kth = torch.empty(Bt * N, dtype=torch.float32, device=X.device)
     with profiler.span("kth_smallest", 4.0 * Bt * N * N):
         call("prifit_kth_smallest_rows", ptr(dist), _LL(Bt * N), N, k, ptr(kth), cur_stream())
-    return torch.sqrt(torch.clamp(kth, min=1e-6)).view(Bt, N).mean(dim=1)
+    bw = torch.empty(Bt, dtype=torch.float32, device=X.device)
+    call("prifit_bandwidth_from_kth", ptr(kth), Bt, N, ptr(bw), cur_stream())     # mean(sqrt(clamp(kth, 1e-6))) per shape
+    return bw
 
 
 class Normalize2Fn(torch.autograd.Function):
@@ -366,8 +368,13 @@ class MembershipFn(torch.autograd.Function):
         dev = X.device
         dots = torch.empty(Bt, N, K, dtype=torch.float32, device=dev)
         _bgemm(NT, N, K, D, X, D, centres, D, dots, K, Bt, N * D, K * D, N * K)
-        live = torch.arange(K, device=dev).view(1, 1, K) < count.view(Bt, 1, 1)
-        gmax = dots.masked_fill(~live, float("-inf")).amax(dim=(1, 2)) / (bw * bw)  # global max, detached (:242)
+        gmax = torch.empty(Bt, dtype=torch.float32, device=dev)    # global max over the live (point, cluster) pairs, detached (:242)
+        if K % 4 == 0:
+            ws = torch.empty(dll().prifit_membership_gmax_workspace(Bt), dtype=torch.float32, device=dev)
+            call("prifit_membership_gmax", ptr(dots), ptr(bw), ptr(count), Bt, N, K, ptr(gmax), ptr(ws), cur_stream())
+        else:   # (a slot count that is not a multiple of 4: never on the loss path, KM = 32)
+            live = torch.arange(K, device=dev).view(1, 1, K) < count.view(Bt, 1, 1)
+            gmax = dots.masked_fill(~live, float("-inf")).amax(dim=(1, 2)) / (bw * bw)
         W = torch.empty_like(dots)
         with profiler.span("membership", 8.0 * Bt * N * K):
             call("prifit_membership_fwd", ptr(dots), ptr(bw), ptr(gmax), ptr(count), Bt, N, K, ptr(W), cur_stream())
@@ -505,6 +512,34 @@ class SampleNNLossFn(torch.autograd.Function):
         return g_r, g_V, g_c, None, None, None
 
 
+class ChamferCombineFn(torch.autograd.Function):
+    """The last step of analytic_chamfer_distance (src/utils.py:417-426): per shape (d2_sum / max(total, 1) + sdf_sum / M) / 2,
+    mean over the shapes with at least one valid primitive -> (loss [], dist_st [B], sdf_ts [B]); one launch each way
+    instead of ~25 elementwise / reduce launches over B numbers."""
+
+    @staticmethod
+    def forward(ctx, d2_sum, total, sdf_sum, valid, M):
+        Bt, K = valid.shape
+        dev = d2_sum.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        part = torch.empty(2, Bt, dtype=torch.float32, device=dev)
+        coef = torch.empty(2 * Bt + 1, dtype=torch.float32, device=dev)
+        call("prifit_chamfer_combine_fwd", ptr(d2_sum.contiguous()), ptr(total.contiguous()), ptr(sdf_sum.contiguous()),
+             ptr(valid.contiguous()), Bt, K, int(M), ptr(loss), ptr(part), ptr(coef), cur_stream())
+        ctx.save_for_backward(coef)
+        ctx.Bt = Bt
+        ctx.mark_non_differentiable(part)
+        return loss.view(()), part
+
+    @staticmethod
+    def backward(ctx, g, _gpart):
+        (coef,) = ctx.saved_tensors
+        g_d2 = torch.empty(ctx.Bt, dtype=torch.float32, device=coef.device)
+        g_sdf = torch.empty_like(g_d2)
+        call("prifit_chamfer_combine_bwd", ptr(g.contiguous()), ptr(coef), ctx.Bt, ptr(g_d2), ptr(g_sdf), cur_stream())
+        return g_d2, None, g_sdf, None, None
+
+
 # ------------------------------------------------------------------------------------------------
 # Speculative clustering.  guard_mean_shift (src/mean_shift.py) reads the number of clusters on the host to
 # decide whether to retry with a doubled quantile; that read-back drains the GPU queue in the middle of a step.
@@ -575,8 +610,9 @@ def _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples=
     Z, handle = _shift(X, bw, iterations)
     with torch.no_grad():
         ids, count, labels, used = nms(Z, bw)
-        nuniq = torch.where(count > NMS_CAP, count, used.sum(dim=1).to(torch.int32))
-        bad = ((nuniq > max_num_clusters) | (count > KM)).any().to(torch.int32).reshape(1)
+        bad = torch.empty(1, dtype=torch.int32, device=X.device)
+        call("prifit_cluster_verdict", ptr(count), ptr(used), Bt, NMS_CAP, int(max_num_clusters), KM, None, ptr(bad),
+             cur_stream())
         flag = _pinned_flag()
         flag.copy_(bad, non_blocking=True)
         ev = torch.cuda.Event()
@@ -643,8 +679,13 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
         Z, handle = _shift(Xp, bw, iterations)
         with torch.no_grad():
             ids, count, labels, used = nms(Z, bw)
-            nuniq = torch.where(count > NMS_CAP, count, used.sum(dim=1).to(torch.int32))
-            host = torch.stack([count, nuniq]).cpu()  # the one host sync of the round (guard_mean_shift's check)
+            nb = count.shape[0]
+            both = torch.empty(2, nb, dtype=torch.int32, device=dev)
+            both[0].copy_(count)
+            scratch = torch.empty(1, dtype=torch.int32, device=dev)
+            call("prifit_cluster_verdict", ptr(count), ptr(used), nb, NMS_CAP, int(max_num_clusters), KM, ptr(both[1]),
+                 ptr(scratch), cur_stream())
+            host = both.cpu()  # the one host sync of the round (guard_mean_shift's check)
         ok = host[1] <= max_num_clusters
         if bool((ok & (host[0] > KM)).any()):
             raise RuntimeError("more than %d kept centres with <= %d distinct labels: unsupported corner" % (KM, max_num_clusters))

@@ -263,7 +263,11 @@ class SharedMLPFn(torch.autograd.Function):
         training = cfg["training"]
         P = x.shape[0]
         dev = x.device
-        gout = gout.contiguous()
+        # a pooled stack takes its gradient with any row stride (a column slice of the concatenated multi-scale gradient:
+        # every kernel that reads it has a leading dimension) -- no copy; the unpooled paths index rows densely
+        if not (cfg["pool_K"] and L > 1 and gout.dim() == 2 and gout.stride(1) == 1 and gout.stride(0) % 4 == 0 and
+                gout.data_ptr() % 16 == 0):
+            gout = gout.contiguous()
         rps = _rows_per_slab()
         grads = [None] * (6 * L)
         extra_grads = (None,) if ctx.preact_gather is not None else ()

@@ -86,6 +86,103 @@ def get_graph_feature(x, k1=20, k2=20, idx=None):
     return rows[:, :2 * C].reshape(B, N, k1, 2 * C).permute(0, 3, 1, 2), idx
 
 
+def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None):
+    """GroupNorm statistics from the 128-row (or `tile`-row) column-statistics slabs of Y [P, C] -> per-sample coefficient
+    tables, then LeakyReLU [+ max over the pool_K rows of each group].  Returns (out, scale, shift, mean, invstd, arg).
+    offset [Bs, C] (optional): the normalised tensor is Y + offset[sample] (prifit_gn_finalize_offset: the tables come out
+    relative to Y, so nothing downstream changes)."""
+    P, Cout = Y.shape
+    G, rps, slope, pool_K, eps = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"], cfg["eps"]
+    assert P % rps == 0 and rps % tile == 0 and Cout % G == 0
+    Bs = P // rps
+    dev = Y.device
+    m = float(rps * (Cout // G))
+    if offset is not None:
+        assert dll().prifit_gn_finalize_supported(Cout, G) and offset.shape == (Bs, Cout)
+        scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
+        call("prifit_gn_finalize_offset", ptr(slab), Bs, rps // tile, Cout, G, _D(m), ptr(gamma.contiguous()),
+             ptr(beta.contiguous()), _D(float(eps)), ptr(offset.contiguous()), _D(float(rps)), ptr(scale), ptr(shift), ptr(mean),
+             ptr(invstd), cur_stream())
+    elif _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+        # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
+        scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
+        call("prifit_gn_finalize", ptr(slab), Bs, rps // tile, Cout, G, _D(m), ptr(gamma.contiguous()),
+             ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), cur_stream())
+    else:
+        sums = slab.view(Bs, rps // tile, 2, Cout).double().sum(dim=1)       # [Bs, 2, C] per-sample column sums
+        s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
+        s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
+        var = (s2 - s1 * s1).clamp_min(0.0)
+        invstd_g = torch.rsqrt(var + eps)
+        mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()   # [Bs, C] tables
+        invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
+        scale = (gamma.unsqueeze(0) * invstd).contiguous()
+        shift = (beta.unsqueeze(0) - mean * scale).contiguous()
+    arg = None
+    if pool_K:
+        Gp = P // pool_K
+        out = torch.empty(Gp, Cout, dtype=torch.float32, device=dev)
+        arg = torch.empty(Gp, Cout, dtype=torch.int32, device=dev)
+        call("prifit_pool_fwd", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope),
+             ptr(out), _LL(Cout), ptr(arg), cur_stream())
+    else:
+        out = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+        call("prifit_affine_relu", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), P, Cout, rps, _F(slope), ptr(out),
+             _LL(Cout), cur_stream())
+    return out, scale, shift, mean, invstd, arg
+
+
+def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
+    """Gradient of _gn_forward w.r.t. Y (written as dY [P, C]), gamma and beta."""
+    P, Cout = Y.shape
+    G, rps, slope, pool_K = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"]
+    Bs = P // rps
+    dev = Y.device
+    gout = gout.contiguous()
+    rows = dll().prifit_reduce_rows_per_slab()
+    if pool_K:
+        Gp = P // pool_K
+        rows = dll().prifit_pool_reduce_groups_per_slab()
+        nslab = (Gp + rows - 1) // rows
+        slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+        call("prifit_pool_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+             ptr(shift), ptr(mean), ptr(invstd), Gp, pool_K, Cout, rps, _F(slope), ptr(slab), cur_stream())
+    else:
+        nslab = (P + rows - 1) // rows
+        slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+        call("prifit_bn_relu_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
+             ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), cur_stream())
+    m = float(rps * (Cout // G))
+    ca = scale.contiguous()
+    if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+        cb, cd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(2))
+        S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
+        call("prifit_gn_bwd_finalize", ptr(slab), Bs, nslab // Bs, Cout, G, _D(m), ptr(gamma.contiguous()), ptr(mean),
+             ptr(invstd), ptr(cb), ptr(cd), ptr(S), cur_stream())
+        dgamma, dbeta = S[:, 1].sum(0).float(), S[:, 0].sum(0).float()
+    else:
+        S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)          # [Bs, 2, C]: sum Gm, sum Gm*yhat
+        dgamma = S[:, 1].sum(0).float()
+        dbeta = S[:, 0].sum(0).float()
+        gd = gamma.double().unsqueeze(0)
+        m1 = (gd * S[:, 0]).view(Bs, G, -1).sum(-1) / m                      # group means of dyhat, dyhat*yhat
+        m2 = (gd * S[:, 1]).view(Bs, G, -1).sum(-1) / m
+        rep = Cout // G
+        m1c, m2c = m1.repeat_interleave(rep, dim=1), m2.repeat_interleave(rep, dim=1)
+        isd, mu = invstd.double(), mean.double()
+        cb = (-(isd * isd) * m2c).float().contiguous()
+        cd = (-isd * m1c + mu * isd * isd * m2c).float().contiguous()
+    dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
+    if pool_K:
+        call("prifit_pool_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+             ptr(shift), ptr(ca), ptr(cb), ptr(cd), P // pool_K, pool_K, Cout, rps, _F(slope), ptr(dY), _LL(Cout),
+             cur_stream())
+    else:
+        call("prifit_bn_relu_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
+             ptr(ca), ptr(cb), ptr(cd), P, Cout, rps, _F(slope), ptr(dY), _LL(Cout), cur_stream())
+    return dY, dgamma, dbeta
+
+
 class ConvGNActFn(torch.autograd.Function):
     """conv1x1 (+bias) -> GroupNorm(groups) -> LeakyReLU(slope) [-> max over the K rows of each group].
 
@@ -94,48 +191,23 @@ class ConvGNActFn(torch.autograd.Function):
     cfg = dict(groups, rps, slope, pool_K, eps)."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, gamma, beta, cfg):
+    def forward(ctx, x, W, bias, gamma, beta, cfg, offset=None):
+        """offset [Bs, Cout] (optional, differentiable): a per-sample row added to the convolution's output BEFORE the
+        normalisation -- never added to the rows, only folded into the coefficient tables (_gn_forward)."""
         x, W = x.contiguous(), W.contiguous()
         P, Kin = x.shape
         Cout = W.shape[0]
-        G, rps, slope, pool_K, eps = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"], cfg["eps"]
-        assert P % rps == 0 and rps % 512 == 0 and Cout % G == 0
-        Bs = P // rps
+        assert cfg["rps"] % 512 == 0
         dev = x.device
         Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
         tile = dll().prifit_gemm_stats_tile_m(P, Cout)   # rows per statistics slab (divides rps: 64 or 128)
         nslab = (P + tile - 1) // tile
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
-        m = float(rps * (Cout // G))
-        if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
-            # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
-            scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
-            call("prifit_gn_finalize", ptr(slab), Bs, rps // tile, Cout, G, _D(m), ptr(gamma.contiguous()),
-                 ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), cur_stream())
-        else:
-            sums = slab.view(Bs, rps // tile, 2, Cout).double().sum(dim=1)       # [Bs, 2, C] per-sample column sums
-            s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
-            s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
-            var = (s2 - s1 * s1).clamp_min(0.0)
-            invstd_g = torch.rsqrt(var + eps)
-            mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()   # [Bs, C] tables
-            invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
-            scale = (gamma.unsqueeze(0) * invstd).contiguous()
-            shift = (beta.unsqueeze(0) - mean * scale).contiguous()
-        arg = None
-        if pool_K:
-            Gp = P // pool_K
-            out = torch.empty(Gp, Cout, dtype=torch.float32, device=dev)
-            arg = torch.empty(Gp, Cout, dtype=torch.int32, device=dev)
-            call("prifit_pool_fwd", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope),
-                 ptr(out), _LL(Cout), ptr(arg), cur_stream())
-        else:
-            out = torch.empty(P, Cout, dtype=torch.float32, device=dev)
-            call("prifit_affine_relu", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), P, Cout, rps, _F(slope), ptr(out),
-                 _LL(Cout), cur_stream())
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
+        ctx.has_offset = offset is not None
         ctx.save_for_backward(x, W, gamma, Y, scale, shift, mean, invstd, *([arg] if arg is not None else []))
         return out
 
@@ -146,58 +218,48 @@ class ConvGNActFn(torch.autograd.Function):
         arg = ctx.saved_tensors[8] if len(ctx.saved_tensors) > 8 else None
         P, Kin = x.shape
         Cout = W.shape[0]
-        G, rps, slope, pool_K = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"]
-        Bs = P // rps
         dev = x.device
-        gout = gout.contiguous()
-        rows = dll().prifit_reduce_rows_per_slab()
-        if pool_K:
-            Gp = P // pool_K
-            rows = dll().prifit_pool_reduce_groups_per_slab()
-            nslab = (Gp + rows - 1) // rows
-            slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
-            call("prifit_pool_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
-                 ptr(shift), ptr(mean), ptr(invstd), Gp, pool_K, Cout, rps, _F(slope), ptr(slab), cur_stream())
-        else:
-            nslab = (P + rows - 1) // rows
-            slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
-            call("prifit_bn_relu_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
-                 ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), cur_stream())
-        m = float(rps * (Cout // G))
-        ca = scale.contiguous()
-        if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
-            cb, cd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(2))
-            S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
-            call("prifit_gn_bwd_finalize", ptr(slab), Bs, nslab // Bs, Cout, G, _D(m), ptr(gamma.contiguous()), ptr(mean),
-                 ptr(invstd), ptr(cb), ptr(cd), ptr(S), cur_stream())
-            dgamma, dbeta = S[:, 1].sum(0).float(), S[:, 0].sum(0).float()
-        else:
-            S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)          # [Bs, 2, C]: sum Gm, sum Gm*yhat
-            dgamma = S[:, 1].sum(0).float()
-            dbeta = S[:, 0].sum(0).float()
-            gd = gamma.double().unsqueeze(0)
-            m1 = (gd * S[:, 0]).view(Bs, G, -1).sum(-1) / m                      # group means of dyhat, dyhat*yhat
-            m2 = (gd * S[:, 1]).view(Bs, G, -1).sum(-1) / m
-            rep = Cout // G
-            m1c, m2c = m1.repeat_interleave(rep, dim=1), m2.repeat_interleave(rep, dim=1)
-            isd, mu = invstd.double(), mean.double()
-            cb = (-(isd * isd) * m2c).float().contiguous()
-            cd = (-isd * m1c + mu * isd * isd * m2c).float().contiguous()
-        dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
-        if pool_K:
-            call("prifit_pool_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
-                 ptr(shift), ptr(ca), ptr(cb), ptr(cd), P // pool_K, pool_K, Cout, rps, _F(slope), ptr(dY), _LL(Cout),
-                 cur_stream())
-        else:
-            call("prifit_bn_relu_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
-                 ptr(ca), ptr(cb), ptr(cd), P, Cout, rps, _F(slope), ptr(dY), _LL(Cout), cur_stream())
+        dY, dgamma, dbeta = _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg)
         dW = nn_ops._weight_grad(dY, P, Cout, x, Kin, None) if ctx.needs_input_grad[1] else None
-        db = dY.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        doff = None
+        if ctx.has_offset and ctx.needs_input_grad[6]:
+            doff = dY.view(P // cfg["rps"], cfg["rps"], Cout).sum(dim=1)          # the offset reaches every row of its sample
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = doff.sum(dim=0) if doff is not None else dY.sum(dim=0)
+        else:
+            db = None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(P, Kin, dtype=torch.float32, device=dev)
             gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, dx, Kin)
-        return dx, dW, db, dgamma, dbeta, None
+        return dx, dW, db, dgamma, dbeta, None, doff
+
+
+class GNActFn(torch.autograd.Function):
+    """GroupNorm -> LeakyReLU [-> max over pool_K rows] on PRE-ACTIVATION rows Y [P, C] that come with their 128-row
+    column-statistics slabs (the by-linearity edge convolution: nn_ops.GatherLinearFn).  apply(Y, slab, gamma, beta, cfg)."""
+
+    @staticmethod
+    def forward(ctx, Y, slab, gamma, beta, cfg):
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, dll().prifit_reduce_rows_per_slab(), gamma, beta, cfg)
+        ctx.cfg = cfg
+        ctx.save_for_backward(gamma, Y, scale, shift, mean, invstd, *([arg] if arg is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gamma, Y, scale, shift, mean, invstd = ctx.saved_tensors[:6]
+        arg = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
+        dY, dgamma, dbeta = _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, ctx.cfg)
+        return dY, None, dgamma, dbeta, None
+
+
+# The edge convolution by linearity (default): W [x_j - x_i | x_i] = Wa x_j + (Wb - Wa) x_i = U_j - Vc_i with U = X Wa^T and
+# Vc = X (Wa - Wb)^T computed once per POINT (two products over B N rows); per EDGE only a gather of Cout-wide rows of U
+# (nn_ops.GatherLinearFn, the kernel of the set-abstraction first layers).  The [B N k, 2C] edge rows of upstream
+# (src/dgcnn.py:98-105), the products over B N k rows (49 GFLOP forward at B = 24, k = 20) and their autograd (a dA and a dW
+# product over the edge rows, a 2C-wide scatter) never exist.  PRIFIT_EDGE_LINEARITY=0: rows + product (A/B arm; tested).
+_EDGE_LINEARITY = __import__("os").environ.get("PRIFIT_EDGE_LINEARITY", "1") != "0"
 
 
 def _w2d(conv, kp=None):
@@ -232,9 +294,24 @@ class DGCNNEncoderGn(nn.Module):
         conv, gn = seq[0], seq[1]
         C = feats.shape[-1]
         k = idx.shape[2]
+        cfg = {"groups": gn.num_groups, "rps": N * k, "slope": 0.2, "pool_K": k, "eps": gn.eps}
+        B = feats.shape[0]
+        Cout = conv.weight.shape[0]
+        if _EDGE_LINEARITY and conv.bias is None and (N * k) % dll().prifit_reduce_rows_per_slab() == 0 and Cout % 4 == 0:
+            w = conv.weight.reshape(Cout, 2 * C)
+            wa, wb = w[:, :C], w[:, C:]
+            X = feats.reshape(B * N, C)
+            if C % 4:                                   # 16-byte rows for the product kernels (the 3 input coordinates)
+                pad = _pad4(C) - C
+                X = torch.cat([X, X.new_zeros(B * N, pad)], dim=1)
+                wa = torch.cat([wa, wa.new_zeros(Cout, pad)], dim=1)
+                wb = torch.cat([wb, wb.new_zeros(Cout, pad)], dim=1)
+            U = LinearFn.apply(X, wa, None).view(B, N, Cout)             # neighbour term, per point
+            Vc = LinearFn.apply(X, wa - wb, None).view(B, N, Cout)       # minus the centre term, per point
+            Y, slab = nn_ops.GatherLinearFn.apply(U, Vc, None, idx, True)
+            return GNActFn.apply(Y, slab, gn.weight, gn.bias, cfg)       # [B*N, Cout]
         ld = _pad4(2 * C)
         rows = EdgeGatherFn.apply(feats, idx, ld)
-        cfg = {"groups": gn.num_groups, "rps": N * k, "slope": 0.2, "pool_K": k, "eps": gn.eps}
         return ConvGNActFn.apply(rows, _w2d(conv, ld), None, gn.weight, gn.bias, cfg)   # [B*N, Cout]
 
     def forward_cl(self, pts):
@@ -284,8 +361,19 @@ class DGCNGn(nn.Module):
     def forward(self, points):
         B, _, N = points.shape
         x4, feats = self.encoder.forward_cl(points.transpose(1, 2).contiguous())
-        x = torch.cat([x4.unsqueeze(1).expand(B, N, 1024).reshape(B * N, 1024), feats], dim=1)
-        x = self._block(x, self.conv1, self.bn1, N)
+        if _EDGE_LINEARITY and dll().prifit_gn_finalize_supported(self.conv1.weight.shape[0], self.bn1.num_groups):
+            # upstream :253-257 repeats the global feature x4 [B,1024] over the N points and concatenates it with the 256
+            # point features in front of conv1 (1280 -> 512).  The x4 part of that product is the same for every point of a
+            # sample: ONE row per sample (24 x 1024 x 512) instead of N (49152 x 1024 x 512, 4/5 of the layer's flops, and the
+            # [B N, 1280] input never exists); it enters the GroupNorm as a per-sample offset of the pre-activation.
+            w = self.conv1.weight.reshape(self.conv1.weight.shape[0], -1)
+            w4, wf = w[:, :1024].contiguous(), w[:, 1024:].contiguous()
+            off = LinearFn.apply(x4.contiguous(), w4, self.conv1.bias)                      # [B, 512], bias included
+            cfg = {"groups": self.bn1.num_groups, "rps": N, "slope": 0.0, "pool_K": 0, "eps": self.bn1.eps}
+            x = ConvGNActFn.apply(feats, wf, None, self.bn1.weight, self.bn1.bias, cfg, off)
+        else:
+            x = torch.cat([x4.unsqueeze(1).expand(B, N, 1024).reshape(B * N, 1024), feats], dim=1)
+            x = self._block(x, self.conv1, self.bn1, N)
         x_all = self._block(x, self.conv2, self.bn2, N)
         x = self._block(x_all, self.mlp_seg_prob1, self.bn_seg_prob1, N)
         seg = LinearFn.apply(x, _w2d(self.mlp_segmentation), self.mlp_segmentation.bias)

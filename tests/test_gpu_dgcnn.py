@@ -78,6 +78,56 @@ def test_conv_groupnorm_block(D, pool, gn_kernels, monkeypatch):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4 * b.grad.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
 
 
+def test_conv_groupnorm_block_with_per_sample_offset(D):
+    """conv -> (+ one row per sample) -> GroupNorm -> ReLU with the offset folded into the coefficient tables
+    (prifit_gn_finalize_offset; the decoder's first layer by linearity, src/dgcnn.py:253-257) against plain torch."""
+    B, N, Cin, Cout, G = 3, 512, 24, 32, 4
+    x = _t(synth.features(1, B * N, Cin, 15))[0]
+    W = _t(synth.features(1, Cout, Cin, 16))[0] * 0.2
+    off = _t(synth.features(1, B, Cout, 17))[0] * 1.5
+    gamma = _t(synth.features(1, 1, Cout, 18))[0, 0] * 0.5 + 0.8
+    beta = _t(synth.features(1, 1, Cout, 19))[0, 0] * 0.2
+    leaves = [t.clone().requires_grad_(True) for t in (x, W, gamma, beta, off)]
+    xr, Wr, gr, br, orf = leaves
+    y = torch.nn.functional.linear(xr, Wr).view(B, N, Cout) + orf.view(B, 1, Cout)
+    y = torch.nn.functional.group_norm(y.permute(0, 2, 1), G, gr, br, 1e-5)
+    ref = torch.relu(y).permute(0, 2, 1).reshape(B * N, Cout)
+    go = _t(synth.features(1, B * N, Cout, 20))[0]
+    (ref * go).sum().backward()
+    dl = [t.detach().cuda().requires_grad_(True) for t in leaves]
+    cfg = {"groups": G, "rps": N, "slope": 0.0, "pool_K": 0, "eps": 1e-5}
+    out = D.ConvGNActFn.apply(dl[0], dl[1], None, dl[2], dl[3], cfg, dl[4])
+    (out * go.cuda()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for a, b, name in zip(dl, leaves, ["x", "W", "gamma", "beta", "offset"]):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4 * b.grad.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
+
+
+def test_edge_conv_by_linearity_equals_rows_and_product(D, monkeypatch):
+    """The edge convolution W [x_j - x_i | x_i] = U_j - Vc_i (two products per POINT + a gather, the default) against the
+    materialised edge rows + product over B N k rows (PRIFIT_EDGE_LINEARITY=0): same outputs and gradients to rounding."""
+    B, N, k = 2, 512, 20
+    torch.manual_seed(7)
+    enc = D.DGCNNEncoderGn(input_channels=3, nn_nb=k).cuda()
+    pts = _t(synth.cloud("surface", B, N, 41)).cuda()
+    feats = _t(synth.features(B, N, 64, 42)).cuda()
+    res = {}
+    for arm in (True, False):
+        monkeypatch.setattr(D, "_EDGE_LINEARITY", arm)
+        enc.zero_grad()
+        with torch.no_grad():
+            idx = D._knn_cl(pts, k)
+        f = feats.clone().requires_grad_(True)
+        x1 = enc._edge_conv(pts, idx, enc.conv1, N)
+        x2 = enc._edge_conv(f, idx, enc.conv2, N)
+        go1 = _t(synth.features(1, B * N, 64, 43))[0].cuda()
+        ((x1 + x2) * go1).sum().backward()
+        res[arm] = (x1.detach(), x2.detach(), f.grad.clone(), enc.conv1[0].weight.grad.clone(), enc.conv2[0].weight.grad.clone(),
+                    enc.bn2.weight.grad.clone())
+    for a, b, name in zip(res[True], res[False], ["x1", "x2", "dfeat", "dW1", "dW2", "dgamma2"]):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(1.0, b.abs().max().item()), msg=lambda m, name=name: name + ": " + m)
+
+
 def test_dgcnn_network(D, golden):
     g = golden("model_dgcnn")
     B, N, k, seed = 2, 1024, 20, int(g["seed"])
