@@ -152,7 +152,8 @@ int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float
  * the streaming shapes (models/pointnet_util.py:252-257): Y = relu(bn(A)) W^T + bias with the column statistics AND the
  * pool candidates cand[M / 32][4][N] (max, argmax, min, argmin per 32 rows and column) for
  * prifit_pool_from_candidates.  prifit_gemm_pool_supported(M, N, K): 1 when the shape is taken (M % 32 == 0, N > 96, more
- * than 512 output tiles, 16-byte rows). */
+ * than 512 output tiles, 16-byte rows).  a_scale / a_shift both NULL: no prologue on A (the DGCNN global-feature layer,
+ * src/dgcnn.py:194-197, whose input is already activated). */
 int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, const float *W, long long ldb, float *Y,
                          long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
                          float *cand, void *stream);
@@ -187,12 +188,13 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
  * prifit_gemm_stream_f32 (NT, prologue required, M % 32 == 0) that also emits, per 32-row block and column, the largest
  * and smallest stored C and the row of their first occurrence, cand [M/32][4][N]; once the BatchNorm affine (scale,
  * shift) of this layer is final, prifit_pool_from_candidates gives out [G, ldo] = max_k relu(bn(Y)) and arg [G, C] (the
- * winning sample, first maximum) for groups of K rows, K % 32 == 0 -- what prifit_pool_fwd computes from Y itself. */
+ * winning sample, first maximum) for groups of K rows, K % 32 == 0 -- what prifit_pool_fwd computes from Y itself.
+ * rows_per_sample > 0 (a multiple of K): scale / shift are per-sample tables [Bs][C] (GroupNorm), else one row [C]. */
 int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
                                 float *C, long long ldc, const float *a_scale, const float *a_shift, const float *bias,
                                 float *col_stats, float *cand, void *stream);
 int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
-                                float slope, float *out, long long ldo, int32_t *arg, void *stream);
+                                int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, void *stream);
 
 /* dA of a shared-MLP layer with the BatchNorm-backward reduction of the layer below fused into the epilogue:
  * G [M,N] = dY [M,K] . W [K,N] (PRIFIT_GEMM_NN, streaming shapes), and red_slab [prifit_gemm_stream_slabs(M,K)][2][N]
@@ -328,6 +330,17 @@ int prifit_gather_linear_fwd(const float *U, const float *Vc, const float *bias,
 /* autograd: dU [B,N,C] (initialised by the caller) += scatter of dY; dVc [B,S,C] = -sum_k dY. */
 int prifit_gather_linear_bwd(const float *dY, const int32_t *idx, int B, int N, int S, int K, int C,
                              float *dU, float *dVc, void *stream);
+/* Backward of a max-pooled, normalised by-linearity layer in one pass (the DGCNN edge convolution of src/dgcnn.py:98-107,
+ * :157-171 written as y[(g,k)] = U[idx[g,k]] - Vc[g] -> GroupNorm -> LeakyReLU -> max over the K neighbours): with gp [G, C]
+ * the gradient of the pooled output (G = B S groups), Y [G K, C] the pre-activations, arg [G, C] the winners, and the
+ * coefficient tables of prifit_pool_bwd_apply (rows_per_sample > 0: per-sample rows, GroupNorm), forms
+ * dy = a (k == arg ? act'(y) gp : 0) + b y + d on the fly and accumulates dU [B,N,C] += dy at idx (float atomics; zero it
+ * first) and dVc [B,S,C] = -sum_k dy.  dY is never written. */
+int prifit_gather_linear_bwd_pool(const float *gp, long long ldgp, const float *Y, const int32_t *arg, const float *scale,
+                                  const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                                  const int32_t *idx, int B, int N, int S, int K, int C, int rows_per_sample, float slope,
+                                  float *dU, float *dVc, void *stream);
+
 /* The same autograd with the train-mode BatchNorm + ReLU backward of the gathered layer folded in (what
  * prifit_bn_relu_bwd_apply would have written first): dY = a (Y s + t > 0 ? G : 0) + (b Y + d) is formed on load from G
  * (gradient w.r.t. the layer's ReLU output) and Y (its pre-activation), [B*S*K, C] each; per-channel scale / shift and

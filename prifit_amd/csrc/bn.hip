@@ -686,6 +686,55 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_rows_kernel(const float *_
     }
 }
 
+// Backward of a max-pooled, normalised by-linearity layer in ONE pass (the DGCNN edge convolution, src/dgcnn.py:98-107 +
+// :157-171: y[(g,k)] = U[idx[g,k]] - Vc[g], GroupNorm / BatchNorm, LeakyReLU, max over the K rows of group g):
+//   dy = a * (k == arg[g,c] ? act'(y) * gp[g,c] : 0) + b * y + d          (pool_bwd_apply's expression, term by term)
+//   dU[idx[g,k]] += dy (one float atomic per element: a wave instruction covers 256 contiguous bytes, the full-rate form),
+//   dVc[g] = -sum_k dy.
+// The dY tensor ([B N k, C]: 0.25 - 0.5 GB per layer) is neither written nor read back.  One thread = (group, channel).
+__global__ __launch_bounds__(256) void gather_linear_bwd_pool_kernel(
+    const float *__restrict__ gp, long long ldgp, const float *__restrict__ Y, const int32_t *__restrict__ arg,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ ca,
+    const float *__restrict__ cb, const float *__restrict__ cd, const int32_t *__restrict__ idx, int N, int S, int K, int C,
+    int rps, float slope, long long total, float *__restrict__ dU, float *__restrict__ dVc)
+{
+    constexpr int UNR = 4;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long g = id / C;   // b*S + s
+        const int c = (int)(id - g * C);
+        const int b = (int)(g / S);
+        const long long to = (rps ? ((g * K) / rps) * C : 0) + c;       // per-sample table row (GroupNorm) or the one row
+        const float s = scale[to], t = shift[to], a = ca[to], bb = cb[to], d = cd[to];
+        const float gv = gp[g * ldgp + c];
+        const int w = arg[g * C + c];
+        const float *src = Y + (size_t)g * K * C + c;
+        const int32_t *ix = idx + (size_t)g * K;
+        float *dst = dU + (size_t)b * N * C + c;
+        float acc = 0.f;
+        int k = 0;
+        for (; k + UNR <= K; k += UNR) {
+            float y[UNR];
+            int n[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) { y[j] = src[(size_t)(k + j) * C]; n[j] = ix[k + j]; }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                const float v = fmaf(a, (k + j) == w ? (fmaf(y[j], s, t) > 0.f ? gv : gv * slope) : 0.f, fmaf(bb, y[j], d));
+                if (n[j] >= 0 && n[j] < N) unsafeAtomicAdd(dst + (size_t)n[j] * C, v);
+                acc += v;
+            }
+        }
+        for (; k < K; ++k) {
+            const float y = src[(size_t)k * C];
+            const int n = ix[k];
+            const float v = fmaf(a, k == w ? (fmaf(y, s, t) > 0.f ? gv : gv * slope) : 0.f, fmaf(bb, y, d));
+            if (n >= 0 && n < N) unsafeAtomicAdd(dst + (size_t)n * C, v);
+            acc += v;
+        }
+        dVc[id] = -acc;
+    }
+}
+
 // T[g,c] = a[c] * (relu'(y at the winning sample) * gp[g,c]): the sparse term of the pooled layer's dY
 // (dY[g,k,c] = T[g,c] * [k == arg[g,c]] + b[c] * Y + d[c]) for consumers that form dY in their operand staging.
 __global__ __launch_bounds__(256) void pool_bwd_table_kernel(const float *__restrict__ gp, long long ldgp,
@@ -714,7 +763,7 @@ __global__ __launch_bounds__(256) void pool_bwd_table_kernel(const float *__rest
 __global__ __launch_bounds__(256) void pool_from_candidates_kernel(const float *__restrict__ cand,
                                                                    const float *__restrict__ scale,
                                                                    const float *__restrict__ shift, int G, int K, int C,
-                                                                   float slope, float *__restrict__ out, long long ldo,
+                                                                   int rps, float slope, float *__restrict__ out, long long ldo,
                                                                    int32_t *__restrict__ arg)
 {
     const long long total = (long long)G * C;
@@ -722,7 +771,8 @@ __global__ __launch_bounds__(256) void pool_from_candidates_kernel(const float *
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const long long gidx = id / C;
         const int c = (int)(id - gidx * C);
-        const float s = scale[c], t = shift[c];
+        const long long to = tab_off(gidx * K, rps, C) + c;   // rps != 0: per-sample coefficient rows (GroupNorm)
+        const float s = scale[to], t = shift[to];
         const float *cd = cand + gidx * nb * 4 * C + c;
         float best;
         int bi = 0;
@@ -945,7 +995,10 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
         return PRIFIT_EINVAL;
     const int C4 = C / 4;
     // the row-walking form takes the per-sample coefficient row from a group's FIRST row: groups must not straddle samples
-    if (C4 <= 256 && 256 % C4 == 0 && (long long)G * K < 2147483647LL && (rows_per_sample == 0 || rows_per_sample % K == 0))
+    // (and a thread walks ALL K rows of its group: only for the usual short groups -- a whole-cloud pool, K = N, takes the
+    // element-per-thread form)
+    if (C4 <= 256 && 256 % C4 == 0 && K <= 256 && (long long)G * K < 2147483647LL &&
+        (rows_per_sample == 0 || rows_per_sample % K == 0))
         hipLaunchKernelGGL(pool_bwd_apply_rows_kernel, dim3(ew_grid((long long)G * C4)), dim3(256), 0, as_stream(stream),
                            gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C4, rows_per_sample, slope, dY,
                            ldd);
@@ -953,6 +1006,20 @@ int prifit_pool_bwd_apply(const float *gp, long long ldgp, const float *Y, long 
         hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(ew_grid((long long)G * K * C4)), dim3(256), 0,
                            as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, coef_a, coef_b, coef_d, G, K, C4,
                            rows_per_sample, slope, dY, ldd);
+    return prifit_check_launch();
+}
+
+int prifit_gather_linear_bwd_pool(const float *gp, long long ldgp, const float *Y, const int32_t *arg, const float *scale,
+                                  const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                                  const int32_t *idx, int B, int N, int S, int K, int C, int rows_per_sample, float slope,
+                                  float *dU, float *dVc, void *stream)
+{
+    if (!gp || !Y || !arg || !scale || !shift || !coef_a || !coef_b || !coef_d || !idx || !dU || !dVc || B <= 0 || N <= 0 ||
+        S <= 0 || K <= 0 || C <= 0 || ldgp < C || rows_per_sample < 0 || (rows_per_sample % K) != 0)
+        return PRIFIT_EINVAL;
+    const long long total = (long long)B * S * C;
+    hipLaunchKernelGGL(gather_linear_bwd_pool_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), gp, ldgp, Y, arg,
+                       scale, shift, coef_a, coef_b, coef_d, idx, N, S, K, C, rows_per_sample, slope, total, dU, dVc);
     return prifit_check_launch();
 }
 
@@ -968,12 +1035,13 @@ int prifit_pool_bwd_table(const float *gp, long long ldgp, const float *Y, long 
 }
 
 int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
-                                float slope, float *out, long long ldo, int32_t *arg, void *stream)
+                                int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, void *stream)
 {
-    if (!cand || !scale || !shift || !out || !arg || G <= 0 || K < 32 || (K & 31) || C <= 0 || ldo < C)
+    if (!cand || !scale || !shift || !out || !arg || G <= 0 || K < 32 || (K & 31) || C <= 0 || ldo < C || rows_per_sample < 0 ||
+        (rows_per_sample % K) != 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_from_candidates_kernel, dim3(ew_grid((long long)G * C)), dim3(256), 0, as_stream(stream), cand,
-                       scale, shift, G, K, C, slope, out, ldo, arg);
+                       scale, shift, G, K, C, rows_per_sample, slope, out, ldo, arg);
     return prifit_check_launch();
 }
 

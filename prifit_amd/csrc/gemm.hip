@@ -1129,9 +1129,9 @@ static bool launch_persistent(const GemmArgs &g_, int lay, hipStream_t st, float
     if (lay == LAY_NT) {
         if (g.epi != EPI_NONE) return false;
         if (want_cand) {
-            if (!g.a_scale) return false;
             g.cand = want_cand;
-            hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false, true>), grid, block, 0, st, g);
+            if (g.a_scale) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, false, false, true>), grid, block, 0, st, g);
         } else if (g.a_scale) hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, true, false>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((gemm_pers_kernel<LAY_NT, false, false>), grid, block, 0, st, g);
     } else {
@@ -1450,7 +1450,8 @@ int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, con
                          long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
                          float *cand, void *stream)
 {
-    if (!A || !W || !Y || !a_scale || !a_shift || !cand || !prifit_gemm_pool_supported(M, N, K) || lda < K || ldb < K || ldc < N)
+    if (!A || !W || !Y || ((a_scale == nullptr) != (a_shift == nullptr)) || !cand || !prifit_gemm_pool_supported(M, N, K) ||
+        lda < K || ldb < K || ldc < N)
         return PRIFIT_EINVAL;
     GemmArgs g;
     pool_gemm_args(g, M, N, K, A, lda, W, ldb, Y, ldc, a_scale, a_shift, bias, col_stats);

@@ -86,7 +86,7 @@ def get_graph_feature(x, k1=20, k2=20, idx=None):
     return rows[:, :2 * C].reshape(B, N, k1, 2 * C).permute(0, 3, 1, 2), idx
 
 
-def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None):
+def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None):
     """GroupNorm statistics from the 128-row (or `tile`-row) column-statistics slabs of Y [P, C] -> per-sample coefficient
     tables, then LeakyReLU [+ max over the pool_K rows of each group].  Returns (out, scale, shift, mean, invstd, arg).
     offset [Bs, C] (optional): the normalised tensor is Y + offset[sample] (prifit_gn_finalize_offset: the tables come out
@@ -123,8 +123,12 @@ def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None):
         Gp = P // pool_K
         out = torch.empty(Gp, Cout, dtype=torch.float32, device=dev)
         arg = torch.empty(Gp, Cout, dtype=torch.int32, device=dev)
-        call("prifit_pool_fwd", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope),
-             ptr(out), _LL(Cout), ptr(arg), cur_stream())
+        if cand is not None:    # (max, argmax, min, argmin) per 32 rows from the product's epilogue: Y is not read again
+            call("prifit_pool_from_candidates", ptr(cand), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope), ptr(out),
+                 _LL(Cout), ptr(arg), cur_stream())
+        else:
+            call("prifit_pool_fwd", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope),
+                 ptr(out), _LL(Cout), ptr(arg), cur_stream())
     else:
         out = torch.empty(P, Cout, dtype=torch.float32, device=dev)
         call("prifit_affine_relu", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), P, Cout, rps, _F(slope), ptr(out),
@@ -134,13 +138,38 @@ def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None):
 
 def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
     """Gradient of _gn_forward w.r.t. Y (written as dY [P, C]), gamma and beta."""
+    gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg)
+    P, Cout = Y.shape
+    rps, slope, pool_K = cfg["rps"], cfg["slope"], cfg["pool_K"]
+    dY = torch.empty(P, Cout, dtype=torch.float32, device=Y.device)
+    if pool_K:
+        call("prifit_pool_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+             ptr(shift), ptr(ca), ptr(cb), ptr(cd), P // pool_K, pool_K, Cout, rps, _F(slope), ptr(dY), _LL(Cout),
+             cur_stream())
+    else:
+        call("prifit_bn_relu_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
+             ptr(ca), ptr(cb), ptr(cd), P, Cout, rps, _F(slope), ptr(dY), _LL(Cout), cur_stream())
+    return dY, dgamma, dbeta
+
+
+def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
+    """The reduction half of the GroupNorm backward: (gout contiguous, ca, cb, cd [Bs, C], dgamma, dbeta) with
+    dY = ca * act'(.) * g + cb * Y + cd."""
     P, Cout = Y.shape
     G, rps, slope, pool_K = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"]
     Bs = P // rps
     dev = Y.device
     gout = gout.contiguous()
     rows = dll().prifit_reduce_rows_per_slab()
-    if pool_K:
+    if pool_K and pool_K == rps:
+        # one pooling group per sample (the global max over a cloud, src/dgcnn.py:197): the per-sample partials are the
+        # winners' terms themselves, [Bs, C] numbers -- (sum Gm, sum Gm * yhat) with Gm = act'(.) * gout at the winning row
+        Gp = P // pool_K
+        yw = torch.gather(Y.view(Gp, pool_K, Cout), 1, arg.long().unsqueeze(1)).squeeze(1)       # [Bs, C]
+        gm = torch.where(yw * scale + shift > 0, gout, gout * slope)
+        slab = torch.stack([gm, gm * ((yw - mean) * invstd)], dim=1).contiguous()                # [Bs, 2, C]
+        nslab = Gp
+    elif pool_K:
         Gp = P // pool_K
         rows = dll().prifit_pool_reduce_groups_per_slab()
         nslab = (Gp + rows - 1) // rows
@@ -172,15 +201,12 @@ def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
         isd, mu = invstd.double(), mean.double()
         cb = (-(isd * isd) * m2c).float().contiguous()
         cd = (-isd * m1c + mu * isd * isd * m2c).float().contiguous()
-    dY = torch.empty(P, Cout, dtype=torch.float32, device=dev)
-    if pool_K:
-        call("prifit_pool_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
-             ptr(shift), ptr(ca), ptr(cb), ptr(cd), P // pool_K, pool_K, Cout, rps, _F(slope), ptr(dY), _LL(Cout),
-             cur_stream())
-    else:
-        call("prifit_bn_relu_bwd_apply", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
-             ptr(ca), ptr(cb), ptr(cd), P, Cout, rps, _F(slope), ptr(dY), _LL(Cout), cur_stream())
-    return dY, dgamma, dbeta
+    return gout, ca, cb, cd, dgamma, dbeta
+
+
+def pool_product_ok(P, Cout, Kin):
+    """prifit_gemm_pool_f32 takes this product (more output tiles than resident workgroups, 16-byte rows)."""
+    return Kin % 4 == 0 and bool(dll().prifit_gemm_pool_supported(P, Cout, Kin))
 
 
 class ConvGNActFn(torch.autograd.Function):
@@ -203,8 +229,16 @@ class ConvGNActFn(torch.autograd.Function):
         tile = dll().prifit_gemm_stats_tile_m(P, Cout)   # rows per statistics slab (divides rps: 64 or 128)
         nslab = (P + tile - 1) // tile
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
-        gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
-        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset)
+        cand = None
+        if cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and tile == 128 and pool_product_ok(P, Cout, Kin):
+            # the pooled layer on the persistent kernel: its epilogue leaves the per-32-row (max, argmax, min, argmin)
+            # candidates, so neither the pool nor an activation pass reads Y again
+            cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
+            call("prifit_gemm_pool_f32", P, Cout, Kin, ptr(x), _LL(Kin), ptr(W), _LL(Kin), ptr(Y), _LL(Cout), None, None,
+                 ptr(bias), ptr(slab), ptr(cand), cur_stream())
+        else:
+            gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset, cand)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_offset = offset is not None
@@ -254,12 +288,51 @@ class GNActFn(torch.autograd.Function):
         return dY, None, dgamma, dbeta, None
 
 
+class EdgeConvLinFn(torch.autograd.Function):
+    """The by-linearity edge convolution block in one autograd node: y[(i,j)] = U[idx[i,j]] - Vc[i] (gather kernel) ->
+    GroupNorm -> LeakyReLU -> max over the k neighbours.  apply(U [B,N,C], Vc [B,N,C], idx [B,N,k] int32, gamma, beta, cfg)
+    -> [B*N, C].  Backward: the pooled GroupNorm backward is formed on the fly inside the scatter (prifit_gather_linear_
+    bwd_pool): no dY tensor between an apply pass and the scatter."""
+
+    @staticmethod
+    def forward(ctx, U, Vc, idx, gamma, beta, cfg):
+        U, Vc, idx = U.contiguous(), Vc.contiguous(), idx.contiguous()
+        B, N, C = U.shape
+        k = idx.shape[2]
+        P = B * N * k
+        dev = U.device
+        Y = torch.empty(P, C, dtype=torch.float32, device=dev)
+        rows = dll().prifit_reduce_rows_per_slab()
+        slab = torch.empty((P + rows - 1) // rows, 2, C, dtype=torch.float32, device=dev)
+        call("prifit_gather_linear_fwd", ptr(U), ptr(Vc), None, ptr(idx), B, N, N, k, C, ptr(Y), ptr(slab), cur_stream())
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, rows, gamma, beta, cfg)
+        ctx.cfg, ctx.dims = cfg, (B, N, k, C)
+        ctx.save_for_backward(idx, gamma, Y, scale, shift, mean, invstd, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, gamma, Y, scale, shift, mean, invstd, arg = ctx.saved_tensors
+        B, N, k, C = ctx.dims
+        cfg = ctx.cfg
+        gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg)
+        dU = torch.zeros(B, N, C, dtype=torch.float32, device=Y.device)
+        dVc = torch.empty(B, N, C, dtype=torch.float32, device=Y.device)
+        call("prifit_gather_linear_bwd_pool", ptr(gout), _LL(gout.stride(0)), ptr(Y), ptr(arg), ptr(scale), ptr(shift), ptr(ca),
+             ptr(cb), ptr(cd), ptr(idx), B, N, N, k, C, cfg["rps"], _F(cfg["slope"]), ptr(dU), ptr(dVc), cur_stream())
+        return dU, dVc, None, dgamma, dbeta, None
+
+
 # The edge convolution by linearity (default): W [x_j - x_i | x_i] = Wa x_j + (Wb - Wa) x_i = U_j - Vc_i with U = X Wa^T and
 # Vc = X (Wa - Wb)^T computed once per POINT (two products over B N rows); per EDGE only a gather of Cout-wide rows of U
 # (nn_ops.GatherLinearFn, the kernel of the set-abstraction first layers).  The [B N k, 2C] edge rows of upstream
 # (src/dgcnn.py:98-105), the products over B N k rows (49 GFLOP forward at B = 24, k = 20) and their autograd (a dA and a dW
 # product over the edge rows, a 2C-wide scatter) never exist.  PRIFIT_EDGE_LINEARITY=0: rows + product (A/B arm; tested).
 _EDGE_LINEARITY = __import__("os").environ.get("PRIFIT_EDGE_LINEARITY", "1") != "0"
+# ... with its pooled GroupNorm backward formed inside the scatter (0: apply pass writes dY, then the scatter; A/B arm, tested)
+_EDGE_FUSED_BWD = __import__("os").environ.get("PRIFIT_EDGE_FUSED_BWD", "1") != "0"
+# the global max over the cloud fused into the mlp1 block (0: activation pass + torch max; A/B arm, tested)
+_GLOBAL_POOL_FUSED = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_FUSED", "1") != "0"
 
 
 def _w2d(conv, kp=None):
@@ -308,8 +381,10 @@ class DGCNNEncoderGn(nn.Module):
                 wb = torch.cat([wb, wb.new_zeros(Cout, pad)], dim=1)
             U = LinearFn.apply(X, wa, None).view(B, N, Cout)             # neighbour term, per point
             Vc = LinearFn.apply(X, wa - wb, None).view(B, N, Cout)       # minus the centre term, per point
+            if _EDGE_FUSED_BWD:
+                return EdgeConvLinFn.apply(U, Vc, idx, gn.weight, gn.bias, cfg)      # [B*N, Cout]
             Y, slab = nn_ops.GatherLinearFn.apply(U, Vc, None, idx, True)
-            return GNActFn.apply(Y, slab, gn.weight, gn.bias, cfg)       # [B*N, Cout]
+            return GNActFn.apply(Y, slab, gn.weight, gn.bias, cfg)
         ld = _pad4(2 * C)
         rows = EdgeGatherFn.apply(feats, idx, ld)
         return ConvGNActFn.apply(rows, _w2d(conv, ld), None, gn.weight, gn.bias, cfg)   # [B*N, Cout]
@@ -328,6 +403,13 @@ class DGCNNEncoderGn(nn.Module):
         x3 = self._edge_conv(x2.view(B, N, -1), idx2, self.conv3, N)      # re-uses the second graph (:191)
         feats = torch.cat((x1, x2, x3), dim=1)
         cfg = {"groups": self.bnmlp1.num_groups, "rps": N, "slope": 0.0, "pool_K": 0, "eps": self.bnmlp1.eps}
+        if _GLOBAL_POOL_FUSED and N % 32 == 0 and pool_product_ok(B * N, self.mlp1.weight.shape[0], feats.shape[1]):
+            # relu(gn(mlp1(.))) and the max over the cloud (upstream :194-197) as ONE pooled block with K = N: the [B N, 1024]
+            # activation is neither written nor reduced by a separate pass, and the backward routes the gradient through the
+            # winners' indices instead of a dense [B, N, 1024] tensor of mostly zeros
+            cfg["pool_K"] = N
+            x4 = ConvGNActFn.apply(feats, _w2d(self.mlp1), self.mlp1.bias, self.bnmlp1.weight, self.bnmlp1.bias, cfg)
+            return x4, feats
         h = ConvGNActFn.apply(feats, _w2d(self.mlp1), self.mlp1.bias, self.bnmlp1.weight, self.bnmlp1.bias, cfg)
         x4 = h.view(B, N, -1).max(dim=1)[0]
         return x4, feats

@@ -349,7 +349,7 @@ def test_pool_candidates_match_pool_fwd(nn_ops, P, K, N, Kin):
     s2d, t2d = s2.cuda(), t2.cuda()
     out1, arg1 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")
     out2, arg2 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")
-    call("prifit_pool_from_candidates", ptr(cand), ptr(s2d), ptr(t2d), G, K, N, _F(0.0), ptr(out1), _LL(N), ptr(arg1), cur_stream())
+    call("prifit_pool_from_candidates", ptr(cand), ptr(s2d), ptr(t2d), G, K, N, 0, _F(0.0), ptr(out1), _LL(N), ptr(arg1), cur_stream())
     call("prifit_pool_fwd", ptr(Y), _LL(N), ptr(s2d), ptr(t2d), G, K, N, 0, _F(0.0), ptr(out2), _LL(N), ptr(arg2), cur_stream())
     assert torch.equal(out1, out2)
     live = out2 > 0

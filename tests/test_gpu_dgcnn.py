@@ -103,6 +103,33 @@ def test_conv_groupnorm_block_with_per_sample_offset(D):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4 * b.grad.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
 
 
+def test_global_max_pool_fused_into_the_block(D):
+    """relu(gn(conv(.))) followed by the max over the whole cloud (src/dgcnn.py:194-197) as one pooled block with K = N
+    (candidates from the product's epilogue, gradient routed through the winners) against plain torch."""
+    B, N, Cin, Cout, G = 6, 2048, 64, 1024, 8
+    assert D.pool_product_ok(B * N, Cout, Cin)
+    x = _t(synth.features(1, B * N, Cin, 25))[0]
+    W = _t(synth.features(1, Cout, Cin, 26))[0] * 0.2
+    bias = _t(synth.features(1, 1, Cout, 27))[0, 0]
+    gamma = _t(synth.features(1, 1, Cout, 28))[0, 0] * 0.5 + 0.8
+    beta = _t(synth.features(1, 1, Cout, 29))[0, 0] * 0.2
+    leaves = [t.clone().requires_grad_(True) for t in (x, W, gamma, beta, bias)]
+    xr, Wr, gr, br, bi = leaves
+    y = torch.nn.functional.linear(xr, Wr, bi).view(B, N, Cout).permute(0, 2, 1)
+    y = torch.relu(torch.nn.functional.group_norm(y, G, gr, br, 1e-5))
+    ref = y.max(dim=2)[0]                                                  # [B, Cout]
+    go = _t(synth.features(1, B, Cout, 30))[0]
+    (ref * go).sum().backward()
+    dl = [t.detach().cuda().requires_grad_(True) for t in leaves]
+    cfg = {"groups": G, "rps": N, "slope": 0.0, "pool_K": N, "eps": 1e-5}
+    out = D.ConvGNActFn.apply(dl[0], dl[1], dl[4], dl[2], dl[3], cfg)
+    assert out.shape == (B, Cout)
+    (out * go.cuda()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for a, b, name in zip(dl, leaves, ["x", "W", "gamma", "beta", "bias"]):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4 * b.grad.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
+
+
 def test_edge_conv_by_linearity_equals_rows_and_product(D, monkeypatch):
     """The edge convolution W [x_j - x_i | x_i] = U_j - Vc_i (two products per POINT + a gather, the default) against the
     materialised edge rows + product over B N k rows (PRIFIT_EDGE_LINEARITY=0): same outputs and gradients to rounding."""
@@ -112,8 +139,9 @@ def test_edge_conv_by_linearity_equals_rows_and_product(D, monkeypatch):
     pts = _t(synth.cloud("surface", B, N, 41)).cuda()
     feats = _t(synth.features(B, N, 64, 42)).cuda()
     res = {}
-    for arm in (True, False):
-        monkeypatch.setattr(D, "_EDGE_LINEARITY", arm)
+    for arm in (True, "unfused", False):
+        monkeypatch.setattr(D, "_EDGE_LINEARITY", bool(arm))
+        monkeypatch.setattr(D, "_EDGE_FUSED_BWD", arm is True)     # "unfused": apply pass + scatter as two launches
         enc.zero_grad()
         with torch.no_grad():
             idx = D._knn_cl(pts, k)
@@ -124,8 +152,10 @@ def test_edge_conv_by_linearity_equals_rows_and_product(D, monkeypatch):
         ((x1 + x2) * go1).sum().backward()
         res[arm] = (x1.detach(), x2.detach(), f.grad.clone(), enc.conv1[0].weight.grad.clone(), enc.conv2[0].weight.grad.clone(),
                     enc.bn2.weight.grad.clone())
-    for a, b, name in zip(res[True], res[False], ["x1", "x2", "dfeat", "dW1", "dW2", "dgamma2"]):
-        torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(1.0, b.abs().max().item()), msg=lambda m, name=name: name + ": " + m)
+    for other in ("unfused", False):
+        for a, b, name in zip(res[True], res[other], ["x1", "x2", "dfeat", "dW1", "dW2", "dgamma2"]):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(1.0, b.abs().max().item()),
+                                       msg=lambda m, name=name: "%s vs %s: %s" % (name, other, m))
 
 
 def test_dgcnn_network(D, golden):
