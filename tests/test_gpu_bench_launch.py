@@ -35,6 +35,12 @@ def test_bench_launch_paths_agree(hiplib):
     assert plain["n_gpus"] == 1 and plain["config"]["global_batch"] == 24
     one = _line([sys.executable, bench, "--gpus", "1"] + ARGS, launch.rank_env(0, 1, launch.free_port(), base))
     assert one["n_gpus"] == 1
+    # the N > 1 line proves itself: world size and backend from the communicator, who ran where
+    d1 = one["distributed"]
+    assert d1["world_size"] == 1 and d1["backend"] == "nccl" and d1["distinct_gpus"] == 1
+    r0 = d1["ranks"][0]
+    assert r0["rank"] == 0 and r0["device_index"] == 0 and (r0["pci_bus_id"] or r0["uuid"]) and r0["ms_per_step"] > 0
+    assert one["allreduce_ms_per_step"] >= 0 and "distributed" not in plain
     # same seeds, same step: the loss after 4 steps agrees (split-K float atomics: reproducible to rounding only)
     assert abs(one["config"]["loss"] - plain["config"]["loss"]) < 1e-3 * abs(plain["config"]["loss"])
     env = dict(base, PRIFIT_DIST_BACKEND="gloo", PRIFIT_BENCH_SHARE_GPU="1")
@@ -44,6 +50,11 @@ def test_bench_launch_paths_agree(hiplib):
         assert sorted(open(os.path.join(d, f)).read() for f in os.listdir(d)) == ["rank 0 of 2 local 0", "rank 1 of 2 local 1"]
     assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 48 and two["config"]["parallelism"] == "dp2"
     assert "rehearsal" in two and two["value"] > 0
+    d2 = two["distributed"]
+    assert d2["world_size"] == 2 and d2["backend"] == "gloo" and [r["rank"] for r in d2["ranks"]] == [0, 1]
+    assert d2["distinct_gpus"] == 1            # both ranks on the one GPU: accepted only because the line is a labelled rehearsal
+    assert d2["ms_per_step_min"] <= d2["ms_per_step_max"] and len(d2["speculation_fallbacks_per_rank"]) == 2
+    assert two["allreduce_ms_per_step"] > 0    # the exchange really ran (event-bracketed, per step)
 
 
 @pytest.mark.timeout(600)
