@@ -184,6 +184,24 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
                                 void *stream);
+/* Rows that are never stored (round 4).  The first layer of a set-abstraction MLP written by linearity --
+ * y1[row] = U[b, idx[row]] - Vc[b, s], U [B,N,64] per point (bias folded in), Vc [B,S,64] per centre, models/pointnet_util.py
+ * :243-252 -- has ~10^6 rows of 256 bytes that its three consumers used to read back from HBM (0.6 GB written + 3 reads per
+ * step for SA1); U itself is 12 MB and stays in L2 / MALL.  These entry points re-form the rows on load instead:
+ * prifit_gemm_stream_gather_f32      = prifit_gemm_stream_f32 (NT, K = 64, prologue relu(a_scale y1 + a_shift)) with A = y1;
+ * prifit_gemm_stream_bwd_gather_f32  = prifit_gemm_stream_bwd_f32 (Cin = 64, middle layer) with Yp = y1;
+ * prifit_sa_first_layer_dw_bn_gather = prifit_sa_first_layer_dw_bn with Y1 = y1.
+ * idx [M]: the index lists of prifit_sa_group_linear_fwd (which, in gather mode, takes Y[r] = NULL: lists + statistics
+ * only); rows_per_centre % 64 == 0, M % (n_centres * rows_per_centre) == 0. */
+int prifit_gemm_stream_gather_f32(int M, int N, const int32_t *idx, const float *U, const float *Vc, int n_points, int n_centres,
+                                  int rows_per_centre, const float *B, long long ldb, float *C, long long ldc,
+                                  const float *a_scale, const float *a_shift, const float *bias, float *col_stats, void *stream);
+int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, const float *Y, const float *scale,
+                                      const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                                      const float *W, long long ldw, const int32_t *idx, const float *U, const float *Vc,
+                                      int n_points, int n_centres, int rows_per_centre, const float *p_scale,
+                                      const float *p_shift, const float *p_mean, const float *p_invstd, float *Gp, long long ldgp,
+                                      float *red_slab, float *dW, long long lddw, float *workspace, void *stream);
 /* Forward of a max-pooled last layer without re-reading it for the pool (models/pointnet_util.py:199,256):
  * prifit_gemm_stream_f32 (NT, prologue required, M % 32 == 0) that also emits, per 32-row block and column, the largest
  * and smallest stored C and the row of their first occurrence, cand [M/32][4][N]; once the BatchNorm affine (scale,
@@ -387,6 +405,21 @@ int prifit_sa_first_layer_dw_bn(const float *G, const float *Y1, const float *sc
                                 const float *coef_a, const float *coef_b, const float *coef_d, const int32_t *idx,
                                 const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int K,
                                 int C, int D, int feat_first, int nblocks, float *partial, void *stream);
+/* The first layer by linearity for NARROW inputs (models/pointnet_util.py:243-252 with 3..9 data channels): the per-point
+ * table U_r [B,N,C_r] = W_r [feat_n | xyz_n] + b_r and the per-centre table Vc_r [B,S,C_r] = W_r,x c_s of every radius of a
+ * level in one launch (W_r [C_r][D+3] in upstream column order, MSG [feat, rel] or SSG [rel, feat]), so that the layer's
+ * pre-activation of grouped sample (s, j) is U_j - Vc_s.  feat [B,N,D] or NULL (D = 0). */
+int prifit_sa_point_tables(const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int D, int feat_first,
+                           int R, const int *width, const float *const *W, const float *const *bias, float *const *U,
+                           float *const *Vc, void *stream);
+
+/* The same when the first-layer rows Y1 are NOT stored (the layer written by linearity, y1[row] = U[b, idx[row]] - Vc[b, s]
+ * with U [B,N,C] per point and Vc [B,S,C] per centre, bias folded into U): Y1 is re-formed on load from (idx, U, Vc). */
+int prifit_sa_first_layer_dw_bn_gather(const float *G, const float *U, const float *Vc, const float *scale, const float *shift,
+                                       const float *coef_a, const float *coef_b, const float *coef_d, const int32_t *idx,
+                                       const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int K,
+                                       int C, int D, int feat_first, int nblocks, float *partial, void *stream);
+
 
 /* Backward of relu(bn(Y)) given G = dL/d(relu output): partial slabs of m1 = sum(G*mask) and
  * m2 = sum(G*mask*yhat). */

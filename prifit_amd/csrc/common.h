@@ -72,3 +72,16 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// A [P, C] operand that is NOT stored: row r of it is the first-layer pre-activation of a set-abstraction MLP written by
+// linearity (models/pointnet_util.py:243-252: conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g with U per point, Vc per centre
+// and the bias folded into U), re-formed on load as U[shape(r) * N + idx[r]] - Vc[r / Kg].  U is small (B N C floats, L2 /
+// MALL resident) where the rows are hundreds of MB.  Kg (rows per centre) is a multiple of the 64-row tiles: a tile has one
+// centre.  NULL idx = no gather.
+struct GatherSrc {
+    const int32_t *idx;   // [P] point index of every row (first-index padded, as prifit_sa_group_linear_fwd writes them)
+    const float *U;       // [B * N, C]
+    const float *Vc;      // [B * S, C]
+    int N, S, Kg, C;
+    unsigned ubytes;      // B * N * C * 4
+};

@@ -56,16 +56,19 @@ struct StreamArgs {
     // formed when the tile is staged (coefficients [K] each)
     const float *bna_G;
     const float *bna_s, *bna_t, *bna_a, *bna_b, *bna_d;
+    // GATH (forward, K = 64): A is not stored -- its rows are re-formed from (gs.idx, gs.U, gs.Vc), see GatherSrc
+    GatherSrc gs;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 // WN: waves along N (2 or 4; 256 threads = 4 waves, WM = 4 / WN waves along M); KG = K / 8;
 // BKC: B is [N][K] (NT) else [K][N] (NN); AFF: prologue on A
-template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL, bool PMAX, bool BNA = false>
+template <int WN, int KG, bool BKC, bool AFF, bool RED, bool POOL, bool PMAX, bool BNA = false, bool GATH = false>
 __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (KG <= 12 ? ((RED || PMAX || POOL) ? 2 : 3) : 2))) void gemm_stream_kernel(const StreamArgs g)
 {
     static_assert(!BNA || (!AFF && !POOL && !PMAX && !BKC), "BNA: a plain NN product with the operand transform");
+    static_assert(!GATH || (AFF && BKC && !RED && !POOL && !PMAX && !BNA && (256 % (2 * KG)) == 0), "GATH: the forward product");
     constexpr int K = KG * 8;
     constexpr int WM = 4 / WN;
     constexpr int TM = SBM / (32 * WM);       // 32-row accumulator tiles per wave
@@ -129,6 +132,19 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     // POOL: the (arg, T) entries of a thread's four channels (the same four for all its NV rows of a tile: K / 4 divides 256)
     static_assert(!POOL || (256 % (K / 4)) == 0, "POOL: one channel group per thread");
     const int pool_c4 = threadIdx.x % (K / 4);
+    // GATH: point indices of the thread's NV rows of the tile that is loaded NEXT (requested one tile ahead), the centre
+    // term of its four channels
+    int nid[GATH ? NV : 1];
+    float4 gvc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(GATH ? g.gs.U : nullptr), 0,
+                                                                         GATH ? g.gs.ubytes : 0, 0x00020000);
+    auto load_idx = [&](int tile) {
+        if (GATH) {
+            const int m0 = tile * SBM;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) nid[p] = g.gs.idx[m0 + (threadIdx.x + 256 * p) / (K / 4)];   // (M % SBM == 0)
+        }
+    };
     auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
         const int rows = g.M - m0 < SBM ? g.M - m0 : SBM;
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0,
@@ -144,11 +160,25 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
             st_arg = *reinterpret_cast<const int4 *>(g.pool_arg + po);
             st_T = ld4(g.pool_T + po);
         }
-        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g.A, g.lda, m0, K);
+        if (GATH) {
+            // rows of U picked by the tile's index list (read one tile ahead); one centre per tile (Kg % SBM == 0)
+            const int grp = m0 / g.gs.Kg;
+            const int pbase = (grp / g.gs.S) * g.gs.N;
+            gvc = ld4(g.gs.Vc + (long long)grp * K + 4 * pool_c4);
 #pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aoff[p], 0, 0));
-            st[p] = make_float4(v.x, v.y, v.z, v.w);
+            for (int p = 0; p < NV; ++p) {
+                const int n = nid[p];
+                const int voff = ((pbase + ((n >= 0 && n < g.gs.N) ? n : 0)) * K + 4 * pool_c4) * 4;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, voff, 0, 0));
+                st[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g.A, g.lda, m0, K);
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aoff[p], 0, 0));
+                st[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
         }
         if (BNA) {
             const __amdgpu_buffer_rsrc_t rg = tile_rsrc(g.bna_G, g.lda, m0, K);
@@ -167,6 +197,7 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
             const int id = threadIdx.x + 256 * p;
             const int row = id / (K / 4), c4 = id - row * (K / 4);
             float4 x = st[p];
+            if (GATH) { x.x -= gvc.x; x.y -= gvc.y; x.z -= gvc.z; x.w -= gvc.w; }   // y = U_j - Vc_g
             if (AFF) {
                 const float4 s = *reinterpret_cast<const float4 *>(&s_aff[0][4 * c4]);
                 const float4 t = *reinterpret_cast<const float4 *>(&s_aff[1][4 * c4]);
@@ -211,7 +242,12 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     // the last iteration fetches its own tile again (32 KB per workgroup) instead of branching around the prefetch.
     int tile = blockIdx.x;
     if (tile >= tiles) tile = tiles - 1;   // (the launcher never starts more workgroups than tiles)
+    load_idx(tile);
     load_tile(tile);
+    {
+        const int nx = tile + (int)gridDim.x;
+        load_idx(nx < tiles ? nx : tile);
+    }
     if (AFF || POOL || BNA) __syncthreads();  // s_aff / s_bna visible before the first staging
     store_tile(tile, s_a[0], 0);
     __syncthreads();
@@ -220,6 +256,10 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
         const int next = tile + gridDim.x;
         const int ntile = next < tiles ? next : tile;
         load_tile(ntile);
+        if (GATH) {   // the index list of the tile after that, a whole iteration ahead of the loads that use it
+            const int n2 = ntile + (int)gridDim.x;
+            load_idx(n2 < tiles ? n2 : ntile);
+        }
 
         f32x16 acc[TM];
 #pragma unroll
@@ -645,6 +685,9 @@ void launch_aff(const StreamArgs &g_, int nslab, hipStream_t st)
         }
     }
     else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (BKC && g.gs.idx) {
+        if constexpr (KG == 8 && BKC) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, true, true, false, false, false, false, true>), dim3(grid), dim3(256), 0, st, g);
+    }
     else if (BKC && g.cand && g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, true, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
     else if (g.a_scale) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, true, false, false, false>), dim3(grid), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, BKC, false, false, false, false>), dim3(grid), dim3(256), 0, st, g);
@@ -769,6 +812,7 @@ int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long
         ((uintptr_t)dY & 15))
         return PRIFIT_EINVAL;
     StreamArgs g;
+    g.gs.idx = nullptr;
     g.A = dY; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
@@ -788,6 +832,7 @@ int prifit_gemm_stream_dgrad_bn_f32(int M, int N, int K, const float *Gin, const
         ldy < N || (lda & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)Gin & 15))
         return PRIFIT_EINVAL;
     StreamArgs g;
+    g.gs.idx = nullptr;
     g.A = Y; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
@@ -809,6 +854,7 @@ int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long 
         return PRIFIT_EINVAL;
     if (red_slab && (!Yprev || !scale || !shift || !mean || !invstd || ldy < N)) return PRIFIT_EINVAL;
     StreamArgs g;
+    g.gs.idx = nullptr;
     g.A = Y; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = bias_dW; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
@@ -826,11 +872,38 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
         (layout == 0 && ((ldb & 3) || ((uintptr_t)B & 15) || ldb < K)) || (layout == 1 && ldb < N))
         return PRIFIT_EINVAL;
     StreamArgs g;
+    g.gs.idx = nullptr;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
     return stream_launch(g, layout, stream);
+}
+
+static bool gather_src_ok(const GatherSrc &gs, long long P, int C)
+{
+    return gs.idx && gs.U && gs.Vc && gs.N > 0 && gs.S > 0 && gs.Kg > 0 && (gs.Kg % SBM) == 0 && gs.C == C &&
+           P % ((long long)gs.S * gs.Kg) == 0 && !(((uintptr_t)gs.U | (uintptr_t)gs.Vc) & 15) &&
+           (P / ((long long)gs.S * gs.Kg)) * gs.N * C * 4 < 0x7ff00000LL;
+}
+
+int prifit_gemm_stream_gather_f32(int M, int N, const int32_t *idx, const float *U, const float *Vc, int n_points, int n_centres,
+                                  int rows_per_centre, const float *B, long long ldb, float *C, long long ldc,
+                                  const float *a_scale, const float *a_shift, const float *bias, float *col_stats, void *stream)
+{
+    const int K = 64;
+    GatherSrc gs = {idx, U, Vc, n_points, n_centres, rows_per_centre, K, 0u};
+    if (!B || !C || !a_scale || !a_shift || !prifit_gemm_stream_supported(0, M, N, K) || ldc < N || (ldb & 3) ||
+        ((uintptr_t)B & 15) || ldb < K || !gather_src_ok(gs, M, K))
+        return PRIFIT_EINVAL;
+    gs.ubytes = (unsigned)((M / ((long long)n_centres * rows_per_centre)) * n_points * K * 4);
+    StreamArgs g;
+    g.A = U; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = ldb; g.ldc = ldc;
+    g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
+    g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
+    g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
+    g.gs = gs;
+    return stream_launch(g, 0, stream);
 }
 
 int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
@@ -841,6 +914,7 @@ int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long l
         ldc < N || (lda & 3) || ((uintptr_t)A & 15) || (ldb & 3) || ((uintptr_t)B & 15) || ldb < K || (M & 31))
         return PRIFIT_EINVAL;
     StreamArgs g;
+    g.gs.idx = nullptr;
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;

@@ -42,6 +42,7 @@ struct BwdArgs {
     long long ldgp;
     float *red_slab;                          // [grid][2][Cin]
     float *dw_part;                           // [grid][Cout][Cin]
+    GatherSrc gs;                             // GATH: Yp is not stored, its rows are re-formed from (idx, U, Vc) -- common.h
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -60,10 +61,11 @@ template <> struct Roles<128, 128> { static constexpr int NW = 8; static constex
 
 template <int V> struct IC { static constexpr int value = V; };
 
-template <int COUT, int CIN, bool POOL>
+template <int COUT, int CIN, bool POOL, bool GATH = false>
 __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bwd_kernel(const BwdArgs g)
 {
     using R = Roles<COUT, CIN>;
+    static_assert(!GATH || (!POOL && (64 * Roles<COUT, CIN>::NW) % (CIN / 4) == 0), "GATH: one channel group per thread");
     constexpr int NA = CIN / 32, NTH = 64 * R::NW;
     constexpr int LDY = COUT + 4, LDP = CIN + 4;     // padded rows: conflict-free ds_read_b128 fragments / b32 columns
     constexpr int KG = COUT / 8;
@@ -106,6 +108,22 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0,
                                                  ((rows - 1) * (int)ld + width) * 4, 0x00020000);
     };
+    // GATH: point indices of the thread's Yp rows of the tile loaded next (requested one tile ahead), its centre term
+    int nid[GATH ? NVP : 1];
+    float4 gvc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int g_c4 = threadIdx.x % P4;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(GATH ? g.gs.U : nullptr), 0,
+                                                                         GATH ? g.gs.ubytes : 0, 0x00020000);
+    auto load_idx = [&](int tile) {
+        if (GATH) {
+            const int m0 = tile * SBM;
+#pragma unroll
+            for (int p = 0; p < NVP; ++p) {
+                const int id = threadIdx.x + NTH * p;
+                nid[p] = g.gs.idx[m0 + (id < NP4 ? id / P4 : 0)];   // (P % SBM == 0)
+            }
+        }
+    };
     auto load_tile = [&](int tile) {
         const int m0 = tile * SBM;
         if (POOL) {
@@ -127,11 +145,25 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
                 stg[p] = make_float4(v.x, v.y, v.z, v.w);
             }
         }
-        const __amdgpu_buffer_rsrc_t rp = tile_rsrc(g.Yp, g.ldyp, m0, CIN);
+        if (GATH) {
+            const int grp = m0 / g.gs.Kg;
+            const int pbase = (grp / g.gs.S) * g.gs.N;
+            gvc = ld4(g.gs.Vc + (long long)grp * CIN + 4 * g_c4);
 #pragma unroll
-        for (int p = 0; p < NVP; ++p) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, poff[p], 0, 0));
-            stp[p] = make_float4(v.x, v.y, v.z, v.w);
+            for (int p = 0; p < NVP; ++p) {
+                const int id = threadIdx.x + NTH * p;
+                const int n = nid[p];
+                const int voff = id < NP4 ? ((pbase + ((n >= 0 && n < g.gs.N) ? n : 0)) * CIN + 4 * g_c4) * 4 : 0x7fffffff;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, voff, 0, 0));
+                stp[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rp = tile_rsrc(g.Yp, g.ldyp, m0, CIN);
+#pragma unroll
+            for (int p = 0; p < NVP; ++p) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, poff[p], 0, 0));
+                stp[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
         }
     };
     auto store_tile = [&](int tile, int buf) {
@@ -169,13 +201,24 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
             const int id = threadIdx.x + NTH * p;
             if (NVP * NTH != NP4 && id >= NP4) continue;
             const int row = id / P4, c4 = id - row * P4;
-            *reinterpret_cast<float4 *>(&s_p[buf][row * LDP + 4 * c4]) = stp[p];
+            float4 x = stp[p];
+            if (GATH) { x.x -= gvc.x; x.y -= gvc.y; x.z -= gvc.z; x.w -= gvc.w; }   // y = U_j - Vc_g
+            *reinterpret_cast<float4 *>(&s_p[buf][row * LDP + 4 * c4]) = x;
+        }
+    };
+    // (GATH) the index list of the tile after `t`, requested behind t's loads: a whole iteration ahead of its use
+    auto idx_after = [&](int t) {
+        if (GATH) {
+            const int n2 = t + (int)gridDim.x;
+            load_idx(n2 < tiles ? n2 : t);
         }
     };
 
     int tile = blockIdx.x;
     if (tile >= tiles) tile = tiles - 1;   // (the launcher never starts more workgroups than tiles)
+    load_idx(tile);
     load_tile(tile);
+    idx_after(tile);
     __syncthreads();                        // s_co visible before the first staging
     store_tile(tile, 0);
     __syncthreads();
@@ -209,6 +252,7 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
             const int next = tile + gridDim.x;
             const int ntile = next < tiles ? next : tile;
             load_tile(ntile);
+            idx_after(ntile);
             __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued HERE, ahead of the MFMAs
             f32x16 acc[2];
 #pragma unroll
@@ -283,6 +327,7 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
                 const int next = tile + gridDim.x;
                 const int ntile = next < tiles ? next : tile;
                 load_tile(ntile);
+                idx_after(ntile);
                 __builtin_amdgcn_sched_barrier(0);
                 const float *dcol = &s_dy[cur][lh * LDY + li];
                 const float *prow = &s_p[cur][lh * LDP + li];
@@ -382,6 +427,10 @@ template <int COUT, int CIN>
 void bwd_launch(const BwdArgs &g, bool pool, int grid, hipStream_t st)
 {
     constexpr int NTH = 64 * Roles<COUT, CIN>::NW;
+    if (g.gs.idx) {
+        if constexpr (CIN == 64 && NTH % (CIN / 4) == 0) hipLaunchKernelGGL((gemm_stream_bwd_kernel<COUT, CIN, false, true>), dim3(grid), dim3(NTH), 0, st, g);
+        return;
+    }
     if (pool) {
         if constexpr (NTH % (COUT / 4) == 0) hipLaunchKernelGGL((gemm_stream_bwd_kernel<COUT, CIN, true>), dim3(grid), dim3(NTH), 0, st, g);
     } else {
@@ -409,14 +458,22 @@ long long prifit_gemm_stream_bwd_workspace(long long P, int Cout, int Cin)
     return bwd_shape_ok(Cout, Cin) ? (long long)bwd_grid(P, Cout, Cin) * Cout * Cin : 0;
 }
 
-int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, const float *Y, const float *scale,
-                               const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
-                               const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
-                               const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
-                               const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
-                               float *dW, long long lddw, float *workspace, void *stream)
+static int stream_bwd_impl(long long P, int Cout, int Cin, const float *G, const float *Y, const float *scale,
+                           const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                           const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
+                           const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
+                           const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
+                           float *dW, long long lddw, float *workspace, const GatherSrc *gs, void *stream)
 {
     const bool pool = pool_arg != nullptr;
+    if (gs) {   // Yp re-formed from (idx, U, Vc): middle layers on a 64-wide first layer only
+        if (pool || Cin != 64 || !gs->idx || !gs->U || !gs->Vc || gs->N <= 0 || gs->S <= 0 || gs->Kg <= 0 || (gs->Kg % SBM) ||
+            gs->C != Cin || P % ((long long)gs->S * gs->Kg) != 0 || (((uintptr_t)gs->U | (uintptr_t)gs->Vc) & 15) ||
+            (P / ((long long)gs->S * gs->Kg)) * gs->N * Cin * 4 >= 0x7ff00000LL)
+            return PRIFIT_EINVAL;
+        Yp = gs->U;   // (only checked for presence and alignment below)
+        ldyp = Cin;
+    }
     if (!Y || !coef_b || !coef_d || !W || !Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !Gp || !red_slab || !dW ||
         !workspace || !prifit_gemm_stream_bwd_supported(P, Cout, Cin, pool ? pool_K : 0) || ldw < Cin || ldyp < Cin || ldgp < Cin ||
         lddw < Cin || (ldyp & 3) || (pool ? (!pool_T) : (!G || !scale || !shift || !coef_a)) ||
@@ -428,6 +485,11 @@ int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, c
     g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_K = pool ? pool_K : 1;
     g.W = W; g.ldw = ldw; g.Yp = Yp; g.ldyp = ldyp; g.ps = p_scale; g.pt = p_shift; g.pmu = p_mean; g.pis = p_invstd;
     g.Gp = Gp; g.ldgp = ldgp; g.red_slab = red_slab; g.dw_part = workspace;
+    g.gs.idx = nullptr;
+    if (gs) {
+        g.gs = *gs;
+        g.gs.ubytes = (unsigned)((P / ((long long)gs->S * gs->Kg)) * gs->N * Cin * 4);
+    }
     const int grid = bwd_grid(P, Cout, Cin);
     hipStream_t st = as_stream(stream);
     if (Cout == 128 && Cin == 128) bwd_launch<128, 128>(g, pool, grid, st);
@@ -438,6 +500,29 @@ int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, c
     const int n = Cout * Cin;
     hipLaunchKernelGGL(stream_bwd_dw_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grid, n, Cin, lddw, dW);
     return prifit_check_launch();
+}
+
+int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, const float *Y, const float *scale,
+                               const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                               const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
+                               const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
+                               const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
+                               float *dW, long long lddw, float *workspace, void *stream)
+{
+    return stream_bwd_impl(P, Cout, Cin, G, Y, scale, shift, coef_a, coef_b, coef_d, pool_arg, pool_T, pool_K, W, ldw, Yp, ldyp,
+                           p_scale, p_shift, p_mean, p_invstd, Gp, ldgp, red_slab, dW, lddw, workspace, nullptr, stream);
+}
+
+int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, const float *Y, const float *scale,
+                                      const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                                      const float *W, long long ldw, const int32_t *idx, const float *U, const float *Vc,
+                                      int n_points, int n_centres, int rows_per_centre, const float *p_scale,
+                                      const float *p_shift, const float *p_mean, const float *p_invstd, float *Gp, long long ldgp,
+                                      float *red_slab, float *dW, long long lddw, float *workspace, void *stream)
+{
+    const GatherSrc gs = {idx, U, Vc, n_points, n_centres, rows_per_centre, 64, 0u};
+    return stream_bwd_impl(P, Cout, 64, G, Y, scale, shift, coef_a, coef_b, coef_d, nullptr, nullptr, 0, W, ldw, nullptr, 64,
+                           p_scale, p_shift, p_mean, p_invstd, Gp, ldgp, red_slab, dW, lddw, workspace, &gs, stream);
 }
 
 }  // extern "C"

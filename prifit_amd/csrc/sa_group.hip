@@ -199,8 +199,9 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
             const float *Fb = (MODE == 0 && D > 0) ? a.feat + (size_t)b * N * D : nullptr;
             // the rows of this (centre, radius): one buffer resource, the lane's part of the address (its row inside a wave
             // instruction, its 4 channels) is a loop-invariant VGPR -- one 32-bit add per store instead of a 64-bit chain
+            const bool rows_out = a.Y[r] != nullptr;
             const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-                a.Y[r] + ((size_t)b * S + qid) * K * C, 0, K * C * 4, 0x00020000);
+                rows_out ? a.Y[r] + ((size_t)b * S + qid) * K * C : nullptr, 0, rows_out ? K * C * 4 : 0, 0x00020000);
             const int y_voff = (rsel * C + 4 * c4) * 4;
             const int C4 = C * 4;
             // ALL: K is a whole number of row blocks (every configured layer): no per-row predicates, straight-line code
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                     // (the row block goes into the LANE offset, one v_add per store, not into the scalar offset: with an SGPR
                     // offset hipcc 7.2 leaves out the wait state between a 128-bit buffer store and the next VALU write of its
                     // data registers -- lanes 12-15 of every 16 stored the following row's second dword)
-                    __builtin_amdgcn_raw_buffer_store_b128(tv, yrs, y_voff + (k0 + u * rpi) * C4, 0, 2 /* nt */);
+                    if (rows_out)   // (wave-uniform: a scale whose rows every consumer re-forms from U / Vc stores none)
+                        __builtin_amdgcn_raw_buffer_store_b128(tv, yrs, y_voff + (k0 + u * rpi) * C4, 0, 2 /* nt */);
                     if (!okk[u]) y = make_float4(0.f, 0.f, 0.f, 0.f);
                     s0.x += y.x; s0.y += y.y; s0.z += y.z; s0.w += y.w;
                     s1.x += y.x * y.x; s1.y += y.y * y.y; s1.z += y.z * y.z; s1.w += y.w * y.w;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
 // that would write dY and the read of it here are gone.
 struct DwBn {
     const float *Y1, *scale, *shift, *ca, *cb, *cd;
+    const float *U, *Vc;   // Y1 == NULL: the rows are not stored, y1[row] = U[b * N + idx[row]] - Vc[row / K]  (first layer by linearity)
 };
 
 template <int D, bool BNB>
@@ -362,7 +365,17 @@ __global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
                 const bool ok = (i0 + u * rpi + rsel) < 64 && row < r_end;
                 gy[u] = ld4g(dY + (size_t)(ok ? row : r_begin) * C + 4 * c4);
                 if (BNB) {
-                    const float4 y = ld4g(bn.Y1 + (size_t)(ok ? row : r_begin) * C + 4 * c4);
+                    float4 y;
+                    if (bn.Y1) {
+                        y = ld4g(bn.Y1 + (size_t)(ok ? row : r_begin) * C + 4 * c4);
+                    } else {   // (block-uniform branch)
+                        const long long rr = ok ? row : r_begin;
+                        const long long gq = rr / K;
+                        const int nn = idx[rr];
+                        const float4 u = ld4g(bn.U + ((size_t)(gq / S) * N + ((nn >= 0 && nn < N) ? nn : 0)) * C + 4 * c4);
+                        const float4 v = ld4g(bn.Vc + (size_t)gq * C + 4 * c4);
+                        y = make_float4(u.x - v.x, u.y - v.y, u.z - v.z, u.w - v.w);
+                    }
                     gy[u].x = fmaf(b_a.x, fmaf(y.x, b_s.x, b_t.x) > 0.f ? gy[u].x : 0.f, fmaf(b_b.x, y.x, b_d.x));
                     gy[u].y = fmaf(b_a.y, fmaf(y.y, b_s.y, b_t.y) > 0.f ? gy[u].y : 0.f, fmaf(b_b.y, y.y, b_d.y));
                     gy[u].z = fmaf(b_a.z, fmaf(y.z, b_s.z, b_t.z) > 0.f ? gy[u].z : 0.f, fmaf(b_b.z, y.z, b_d.z));
@@ -402,6 +415,55 @@ __global__ __launch_bounds__(256) void sa_first_layer_dw_kernel(
         const int c = t / KP, k = t - c * KP;
         const int col = k < 3 ? (feat_first ? D + k : k) : (feat_first ? k - 3 : k);
         partial[(size_t)blockIdx.x * C * KP + c * KP + col] = s_acc[0][t] + s_acc[1][t] + s_acc[2][t] + s_acc[3][t];
+    }
+}
+
+// The per-point / per-centre tables of the first layer by linearity for narrow inputs (3..9 data channels), all radii of a
+// level in ONE launch: U_r[b,n,:] = W_r [feat_n | xyz_n] + b_r, Vc_r[b,s,:] = W_r,x c_s (W_r [C_r][D+3] in upstream column
+// order, see sa_group_kernel), so that conv1([feat_j | xyz_j - c]) + b = U_j - Vc.  One thread per (row, 4 channels).
+struct SATablesArgs {
+    const float *xyz, *new_xyz, *feat;
+    int B, N, S, D, feat_first, R;
+    int C[4];
+    const float *W[4], *bias[4];
+    float *U[4], *Vc[4];
+};
+
+__global__ __launch_bounds__(256) void sa_point_tables_kernel(const SATablesArgs a)
+{
+    const int r = blockIdx.y;
+    const int C = a.C[r], L = C >> 2, KP = a.D + 3;
+    const long long nu = (long long)a.B * a.N, nv = (long long)a.B * a.S;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = id / L;
+    const int c4 = (int)(id - row * L);
+    if (row >= nu + nv) return;
+    const float *Wr = a.W[r] + (size_t)(4 * c4) * KP;
+    const int xc = a.feat_first ? a.D : 0, fc = a.feat_first ? 0 : 3;   // columns of rel_xyz / features in W
+    float y[4];
+    if (row < nu) {
+        const float *p = a.xyz + row * 3;
+        const float px = p[0], py = p[1], pz = p[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *w = Wr + j * KP;
+            float acc = w[xc] * px;
+            acc = fmaf(w[xc + 1], py, acc);
+            acc = fmaf(w[xc + 2], pz, acc);
+            for (int i = 0; i < a.D; ++i) acc = fmaf(w[fc + i], a.feat[row * a.D + i], acc);
+            y[j] = acc + (a.bias[r] ? a.bias[r][4 * c4 + j] : 0.f);
+        }
+        *reinterpret_cast<float4 *>(a.U[r] + row * C + 4 * c4) = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+        const long long g = row - nu;
+        const float *c = a.new_xyz + g * 3;
+        const float cx = c[0], cy = c[1], cz = c[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *w = Wr + j * KP;
+            y[j] = fmaf(w[xc + 2], cz, fmaf(w[xc + 1], cy, w[xc] * cx));
+        }
+        *reinterpret_cast<float4 *>(a.Vc[r] + g * C + 4 * c4) = make_float4(y[0], y[1], y[2], y[3]);
     }
 }
 
@@ -469,7 +531,8 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
         a.idx[r] = in ? idx[r] : nullptr;
         if (!in) continue;
         const int C = width[r];
-        if (nsample[r] < 1 || C < 16 || C > SG_CMAX || (C & (C - 1)) || !Y[r] || !idx[r] ||
+        // (gather mode: Y[r] may be NULL -- index lists and statistics only, the rows are re-formed by their consumers)
+        if (nsample[r] < 1 || C < 16 || C > SG_CMAX || (C & (C - 1)) || (!Y[r] && mode == 0) || !idx[r] ||
             (mode == 0 ? !W[r] : (!U[r] || !Vc[r])) || ((uintptr_t)Y[r] & 15) ||
             (mode == 1 && (((uintptr_t)U[r] | (uintptr_t)Vc[r]) & 15)) || (bias[r] && ((uintptr_t)bias[r] & 15)))
             return PRIFIT_EINVAL;
@@ -481,6 +544,30 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
     if (D == 0) return launch_r<0, 0, false>(a, R, st);
     if (D == 3) return feat_xyz ? launch_r<0, 3, true>(a, R, st) : launch_r<0, 3, false>(a, R, st);
     return feat_xyz ? launch_r<0, 6, true>(a, R, st) : launch_r<0, 6, false>(a, R, st);
+}
+
+int prifit_sa_point_tables(const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int D, int feat_first,
+                           int R, const int *width, const float *const *W, const float *const *bias, float *const *U,
+                           float *const *Vc, void *stream)
+{
+    if (!xyz || !new_xyz || !width || !W || !bias || !U || !Vc || B <= 0 || N <= 0 || S <= 0 || D < 0 || D > 9 || (D > 0 && !feat) ||
+        R < 1 || R > 4)
+        return PRIFIT_EINVAL;
+    SATablesArgs a;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.feat = feat; a.B = B; a.N = N; a.S = S; a.D = D; a.feat_first = feat_first; a.R = R;
+    int lmax = 0;
+    for (int r = 0; r < 4; ++r) {
+        const bool in = r < R;
+        a.C[r] = in ? width[r] : 0; a.W[r] = in ? W[r] : nullptr; a.bias[r] = in ? bias[r] : nullptr;
+        a.U[r] = in ? U[r] : nullptr; a.Vc[r] = in ? Vc[r] : nullptr;
+        if (!in) continue;
+        if (width[r] < 4 || (width[r] & 3) || !W[r] || !U[r] || !Vc[r] || (((uintptr_t)U[r] | (uintptr_t)Vc[r]) & 15))
+            return PRIFIT_EINVAL;
+        lmax = width[r] / 4 > lmax ? width[r] / 4 : lmax;
+    }
+    const long long threads = ((long long)B * N + (long long)B * S) * lmax;
+    hipLaunchKernelGGL(sa_point_tables_kernel, dim3((unsigned)((threads + 255) / 256), R), dim3(256), 0, as_stream(stream), a);
+    return prifit_check_launch();
 }
 
 static int dw_launch(const float *dY, const int32_t *idx, const float *xyz, const float *new_xyz, const float *feat,
@@ -496,7 +583,7 @@ static int dw_launch(const float *dY, const int32_t *idx, const float *xyz, cons
     per = (per + 255) / 256 * 256;
     if ((long long)nblocks * per < P) return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
-    DwBn none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DwBn none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 #define DW_LAUNCH(DD)                                                                                                \
     if (bn) hipLaunchKernelGGL((sa_first_layer_dw_kernel<DD, true>), dim3(nblocks), dim3(256), 0, st, dY, idx, xyz,     \
                                new_xyz, feat, N, S, K, C, feat_first, P, per, partial, *bn);                          \
@@ -522,7 +609,18 @@ int prifit_sa_first_layer_dw_bn(const float *G, const float *Y1, const float *sc
                                 int C, int D, int feat_first, int nblocks, float *partial, void *stream)
 {
     if (!Y1 || !scale || !shift || !coef_a || !coef_b || !coef_d || ((uintptr_t)Y1 & 15)) return PRIFIT_EINVAL;
-    const DwBn bn = {Y1, scale, shift, coef_a, coef_b, coef_d};
+    const DwBn bn = {Y1, scale, shift, coef_a, coef_b, coef_d, nullptr, nullptr};
+    return dw_launch(G, idx, xyz, new_xyz, feat, B, N, S, K, C, D, feat_first, nblocks, partial, &bn, stream);
+}
+
+int prifit_sa_first_layer_dw_bn_gather(const float *G, const float *U, const float *Vc, const float *scale, const float *shift,
+                                       const float *coef_a, const float *coef_b, const float *coef_d, const int32_t *idx,
+                                       const float *xyz, const float *new_xyz, const float *feat, int B, int N, int S, int K,
+                                       int C, int D, int feat_first, int nblocks, float *partial, void *stream)
+{
+    if (!U || !Vc || !scale || !shift || !coef_a || !coef_b || !coef_d || (((uintptr_t)U | (uintptr_t)Vc) & 15))
+        return PRIFIT_EINVAL;
+    const DwBn bn = {nullptr, scale, shift, coef_a, coef_b, coef_d, U, Vc};
     return dw_launch(G, idx, xyz, new_xyz, feat, B, N, S, K, C, D, feat_first, nblocks, partial, &bn, stream);
 }
 

@@ -133,9 +133,9 @@ def _use_linearity(conv, kp):
     return _SA_LINEARITY and kp > conv.weight.shape[0]
 
 
-def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first):
+def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first, fold_bias=False):
     """U [B,N,C1] = [feat | xyz] W1^T per POINT and Vc [B,S,C1] = c W1x^T per CENTRE (two small GEMMs):
-    conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias."""
+    conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias.  fold_bias: the bias is added to U (then y = U_j - Vc_g)."""
     B, N, _ = xyz.shape
     D = 0 if feats is None else feats.shape[-1]
     S = new_xyz.shape[1]
@@ -150,7 +150,7 @@ def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first):
         parts.append(_z(xyz, B, N, kp - D - 3))
     rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
     w_pt = _pack_cols(w, fcols + xcols + [-1] * (kp - D - 3))
-    U = LinearFn.apply(rows, w_pt, None).reshape(B, N, C1)
+    U = LinearFn.apply(rows, w_pt, conv.bias if fold_bias else None).reshape(B, N, C1)
     c4 = torch.cat([new_xyz, _z(new_xyz, B, S, 1)], dim=-1).reshape(B * S, 4)
     Vc = LinearFn.apply(c4, _pack_cols(w, xcols + [-1]), None).reshape(B, S, C1)
     return U, Vc
@@ -182,6 +182,78 @@ def _fused_mode(first_convs, feats, N, nsamples, kp):
     if all(_use_linearity(c, kp) for c in first_convs):
         return "gather"
     return None
+
+
+# Direct-mode levels (SA1) in training: the 64-wide first-layer rows of a scale are NOT stored when every consumer can
+# re-form them from the L2-resident per-point table U (first layer by linearity, bias folded in) -- the forward product of
+# layer 2, the one-pass backward of layer 2 and the first conv's weight-gradient reduction (nn_ops.SharedMLPFn, cfg
+# "norows").  SA1 at B = 24: 0.6 GB less written and 1.8 GB less read per step (2.4 GB of the step's ~36 GB of HBM traffic).
+# MEASURED AND NOT THE DEFAULT: the grouping launches drop from 0.21 to 0.125 ms, but every consumer is SLOWER on
+# rows gathered from L2 than on rows streamed from HBM (forward product +6 us, one-pass backward +26 us, weight-gradient
+# reduction +22 us per scale): c2 10.09 -> 10.17 ms, c3 15.19 -> 15.30 ms on one box, alternating runs.  These kernels are
+# not limited by HBM bytes alone.  PRIFIT_SA_NOROWS=1 turns it on (both arms are tested).
+_SA_NOROWS = os.environ.get("PRIFIT_SA_NOROWS", "0") != "0"
+
+
+def _norows_scales(mode, conv_blocks, training, B, S, nsamples):
+    """Per scale: can its first-layer rows stay unstored?  (64-wide first layer, whole 64-row tiles per centre, >= 3 layers,
+    the second layer on the streaming forward kernel and the one-pass backward kernel.)"""
+    from .._lib import dll
+    from .. import nn_ops
+    if not (_SA_NOROWS and mode == "direct" and training and _DIRECT_FUSED_BWD and nn_ops._FUSE_RED and nn_ops._FUSE_BN_APPLY and
+            nn_ops._STREAM):
+        return [False] * len(conv_blocks)
+    out = []
+    for convs, K in zip(conv_blocks, nsamples):
+        P = B * S * K
+        C1 = convs[0].weight.shape[0]
+        ok = (len(convs) >= 3 and C1 == 64 and K % 64 == 0 and P < (1 << 24) and convs[1].weight.shape[1] == 64)
+        if ok:
+            C2 = convs[1].weight.shape[0]
+            ok = bool(dll().prifit_gemm_stream_supported(0, P, C2, 64)) and bool(dll().prifit_gemm_stream_bwd_supported(P, C2, 64, 0))
+        out.append(ok)
+    return out
+
+
+def nn_ops_point_tables(first_convs, feats, xyz, new_xyz, feat_first):
+    """U_r [B,N,C_r] (bias folded in) and Vc_r [B,S,C_r] of every radius in one launch (prifit_sa_point_tables)."""
+    import ctypes
+    from .._lib import call, cur_stream, ptr
+    from ..nn_ops import _ptr_array
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    D = 0 if feats is None else feats.shape[-1]
+    R = len(first_convs)
+    Ws = [c.weight.detach().reshape(c.weight.shape[0], -1).contiguous() for c in first_convs]
+    bs = [None if c.bias is None else c.bias.detach().contiguous() for c in first_convs]
+    Us = [torch.empty(B, N, w.shape[0], dtype=torch.float32, device=xyz.device) for w in Ws]
+    Vcs = [torch.empty(B, S, w.shape[0], dtype=torch.float32, device=xyz.device) for w in Ws]
+    wd = (ctypes.c_int * R)(*[int(w.shape[0]) for w in Ws])
+    call("prifit_sa_point_tables", ptr(xyz.contiguous()), ptr(new_xyz.contiguous()), ptr(None if feats is None else feats.contiguous()),
+         B, N, S, D, int(feat_first), R, wd, _ptr_array(Ws), _ptr_array(bs), _ptr_array(Us), _ptr_array(Vcs), cur_stream())
+    return Us, Vcs
+
+
+def _fused_first_layers_norows(first_convs, norows, feats, xyz, new_xyz, radii, nsamples, kp, feat_first):
+    """Direct-mode level in training with some scales' rows unstored: ONE launch in the by-linearity form for all scales
+    (y = U_j - Vc_g, U = [feat | xyz] W1^T + b per point, Vc = c W1x^T per centre: the index lists and the BatchNorm
+    statistics of every scale, rows only where `norows` is False).  The first conv's weight gradient stays the direct
+    reduction dW1 = dY1^T [feat | rel] (SharedMLPFn owns it), so U / Vc are plain data for autograd."""
+    D = 0 if feats is None else feats.shape[-1]
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    with torch.no_grad():
+        Us, Vcs = nn_ops_point_tables(first_convs, feats, xyz, new_xyz, feat_first)
+        Ys, slabs, idxs = _sa_group_launch(1, xyz, new_xyz, None, True, list(radii), list(nsamples),
+                                           [u.shape[-1] for u in Us], None, Us, Vcs, [None] * len(first_convs),
+                                           rows=[not nr for nr in norows])
+    out = []
+    for i in range(len(first_convs)):
+        info = {"idx": idxs[i], "xyz": xyz, "new_xyz": new_xyz, "feat": feats, "feat_first": feat_first, "K": nsamples[i], "D": D}
+        if norows[i]:
+            info.update(norows=True, U=Us[i], Vc=Vcs[i], P=B * S * nsamples[i], N=N, S=S)
+        out.append((Ys[i], slabs[i], info))
+    return out
 
 
 def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii, nsamples, kp, feat_first,
@@ -404,9 +476,14 @@ class PointNetSetAbstractionMsg(nn.Module):
         firsts = [blk[0] for blk in self.conv_blocks]
         mode = _fused_mode(firsts, feats, N, self.nsample_list, kp) if len(firsts) <= 4 else None
         if mode is not None:
-            ys = _fused_first_layers(mode, firsts, self.training, feats, xyz, new_xyz, self.radius_list,
-                                     self.nsample_list, kp, feat_first=True,
-                                     fused_gather_bwd=_gather_bwd_ok(mode, self.conv_blocks, N))
+            norows = _norows_scales(mode, self.conv_blocks, self.training, B, S, self.nsample_list)
+            if any(norows):
+                ys = _fused_first_layers_norows(firsts, norows, feats, xyz, new_xyz, self.radius_list, self.nsample_list, kp,
+                                                feat_first=True)
+            else:
+                ys = _fused_first_layers(mode, firsts, self.training, feats, xyz, new_xyz, self.radius_list,
+                                         self.nsample_list, kp, feat_first=True,
+                                         fused_gather_bwd=_gather_bwd_ok(mode, self.conv_blocks, N))
             for i, K in enumerate(self.nsample_list):
                 cfg = _preact_cfg(_mlp_cfg(self.bn_blocks[i], K, self.training), ys[i][1], ys[i][2])
                 pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i],

@@ -34,14 +34,20 @@ _FUSE_BN_APPLY = os.environ.get("PRIFIT_FUSE_BN_APPLY", "1") != "0"  # 0: bn_rel
 _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_apply writes the pooled layer's dY (A/B runs)
 # dA and dW of a streaming-shape layer from ONE pass over its rows (csrc/gemm_stream_bwd.hip) instead of the separate
 # streaming dA (NN) and dW (TN) kernels, which each read G, Y and the previous layer's pre-activation.  "auto" (default):
-# where it measured faster -- the 96 -> 64 middle layer of SA1's widest scale (598 against 712 us, tools/stream_bwd_bench.py);
+# where it measured faster -- the unpooled middle layers (_FUSE_BWD_AUTO below; round 3 had only the 96 -> 64 one);
 # "1": every supported shape (slower on the others: the kernel's dW role is latency-bound); "0": never.
 _FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "auto")
 
 
+# (round 4, tools/fam_table.py on one box: one-pass kernel against the separate dA + dW pair)
+#   [1.57 M x 96 x 64] 546 / 712 us, [786 K x 64 x 64] 171 / 282, [197 K x 128 x 128] 152 / 176, [49 K x 128 x 128] 54 / 72;
+#   pooled layers stay on the pairs: [1.57 M x 128 x 96] 887 / 874, [786 K x 128 x 64] 337 / 304
+_FUSE_BWD_AUTO = {(96, 64), (64, 64), (128, 128)}
+
+
 def _fuse_bwd_on(Cout, Kin, pooled):
     if _FUSE_BWD == "auto":
-        return (Cout, Kin) == (96, 64) and not pooled
+        return (Cout, Kin) in _FUSE_BWD_AUTO and not pooled
     return _FUSE_BWD not in ("0", "", False)
 
 
@@ -160,8 +166,14 @@ class SharedMLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
         L = len(tensors) // 6
-        P, K0 = x.shape
-        dev = x.device
+        # norows: layer 0's pre-activation rows are not stored (x is None); they are re-formed from (idx, U, Vc) by the
+        # three kernels that consume them (cfg["preact_direct"]: norows, U, Vc, idx, P, N, S, K -- pointnet_util)
+        nr = cfg.get("preact_direct") if (cfg.get("preact_direct") or {}).get("norows") else None
+        if nr is not None:
+            P, dev = nr["P"], nr["U"].device
+        else:
+            P, K0 = x.shape
+            dev = x.device
         training = cfg["training"]
         gather = cfg.get("preact_gather") if cfg.get("preact_slab") is not None else None
         tile_m = 128
@@ -172,11 +184,11 @@ class SharedMLPFn(torch.autograd.Function):
             W, b, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 6]
             preact = l == 0 and cfg.get("preact_slab") is not None
             if preact:
-                W, Cout, Kin, Y = None, x.shape[1], 0, x
+                W, Cout, Kin, Y = None, (nr["U"].shape[-1] if nr is not None else x.shape[1]), 0, x
             else:
                 W = W.contiguous()
                 Cout, Kin = W.shape
-                assert Kin == prev.shape[1], (Kin, prev.shape)
+                assert Kin == (nr["U"].shape[-1] if (l == 1 and nr is not None) else prev.shape[1]), (Kin, l)
                 Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
             scale = torch.empty(Cout, dtype=torch.float32, device=dev)
             shift = torch.empty_like(scale)
@@ -193,6 +205,17 @@ class SharedMLPFn(torch.autograd.Function):
                     mean = rmean.clone()
                     scale = gamma * invstd
                     shift = beta - mean * scale
+            elif training and l == 1 and nr is not None:
+                # layer 2 on rows that were never stored: the streaming product gathers them from U (prifit_gemm_stream_gather_f32)
+                nslab = dll().prifit_gemm_stream_slabs(P, Kin)
+                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                with profiler.span(profiler.tag("gemm_stream_nt", P, Cout, Kin, "gather"), 4.0 * (P * Cout + P + Cout * Kin)):
+                    call("prifit_gemm_stream_gather_f32", P, Cout, ptr(nr["idx"]), ptr(nr["U"]), ptr(nr["Vc"]), nr["N"], nr["S"],
+                         nr["K"], ptr(W), _LL(Kin), ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab),
+                         cur_stream())
+                call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
+                     _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
+                     ptr(mean), ptr(invstd), cur_stream())
             elif training:
                 aligned = prev.stride(0) % 4 == 0 and prev.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
                 tile_m = dll().prifit_gemm_stats_tile_m(P, Cout)
@@ -253,6 +276,8 @@ class SharedMLPFn(torch.autograd.Function):
         # upstream layout [C1, D+3]) and computes it with the BatchNorm backward fused in (prifit_sa_first_layer_dw_bn)
         ctx.preact_direct = cfg.get("preact_direct") if ctx.preact else None
         ctx.L = L
+        ctx.P, ctx.dev = P, dev
+        assert nr is None or (training and L >= 3 and Ys[0] is None)
         ctx.saved = (x, Ys, Ws, affines, stats_saved, arg)
         return out
 
@@ -261,8 +286,8 @@ class SharedMLPFn(torch.autograd.Function):
         cfg, L = ctx.cfg, ctx.L
         x, Ys, Ws, affines, stats_saved, arg = ctx.saved
         training = cfg["training"]
-        P = x.shape[0]
-        dev = x.device
+        P, dev = ctx.P, ctx.dev
+        nr = ctx.preact_direct if (ctx.preact_direct or {}).get("norows") else None
         # a pooled stack takes its gradient with any row stride (a column slice of the concatenated multi-scale gradient:
         # every kernel that reads it has a leading dimension) -- no copy; the unpooled paths index rows densely
         if not (cfg["pool_K"] and L > 1 and gout.dim() == 2 and gout.stride(1) == 1 and gout.stride(0) % 4 == 0 and
@@ -286,7 +311,7 @@ class SharedMLPFn(torch.autograd.Function):
         fused_red = None
         for l in range(L - 1, -1, -1):
             Y, W = Ys[l], Ws[l]
-            Cout, Kin = W.shape if W is not None else (Y.shape[1], 0)
+            Cout, Kin = W.shape if W is not None else ((nr["U"].shape[-1] if Y is None else Y.shape[1]), 0)
             scale, shift = affines[l]
             mean, invstd = stats_saved[l]
             dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -376,10 +401,16 @@ class SharedMLPFn(torch.autograd.Function):
                     Sq, Kq, Dq = info["new_xyz"].shape[1], info["K"], info["D"]
                     nblk = int(max(1, min(1024, (P + 1023) // 1024)))
                     part = torch.empty(nblk, Cout, Dq + 3, dtype=torch.float32, device=dev)
-                    with profiler.span("sa_first_layer_dw", 4.0 * P * (2 * Cout + 1)):
-                        call("prifit_sa_first_layer_dw_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
-                             ptr(info["idx"]), ptr(info["xyz"]), ptr(info["new_xyz"]), ptr(info["feat"]), Bq, Nq, Sq, Kq, Cout,
-                             Dq, int(info["feat_first"]), nblk, ptr(part), cur_stream())
+                    if nr is not None:
+                        with profiler.span("sa_first_layer_dw", 4.0 * P * (Cout + 1)):
+                            call("prifit_sa_first_layer_dw_bn_gather", ptr(G_in), ptr(nr["U"]), ptr(nr["Vc"]), ptr(scale), ptr(shift),
+                                 ptr(ca), ptr(cb), ptr(cd), ptr(info["idx"]), ptr(info["xyz"]), ptr(info["new_xyz"]),
+                                 ptr(info["feat"]), Bq, Nq, Sq, Kq, Cout, Dq, int(info["feat_first"]), nblk, ptr(part), cur_stream())
+                    else:
+                        with profiler.span("sa_first_layer_dw", 4.0 * P * (2 * Cout + 1)):
+                            call("prifit_sa_first_layer_dw_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
+                                 ptr(info["idx"]), ptr(info["xyz"]), ptr(info["new_xyz"]), ptr(info["feat"]), Bq, Nq, Sq, Kq, Cout,
+                                 Dq, int(info["feat_first"]), nblk, ptr(part), cur_stream())
                     grads[0] = part.sum(dim=0)
                 if ctx.needs_input_grad[3]:
                     grads[1] = zero_pool.zeros(Cout, device=dev)  # bias in front of a batch-stat BatchNorm
@@ -403,6 +434,30 @@ class SharedMLPFn(torch.autograd.Function):
                 extra_grads = (dVc,)
                 G_in = None
                 break
+            if l == 1 and nr is not None:
+                # layer 2 over rows that were never stored: dA + dW + the BatchNorm-backward sums of layer 1 in the one-pass
+                # kernel, which re-forms layer 1's pre-activations from U (prifit_gemm_stream_bwd_gather_f32)
+                assert fuse_bn, "norows: the streaming backward of layer 2 is required (pointnet_util._norows_scales)"
+                wo, wn, bo, bn_ = wslots[l]
+                dW = arena[wo:wo + wn].view(Cout, Kin)
+                ns = dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin)
+                rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                ws = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
+                G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+                (sc1, sh1), (mu1, is1) = affines[0], stats_saved[0]
+                with profiler.span(profiler.tag("gemm_stream_bwd", P, Cout, Kin, "gather"), 4.0 * P * (2 * Cout + Kin)):
+                    call("prifit_gemm_stream_bwd_gather_f32", _LL(P), Cout, ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca),
+                         ptr(cb), ptr(cd), ptr(W), _LL(Kin), ptr(nr["idx"]), ptr(nr["U"]), ptr(nr["Vc"]), nr["N"], nr["S"], nr["K"],
+                         ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(G_prev), _LL(Kin), ptr(rslab), ptr(dW), _LL(Kin), ptr(ws),
+                         cur_stream())
+                grads[6 * l] = dW
+                if ctx.needs_input_grad[2 + 6 * l + 1]:
+                    grads[6 * l + 1] = arena[bo:bo + bn_]   # bias in front of a batch-stat BatchNorm: zero gradient
+                grads[6 * l + 2] = dgamma
+                grads[6 * l + 3] = dbeta
+                fused_red = (rslab, ns)
+                G_in = G_prev
+                continue
             if fuse_bn:
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
@@ -545,9 +600,10 @@ def sa_group_supported(N, nsamples, widths):
 
 
 def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, Us, Vcs, biases,
-                     feat_xyz=False):
+                     feat_xyz=False, rows=None):
     """One launch: ball query for every radius + the first-layer pre-activations Y_r [B*S*K_r, C_r], their
-    BatchNorm column-statistics slabs and the int32 index lists."""
+    BatchNorm column-statistics slabs and the int32 index lists.  rows (gather mode): per radius False = do not store
+    Y_r (None is returned for it): index lists and statistics only."""
     import numpy as np
 
     B, N, _ = xyz.shape
@@ -556,7 +612,10 @@ def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widt
     dev = xyz.device
     q = dll().prifit_sa_group_queries_per_slab(B, S)
     nslab = B * ((S + q - 1) // q)
-    Ys = [torch.empty(B * S * k, c, dtype=torch.float32, device=dev) for k, c in zip(nsamples, widths)]
+    rows = [True] * R if rows is None else list(rows)
+    assert mode == 1 or all(rows)
+    Ys = [torch.empty(B * S * k, c, dtype=torch.float32, device=dev) if keep else None
+          for k, c, keep in zip(nsamples, widths, rows)]
     slabs = [torch.empty(nslab, 2, c, dtype=torch.float32, device=dev) for c in widths]
     idxs = [torch.empty(B, S, k, dtype=torch.int32, device=dev) for k in nsamples]
     r2 = (ctypes.c_float * R)(*[float(np.float32(r ** 2)) for r in radii])  # fp32(radius^2), like ops.ball_query_multi
@@ -566,7 +625,7 @@ def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widt
     # algorithmic bytes (SURVEY.md 8d with the grouped-out term = the C1-wide first-layer rows this launch writes):
     # clouds and centres once, index lists once, rows once, plus the per-point / per-centre projections (gather mode)
     # or the feature table (direct mode)
-    work = B * (12.0 * (N + S) + sum(4.0 * S * k * (1 + c) for k, c in zip(nsamples, widths)) +
+    work = B * (12.0 * (N + S) + sum(4.0 * S * k * (1 + (c if keep else 0)) for k, c, keep in zip(nsamples, widths, rows)) +
                 (sum(4.0 * (N + S) * c for c in widths) if mode == 1 else 4.0 * N * D))
     with profiler.span("sa_group_linear", work):
         call("prifit_sa_group_linear_fwd", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, wd, mode, ptr(feat), D,

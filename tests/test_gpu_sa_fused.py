@@ -218,11 +218,12 @@ def test_gather_mode_fused_first_layer_backward(mods):
             assert torch.equal(st_a[n], st_b[n]), n
 
 
-@pytest.mark.parametrize("switch,case", [("_SA_LINEARITY", "msg_sa2"), ("_DIRECT_FUSED_BWD", "msg_sa1")])
+@pytest.mark.parametrize("switch,case", [("_SA_LINEARITY", "msg_sa2"), ("_DIRECT_FUSED_BWD", "msg_sa1"), ("_SA_NOROWS", "msg_sa1")])
 def test_ab_arms_of_the_front_end(mods, switch, case):
-    """The two remaining A/B arms of the set-abstraction front end against the default: PRIFIT_SA_LINEARITY=0 (materialised
-    grouped rows + GEMM: the bytes of the SURVEY 8d grouping formula) and PRIFIT_SA_DIRECT_FUSED_BWD=0 (separate
-    bn_relu_bwd_apply pass + SAGroupDirectFn autograd)."""
+    """The A/B arms of the set-abstraction front end against the default: PRIFIT_SA_LINEARITY=0 (materialised grouped rows
+    + GEMM: the bytes of the SURVEY 8d grouping formula), PRIFIT_SA_DIRECT_FUSED_BWD=0 (separate bn_relu_bwd_apply pass +
+    SAGroupDirectFn autograd) and PRIFIT_SA_NOROWS=0 (SA1's 64-wide first-layer rows stored and read back, instead of re-formed
+    from the per-point table U by the layer-2 forward product, its one-pass backward and the weight-gradient reduction)."""
     ops, nn_ops, pu = mods
     B = 3
     if case == "msg_sa1":
