@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     // (readfirstlane: wm / wn are wave-uniform and the compiler has to know it, see gemm_stream_tn_kernel)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
+    // (measured, round 4: with N = 96 -- three 32-column blocks for the four waves of WN = 4 -- wave 3 of every workgroup has
+    // no columns; rotating the block assignment by the workgroup index, so that the idle wave lands on a different SIMD in
+    // each co-resident workgroup, changed nothing: [1.57 M x 96 x 64] 239 us, [1.57 M x 96 x 128 pooled] 504 -> 510 us)
     const int wm = wave / WN, wn = wave % WN;
     const int col = 32 * wn + li;
     const bool col_ok = col < g.N;   // wave-uniform for N % 32 == 0

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import nn_ops
+from .. import profiler
 from .._lib import call, cur_stream, dll, ptr
 from ..nn_ops import NN, NT, TN, LinearFn, gemm
 
@@ -41,7 +42,8 @@ def _knn_cl(x, k):
     else:
         xx = (x * x).sum(dim=-1)
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
-    call("prifit_knn_topk", ptr(G), ptr(xx.contiguous()), B, N, k, ptr(idx), cur_stream())
+    with profiler.span("knn_topk", 4.0 * B * N * N + 4.0 * B * N * k):      # HBM: the pairwise matrix once, the lists once
+        call("prifit_knn_topk", ptr(G), ptr(xx.contiguous()), B, N, k, ptr(idx), cur_stream())
     return idx
 
 
@@ -304,7 +306,9 @@ class EdgeConvLinFn(torch.autograd.Function):
         Y = torch.empty(P, C, dtype=torch.float32, device=dev)
         rows = dll().prifit_reduce_rows_per_slab()
         slab = torch.empty((P + rows - 1) // rows, 2, C, dtype=torch.float32, device=dev)
-        call("prifit_gather_linear_fwd", ptr(U), ptr(Vc), None, ptr(idx), B, N, N, k, C, ptr(Y), ptr(slab), cur_stream())
+        # HBM: U and Vc once, the index lists, the C-wide edge pre-activations written once
+        with profiler.span("edge_gather_linear", 4.0 * (2.0 * B * N * C + P + P * C)):
+            call("prifit_gather_linear_fwd", ptr(U), ptr(Vc), None, ptr(idx), B, N, N, k, C, ptr(Y), ptr(slab), cur_stream())
         out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, rows, gamma, beta, cfg)
         ctx.cfg, ctx.dims = cfg, (B, N, k, C)
         ctx.save_for_backward(idx, gamma, Y, scale, shift, mean, invstd, arg)
@@ -318,8 +322,10 @@ class EdgeConvLinFn(torch.autograd.Function):
         gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg)
         dU = torch.zeros(B, N, C, dtype=torch.float32, device=Y.device)
         dVc = torch.empty(B, N, C, dtype=torch.float32, device=Y.device)
-        call("prifit_gather_linear_bwd_pool", ptr(gout), _LL(gout.stride(0)), ptr(Y), ptr(arg), ptr(scale), ptr(shift), ptr(ca),
-             ptr(cb), ptr(cd), ptr(idx), B, N, N, k, C, cfg["rps"], _F(cfg["slope"]), ptr(dU), ptr(dVc), cur_stream())
+        # float atomics (one per edge element into dU): priced as bytes -- Y read once, 4 B per atomic, the index lists, dVc
+        with profiler.span("edge_scatter_pool", 4.0 * (2.0 * B * N * k * C + B * N * k + 2.0 * B * N * C)):
+            call("prifit_gather_linear_bwd_pool", ptr(gout), _LL(gout.stride(0)), ptr(Y), ptr(arg), ptr(scale), ptr(shift), ptr(ca),
+                 ptr(cb), ptr(cd), ptr(idx), B, N, N, k, C, cfg["rps"], _F(cfg["slope"]), ptr(dU), ptr(dVc), cur_stream())
         return dU, dVc, None, dgamma, dbeta, None
 
 
