@@ -221,3 +221,60 @@ def test_graphed_backbone_matches_eager(hiplib):
                 assert (ge[n] - gg[n]).norm() <= 2e-3 * ge[n].norm(), (n, (ge[n] - gg[n]).norm().item(), ge[n].norm().item())
     for n, b in eager.named_buffers():
         torch.testing.assert_close(b, dict(graphed.named_buffers())[n], rtol=1e-5, atol=1e-6)
+    # an evaluation forward must NOT replay the training-mode graph (batch statistics, running-stat updates): the installed
+    # embed_features falls back to the eager backbone in eval mode / under no_grad (advisor, round 3)
+    xyz, _ = batch(7)
+    eager.eval()
+    graphed.eval()
+    snap = {n: b.clone() for n, b in graphed.named_buffers()}
+    with torch.no_grad():
+        se = eager(xyz, cls, fps_start=starts)[0]
+        sg = graphed(xyz, cls, fps_start=starts)[0]
+    torch.testing.assert_close(sg, se, rtol=1e-5, atol=1e-5)
+    for n, b in graphed.named_buffers():
+        assert torch.equal(b, snap[n]), n                    # running statistics untouched
+
+
+def test_prefetched_selfsup_step_equals_inline_step(hiplib):
+    """Trainer.prefetch_selfsup prepares the NEXT batch (augmentation off here, explicit subset) and starts its
+    farthest-point sampling on a side stream behind the backbone forward of the step that runs in between; the following
+    selfsup_step() consumes it.  Same loss and the same parameters afterwards as the in-line step on an identical model:
+    the samples are the ones the in-line launch computes (the headline's FPS placement is something the
+    trainer can do)."""
+    from tests_helpers import fit_inputs
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    from prifit_amd.ops import SampledAhead
+    from prifit_amd.train_step import Trainer
+    B, N, Mpts = 2, 1024, 2500
+    _, cham, _ = fit_inputs(B, N, 128, 8, M=Mpts)
+    cham = cham.cuda()
+    _, cham0, _ = fit_inputs(B, N, 128, 9, M=Mpts)
+    cham0 = cham0.cuda()
+    subset = torch.from_numpy(np.random.default_rng(3).choice(Mpts, N, replace=False)).cuda()
+    starts = (torch.from_numpy(synth.fps_start(B, N, 5)).cuda(), torch.from_numpy(synth.fps_start(B, 512, 6)).cuda())
+    kw = dict(npoint=N, quantile=0.05, msc_iterations=5, max_num_clusters=25)
+    res = []
+    for prefetch in (True, False):
+        torch.manual_seed(11)
+        net = M.get_model(50)
+        synth.xavier_like_trainer(net)
+        net.cuda()
+        tr = Trainer(net)
+        torch.manual_seed(12)                      # dropout / covariance-noise streams identical in both arms
+        if prefetch:
+            tr.prefetch_selfsup(cham, npoint=N, augment=False, subset=subset, fps_start=starts)
+            assert net.after_backbone is not None
+        l0 = tr.selfsup_step(cham0, augment=False, subset=subset, fps_start=starts, **kw)      # the step in between
+        if prefetch:
+            assert net.after_backbone is None and isinstance(tr._next["ahead"][0], SampledAhead)   # launched behind its backbone
+            l1 = tr.selfsup_step(**kw)
+            assert tr._next is None
+        else:
+            l1 = tr.selfsup_step(cham, augment=False, subset=subset, fps_start=starts, **kw)
+        tr.finish()
+        res.append((l0.item(), l1.item(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()))
+    (a0, a1, pa), (b0, b1, pb) = res
+    assert abs(a0 - b0) <= 1e-5 * abs(b0) and abs(a1 - b1) <= 1e-4 * abs(b1), (a0, b0, a1, b1)
+    torch.testing.assert_close(pa, pb, rtol=1e-3, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        tr.selfsup_step(**kw)                      # nothing prefetched
