@@ -78,6 +78,63 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
     unsigned key[VPT];   // padding columns: key 0 (below every real value, -inf included: its key is 0x007fffff)
 #pragma unroll
     for (int j = 0; j < VPT; ++j) key[j] = (lane + 64 * j) < N ? knn_key((nxi - (-2.0f * gv[j])) - xv[j]) : 0u;
+    // (0) fast path (round 4).  The k-th largest of the 64 per-lane maxima, t0, is a conservative threshold: at least k keys
+    // (those maxima) are >= t0, so the k largest keys of the row are all >= t0 -- and usually little more than k keys are.
+    // When at most 64 keys pass, they are compacted and sorted right away: the composite (key, ~index) order of the sort IS
+    // topk's order (descending value, ties to the lower index), so the result is the one the bisection below would give.
+    // One compare + ballot per key instead of one per key and BISECTION ROUND (~12 rounds): 293 -> see DESIGN 5g.  Rows with
+    // more than 64 keys >= t0 (clouds full of exact ties) take the general path.
+    {
+        unsigned lmax = 0u;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) lmax = max(lmax, key[j]);
+        // t0 = the largest p with count(lane maxima >= p) >= k   (k <= 64 on this path)
+        unsigned t0 = 0u;
+        {
+            const unsigned hi = wave_max_u32_dpp(lmax), lo = ~wave_max_u32_dpp(~lmax);
+            t0 = lo;
+            if (hi != lo) {
+                const int top = 31 - __builtin_clz(hi ^ lo);
+                t0 = top == 31 ? 0u : (lo >> (top + 1)) << (top + 1);
+                for (int bit = top; bit >= 0; --bit) {
+                    const unsigned p = t0 | (1u << bit);
+                    if (__builtin_popcountll(__ballot(lmax >= p)) >= k) t0 = p;
+                }
+            }
+        }
+        const unsigned long long ltm = (1ull << lane) - 1ull;
+        int n0 = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const bool take = key[j] >= t0 && key[j] != 0u;
+            const unsigned long long mt = __ballot(take);
+            const int pos = n0 + __builtin_popcountll(mt & ltm);
+            if (take && pos < 64)
+                s_sel[wave][pos] = ((unsigned long long)key[j] << 32) | (unsigned)(~(unsigned)(lane + 64 * j));
+            n0 += __builtin_popcountll(mt);
+        }
+        if (n0 >= k && n0 <= 64) {   // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned long long v = lane < n0 ? s_sel[wave][lane] : 0ull;
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+                for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                    const unsigned lo2 = __shfl_xor((unsigned)v, stride, 64), hi2 = __shfl_xor((unsigned)(v >> 32), stride, 64);
+                    const unsigned long long o = ((unsigned long long)hi2 << 32) | lo2;
+                    const bool up = (lane & size) != 0;
+                    const bool lower = (lane & stride) == 0;
+                    const bool keep_max = up ? !lower : lower;
+                    v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
+                }
+            }
+            if (lane < k) idx[row * k + lane] = (int)(~(unsigned)v);
+            return;
+        }
+        __builtin_amdgcn_wave_barrier();   // (the general path below rewrites s_sel)
+    }
     // (1) tau = the k-th largest key: the largest p with count(key >= p) >= k
     unsigned kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll

@@ -58,6 +58,63 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
         if (lane == 0) out[row] = key2f(kmin);
         return;
     }
+    // Fast path (round 4) for k <= 256.  The k-th smallest of the m = ceil(k / 64) smallest keys OF EVERY LANE (64 m >= k
+    // candidates, a subset of the row) is an upper bound t0 of the answer, so the answer is the k-th smallest among the keys
+    // <= t0 -- usually little more than k of the C keys.  Those are compacted into LDS (at most 256) and the bisection runs on
+    // four keys per lane instead of VPT: one compare + ballot per key of the row instead of one per key and ROUND.
+    // The value is the same (a selection by value: ties do not matter).  Rows with more than 256 keys <= t0 (many exact
+    // ties) take the general path below.
+    if (k <= 256) {
+        __shared__ unsigned s_c[4][256];
+        const int wv = threadIdx.x >> 6;
+        const int m = (k + 63) >> 6;                       // wave-uniform, 1..4
+        unsigned sm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // the lane's m smallest keys, ascending
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            unsigned x = key[j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < m) { const unsigned lo = min(x, sm[t]); x = max(x, sm[t]); sm[t] = lo; }
+            }
+        }
+        // t0 = k-th smallest of the 64 m candidates: the largest p with count(candidates < p) < k (>= kmin; bits above `top`
+        // are shared by every key of the row)
+        auto kth_of = [&](const unsigned (&v)[4], int nv, int kk) {
+            const int tp = 31 - __builtin_clz(kmin ^ kmax);
+            unsigned pre = tp == 31 ? 0u : (kmin >> (tp + 1)) << (tp + 1);
+            for (int bit = tp; bit >= 0; --bit) {
+                const unsigned p = pre | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < nv) cnt += __builtin_popcountll(__ballot(v[t] < p));
+                if (cnt < kk) pre = p;
+            }
+            return pre;   // = the kk-th smallest value itself (the largest p with fewer than kk values below it)
+        };
+        const unsigned t0 = kth_of(sm, m, k);
+        const unsigned long long ltm = (1ull << lane) - 1ull;
+        int n0 = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const bool take = key[j] <= t0;                // (padding keys 0xffffffff: only if t0 is, i.e. never for k <= C)
+            const unsigned long long mt = __ballot(take);
+            const int pos = n0 + __builtin_popcountll(mt & ltm);
+            if (take && pos < 256) s_c[wv][pos] = key[j];
+            n0 += __builtin_popcountll(mt);
+        }
+        if (n0 <= 256) {   // wave-uniform (n0 >= k by construction)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned cv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cv[t] = (lane + 64 * t) < n0 ? s_c[wv][lane + 64 * t] : 0xffffffffu;
+            const unsigned ans = kth_of(cv, 4, k);
+            if (lane == 0) out[row] = key2f(ans);
+            return;
+        }
+    }
     const int top = 31 - __builtin_clz(kmin ^ kmax);
     unsigned prefix = top == 31 ? 0u : (kmin >> (top + 1)) << (top + 1);
     int c_lo = 0, c_hi = C;   // keys below the lower / the upper end of the bracket [prefix, prefix + 2^(top+1))

@@ -728,6 +728,16 @@ class SAGroupGatherFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+def _few_rows_splitk(M, N, K):
+    """Split of the reduction for a product with at most one row tile (M <= 128: the per-SAMPLE rows of the DGCNN decoder's
+    offset, 24 x 512 x 1024) and a deep K: its N / 128 workgroups would each walk all of K serially (88 us for 25 MFLOP).
+    Aim at ~256 workgroups, >= 2 k-tiles of 32 each."""
+    if M > 128 or K < 256:
+        return 1
+    tiles = max(1, (N + 127) // 128)
+    return int(max(1, min(256 // tiles, K // 64)))
+
+
 class LinearFn(torch.autograd.Function):
     """Y = X W^T + b on [P, C] rows (a conv1x1 without BatchNorm: conv2 / extra_conv_emb,
     models/pointnet2_part_seg_msg.py:109,128)."""
@@ -738,8 +748,13 @@ class LinearFn(torch.autograd.Function):
         W = W.contiguous()
         P, Kin = x.shape
         Cout = W.shape[0]
-        Y = torch.empty(P, Cout, dtype=torch.float32, device=x.device)
-        gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=b)
+        sk = _few_rows_splitk(P, Cout, Kin)
+        if sk > 1:   # a handful of rows against a deep reduction: a few workgroups would each walk the whole K serially
+            Y = zero_pool.zeros(P, Cout, device=x.device)
+            gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=b, splitk=sk)
+        else:
+            Y = torch.empty(P, Cout, dtype=torch.float32, device=x.device)
+            gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=b)
         ctx.save_for_backward(x, W)
         return Y
 
@@ -751,8 +766,13 @@ class LinearFn(torch.autograd.Function):
         Cout = W.shape[0]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(P, Kin, dtype=torch.float32, device=x.device)
-            gemm(NN, P, Kin, Cout, gy, Cout, W, Kin, dx, Kin)
+            sk = _few_rows_splitk(P, Kin, Cout)
+            if sk > 1:
+                dx = zero_pool.zeros(P, Kin, device=x.device)
+                gemm(NN, P, Kin, Cout, gy, Cout, W, Kin, dx, Kin, splitk=sk)
+            else:
+                dx = torch.empty(P, Kin, dtype=torch.float32, device=x.device)
+                gemm(NN, P, Kin, Cout, gy, Cout, W, Kin, dx, Kin)
         if ctx.needs_input_grad[1]:
             dW = _weight_grad(gy, P, Cout, x, Kin, None)
         if ctx.needs_input_grad[2]:
