@@ -278,3 +278,43 @@ def test_prefetched_selfsup_step_equals_inline_step(hiplib):
     torch.testing.assert_close(pa, pb, rtol=1e-3, atol=1e-5)
     with pytest.raises(RuntimeError):
         tr.selfsup_step(**kw)                      # nothing prefetched
+
+
+def test_alternating_trainer_steps_train(hiplib):
+    """The reference's loop (train_partseg_shapenet.py:346-451): supervised step, then self-supervised step, several times on
+    one synthetic batch through Trainer -- prefetching the self-supervised batch each time.  Everything stays finite, the
+    supervised loss goes down, every parameter has moved, and the optimizer has stepped each parameter 2 x iterations times
+    (zero-filled gradients for the parameters a step does not reach: the reference's zero_grad semantics)."""
+    from tests_helpers import fit_inputs
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    from prifit_amd.train_step import Trainer
+    B, N, Mpts, iters = 4, 1024, 2500, 5
+    _, cham, _ = fit_inputs(B, N, 128, 21, M=Mpts)
+    cham = cham.cuda()
+    sup_pts = cham[:, :N].contiguous()
+    target = torch.from_numpy(synth.part_labels(sup_pts.cpu().numpy(), 8, 3)).long().cuda()     # spatial parts: learnable
+    torch.manual_seed(5)
+    np.random.seed(5)
+    net = M.get_model(50)
+    synth.xavier_like_trainer(net)
+    net.cuda()
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    tr = Trainer(net, learning_rate=0.002)
+    sup, ss = [], []
+    for it in range(iters):
+        tr.prefetch_selfsup(cham, npoint=N)
+        loss, acc = tr.supervised_step(sup_pts, target)
+        sup.append(loss.item())
+        ss.append(tr.selfsup_step(quantile=0.05, msc_iterations=5, max_num_clusters=25).item())
+    tr.finish()
+    assert all(np.isfinite(sup)) and all(np.isfinite(ss)), (sup, ss)
+    assert sup[-1] < 0.9 * sup[0], sup
+    for k, p in net.named_parameters():
+        assert torch.isfinite(p).all(), k
+        # (a conv bias in front of a batch-statistics BatchNorm has an exactly zero gradient and starts at zero: it stays there)
+        if k.endswith("weight"):
+            assert not torch.equal(p.detach(), before[k]), k
+    steps = {int(st["step"]) for st in tr.optimizer.state.values()}
+    # conv2 first gets a gradient in step 1 (supervised), extra_conv_emb in step 2 (self-supervised): afterwards every
+    # parameter steps every time
+    assert steps <= {2 * iters, 2 * iters - 1}, steps
