@@ -133,9 +133,24 @@ def _use_linearity(conv, kp):
     return _SA_LINEARITY and kp > conv.weight.shape[0]
 
 
-def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first, fold_bias=False):
+def _linearity_rows(feats, xyz, new_xyz, kp):
+    """The two row tables every radius of a level multiplies: rows [B N, kp] = [feat | xyz | 0-pad] per point and
+    c4 [B S, 4] = [centre | 0] per centre (built once per level, not once per radius)."""
+    B, N, _ = xyz.shape
+    D = 0 if feats is None else feats.shape[-1]
+    S = new_xyz.shape[1]
+    parts = ([feats] if feats is not None else []) + [xyz]
+    if kp > D + 3:
+        parts.append(_z(xyz, B, N, kp - D - 3))
+    rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
+    c4 = torch.cat([new_xyz, _z(new_xyz, B, S, 1)], dim=-1).reshape(B * S, 4)
+    return rows, c4
+
+
+def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first, fold_bias=False, tables=None):
     """U [B,N,C1] = [feat | xyz] W1^T per POINT and Vc [B,S,C1] = c W1x^T per CENTRE (two small GEMMs):
-    conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias.  fold_bias: the bias is added to U (then y = U_j - Vc_g)."""
+    conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g + bias.  fold_bias: the bias is added to U (then y = U_j - Vc_g).
+    tables: `_linearity_rows(...)` of the level when several radii share them."""
     B, N, _ = xyz.shape
     D = 0 if feats is None else feats.shape[-1]
     S = new_xyz.shape[1]
@@ -145,13 +160,9 @@ def _linearity_operands(conv, feats, xyz, new_xyz, kp, feat_first, fold_bias=Fal
         fcols, xcols = list(range(D)), list(range(D, D + 3))
     else:            # upstream single-scale order [rel_xyz, features] (:131)
         fcols, xcols = list(range(3, 3 + D)), list(range(3))
-    parts = ([feats] if feats is not None else []) + [xyz]
-    if kp > D + 3:
-        parts.append(_z(xyz, B, N, kp - D - 3))
-    rows = torch.cat(parts, dim=-1).reshape(B * N, kp)
+    rows, c4 = tables if tables is not None else _linearity_rows(feats, xyz, new_xyz, kp)
     w_pt = _pack_cols(w, fcols + xcols + [-1] * (kp - D - 3))
     U = LinearFn.apply(rows, w_pt, conv.bias if fold_bias else None).reshape(B, N, C1)
-    c4 = torch.cat([new_xyz, _z(new_xyz, B, S, 1)], dim=-1).reshape(B * S, 4)
     Vc = LinearFn.apply(c4, _pack_cols(w, xcols + [-1]), None).reshape(B, S, C1)
     return U, Vc
 
@@ -276,7 +287,8 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
         # SharedMLPFn that consumes Y1 returns dU / dVc with its first BatchNorm backward folded in (cfg["preact_gather"])
         B, N, _ = xyz.shape
         S = new_xyz.shape[1]
-        ops_ = [_linearity_operands(c, feats, xyz, new_xyz, kp, feat_first) for c in first_convs]
+        tables = _linearity_rows(feats, xyz, new_xyz, kp)
+        ops_ = [_linearity_operands(c, feats, xyz, new_xyz, kp, feat_first, tables=tables) for c in first_convs]
         with torch.no_grad():
             Us = [u.detach().contiguous() for u, _ in ops_]
             Vcs = [v.detach().contiguous() for _, v in ops_]
@@ -292,8 +304,9 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
         out = SAGroupDirectFn.apply(xyz, new_xyz, feats, (list(radii), list(nsamples), feat_first, training), *ts)
     else:
         ts = []
+        tables = _linearity_rows(feats, xyz, new_xyz, kp)
         for c in first_convs:
-            U, Vc = _linearity_operands(c, feats, xyz, new_xyz, kp, feat_first)
+            U, Vc = _linearity_operands(c, feats, xyz, new_xyz, kp, feat_first, tables=tables)
             ts += [U, Vc, c.bias]
         out = SAGroupGatherFn.apply(xyz, new_xyz, (list(radii), list(nsamples), training), *ts)
     return [(out[2 * i], out[2 * i + 1], None) for i in range(len(first_convs))]
