@@ -747,4 +747,7 @@ if __name__ == "__main__":
     if "prune" in which:
         import make_golden_fit
         make_golden_fit.run_prune(save, eq, close)
+    if "intersections" in which:
+        import make_golden_fit
+        make_golden_fit.run_intersections(save, eq, close)
     print("all oracle-vs-reference checks passed; fixtures under", GOLD)

@@ -184,6 +184,71 @@ def run_prune(save, eq, close):
     save("fit_prune", **out)
 
 
+def overlapping_params(seed, Ks, grad=False):
+    """Ellipsoids with close centres (heavy overlap), one list per shape."""
+    rng = np.random.default_rng(seed)
+    batch = []
+    for K in Ks:
+        params = []
+        for k in range(K):
+            r = torch.from_numpy(rng.uniform(0.15, 0.5, 3).astype(np.float32))
+            Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            if np.linalg.det(Q) < 0:
+                Q[:, 2] = -Q[:, 2]
+            c = torch.from_numpy(rng.uniform(-0.25, 0.25, 3).astype(np.float32))
+            params.append(tuple(t.requires_grad_(grad) for t in (r, torch.from_numpy(Q.astype(np.float32)), c)))
+        batch.append(params)
+    return batch
+
+
+def run_intersections(save, eq, close):
+    """The intersection-loss variants upstream keeps but does not call (convex_loss.py:106, :163, :227, :346, :416) and
+    sample_axis (:285): oracle vs reference, value and gradient with respect to every (r, V, c); fixture for the HIP-side
+    adapters (`make_golden.py intersections`)."""
+    CL = refshim.ref("convex_loss")
+    Ks = (3, 5, 1, 2)
+    rng = np.random.default_rng(91)
+    surf = [torch.from_numpy(rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32)) for n in (300, 257, 64, 128)]
+    pts = torch.from_numpy(rng.uniform(-0.6, 0.6, (len(Ks), 256, 3)).astype(np.float32))
+    out = {"Ks": np.array(Ks, np.int32), "pts": pts}
+    for b, p in enumerate(surf):
+        out[f"surf_{b}"] = p
+    base = overlapping_params(78, Ks)
+    for b in range(len(Ks)):
+        out[f"r_{b}"] = torch.stack([p[0] for p in base[b]])
+        out[f"V_{b}"] = torch.stack([p[1] for p in base[b]])
+        out[f"c_{b}"] = torch.stack([p[2] for p in base[b]])
+    r0, V0, c0 = base[0][1]
+    ax_r, ax_o = CL.sample_axis(r0, V0, c0), orc.sample_axis(r0, V0, c0)
+    close(ax_o, ax_r, "sample_axis", rtol=1e-6, atol=1e-7)
+    out["axis_samples"] = ax_r
+    variants = {
+        "surface": (lambda P: CL.compute_intersection_loss(P, surf), lambda P: orc.intersection_loss_surface(P, surf)),
+        "surface_cuboid": (lambda P: CL.compute_intersection_loss_cuboid(P, surf),
+                           lambda P: orc.intersection_loss_surface(P, surf, cuboid=True)),
+        "volume": (lambda P: CL.compute_intersection_loss_volume(P, surf), lambda P: orc.intersection_loss_volume(P, surf)),
+        "volume_2": (lambda P: CL.compute_intersection_loss_volume_2(P, pts), lambda P: orc.intersection_loss_volume_2(P, pts)),
+        "volume_4": (lambda P: CL.compute_intersection_loss_volume_4(P, pts), lambda P: orc.intersection_loss_volume_4(P, pts)),
+    }
+    for name, (fr, fo) in variants.items():
+        Pr, Po = overlapping_params(78, Ks, grad=True), overlapping_params(78, Ks, grad=True)
+        lr, lo = fr(Pr), fo(Po)
+        close(lo, lr, f"intersection {name}", rtol=1e-5, atol=1e-8)
+        lr.backward()
+        lo.backward()
+        out[f"{name}_loss"] = lr.detach().reshape(())
+        for b in range(len(Ks)):
+            for i, tag in enumerate("rVc"):
+                gr = torch.stack([torch.zeros_like(p[i]) if p[i].grad is None else p[i].grad for p in Pr[b]])
+                go = torch.stack([torch.zeros_like(p[i]) if p[i].grad is None else p[i].grad for p in Po[b]])
+                close(go, gr, f"intersection {name} d{tag} b={b}", rtol=1e-4, atol=1e-6 * max(1.0, gr.abs().max().item()))
+                out[f"{name}_d{tag}_{b}"] = gr
+        print("    %-15s loss %.6e" % (name, lr.item()))
+    empty = CL.compute_intersection_loss([], [])
+    assert empty.shape == (1,) and empty.item() == 0.0
+    save("fit_intersections", **out)
+
+
 def run(save, eq, close):
     print("[fit]")
     MS = refshim.ref("src.mean_shift")

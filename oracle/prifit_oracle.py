@@ -895,6 +895,97 @@ def intersection_loss_volume_3(params_batch, points, cuboid=False):
     return torch.stack(losses).mean()
 
 
+def _local_coords(points, r, V, center):
+    """(V^T (p - c)) per point, convex_loss.py:130, :179, :323, :483."""
+    return (V.t() @ (points - center).t()).t()
+
+
+def intersection_loss_surface(params_batch, sampled_points_batch, cuboid=False):
+    """convex_loss.py:106-160 (`compute_intersection_loss`) and :163-206 (`compute_intersection_loss_cuboid`), unused
+    upstream (only volume_3 is called, :98).  Per shape: SDF of the shape's sampled surface points w.r.t. every primitive,
+    min over the primitives, clamp_max(-1e-3), mean; squared, mean over shapes.  NOTE the ellipsoid SDF here divides by k1
+    WITHOUT the +1e-6 of compute_sdf_ellipsoid (:135 vs :327) and the cuboid SDF is max_i(|q_i| - r_i) only (:184).
+    The ellipsoid variant loops over len(sampled_points_batch) and returns zeros(1) for an empty batch (:122-123, :158)."""
+    n = len(params_batch) if cuboid else len(sampled_points_batch)
+    if n == 0:
+        return torch.zeros(1, requires_grad=True)
+    losses = []
+    for b in range(n):
+        sdfs = []
+        for r, V, c in params_batch[b]:
+            q = _local_coords(sampled_points_batch[b], r, V, c)
+            if cuboid:
+                sdfs.append(torch.max(torch.abs(q) - r, 1)[0])
+            else:
+                k0 = torch.norm(q / (r + 1e-6), p=2, dim=1)
+                k1 = torch.norm(q / (r ** 2 + 1e-6), p=2, dim=1)
+                sdfs.append(k0 * (k0 - 1.0) / k1)
+        s = torch.clamp_max(torch.min(torch.stack(sdfs, 1), 1)[0], -1e-3)
+        losses.append(torch.mean(s))
+    return (torch.stack(losses) ** 2).mean()
+
+
+def sample_axis(r, V, center, num_samples=40):
+    """convex_loss.py:285-310: points on the three principal axes at ratios linspace(-0.9, 0.897, n_i) of the half-length,
+    n_i = int(r_i * num_samples / sum(r)) + 1 (more along the longer axes), centre added."""
+    axes = (V * r.view(1, 3)).t()
+    with torch.no_grad():
+        n = (r * num_samples / torch.sum(r)).int() + 1
+    rows = [axes[i:i + 1] * torch.linspace(-0.9, 0.897, int(n[i])).view(-1, 1) for i in range(3)]
+    return torch.cat(rows, 0) + center.view(1, 3)
+
+
+def intersection_loss_volume(params_batch, sampled_points_batch):
+    """convex_loss.py:227-282 (`compute_intersection_loss_volume`), unused upstream.  As WRITTEN (not as documented): the
+    inner loop over j != i evaluates the axis samples of ellipsoid i against ellipsoid i ITSELF (:252 indexes [b][i]), so
+    every one of the K-1 stacked rows is the same vector; per ellipsoid mean(clamp_max(., -1e-3)), per shape mean of the
+    squares over its ellipsoids, shapes with <= 1 ellipsoid skipped, mean over the rest (zeros(1) if none)."""
+    if len(sampled_points_batch) == 0:
+        return torch.zeros(1, requires_grad=True)
+    losses = []
+    for b in range(len(sampled_points_batch)):
+        params = params_batch[b]
+        if len(params) <= 1:
+            continue
+        per = []
+        for r, V, c in params:
+            s = sdf_ellipsoid(sample_axis(r, V, c), c, r, V)
+            per.append(torch.mean(torch.clamp_max(s, -1e-3)))
+        losses.append(torch.mean(torch.stack(per) ** 2))
+    if not losses:
+        return torch.zeros(1, requires_grad=True)
+    return torch.stack(losses).mean()
+
+
+def intersection_loss_volume_2(params_batch, points):
+    """convex_loss.py:346-371, unused upstream: per shape with > 1 ellipsoid, clamp_max(sdf, -1e-3) minus its detached
+    row minimum, squared, mean over points and ellipsoids; mean over those shapes."""
+    losses = []
+    for b, params in enumerate(params_batch):
+        if len(params) <= 1:
+            continue
+        sdf = torch.clamp_max(torch.stack([sdf_ellipsoid(points[b], c, r, V) for r, V, c in params], 1), -1e-3)
+        sdf = sdf - torch.min(sdf, 1, keepdim=True)[0].detach()
+        losses.append((sdf ** 2).mean())
+    if not losses:
+        return torch.zeros(1, requires_grad=True)
+    return torch.stack(losses).mean()
+
+
+def intersection_loss_volume_4(params_batch, points):
+    """convex_loss.py:416-441, unused upstream: per point sum_k clamp_max(sdf_k, -1e-3)^2 minus the square of the row
+    minimum (gradient flows through the minimum here), mean over points; shapes with exactly one ellipsoid skipped."""
+    losses = []
+    for b, params in enumerate(params_batch):
+        if len(params) == 1:
+            continue
+        sdf = torch.clamp_max(torch.stack([sdf_ellipsoid(points[b], c, r, V) for r, V, c in params], 1), -1e-3)
+        losses.append((torch.sum(sdf ** 2, 1) - torch.min(sdf, 1)[0] ** 2).mean())
+    if not losses:
+        return torch.zeros(1, requires_grad=True)
+    return torch.stack(losses).mean()
+
+
 def convex_loss(points, chamfer_points, X, quantile=0.01, iterations=5, max_num_clusters=25, rand_table=None,
                 canonical=False, return_info=False, include_entropy_loss=False, entropy_indices=None,
                 include_intersect_loss=False, intersect_jitter=None, alpha=1, beta=1, if_cuboid=False, center_ids=None,

@@ -201,6 +201,100 @@ def compute_intersection_loss_volume_3(ellipsoid_params_batch, points, cuboid=Fa
     return intersection_loss_volume_3(r, V, c, valid, points.contiguous(), cuboid=cuboid)
 
 
+# The intersection-loss variants upstream keeps but never calls (only volume_3 is, convex_loss.py:98).  They are here so
+# that code importing them by name keeps working; the two that evaluate the standard SDF at given points run on the HIP
+# SDF kernel, the other three use formulas of their own (or need the gradient through the sampled points) and are torch
+# compositions on the device.
+def _zero_loss(device):
+    return torch.zeros(1, device=device).requires_grad_(True)             # convex_loss.py:158, :275, :369
+
+
+def _local_sdf(points, params, kind):
+    """[n,K] of one shape in torch: 'quotient' = k0 (k0 - 1) / k1 without the +1e-6 of compute_sdf_ellipsoid (:132-135),
+    'ellipsoid' = with it (:324-327), 'boxmax' = max_i(|q_i| - r_i) (:181-184)."""
+    r = torch.stack([p[0] for p in params])                              # [K,3]
+    V = torch.stack([p[1] for p in params])                              # [K,3,3]
+    c = torch.stack([p[2] for p in params])                              # [K,3]
+    q = torch.einsum("kji,nkj->nki", V, points[:, None, :] - c[None])    # V^T (p - c)
+    if kind == "boxmax":
+        return (q.abs() - r[None]).max(dim=2)[0]
+    k0 = torch.norm(q / (r[None] + 1e-6), p=2, dim=2)
+    k1 = torch.norm(q / (r[None] ** 2 + 1e-6), p=2, dim=2)
+    return k0 * (k0 - 1.0) / (k1 + 1e-6 if kind == "ellipsoid" else k1)
+
+
+def _surface_intersection(params_batch, sampled_points_batch, n, kind):
+    per = []
+    for b in range(n):
+        s = _local_sdf(sampled_points_batch[b], params_batch[b], kind).min(dim=1)[0]
+        per.append(torch.clamp_max(s, -1e-3).mean())
+    return (torch.stack(per) ** 2).mean()
+
+
+def compute_intersection_loss(ellipsoid_params_batch, sampled_points_batch):
+    """:106-160: per shape mean over its sampled surface points of clamp_max(min_k sdf_k, -1e-3), squared, mean over the
+    len(sampled_points_batch) shapes; zeros(1) for an empty batch."""
+    if len(sampled_points_batch) == 0:
+        return _zero_loss(torch.device("cuda"))
+    return _surface_intersection(ellipsoid_params_batch, sampled_points_batch, len(sampled_points_batch), "quotient")
+
+
+def compute_intersection_loss_cuboid(ellipsoid_params_batch, sampled_points_batch):
+    """:163-206: the same with the box distance max_i(|q_i| - r_i), over len(ellipsoid_params_batch) shapes."""
+    return _surface_intersection(ellipsoid_params_batch, sampled_points_batch, len(ellipsoid_params_batch), "boxmax")
+
+
+def sample_axis(r, V, center, num_samples=40):
+    """:285-310: points on the principal axes at ratios linspace(-0.9, 0.897, n_i) of the half-lengths, n_i =
+    int(r_i * num_samples / sum r) + 1.  The counts are read on the host (they size the result)."""
+    axes = (V * r.view(1, 3)).t()
+    with torch.no_grad():
+        n = ((r * num_samples / torch.sum(r)).int() + 1).tolist()
+    rows = [axes[i:i + 1] * torch.linspace(-0.9, 0.897, n[i]).view(-1, 1).to(r.device) for i in range(3)]
+    return torch.cat(rows, 0) + center.view(1, 3)
+
+
+def compute_intersection_loss_volume(ellipsoid_params_batch, sampled_points_batch):
+    """:227-282 as WRITTEN: the loop over j != i evaluates ellipsoid i's axis samples against ellipsoid i itself (:252
+    indexes [b][i]), K-1 identical rows; per ellipsoid mean(clamp_max(sdf, -1e-3)), per shape the mean of the squares,
+    shapes with <= 1 ellipsoid skipped.  The samples carry gradient to (r, V, c), so this one is composed in torch."""
+    if len(sampled_points_batch) == 0:
+        return _zero_loss(torch.device("cuda"))
+    losses = []
+    for b in range(len(sampled_points_batch)):
+        params = ellipsoid_params_batch[b]
+        if len(params) <= 1:
+            continue
+        per = [torch.clamp_max(_local_sdf(sample_axis(r, V, c), [(r, V, c)], "ellipsoid")[:, 0], -1e-3).mean()
+               for r, V, c in params]
+        losses.append((torch.stack(per) ** 2).mean())
+    if not losses:
+        return _zero_loss(sampled_points_batch[0].device if torch.is_tensor(sampled_points_batch[0]) else torch.device("cuda"))
+    return torch.stack(losses).mean()
+
+
+def _clamped_sdf_matrices(ellipsoid_params_batch, points, skip):
+    sdfs = _sdf_lists(points, ellipsoid_params_batch, False)              # HIP SDF kernel, all shapes in one launch
+    return [torch.clamp_max(torch.stack(s, 1), -1e-3) for s in sdfs if not skip(len(s))]
+
+
+def compute_intersection_loss_volume_2(ellipsoid_params_batch, points):
+    """:346-371: clamp_max(sdf, -1e-3) minus its detached row minimum, squared, mean; shapes with <= 1 ellipsoid skipped."""
+    mats = _clamped_sdf_matrices(ellipsoid_params_batch, points, lambda k: k <= 1)
+    if not mats:
+        return _zero_loss(points[0].device)
+    return torch.stack([((m - m.min(dim=1, keepdim=True)[0].detach()) ** 2).mean() for m in mats]).mean()
+
+
+def compute_intersection_loss_volume_4(ellipsoid_params_batch, points):
+    """:416-441: per point sum_k clamp_max(sdf_k, -1e-3)^2 minus the squared row minimum, mean; shapes with exactly one
+    ellipsoid skipped (:427); a shape with none is skipped too (upstream's torch.stack([]) would raise)."""
+    mats = _clamped_sdf_matrices(ellipsoid_params_batch, points, lambda k: k <= 1)
+    if not mats:
+        return _zero_loss(points[0].device)
+    return torch.stack([((m ** 2).sum(dim=1) - m.min(dim=1)[0] ** 2).mean() for m in mats]).mean()
+
+
 def prune_points(points, ellipsoid_param_batch, thres=-1e-3):
     """:444-470: of the predicted surface points of every shape keep those whose SDF with respect to the UNION of the
     shape's ellipsoids (min over k) is above `thres`, i.e. drop points well inside another primitive.  points: list[B]

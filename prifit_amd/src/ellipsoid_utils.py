@@ -1,5 +1,6 @@
 """Call surface of the reference's src/ellipsoid_utils.py on the MI355X backend: guard_mean_shift (:9-27),
-clustering (:31-73), sample_from_pred_params (:76-130), compute_approximate_ellipsoid_area (:157-159)."""
+clustering (:31-73), sample_from_pred_params (:76-130), to_one_hot (:146-154), compute_approximate_ellipsoid_area (:157-159),
+sample_from_pred_params_cuboid (:162-214)."""
 import torch
 
 from .. import fit_ops
@@ -32,6 +33,12 @@ def clustering(X, num_samples=1000, quantile=0.01, iterations=5, visualize=False
                          num_samples=num_samples, bandwidth_rows=bandwidth_rows)
     counts = cl["count"].cpu().tolist()
     return [cl["W"][b, :, :counts[b]] for b in range(X.shape[0])], list(cl["labels"].unbind(0))
+
+
+def to_one_hot(target, maxx=50):
+    """upstream :146-154 (unused there): numpy integer labels [N] -> one-hot float [N, maxx] on the device."""
+    idx = torch.as_tensor(target).to(device="cuda", dtype=torch.int64).unsqueeze(1)
+    return torch.zeros(idx.shape[0], maxx, device="cuda").scatter_(1, idx, 1)
 
 
 def compute_approximate_ellipsoid_area(a, b, c, p=1.585):

@@ -6,6 +6,8 @@ goldens captured from the reference (VERDICT r3 "missing" 2-3, "weak" 2-3):
   sample_and_group(..., returnfps=True), sample_and_group_all;
 * convex_loss.py:313-343, :374-413, :444-502 -- compute_sdf_ellipsoid(s)(_batch), compute_sdf_cuboid(s)(_batch),
   compute_intersection_loss_volume_3, prune_points;
+* convex_loss.py:106, :163, :227, :285, :346, :416 -- the intersection variants upstream keeps but never calls, and
+  sample_axis, value and gradient against the reference's autograd;
 * src/ellipsoid_utils.py:162-214 sample_from_pred_params_cuboid, src/sample_ellipsoid.py:65-96 sample_cuboid,
   src/ellipsoid_fitting.py:19-69,119-141 single-cluster weighted_ellipsoid_fitting / principal_axis_ellipsoid;
 * the gradient through `center = new_X[indices]` alone (src/mean_shift.py:46) on the row-sparse engine against the
@@ -19,7 +21,7 @@ import torch
 
 import prifit_oracle as orc
 from prifit_amd import synth
-from tests_helpers import fit_inputs
+from tests_helpers import check_intersection_grads, fit_inputs, intersection_case
 
 pytestmark = pytest.mark.gpu
 
@@ -228,3 +230,40 @@ def test_center_gather_gradient_matches_reference_golden(ref_names, golden):
         torch.testing.assert_close(dX.sum(0), _t(g[f"dX_colsum_{b}"]), rtol=0, atol=2e-3 * float(_t(g[f"dX_colsum_{b}"]).abs().max()))
         torch.testing.assert_close(dX.norm(dim=1), _t(g[f"dX_rownorm_{b}"]), rtol=0, atol=2e-3 * scale)
         assert abs(float(dX.norm()) - float(g[f"dX_norm_{b}"])) <= 1e-3 * float(g[f"dX_norm_{b}"])
+
+
+@pytest.mark.parametrize("name", ["surface", "surface_cuboid", "volume", "volume_2", "volume_4"])
+def test_unused_intersection_variants_by_reference_names(ref_names, golden, name):
+    """compute_intersection_loss(_cuboid / _volume / _volume_2 / _volume_4) as upstream spells them: loss and the gradient
+    with respect to every (r, V, c) against fit_intersections.npz (captured from the reference's autograd)."""
+    CL = ref_names("convex_loss")
+    g = golden("fit_intersections")
+    P, surf, pts = intersection_case(g, "cuda")
+    fn = {"surface": lambda: CL.compute_intersection_loss(P, surf),
+          "surface_cuboid": lambda: CL.compute_intersection_loss_cuboid(P, surf),
+          "volume": lambda: CL.compute_intersection_loss_volume(P, surf),
+          "volume_2": lambda: CL.compute_intersection_loss_volume_2(P, pts),
+          "volume_4": lambda: CL.compute_intersection_loss_volume_4(P, pts)}[name]
+    loss = fn()
+    assert loss.is_cuda
+    torch.testing.assert_close(loss.detach().cpu().reshape(()), _t(g[f"{name}_loss"]), rtol=1e-4, atol=1e-8)
+    loss.backward()
+    check_intersection_grads(g, name, P, rtol=1e-3)
+
+
+def test_sample_axis_and_empty_batches_by_reference_names(ref_names, golden):
+    CL = ref_names("convex_loss")
+    g = golden("fit_intersections")
+    got = CL.sample_axis(_t(g["r_0"][1]).cuda(), _t(g["V_0"][1]).cuda(), _t(g["c_0"][1]).cuda())
+    torch.testing.assert_close(got.cpu(), _t(g["axis_samples"]), rtol=1e-6, atol=1e-6)
+    for fn in (CL.compute_intersection_loss, CL.compute_intersection_loss_volume):
+        z = fn([], [])                                                 # convex_loss.py:158, :280: zeros(1) that needs grad
+        assert z.shape == (1,) and z.item() == 0.0 and z.requires_grad and z.is_cuda
+    labels = np.array([3, 0, 49, 7])
+    hot = ref_names("src.ellipsoid_utils").to_one_hot(labels)          # src/ellipsoid_utils.py:146-154
+    assert hot.shape == (4, 50) and hot.is_cuda and torch.equal(hot.argmax(1).cpu(), _t(labels)) and hot.sum().item() == 4
+    one = [[(_t(g["r_2"][0]).cuda(), _t(g["V_2"][0]).cuda(), _t(g["c_2"][0]).cuda())]]
+    pts = _t(g["pts"])[2:3].cuda()
+    for fn in (CL.compute_intersection_loss_volume_2, CL.compute_intersection_loss_volume_4):
+        z = fn(one, pts)                                               # a lone ellipsoid: every shape skipped (:356, :427)
+        assert z.shape == (1,) and z.item() == 0.0 and z.requires_grad

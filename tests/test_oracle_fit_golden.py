@@ -2,10 +2,12 @@
 (oracle/make_golden_fit.py): bandwidth, mean-shift iterations + autograd, nms, membership, weighted
 ellipsoid fit + autograd, analytic chamfer, convex_loss."""
 import numpy as np
+import pytest
 import torch
 
 import prifit_oracle as orc
 from prifit_amd import synth
+from tests_helpers import check_intersection_grads, intersection_case
 
 
 def _t(a):
@@ -180,3 +182,30 @@ def test_prune_points_golden(golden):
         assert kept[b].shape[0] == int(g[f"keep_{b}"].sum())
         assert torch.equal(kept[b], pts[b][_t(g[f"keep_{b}"])])
         torch.testing.assert_close(kept[b].sum(0), _t(g[f"kept_sum_{b}"]), rtol=1e-5, atol=1e-4)
+
+
+INTERSECTION_VARIANTS = {
+    "surface": lambda P, surf, pts: orc.intersection_loss_surface(P, surf),
+    "surface_cuboid": lambda P, surf, pts: orc.intersection_loss_surface(P, surf, cuboid=True),
+    "volume": lambda P, surf, pts: orc.intersection_loss_volume(P, surf),
+    "volume_2": lambda P, surf, pts: orc.intersection_loss_volume_2(P, pts),
+    "volume_4": lambda P, surf, pts: orc.intersection_loss_volume_4(P, pts),
+}
+
+
+@pytest.mark.parametrize("name", sorted(INTERSECTION_VARIANTS))
+def test_unused_intersection_variants_golden(golden, name):
+    """convex_loss.py:106, :163, :227, :346, :416 (kept upstream, never called): oracle value and gradient with respect to
+    every (r, V, c) against the reference's autograd (fit_intersections.npz)."""
+    g = golden("fit_intersections")
+    P, surf, pts = intersection_case(g)
+    loss = INTERSECTION_VARIANTS[name](P, surf, pts)
+    torch.testing.assert_close(loss.detach().reshape(()), _t(g[f"{name}_loss"]), rtol=1e-5, atol=1e-9)
+    loss.backward()
+    check_intersection_grads(g, name, P)
+
+
+def test_sample_axis_golden(golden):
+    g = golden("fit_intersections")
+    got = orc.sample_axis(_t(g["r_0"][1]), _t(g["V_0"][1]), _t(g["c_0"][1]))
+    torch.testing.assert_close(got, _t(g["axis_samples"]), rtol=1e-6, atol=1e-7)
