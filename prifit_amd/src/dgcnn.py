@@ -88,6 +88,36 @@ def get_graph_feature(x, k1=20, k2=20, idx=None):
     return rows[:, :2 * C].reshape(B, N, k1, 2 * C).permute(0, 3, 1, 2), idx
 
 
+def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None):
+    """Per-sample coefficient tables (scale, shift, mean, invstd), each [Bs, C], from the column-statistics slabs
+    [Bs * sps][2][C] of a tensor with `rows` rows per sample (`sps` consecutive slabs belong to one sample)."""
+    G, eps = cfg["groups"], cfg["eps"]
+    dev = slab.device
+    m = float(rows * (Cout // G))
+    if offset is not None:
+        assert dll().prifit_gn_finalize_supported(Cout, G) and offset.shape == (Bs, Cout)
+        scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
+        call("prifit_gn_finalize_offset", ptr(slab), Bs, sps, Cout, G, _D(m), ptr(gamma.contiguous()),
+             ptr(beta.contiguous()), _D(float(eps)), ptr(offset.contiguous()), _D(float(rows)), ptr(scale), ptr(shift), ptr(mean),
+             ptr(invstd), cur_stream())
+    elif _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+        # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
+        scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
+        call("prifit_gn_finalize", ptr(slab), Bs, sps, Cout, G, _D(m), ptr(gamma.contiguous()),
+             ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), cur_stream())
+    else:
+        sums = slab.view(Bs, sps, 2, Cout).double().sum(dim=1)               # [Bs, 2, C] per-sample column sums
+        s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
+        s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
+        var = (s2 - s1 * s1).clamp_min(0.0)
+        invstd_g = torch.rsqrt(var + eps)
+        mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()   # [Bs, C] tables
+        invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
+        scale = (gamma.unsqueeze(0) * invstd).contiguous()
+        shift = (beta.unsqueeze(0) - mean * scale).contiguous()
+    return scale, shift, mean, invstd
+
+
 def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None):
     """GroupNorm statistics from the 128-row (or `tile`-row) column-statistics slabs of Y [P, C] -> per-sample coefficient
     tables, then LeakyReLU [+ max over the pool_K rows of each group].  Returns (out, scale, shift, mean, invstd, arg).
@@ -98,28 +128,7 @@ def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None):
     assert P % rps == 0 and rps % tile == 0 and Cout % G == 0
     Bs = P // rps
     dev = Y.device
-    m = float(rps * (Cout // G))
-    if offset is not None:
-        assert dll().prifit_gn_finalize_supported(Cout, G) and offset.shape == (Bs, Cout)
-        scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
-        call("prifit_gn_finalize_offset", ptr(slab), Bs, rps // tile, Cout, G, _D(m), ptr(gamma.contiguous()),
-             ptr(beta.contiguous()), _D(float(eps)), ptr(offset.contiguous()), _D(float(rps)), ptr(scale), ptr(shift), ptr(mean),
-             ptr(invstd), cur_stream())
-    elif _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
-        # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
-        scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
-        call("prifit_gn_finalize", ptr(slab), Bs, rps // tile, Cout, G, _D(m), ptr(gamma.contiguous()),
-             ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), cur_stream())
-    else:
-        sums = slab.view(Bs, rps // tile, 2, Cout).double().sum(dim=1)       # [Bs, 2, C] per-sample column sums
-        s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
-        s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
-        var = (s2 - s1 * s1).clamp_min(0.0)
-        invstd_g = torch.rsqrt(var + eps)
-        mean = s1.repeat_interleave(Cout // G, dim=1).float().contiguous()   # [Bs, C] tables
-        invstd = invstd_g.repeat_interleave(Cout // G, dim=1).float().contiguous()
-        scale = (gamma.unsqueeze(0) * invstd).contiguous()
-        shift = (beta.unsqueeze(0) - mean * scale).contiguous()
+    scale, shift, mean, invstd = _gn_tables(slab, Bs, rps // tile, Cout, rps, gamma, beta, cfg, offset)
     arg = None
     if pool_K:
         Gp = P // pool_K
@@ -183,7 +192,7 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         call("prifit_bn_relu_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
              ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), cur_stream())
-    m = float(rps * (Cout // G))
+    m = float(cfg.get("count_rows", rps) * (Cout // G))     # count_rows: Y is a per-group table of a tensor with more rows
     ca = scale.contiguous()
     if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
         cb, cd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(2))
@@ -329,6 +338,62 @@ class EdgeConvLinFn(torch.autograd.Function):
         return dU, dVc, None, dgamma, dbeta, None
 
 
+class EdgeConvTabFn(torch.autograd.Function):
+    """The same block with NO per-edge tensor (csrc/edge_conv.hip): one pass over the neighbour lists leaves per-point tables
+    (max / min / sum over the neighbours of y, their positions, the GroupNorm column sums); the pooled activation comes from
+    the tables once the statistics are final (the activation is monotone in y), and the backward needs the tables, U, Vc and
+    a CSR of the neighbour lists: dU is a gather over a point's in-edges (no atomics).
+    apply(U, Vc, idx, csr, gamma, beta, cfg) -> [B*N, C]; csr = edge_csr(idx)."""
+
+    @staticmethod
+    def forward(ctx, U, Vc, idx, csr, gamma, beta, cfg):
+        U, Vc, idx = U.contiguous(), Vc.contiguous(), idx.contiguous()
+        B, N, C = U.shape
+        k = idx.shape[2]
+        dev = U.device
+        pts = dll().prifit_edge_points_per_slab()
+        ymax, ymin, ysum, ystar, out = (torch.empty(B * N, C, dtype=torch.float32, device=dev) for _ in range(5))
+        karg = torch.empty(B * N, C, dtype=torch.int32, device=dev)
+        slab = torch.empty(B * (N // pts), 2, C, dtype=torch.float32, device=dev)
+        # bytes: the index lists, U / Vc once (the k-fold re-reads of U rows are L2 traffic), four tables written
+        with profiler.span("edge_stats", 4.0 * (B * N * k + 6.0 * B * N * C)):
+            call("prifit_edge_stats", ptr(U), ptr(Vc), ptr(idx), B, N, k, C, ptr(ymax), ptr(ymin), ptr(karg), ptr(ysum),
+                 ptr(slab), cur_stream())
+        scale, shift, mean, invstd = _gn_tables(slab, B, N // pts, C, N * k, gamma, beta, cfg)
+        call("prifit_edge_pool", ptr(ymax), ptr(ymin), ptr(scale), ptr(shift), B, N, C, _F(cfg["slope"]), ptr(out), _LL(C),
+             ptr(ystar), cur_stream())
+        ctx.cfg, ctx.dims = cfg, (B, N, k, C)
+        ctx.save_for_backward(U, Vc, idx, *csr, gamma, ystar, ysum, karg, scale, shift, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        U, Vc, idx, offs, lst, pos, gamma, ystar, ysum, karg, scale, shift, mean, invstd = ctx.saved_tensors
+        B, N, k, C = ctx.dims
+        # the reduction half of the pooled GroupNorm backward sees only the winners: it is the unpooled reduction over the
+        # [B N, C] table of winning pre-activations, with the element count of the full tensor
+        cfg = dict(ctx.cfg, rps=N, pool_K=0, count_rows=N * k)
+        gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, ystar, gamma, scale, shift, mean, invstd, None, cfg)
+        dU, dVc = (torch.empty(B, N, C, dtype=torch.float32, device=U.device) for _ in range(2))
+        # bytes: the CSR lists, U / Vc / four tables / gout once, dU and dVc written (Vc rows k-fold from L2)
+        with profiler.span("edge_bwd_tables", 4.0 * (2.0 * B * N * k + 9.0 * B * N * C)):
+            ws = torch.empty(dll().prifit_edge_bwd_workspace(B, N, k, C) // 8, dtype=torch.int64, device=U.device)
+            call("prifit_edge_bwd", ptr(gout), _LL(gout.stride(0)), ptr(ystar), ptr(ysum), ptr(karg), ptr(scale), ptr(shift),
+                 ptr(ca), ptr(cb), ptr(cd), ptr(U), ptr(Vc), ptr(idx), ptr(offs), ptr(lst), ptr(pos), B, N, k, C, _F(ctx.cfg["slope"]),
+                 ptr(dU), ptr(dVc), ptr(ws), cur_stream())
+        return dU, dVc, None, None, dgamma, dbeta, None
+
+
+def edge_csr(idx):
+    """(offs [B,N+1], lst [B,N*k], pos [B,N*k]) int32: the in-edge lists of the neighbour graph idx [B,N,k] and where each
+    edge sits in them (prifit_edge_csr)."""
+    B, N, k = idx.shape
+    offs = torch.empty(B, N + 1, dtype=torch.int32, device=idx.device)
+    lst, pos = (torch.empty(B, N * k, dtype=torch.int32, device=idx.device) for _ in range(2))
+    call("prifit_edge_csr", ptr(idx), B, N, k, ptr(offs), ptr(lst), ptr(pos), cur_stream())
+    return offs, lst, pos
+
+
 # The edge convolution by linearity (default): W [x_j - x_i | x_i] = Wa x_j + (Wb - Wa) x_i = U_j - Vc_i with U = X Wa^T and
 # Vc = X (Wa - Wb)^T computed once per POINT (two products over B N rows); per EDGE only a gather of Cout-wide rows of U
 # (nn_ops.GatherLinearFn, the kernel of the set-abstraction first layers).  The [B N k, 2C] edge rows of upstream
@@ -337,6 +402,8 @@ class EdgeConvLinFn(torch.autograd.Function):
 _EDGE_LINEARITY = __import__("os").environ.get("PRIFIT_EDGE_LINEARITY", "1") != "0"
 # ... with its pooled GroupNorm backward formed inside the scatter (0: apply pass writes dY, then the scatter; A/B arm, tested)
 _EDGE_FUSED_BWD = __import__("os").environ.get("PRIFIT_EDGE_FUSED_BWD", "1") != "0"
+# ... and, by default, with no per-edge tensor at all (EdgeConvTabFn; 0: the pre-activations are written and re-read; A/B arm, tested)
+_EDGE_TABLES = __import__("os").environ.get("PRIFIT_EDGE_TABLES", "1") != "0"
 # the global max over the cloud fused into the mlp1 block (0: activation pass + torch max; A/B arm, tested)
 _GLOBAL_POOL_FUSED = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_FUSED", "1") != "0"
 
@@ -369,7 +436,7 @@ class DGCNNEncoderGn(nn.Module):
         self.mlp1 = nn.Conv1d(256, 1024, 1)
         self.bnmlp1 = nn.GroupNorm(8, 1024)
 
-    def _edge_conv(self, feats, idx, seq, N):
+    def _edge_conv(self, feats, idx, seq, N, csr=None):
         conv, gn = seq[0], seq[1]
         C = feats.shape[-1]
         k = idx.shape[2]
@@ -387,6 +454,8 @@ class DGCNNEncoderGn(nn.Module):
                 wb = torch.cat([wb, wb.new_zeros(Cout, pad)], dim=1)
             U = LinearFn.apply(X, wa, None).view(B, N, Cout)             # neighbour term, per point
             Vc = LinearFn.apply(X, wa - wb, None).view(B, N, Cout)       # minus the centre term, per point
+            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout):
+                return EdgeConvTabFn.apply(U, Vc, idx, csr, gn.weight, gn.bias, cfg)   # [B*N, Cout]
             if _EDGE_FUSED_BWD:
                 return EdgeConvLinFn.apply(U, Vc, idx, gn.weight, gn.bias, cfg)      # [B*N, Cout]
             Y, slab = nn_ops.GatherLinearFn.apply(U, Vc, None, idx, True)
@@ -400,13 +469,16 @@ class DGCNNEncoderGn(nn.Module):
         B, N, _ = pts.shape
         k, k2 = self.k, self.k * self.dilation_factor
         step = k2 // k
+        tables = _EDGE_TABLES and _EDGE_LINEARITY and _EDGE_FUSED_BWD
         with torch.no_grad():
             idx1 = _knn_cl(pts, k2)[:, :, ::step].contiguous()
-        x1 = self._edge_conv(pts, idx1, self.conv1, N)
+            csr1 = edge_csr(idx1) if tables and N <= 8192 else None
+        x1 = self._edge_conv(pts, idx1, self.conv1, N, csr1)
         with torch.no_grad():
             idx2 = _knn_cl(x1.detach().view(B, N, -1), k2)[:, :, ::step].contiguous()
-        x2 = self._edge_conv(x1.view(B, N, -1), idx2, self.conv2, N)
-        x3 = self._edge_conv(x2.view(B, N, -1), idx2, self.conv3, N)      # re-uses the second graph (:191)
+            csr2 = edge_csr(idx2) if tables and N <= 8192 else None
+        x2 = self._edge_conv(x1.view(B, N, -1), idx2, self.conv2, N, csr2)
+        x3 = self._edge_conv(x2.view(B, N, -1), idx2, self.conv3, N, csr2)      # re-uses the second graph (:191)
         feats = torch.cat((x1, x2, x3), dim=1)
         cfg = {"groups": self.bnmlp1.num_groups, "rps": N, "slope": 0.0, "pool_K": 0, "eps": self.bnmlp1.eps}
         if _GLOBAL_POOL_FUSED and N % 32 == 0 and pool_product_ok(B * N, self.mlp1.weight.shape[0], feats.shape[1]):

@@ -47,7 +47,8 @@ class SampleEllipsoid:
         `transformation` and moved to `center`.  The unit-box parameters are constants (trimesh's sampler upstream, the
         build's table here: csrc/fit.hip cuboid_unit -- area-proportional faces [+z,-z,+x,-x,+y,-y], R2 sequence inside
         a face, scaled (u s) / (s + 1e-6) as upstream :88); gradients flow to a, b, c, transformation and center."""
-        u = cuboid_unit_table(int(n), float(a), float(b), float(c), transformation.device)
+        sa, sb, sc = (float(t.detach()) if torch.is_tensor(t) else float(t) for t in (a, b, c))
+        u = cuboid_unit_table(int(n), sa, sb, sc, transformation.device)
         sides = torch.stack([a, b, c]).view(1, 3)
         return (u * sides) @ transformation.T + center, None
 

@@ -131,31 +131,89 @@ def test_global_max_pool_fused_into_the_block(D):
 
 
 def test_edge_conv_by_linearity_equals_rows_and_product(D, monkeypatch):
-    """The edge convolution W [x_j - x_i | x_i] = U_j - Vc_i (two products per POINT + a gather, the default) against the
-    materialised edge rows + product over B N k rows (PRIFIT_EDGE_LINEARITY=0): same outputs and gradients to rounding."""
+    """The edge convolution W [x_j - x_i | x_i] = U_j - Vc_i by per-point tables (csrc/edge_conv.hip, the default: no per-edge
+    tensor in either direction) against the stored pre-activations + fused scatter (PRIFIT_EDGE_TABLES=0), the unfused
+    backward, and the materialised edge rows + product over B N k rows (PRIFIT_EDGE_LINEARITY=0): same outputs and gradients
+    to rounding."""
     B, N, k = 2, 512, 20
     torch.manual_seed(7)
     enc = D.DGCNNEncoderGn(input_channels=3, nn_nb=k).cuda()
     pts = _t(synth.cloud("surface", B, N, 41)).cuda()
     feats = _t(synth.features(B, N, 64, 42)).cuda()
     res = {}
-    for arm in (True, "unfused", False):
+    for arm in ("tables", True, "unfused", False):
         monkeypatch.setattr(D, "_EDGE_LINEARITY", bool(arm))
-        monkeypatch.setattr(D, "_EDGE_FUSED_BWD", arm is True)     # "unfused": apply pass + scatter as two launches
+        monkeypatch.setattr(D, "_EDGE_FUSED_BWD", arm in (True, "tables"))   # "unfused": apply pass + scatter as two launches
         enc.zero_grad()
         with torch.no_grad():
             idx = D._knn_cl(pts, k)
+            csr = D.edge_csr(idx) if arm == "tables" else None     # the default: per-point tables, no per-edge tensor
         f = feats.clone().requires_grad_(True)
-        x1 = enc._edge_conv(pts, idx, enc.conv1, N)
-        x2 = enc._edge_conv(f, idx, enc.conv2, N)
+        x1 = enc._edge_conv(pts, idx, enc.conv1, N, csr)
+        x2 = enc._edge_conv(f, idx, enc.conv2, N, csr)
         go1 = _t(synth.features(1, B * N, 64, 43))[0].cuda()
         ((x1 + x2) * go1).sum().backward()
         res[arm] = (x1.detach(), x2.detach(), f.grad.clone(), enc.conv1[0].weight.grad.clone(), enc.conv2[0].weight.grad.clone(),
                     enc.bn2.weight.grad.clone())
-    for other in ("unfused", False):
-        for a, b, name in zip(res[True], res[other], ["x1", "x2", "dfeat", "dW1", "dW2", "dgamma2"]):
+    for other in (True, "unfused", False):
+        for a, b, name in zip(res["tables"], res[other], ["x1", "x2", "dfeat", "dW1", "dW2", "dgamma2"]):
             torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4 * max(1.0, b.abs().max().item()),
                                        msg=lambda m, name=name: "%s vs %s: %s" % (name, other, m))
+
+
+def test_edge_csr_lists(D):
+    """prifit_edge_csr: the in-edge lists (edge numbers i k + j) of a neighbour graph (as sets; out-of-range entries dropped)."""
+    B, N, k = 3, 256, 7
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, N, (B, N, k), generator=gen, dtype=torch.int32)
+    idx[0, 5, 2] = -1
+    idx[1, 9, 0] = N
+    idx[2, :, 0] = 17                                         # a hub: every centre of shape 2 points at 17
+    offs, lst, pos = (t.cpu() for t in D.edge_csr(idx.cuda()))
+    for b in range(B):
+        assert offs[b, 0] == 0 and (offs[b, 1:] >= offs[b, :-1]).all()
+        valid = (idx[b] >= 0) & (idx[b] < N)
+        assert int(offs[b, N]) == int(valid.sum())
+        edge = torch.arange(N * k).view(N, k)
+        for n in (0, 17, 100, N - 1):
+            want = sorted(edge[valid & (idx[b] == n)].tolist())
+            assert sorted(lst[b, offs[b, n]:offs[b, n + 1]].tolist()) == want
+        flat_ok = valid.view(-1)
+        assert (pos[b][~flat_ok] == -1).all()
+        assert torch.equal(lst[b][pos[b][flat_ok].long()], torch.arange(N * k, dtype=torch.int32)[flat_ok])
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_edge_tables_forward_and_backward_against_torch(D, C):
+    """EdgeConvTabFn (tables + CSR gather) against the same block written in torch on the explicit [B, N, k, C] tensor,
+    GroupNorm with negative and zero-crossing scales, an out-of-range neighbour, ties between neighbours."""
+    B, N, k, G = 2, 128, 9, 2
+    gen = torch.Generator().manual_seed(C)
+    U = torch.randn(B, N, C, generator=gen)
+    Vc = torch.randn(B, N, C, generator=gen) * 0.5
+    idx = torch.randint(0, N, (B, N, k), generator=gen, dtype=torch.int32)
+    idx[0, 3, 4] = -1                                        # zero row, no gradient
+    idx[1, 7, 5] = idx[1, 7, 1]                              # a repeated neighbour: tie, the first position wins
+    gamma = torch.randn(C, generator=gen)                    # both signs
+    beta = torch.randn(C, generator=gen) * 0.3
+    go = torch.randn(B * N, C, generator=gen)
+    cfg = {"groups": G, "rps": N * k, "slope": 0.2, "pool_K": k, "eps": 1e-5}
+    leaves = [t.clone().requires_grad_(True) for t in (U, Vc, gamma, beta)]
+    Ur, Vr, gr, br = leaves
+    ok = ((idx >= 0) & (idx < N)).unsqueeze(-1)
+    rows = torch.gather(Ur.unsqueeze(1).expand(B, N, N, C), 2, idx.clamp(0, N - 1).long().unsqueeze(-1).expand(B, N, k, C))
+    y = torch.where(ok, rows - Vr.unsqueeze(2), torch.zeros(()))
+    yn = torch.nn.functional.group_norm(y.permute(0, 3, 1, 2), G, gr, br, 1e-5)
+    ref = torch.nn.functional.leaky_relu(yn, 0.2).max(dim=3)[0].permute(0, 2, 1).reshape(B * N, C)
+    (ref * go).sum().backward()
+    dl = [t.detach().clone().cuda().requires_grad_(True) for t in (U, Vc, gamma, beta)]
+    idx_d = idx.cuda()
+    out = D.EdgeConvTabFn.apply(dl[0], dl[1], idx_d, D.edge_csr(idx_d), dl[2], dl[3], cfg)
+    (out * go.cuda()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    for a, b, name in zip(dl, leaves, ["U", "Vc", "gamma", "beta"]):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-3, atol=1e-4 * b.grad.abs().max().item(),
+                                   msg=lambda m, name=name: name + ": " + m)
 
 
 def test_dgcnn_network(D, golden):
