@@ -370,25 +370,31 @@ int prifit_edge_points_per_slab(void);
  * offs[b][n+1]) (the order inside a list is not defined); pos [B][N k]: the position of edge i k + j in lst[b] (-1 for an
  * entry outside [0,N)).  One graph serves every layer that uses it. */
 int prifit_edge_csr(const int32_t *idx, int B, int N, int k, int32_t *offs, int32_t *lst, int32_t *pos, void *stream);
-/* One pass over the neighbour lists: per (point, channel) ymax / ymin = max / min over j of y, karg = first position of the
- * maximum | first position of the minimum << 10 | number of valid neighbours << 20 (k < 1024), ysum = sum over j of y; slab [B N/P][2][C], P =
+/* One pass over the neighbour lists.  U [B N, ldu] and Vc [B N, ldv] rows; selfterm = 0: y[(i,j)] = U[idx[i,j]] - Vc[i];
+ * selfterm = 1: Vc holds Vb = X Wb^T and the centre term is U[i] - Vb[i] (W [x_j - x_i | x_i] = U_j - U_i + Vb_i: U and Vb are
+ * then the two halves of ONE product X [Wa; Wb]^T, ldu = ldv = 2 C).  Per (point, channel): ymax / ymin = max / min over j of
+ * y, karg = first position of the maximum | first position of the minimum << 10 | number of valid neighbours << 20 (k <
+ * 1024), ysum = sum over j of y, vct = the centre term [B N, C] (kept for the backward); slab [B N/P][2][C], P =
  * prifit_edge_points_per_slab() = column sum / sum of squares of y over each P points x k rows (prifit_gn_finalize's layout). */
-int prifit_edge_stats(const float *U, const float *Vc, const int32_t *idx, int B, int N, int k, int C, float *ymax, float *ymin,
-                      int32_t *karg, float *ysum, float *slab, void *stream);
+int prifit_edge_stats(const float *U, long long ldu, const float *Vc, long long ldv, int selfterm, const int32_t *idx, int B, int N,
+                      int k, int C, float *ymax, float *ymin, int32_t *karg, float *ysum, float *vct, float *slab, void *stream);
 /* With the per-sample tables scale / shift [B,C] of the finalized statistics: out [B N, ldo] = act(scale y* + shift), the
  * maximum over the k neighbours of the activation (y* = ymax where scale >= 0, ymin where scale < 0: the activation is
  * monotone in y), and ystar [B N, C] = y* for the backward. */
 int prifit_edge_pool(const float *ymax, const float *ymin, const float *scale, const float *shift, int B, int N, int C,
                      float slope, float *out, long long ldo, float *ystar, void *stream);
 /* Backward with the coefficient tables [B,C] of the pooled GroupNorm backward (dy = a T [j == winner] + b y + d, T =
- * act'(scale y* + shift) gp): dVc [B,N,C] = -(a T + b ysum + (valid neighbours) d); dU [B,N,C] (written, not accumulated) = b
- * (deg U - sum of Vc over the in-edges) + d deg + sum of a T over the in-edges that won, all from the CSR with fp64 sums: no
- * atomics.  workspace: prifit_edge_bwd_workspace bytes, 8-byte aligned. */
+ * act'(scale y* + shift) gp), vct from prifit_edge_stats: the gradient of the centre term dVc [B N, ldd] = -(a T + b ysum +
+ * (valid neighbours) d); dU [B N, ldd] (written, not accumulated) = b (deg U - sum of vct over the in-edges) + d deg + sum of
+ * a T over the in-edges that won, all from the CSR with fp64 sums: no atomics.  selfterm = 1: the second output is the
+ * gradient of Vb (= -dVc) and dU also receives the point's own dVc (dU and dVb are then the halves of one [B N, 2 C] gradient,
+ * ldd = 2 C).  workspace: prifit_edge_bwd_workspace bytes, 8-byte aligned. */
 long long prifit_edge_bwd_workspace(int B, int N, int k, int C);
 int prifit_edge_bwd(const float *gp, long long ldgp, const float *ystar, const float *ysum, const int32_t *karg,
                     const float *scale, const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
-                    const float *U, const float *Vc, const int32_t *idx, const int32_t *offs, const int32_t *lst, const int32_t *pos,
-                    int B, int N, int k, int C, float slope, float *dU, float *dVc, void *workspace, void *stream);
+                    const float *U, long long ldu, const float *vct, int selfterm, const int32_t *idx, const int32_t *offs,
+                    const int32_t *lst, const int32_t *pos, int B, int N, int k, int C, float slope, float *dU, float *dVc,
+                    long long ldd, void *workspace, void *stream);
 
 /* The same autograd with the train-mode BatchNorm + ReLU backward of the gathered layer folded in (what
  * prifit_bn_relu_bwd_apply would have written first): dY = a (Y s + t > 0 ? G : 0) + (b Y + d) is formed on load from G

@@ -110,11 +110,12 @@ __global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restric
 
 // ---- forward pass over the neighbour lists: one wave per point, lane = channels lane, lane + 64, ... ----
 template <int V, int UNR>
-__global__ __launch_bounds__(256) void edge_stats_kernel(const float *__restrict__ U, const float *__restrict__ Vc,
+__global__ __launch_bounds__(256) void edge_stats_kernel(const float *__restrict__ U, long long ldu,
+                                                         const float *__restrict__ Vc, long long ldv, int selfterm,
                                                          const int32_t *__restrict__ idx, int B, int N, int k,
                                                          float *__restrict__ ymax, float *__restrict__ ymin,
                                                          int32_t *__restrict__ karg, float *__restrict__ ysum,
-                                                         float *__restrict__ slab)
+                                                         float *__restrict__ vct, float *__restrict__ slab)
 {
     constexpr int C = 64 * V;
     __shared__ float s_red[4][2][C];
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float *__restrict
     xcd_shape_block(blockIdx.x, N / EC_PTS, B, b, blk);
     const int p0 = blk * EC_PTS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float *Ub = U + (size_t)b * N * C + lane;
+    const float *Ub = U + (size_t)b * N * ldu + lane;
     float ws[V], wq[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) { ws[v] = 0.f; wq[v] = 0.f; }
@@ -134,7 +135,9 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float *__restrict
         int kx[V], kn[V], nv = 0;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            vc[v] = Vc[g * C + lane + 64 * v];
+            vc[v] = Vc[g * ldv + lane + 64 * v];
+            if (selfterm) vc[v] = U[g * ldu + lane + 64 * v] - vc[v];     // centre term U_i - Vb_i (see prifit_edge_stats)
+            vct[g * C + lane + 64 * v] = vc[v];
             s[v] = 0.f; mx[v] = -INFINITY; mn[v] = INFINITY; kx[v] = 0; kn[v] = 0;
         }
         for (int kc = 0; kc < k; kc += 64) {                  // the index list sits in the lanes: no load between two row gathers
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void edge_stats_kernel(const float *__restrict
                     ok[j] = n >= 0 && n < N;
                     const int nn = ok[j] ? n : 0;            // unconditional loads (see edge_bwd_gather_kernel)
 #pragma unroll
-                    for (int v = 0; v < V; ++v) u[j][v] = Ub[(size_t)nn * C + 64 * v];
+                    for (int v = 0; v < V; ++v) u[j][v] = Ub[(size_t)nn * ldu + 64 * v];
                 }
 #pragma unroll
                 for (int j = 0; j < UNR; ++j) {
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void edge_bwd_point_kernel(const float *__rest
                                                              const int32_t *__restrict__ idx, int N, int k, long long points,
                                                              const int32_t *__restrict__ pos, float slope,
                                                              float *__restrict__ aT, unsigned long long *__restrict__ masks,
-                                                             float *__restrict__ dVc)
+                                                             float *__restrict__ dVc, long long ldd, int selfterm)
 {
     constexpr int C = 64 * V;
     const int lane = threadIdx.x & 63;
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(256) void edge_bwd_point_kernel(const float *__rest
             // a zero row (index out of range) is a constant: it takes part in the statistics, not in the gradients
             const bool ok = n >= 0 && n < N;
             aT[id] = T;
-            dVc[id] = -((ok ? T : 0.f) + fmaf(cb[to], ysum[id], (float)(pk >> 20) * cd[to]));
+            const float dvc = -((ok ? T : 0.f) + fmaf(cb[to], ysum[id], (float)(pk >> 20) * cd[to]));
+            dVc[(size_t)g * ldd + c] = selfterm ? -dvc : dvc;     // selfterm: the gradient of Vb = U_i - (centre term)
             for (int jc = 0; jc < k; jc += 64) {
                 const int cnt = min(64, k - jc);
                 unsigned long long mine = 0ull;
@@ -259,13 +263,14 @@ __global__ __launch_bounds__(256) void edge_bwd_point_kernel(const float *__rest
 // ---- backward, per point n (second): its in-edges from the CSR.  dU[n] = b (deg U[n] - sum Vc[i]) + d deg + sum over the
 // in-edges that are winners of aT[i] -- no atomics; the sums in fp64 (the order in which the CSR build filled a list
 // differs from run to run; in fp64 that moves the fp32 result only on a double-rounding tie) ----
-__global__ __launch_bounds__(256) void edge_bwd_gather_kernel(const float *__restrict__ U, const float *__restrict__ Vc,
-                                                              const float *__restrict__ aT,
+__global__ __launch_bounds__(256) void edge_bwd_gather_kernel(const float *__restrict__ U, long long ldu,
+                                                              const float *__restrict__ Vc, const float *__restrict__ aT,
                                                               const unsigned long long *__restrict__ masks,
                                                               const int32_t *__restrict__ offs,
                                                               const int32_t *__restrict__ lst, const float *__restrict__ cb,
                                                               const float *__restrict__ cd, int B, int N, int k, int C,
-                                                              float *__restrict__ dU)
+                                                              float *__restrict__ dU, long long ldd,
+                                                              const float *__restrict__ dVb)
 {
     constexpr int UNR = 12;       // in-degrees of a k = 20 graph: median 21, p90 29 -> two or three batches
     const int lane = threadIdx.x & 63;
@@ -311,9 +316,11 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_kernel(const float *__res
             }
         }
         const double deg = (double)(e1 - e0);
-        const double u = (double)U[(size_t)g * C + c];
+        const double u = (double)U[g * ldu + c];
         const double bb = (double)cb[(size_t)b * C + c], d = (double)cd[(size_t)b * C + c];
-        dU[(size_t)g * C + c] = (float)(bb * (deg * u - acc) + d * deg + accw);
+        // dVb (selfterm): the centre term is U_i - Vb_i, so the point's own row of U also receives dVc_i = -dVb_i
+        const double self = dVb ? -(double)dVb[g * ldd + c] : 0.0;
+        dU[g * ldd + c] = (float)(bb * (deg * u - acc) + d * deg + accw + self);
     }
 }
 
@@ -342,14 +349,17 @@ int prifit_edge_csr(const int32_t *idx, int B, int N, int k, int32_t *offs, int3
     return prifit_check_launch();
 }
 
-int prifit_edge_stats(const float *U, const float *Vc, const int32_t *idx, int B, int N, int k, int C, float *ymax, float *ymin,
-                      int32_t *karg, float *ysum, float *slab, void *stream)
+int prifit_edge_stats(const float *U, long long ldu, const float *Vc, long long ldv, int selfterm, const int32_t *idx, int B, int N,
+                      int k, int C, float *ymax, float *ymin, int32_t *karg, float *ysum, float *vct, float *slab, void *stream)
 {
-    if (!U || !Vc || !idx || !ymax || !ymin || !karg || !ysum || !slab || B <= 0 || !prifit_edge_tables_supported(N, k, C))
+    if (!U || !Vc || !idx || !ymax || !ymin || !karg || !ysum || !vct || !slab || B <= 0 || ldu < C || ldv < C ||
+        !prifit_edge_tables_supported(N, k, C))
         return PRIFIT_EINVAL;
     const dim3 grid((unsigned)(N / EC_PTS) * B);
     hipStream_t st = as_stream(stream);
-#define EDGE_STATS(V, R) hipLaunchKernelGGL((edge_stats_kernel<V, R>), grid, dim3(256), 0, st, U, Vc, idx, B, N, k, ymax, ymin, karg, ysum, slab)
+#define EDGE_STATS(V, R)                                                                                                      \
+    hipLaunchKernelGGL((edge_stats_kernel<V, R>), grid, dim3(256), 0, st, U, ldu, Vc, ldv, selfterm, idx, B, N, k, ymax, ymin, karg, \
+                       ysum, vct, slab)
     // row gathers in flight per wave: k = 20 (the reference's default) goes out as two batches of 10
     if (k % 10 == 0) { if (C == 64) EDGE_STATS(1, 10); else if (C == 128) EDGE_STATS(2, 10); else EDGE_STATS(4, 10); }
     else { if (C == 64) EDGE_STATS(1, 8); else if (C == 128) EDGE_STATS(2, 8); else EDGE_STATS(4, 8); }
@@ -377,11 +387,13 @@ long long prifit_edge_bwd_workspace(int B, int N, int k, int C)
 
 int prifit_edge_bwd(const float *gp, long long ldgp, const float *ystar, const float *ysum, const int32_t *karg,
                     const float *scale, const float *shift, const float *ca, const float *cb, const float *cd, const float *U,
-                    const float *Vc, const int32_t *idx, const int32_t *offs, const int32_t *lst, const int32_t *pos, int B, int N,
-                    int k, int C, float slope, float *dU, float *dVc, void *workspace, void *stream)
+                    long long ldu, const float *vct, int selfterm, const int32_t *idx, const int32_t *offs, const int32_t *lst,
+                    const int32_t *pos, int B, int N, int k, int C, float slope, float *dU, float *dVc, long long ldd,
+                    void *workspace, void *stream)
 {
-    if (!gp || !ystar || !ysum || !karg || !scale || !shift || !ca || !cb || !cd || !U || !Vc || !idx || !offs || !lst || !pos ||
-        !dU || !dVc || !workspace || ((uintptr_t)workspace & 7) || B <= 0 || ldgp < C || !prifit_edge_tables_supported(N, k, C))
+    if (!gp || !ystar || !ysum || !karg || !scale || !shift || !ca || !cb || !cd || !U || !vct || !idx || !offs || !lst || !pos ||
+        !dU || !dVc || !workspace || ((uintptr_t)workspace & 7) || B <= 0 || ldgp < C || ldu < C || ldd < C ||
+        !prifit_edge_tables_supported(N, k, C))
         return PRIFIT_EINVAL;
     const long long points = (long long)B * N;
     hipStream_t st = as_stream(stream);
@@ -390,13 +402,13 @@ int prifit_edge_bwd(const float *gp, long long ldgp, const float *ystar, const f
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(aT + points * C);
 #define EDGE_POINT(V)                                                                                                        \
     hipLaunchKernelGGL(edge_bwd_point_kernel<V>, dim3(grid), dim3(256), 0, st, gp, ldgp, ystar, ysum, karg, scale, shift, ca, cb, \
-                       cd, idx, N, k, points, pos, slope, aT, masks, dVc)
+                       cd, idx, N, k, points, pos, slope, aT, masks, dVc, ldd, selfterm)
     if (C == 64) EDGE_POINT(1);
     else if (C == 128) EDGE_POINT(2);
     else EDGE_POINT(4);
 #undef EDGE_POINT
-    hipLaunchKernelGGL(edge_bwd_gather_kernel, dim3((unsigned)((N + 3) / 4) * B, C / 64), dim3(256), 0, st, U, Vc, aT, masks, offs,
-                       lst, cb, cd, B, N, k, C, dU);
+    hipLaunchKernelGGL(edge_bwd_gather_kernel, dim3((unsigned)((N + 3) / 4) * B, C / 64), dim3(256), 0, st, U, ldu, vct, aT, masks,
+                       offs, lst, cb, cd, B, N, k, C, dU, ldd, selfterm ? (const float *)dVc : (const float *)nullptr);
     return prifit_check_launch();
 }
 

@@ -199,7 +199,8 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
         S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
         call("prifit_gn_bwd_finalize", ptr(slab), Bs, nslab // Bs, Cout, G, _D(m), ptr(gamma.contiguous()), ptr(mean),
              ptr(invstd), ptr(cb), ptr(cd), ptr(S), cur_stream())
-        dgamma, dbeta = S[:, 1].sum(0).float(), S[:, 0].sum(0).float()
+        Ssum = S.sum(0).float()                                             # [2, C]: one reduction for both
+        dgamma, dbeta = Ssum[1], Ssum[0]
     else:
         S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)          # [Bs, 2, C]: sum Gm, sum Gm*yhat
         dgamma = S[:, 1].sum(0).float()
@@ -341,47 +342,57 @@ class EdgeConvLinFn(torch.autograd.Function):
 class EdgeConvTabFn(torch.autograd.Function):
     """The same block with NO per-edge tensor (csrc/edge_conv.hip): one pass over the neighbour lists leaves per-point tables
     (max / min / sum over the neighbours of y, their positions, the GroupNorm column sums); the pooled activation comes from
-    the tables once the statistics are final (the activation is monotone in y), and the backward needs the tables, U, Vc and
-    a CSR of the neighbour lists: dU is a gather over a point's in-edges (no atomics).
-    apply(U, Vc, idx, csr, gamma, beta, cfg) -> [B*N, C]; csr = edge_csr(idx)."""
+    the tables once the statistics are final (the activation is monotone in y), and the backward needs the tables, U, the
+    centre term and a CSR of the neighbour lists: dU is a gather over a point's in-edges (no atomics).
+    apply(U, Vc, idx, csr, gamma, beta, cfg) -> [B*N, C] with U, Vc [B,N,C], csr = edge_csr(idx); or apply(UV, None, ...)
+    with UV [B,N,2C] = X [Wa; Wb]^T, the two halves of ONE product (y = U_j - U_i + Vb_i), whose gradient comes back as one
+    [B,N,2C] tensor."""
 
     @staticmethod
     def forward(ctx, U, Vc, idx, csr, gamma, beta, cfg):
-        U, Vc, idx = U.contiguous(), Vc.contiguous(), idx.contiguous()
-        B, N, C = U.shape
+        stacked = Vc is None
+        U, idx = U.contiguous(), idx.contiguous()
+        B, N, ld = U.shape
+        C = ld // 2 if stacked else ld
+        Vc = U[:, :, C:] if stacked else Vc.contiguous()         # a view: rows of stride ld
         k = idx.shape[2]
         dev = U.device
         pts = dll().prifit_edge_points_per_slab()
-        ymax, ymin, ysum, ystar, out = (torch.empty(B * N, C, dtype=torch.float32, device=dev) for _ in range(5))
+        ymax, ymin, ysum, ystar, vct, out = (torch.empty(B * N, C, dtype=torch.float32, device=dev) for _ in range(6))
         karg = torch.empty(B * N, C, dtype=torch.int32, device=dev)
         slab = torch.empty(B * (N // pts), 2, C, dtype=torch.float32, device=dev)
-        # bytes: the index lists, U / Vc once (the k-fold re-reads of U rows are L2 traffic), four tables written
-        with profiler.span("edge_stats", 4.0 * (B * N * k + 6.0 * B * N * C)):
-            call("prifit_edge_stats", ptr(U), ptr(Vc), ptr(idx), B, N, k, C, ptr(ymax), ptr(ymin), ptr(karg), ptr(ysum),
-                 ptr(slab), cur_stream())
+        # bytes: the index lists, U / Vc once (the k-fold re-reads of U rows are L2 traffic), five tables written
+        with profiler.span("edge_stats", 4.0 * (B * N * k + 7.0 * B * N * C)):
+            call("prifit_edge_stats", ptr(U), _LL(ld), ptr(Vc), _LL(ld), int(stacked), ptr(idx), B, N, k, C, ptr(ymax), ptr(ymin),
+                 ptr(karg), ptr(ysum), ptr(vct), ptr(slab), cur_stream())
         scale, shift, mean, invstd = _gn_tables(slab, B, N // pts, C, N * k, gamma, beta, cfg)
         call("prifit_edge_pool", ptr(ymax), ptr(ymin), ptr(scale), ptr(shift), B, N, C, _F(cfg["slope"]), ptr(out), _LL(C),
              ptr(ystar), cur_stream())
-        ctx.cfg, ctx.dims = cfg, (B, N, k, C)
-        ctx.save_for_backward(U, Vc, idx, *csr, gamma, ystar, ysum, karg, scale, shift, mean, invstd)
+        ctx.cfg, ctx.dims, ctx.stacked = cfg, (B, N, k, C), stacked
+        ctx.save_for_backward(U, vct, idx, *csr, gamma, ystar, ysum, karg, scale, shift, mean, invstd)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        U, Vc, idx, offs, lst, pos, gamma, ystar, ysum, karg, scale, shift, mean, invstd = ctx.saved_tensors
+        U, vct, idx, offs, lst, pos, gamma, ystar, ysum, karg, scale, shift, mean, invstd = ctx.saved_tensors
         B, N, k, C = ctx.dims
         # the reduction half of the pooled GroupNorm backward sees only the winners: it is the unpooled reduction over the
         # [B N, C] table of winning pre-activations, with the element count of the full tensor
         cfg = dict(ctx.cfg, rps=N, pool_K=0, count_rows=N * k)
         gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, ystar, gamma, scale, shift, mean, invstd, None, cfg)
-        dU, dVc = (torch.empty(B, N, C, dtype=torch.float32, device=U.device) for _ in range(2))
-        # bytes: the CSR lists, U / Vc / four tables / gout once, dU and dVc written (Vc rows k-fold from L2)
-        with profiler.span("edge_bwd_tables", 4.0 * (2.0 * B * N * k + 9.0 * B * N * C)):
+        if ctx.stacked:
+            dUV = torch.empty(B, N, 2 * C, dtype=torch.float32, device=U.device)
+            dU, dVc, ld = dUV, dUV[:, :, C:], 2 * C
+        else:
+            dU, dVc = (torch.empty(B, N, C, dtype=torch.float32, device=U.device) for _ in range(2))
+            ld = C
+        # bytes: the CSR lists and positions, U / centre terms / five tables / gout once, dU and dVc written (rows k-fold from L2)
+        with profiler.span("edge_bwd_tables", 4.0 * (3.0 * B * N * k + 10.0 * B * N * C)):
             ws = torch.empty(dll().prifit_edge_bwd_workspace(B, N, k, C) // 8, dtype=torch.int64, device=U.device)
             call("prifit_edge_bwd", ptr(gout), _LL(gout.stride(0)), ptr(ystar), ptr(ysum), ptr(karg), ptr(scale), ptr(shift),
-                 ptr(ca), ptr(cb), ptr(cd), ptr(U), ptr(Vc), ptr(idx), ptr(offs), ptr(lst), ptr(pos), B, N, k, C, _F(ctx.cfg["slope"]),
-                 ptr(dU), ptr(dVc), ptr(ws), cur_stream())
-        return dU, dVc, None, None, dgamma, dbeta, None
+                 ptr(ca), ptr(cb), ptr(cd), ptr(U), _LL(U.shape[2]), ptr(vct), int(ctx.stacked), ptr(idx), ptr(offs), ptr(lst),
+                 ptr(pos), B, N, k, C, _F(ctx.cfg["slope"]), ptr(dU), ptr(dVc), _LL(ld), ptr(ws), cur_stream())
+        return dU, (None if ctx.stacked else dVc), None, None, dgamma, dbeta, None
 
 
 def edge_csr(idx):
@@ -452,10 +463,12 @@ class DGCNNEncoderGn(nn.Module):
                 X = torch.cat([X, X.new_zeros(B * N, pad)], dim=1)
                 wa = torch.cat([wa, wa.new_zeros(Cout, pad)], dim=1)
                 wb = torch.cat([wb, wb.new_zeros(Cout, pad)], dim=1)
+            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout):
+                # ONE product X [Wa; Wb]^T = [U | Vb] per point (y = U_j - U_i + Vb_i) and one [B N, 2 Cout] gradient back
+                UV = LinearFn.apply(X, torch.cat([wa, wb], dim=0), None).view(B, N, 2 * Cout)
+                return EdgeConvTabFn.apply(UV, None, idx, csr, gn.weight, gn.bias, cfg)   # [B*N, Cout]
             U = LinearFn.apply(X, wa, None).view(B, N, Cout)             # neighbour term, per point
             Vc = LinearFn.apply(X, wa - wb, None).view(B, N, Cout)       # minus the centre term, per point
-            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout):
-                return EdgeConvTabFn.apply(U, Vc, idx, csr, gn.weight, gn.bias, cfg)   # [B*N, Cout]
             if _EDGE_FUSED_BWD:
                 return EdgeConvLinFn.apply(U, Vc, idx, gn.weight, gn.bias, cfg)      # [B*N, Cout]
             Y, slab = nn_ops.GatherLinearFn.apply(U, Vc, None, idx, True)

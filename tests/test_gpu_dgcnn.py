@@ -183,14 +183,16 @@ def test_edge_csr_lists(D):
         assert torch.equal(lst[b][pos[b][flat_ok].long()], torch.arange(N * k, dtype=torch.int32)[flat_ok])
 
 
+@pytest.mark.parametrize("stacked", [False, True])
 @pytest.mark.parametrize("C", [64, 128, 256])
-def test_edge_tables_forward_and_backward_against_torch(D, C):
+def test_edge_tables_forward_and_backward_against_torch(D, C, stacked):
     """EdgeConvTabFn (tables + CSR gather) against the same block written in torch on the explicit [B, N, k, C] tensor,
-    GroupNorm with negative and zero-crossing scales, an out-of-range neighbour, ties between neighbours."""
+    GroupNorm with negative and zero-crossing scales, an out-of-range neighbour, ties between neighbours.  stacked: the
+    operands are the halves of one [B, N, 2C] tensor [U | Vb], y = U_j - U_i + Vb_i, one gradient tensor back."""
     B, N, k, G = 2, 128, 9, 2
     gen = torch.Generator().manual_seed(C)
     U = torch.randn(B, N, C, generator=gen)
-    Vc = torch.randn(B, N, C, generator=gen) * 0.5
+    V2 = torch.randn(B, N, C, generator=gen) * 0.5          # the centre term Vc, or Vb when stacked
     idx = torch.randint(0, N, (B, N, k), generator=gen, dtype=torch.int32)
     idx[0, 3, 4] = -1                                        # zero row, no gradient
     idx[1, 7, 5] = idx[1, 7, 1]                              # a repeated neighbour: tie, the first position wins
@@ -198,20 +200,25 @@ def test_edge_tables_forward_and_backward_against_torch(D, C):
     beta = torch.randn(C, generator=gen) * 0.3
     go = torch.randn(B * N, C, generator=gen)
     cfg = {"groups": G, "rps": N * k, "slope": 0.2, "pool_K": k, "eps": 1e-5}
-    leaves = [t.clone().requires_grad_(True) for t in (U, Vc, gamma, beta)]
-    Ur, Vr, gr, br = leaves
+    first = torch.cat([U, V2], dim=2) if stacked else U
+    leaves = [t.clone().requires_grad_(True) for t in (first, V2, gamma, beta)]
+    Fr, Vr, gr, br = leaves
+    Ur = Fr[:, :, :C]
+    centre = Ur - Fr[:, :, C:] if stacked else Vr
     ok = ((idx >= 0) & (idx < N)).unsqueeze(-1)
     rows = torch.gather(Ur.unsqueeze(1).expand(B, N, N, C), 2, idx.clamp(0, N - 1).long().unsqueeze(-1).expand(B, N, k, C))
-    y = torch.where(ok, rows - Vr.unsqueeze(2), torch.zeros(()))
+    y = torch.where(ok, rows - centre.unsqueeze(2), torch.zeros(()))
     yn = torch.nn.functional.group_norm(y.permute(0, 3, 1, 2), G, gr, br, 1e-5)
     ref = torch.nn.functional.leaky_relu(yn, 0.2).max(dim=3)[0].permute(0, 2, 1).reshape(B * N, C)
     (ref * go).sum().backward()
-    dl = [t.detach().clone().cuda().requires_grad_(True) for t in (U, Vc, gamma, beta)]
+    dl = [t.detach().clone().cuda().requires_grad_(True) for t in (first, V2, gamma, beta)]
     idx_d = idx.cuda()
-    out = D.EdgeConvTabFn.apply(dl[0], dl[1], idx_d, D.edge_csr(idx_d), dl[2], dl[3], cfg)
+    out = D.EdgeConvTabFn.apply(dl[0], None if stacked else dl[1], idx_d, D.edge_csr(idx_d), dl[2], dl[3], cfg)
     (out * go.cuda()).sum().backward()
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
-    for a, b, name in zip(dl, leaves, ["U", "Vc", "gamma", "beta"]):
+    for a, b, name in zip(dl, leaves, ["U or [U|Vb]", "Vc", "gamma", "beta"]):
+        if stacked and name == "Vc":
+            continue
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-3, atol=1e-4 * b.grad.abs().max().item(),
                                    msg=lambda m, name=name: name + ": " + m)
 
