@@ -313,6 +313,9 @@ int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int 
 int prifit_gn_finalize_offset(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
                               const float *gamma, const float *beta, double eps, const float *offset, double rows_per_sample,
                               float *scale, float *shift, float *mean, float *invstd, void *stream);
+/* dgamma [C], dbeta [C] = the sums over the samples of S[b][1][:], S[b][0][:] (src/dgcnn.py:150-171: the affine parameters of
+ * nn.GroupNorm are shared by all samples). */
+int prifit_gn_param_grads(const double *S, int Bs, int C, float *dgamma, float *dbeta, void *stream);
 
 /* Batch statistics -> affine form of BatchNorm (torch.nn.BatchNorm{1,2}d in train mode, as used at
  * models/pointnet_util.py:198,254,312): mean/var over `count` positions from the partial slabs,

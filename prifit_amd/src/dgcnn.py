@@ -199,8 +199,8 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
         S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
         call("prifit_gn_bwd_finalize", ptr(slab), Bs, nslab // Bs, Cout, G, _D(m), ptr(gamma.contiguous()), ptr(mean),
              ptr(invstd), ptr(cb), ptr(cd), ptr(S), cur_stream())
-        Ssum = S.sum(0).float()                                             # [2, C]: one reduction for both
-        dgamma, dbeta = Ssum[1], Ssum[0]
+        dgamma, dbeta = (torch.empty(Cout, dtype=torch.float32, device=dev) for _ in range(2))
+        call("prifit_gn_param_grads", ptr(S), Bs, Cout, ptr(dgamma), ptr(dbeta), cur_stream())
     else:
         S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)          # [Bs, 2, C]: sum Gm, sum Gm*yhat
         dgamma = S[:, 1].sum(0).float()
@@ -455,18 +455,22 @@ class DGCNNEncoderGn(nn.Module):
         B = feats.shape[0]
         Cout = conv.weight.shape[0]
         if _EDGE_LINEARITY and conv.bias is None and (N * k) % dll().prifit_reduce_rows_per_slab() == 0 and Cout % 4 == 0:
+            X = feats.reshape(B * N, C)
+            pad = _pad4(C) - C                          # 16-byte rows for the product kernels (the 3 input coordinates)
+            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout):
+                # ONE product X [Wa; Wb]^T = [U | Vb] per point (y = U_j - U_i + Vb_i) and one [B N, 2 Cout] gradient back;
+                # [Wa; Wb] is a permuted copy of the weight (one launch each way, no slices to re-assemble in the backward)
+                Wst = conv.weight.reshape(Cout, 2, C).permute(1, 0, 2).reshape(2 * Cout, C)
+                if pad:
+                    X, Wst = F.pad(X, (0, pad)), F.pad(Wst, (0, pad))
+                UV = LinearFn.apply(X, Wst, None).view(B, N, 2 * Cout)
+                return EdgeConvTabFn.apply(UV, None, idx, csr, gn.weight, gn.bias, cfg)   # [B*N, Cout]
             w = conv.weight.reshape(Cout, 2 * C)
             wa, wb = w[:, :C], w[:, C:]
-            X = feats.reshape(B * N, C)
-            if C % 4:                                   # 16-byte rows for the product kernels (the 3 input coordinates)
-                pad = _pad4(C) - C
+            if pad:
                 X = torch.cat([X, X.new_zeros(B * N, pad)], dim=1)
                 wa = torch.cat([wa, wa.new_zeros(Cout, pad)], dim=1)
                 wb = torch.cat([wb, wb.new_zeros(Cout, pad)], dim=1)
-            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout):
-                # ONE product X [Wa; Wb]^T = [U | Vb] per point (y = U_j - U_i + Vb_i) and one [B N, 2 Cout] gradient back
-                UV = LinearFn.apply(X, torch.cat([wa, wb], dim=0), None).view(B, N, 2 * Cout)
-                return EdgeConvTabFn.apply(UV, None, idx, csr, gn.weight, gn.bias, cfg)   # [B*N, Cout]
             U = LinearFn.apply(X, wa, None).view(B, N, Cout)             # neighbour term, per point
             Vc = LinearFn.apply(X, wa - wb, None).view(B, N, Cout)       # minus the centre term, per point
             if _EDGE_FUSED_BWD:
