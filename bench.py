@@ -479,6 +479,13 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     # the calibration is the per-family MINIMUM of two bracketed steps (the first launch of a kernel also loads its code).)
     ncal = 2   # (so at least two untimed steps run whatever --warmup says; the line reports the number that ran)
     warmup = max(warmup, ncal)
+    if args.workload != "c2" and os.environ.get("PRIFIT_SPECULATE", "1") != "0":
+        # The first warm-up step also goes through the fall-back of the speculative runner once (re-run with the synchronous
+        # clustering), whatever its verdict: the first fall-back of a process grows the caching allocator by ~4 GB (0.2 s of
+        # hipMalloc, tools/step_outliers.py) -- one-time initialisation like the lazy code-object loads, which would
+        # otherwise be charged to whichever timed step happens to fall back first (one in 200 on some runs, none on most).
+        warmup = max(warmup, ncal + 1)
+        runner.force_next = True
     for _ in range(warmup - ncal):
         step()
     torch.cuda.synchronize()
