@@ -88,6 +88,15 @@ int prifit_group_gather(const float *feat, const float *xyz, const float *new_xy
 int prifit_group_scatter_add(const float *gout, int ld_gout, int col0, const int32_t *idx, int B,
                              int N, int S, int K, int C, float *dfeat, void *stream);
 
+/* Column permutation / zero padding of a weight matrix into the internal row layout of a first layer (upstream concatenates
+ * [xyz | feat] or [points1 | interpolated], models/pointnet_util.py:195-197, :306; the build's rows are [feat | xyz | 0-pad] and
+ * [interpolated | points1 | 0-pad], 16-byte rows): out [rows, dst_cols][r][j] = w[r][map[j]] (map[j] < 0: 0), w [rows, src_cols]. */
+int prifit_pack_cols(const float *w, int rows, int src_cols, const int32_t *map, int dst_cols, float *out, void *stream);
+/* Its autograd: gw [rows, src_cols][r][c] = sum of g[r][j] over the output columns j with map[j] == c, given as the CSR
+ * (inv_off [src_cols + 1], inv_idx) of the map's inverse. */
+int prifit_unpack_cols(const float *g, int rows, int dst_cols, const int32_t *inv_off, const int32_t *inv_idx, int src_cols,
+                       float *gw, void *stream);
+
 /* out[(b,n), col0 + c] = sum_j weight[b,n,j] * points2[b, idx[b,n,j], c]
  * (models/pointnet_util.py:298).  points2 [B,S,C], out rows have stride ld_out. */
 int prifit_three_interpolate(const float *points2, const int32_t *idx, const float *weight, int B,

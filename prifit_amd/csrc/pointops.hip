@@ -412,6 +412,34 @@ static inline int grid_for(long long total, int per_block = 256, int cap = 256 *
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+// Column permutation / padding of a weight matrix and its autograd (the internal row layouts of the first layers differ from
+// upstream's column order and are padded to 16-byte rows; models/pointnet_util.py:195-197, :306 decide the order).  One
+// launch each way in place of index_select + mul (forward) and zeros + index_select + index_add_ (backward) per weight.
+__global__ __launch_bounds__(256) void pack_cols_kernel(const float *__restrict__ w, int rows, int scols, const int32_t *__restrict__ map,
+                                                        int dcols, float *__restrict__ out)
+{
+    const int total = rows * dcols;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int r = id / dcols, j = id - r * dcols;
+        const int c = map[j];
+        out[id] = c >= 0 ? w[(size_t)r * scols + c] : 0.f;
+    }
+}
+
+// gw[r][c] = sum over the output columns j fed by source column c (inv_idx[inv_off[c] .. inv_off[c+1]), ascending) of g[r][j]
+__global__ __launch_bounds__(256) void unpack_cols_kernel(const float *__restrict__ g, int rows, int dcols,
+                                                          const int32_t *__restrict__ inv_off, const int32_t *__restrict__ inv_idx,
+                                                          int scols, float *__restrict__ gw)
+{
+    const int total = rows * scols;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int r = id / scols, c = id - r * scols;
+        float acc = 0.f;
+        for (int e = inv_off[c]; e < inv_off[c + 1]; ++e) acc += g[(size_t)r * dcols + inv_idx[e]];
+        gw[id] = acc;
+    }
+}
+
 extern "C" {
 
 int prifit_version(const char **arch)
@@ -545,6 +573,25 @@ int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const
     const long long total = (long long)B * N * C;
     hipLaunchKernelGGL(three_interpolate_bwd_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
                        as_stream(stream), gout, ld_gout, col0, idx, weight, N, S, C, total, dpoints2);
+    return prifit_check_launch();
+}
+
+int prifit_pack_cols(const float *w, int rows, int src_cols, const int32_t *map, int dst_cols, float *out, void *stream)
+{
+    if (!w || !map || !out || rows <= 0 || src_cols <= 0 || dst_cols <= 0 || (long long)rows * dst_cols > 0x7fffffffLL)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(pack_cols_kernel, dim3(grid_for((long long)rows * dst_cols, 256, 256 * 8)), dim3(256), 0, as_stream(stream),
+                       w, rows, src_cols, map, dst_cols, out);
+    return prifit_check_launch();
+}
+
+int prifit_unpack_cols(const float *g, int rows, int dst_cols, const int32_t *inv_off, const int32_t *inv_idx, int src_cols,
+                       float *gw, void *stream)
+{
+    if (!g || !inv_off || !inv_idx || !gw || rows <= 0 || src_cols <= 0 || dst_cols <= 0 || (long long)rows * src_cols > 0x7fffffffLL)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(unpack_cols_kernel, dim3(grid_for((long long)rows * src_cols, 256, 256 * 8)), dim3(256), 0,
+                       as_stream(stream), g, rows, dst_cols, inv_off, inv_idx, src_cols, gw);
     return prifit_check_launch();
 }
 

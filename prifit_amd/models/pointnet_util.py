@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .. import arena as zero_pool
+from .._lib import call, cur_stream, ptr
 from ..nn_ops import (GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
                       ThreeInterpolateFn, _sa_group_launch, sa_group_supported)
 
@@ -61,44 +62,45 @@ _col_index_cache = {}
 
 
 def _col_index(cols, ncols, device):
-    """(src, dst, inv) index tensors of a column map `cols` (tuple; entry j = source column of output column j, -1 = zero
-    column), cached per device: src / dst the used pairs, inv the inverse permutation when every source column is used once."""
+    """(map, inv_off, inv_idx) int32 device tensors of a column map `cols` (tuple; entry j = source column of output column j,
+    -1 = zero column), cached per device: the map itself and the CSR of its inverse (for every source column the output
+    columns it feeds, ascending)."""
     key = (cols, ncols, str(device))
     hit = _col_index_cache.get(key)
     if hit is None:
-        pairs = [(c, j) for j, c in enumerate(cols) if c >= 0]
-        src = torch.tensor([c for c, _ in pairs], dtype=torch.long, device=device)
-        dst = torch.tensor([j for _, j in pairs], dtype=torch.long, device=device)
-        inv = None
-        if sorted(c for c, _ in pairs) == list(range(ncols)):
-            pos = {c: j for c, j in pairs}
-            inv = torch.tensor([pos[c] for c in range(ncols)], dtype=torch.long, device=device)
-        full = torch.tensor([max(c, 0) for c in cols], dtype=torch.long, device=device)      # padded columns read column 0 ...
-        mask = torch.tensor([1.0 if c >= 0 else 0.0 for c in cols], dtype=torch.float32, device=device)   # ... times zero
-        hit = _col_index_cache[key] = (src, dst, inv, full, mask)
+        inv = [[] for _ in range(ncols)]
+        for j, c in enumerate(cols):
+            if c >= 0:
+                inv[c].append(j)
+        off = [0]
+        for lst in inv:
+            off.append(off[-1] + len(lst))
+        flat = [j for lst in inv for j in lst] or [0]
+        hit = _col_index_cache[key] = tuple(torch.tensor(t, dtype=torch.int32, device=device) for t in (list(cols), off, flat))
     return hit
 
 
 class PackColsFn(torch.autograd.Function):
-    """out[:, j] = w[:, cols[j]] (cols[j] < 0: a zero column): a column permutation / padding of a weight matrix as one gather
-    forward and one gather (or scatter) backward.  Slices + cat do the same with a zero-fill and a copy per slice in the
-    backward: ~35 tiny launches per training step over the set-abstraction / feature-propagation first layers."""
+    """out[:, j] = w[:, cols[j]] (cols[j] < 0: a zero column): a column permutation / padding of a weight matrix as one
+    launch forward (prifit_pack_cols) and one backward (prifit_unpack_cols: a source column may feed several output columns --
+    their gradients are summed).  Slices + cat do the same with a zero-fill and a copy per slice in the backward, index_select
+    / index_add_ with 2 + 3 launches per weight: ~30 tiny launches per training step over the first layers."""
 
     @staticmethod
     def forward(ctx, w, cols):
-        src, dst, inv, full, mask = _col_index(cols, w.shape[1], w.device)
-        ctx.idx, ctx.ncols = (src, dst, inv), w.shape[1]
-        if len(cols) == src.numel():            # a pure permutation / selection: no padding
-            return w.index_select(1, src)
-        return w.index_select(1, full) * mask.to(w.dtype)   # (weights are finite: 0 * w = 0)
+        w = w.contiguous()
+        cmap, inv_off, inv_idx = _col_index(cols, w.shape[1], w.device)
+        ctx.idx, ctx.ncols = (inv_off, inv_idx), w.shape[1]
+        out = torch.empty(w.shape[0], len(cols), dtype=torch.float32, device=w.device)
+        call("prifit_pack_cols", ptr(w), w.shape[0], w.shape[1], ptr(cmap), len(cols), ptr(out), cur_stream())
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        src, dst, inv = ctx.idx
-        if inv is not None:                     # every source column used exactly once
-            return g.index_select(1, inv), None
-        gw = g.new_zeros(g.shape[0], ctx.ncols)
-        gw.index_add_(1, src, g.index_select(1, dst))   # a source column may feed several output columns: sum, not overwrite
+        inv_off, inv_idx = ctx.idx
+        g = g.contiguous()
+        gw = torch.empty(g.shape[0], ctx.ncols, dtype=torch.float32, device=g.device)
+        call("prifit_unpack_cols", ptr(g), g.shape[0], g.shape[1], ptr(inv_off), ptr(inv_idx), ctx.ncols, ptr(gw), cur_stream())
         return gw, None
 
 
