@@ -457,7 +457,8 @@ class DGCNNEncoderGn(nn.Module):
         if _EDGE_LINEARITY and conv.bias is None and (N * k) % dll().prifit_reduce_rows_per_slab() == 0 and Cout % 4 == 0:
             X = feats.reshape(B * N, C)
             pad = _pad4(C) - C                          # 16-byte rows for the product kernels (the 3 input coordinates)
-            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout):
+            # (the backward's reduction runs over the [B N, Cout] table of winners in 128-row slabs: whole slabs per sample)
+            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout) and N % dll().prifit_reduce_rows_per_slab() == 0:
                 # ONE product X [Wa; Wb]^T = [U | Vb] per point (y = U_j - U_i + Vb_i) and one [B N, 2 Cout] gradient back;
                 # [Wa; Wb] is a permuted copy of the weight (one launch each way, no slices to re-assemble in the backward)
                 Wst = conv.weight.reshape(Cout, 2, C).permute(1, 0, 2).reshape(2 * Cout, C)
