@@ -378,6 +378,27 @@ def _check_param_grads(my, ref, rtol=2e-4):
         torch.testing.assert_close(b1.cpu().float(), b2.float(), rtol=1e-4, atol=1e-5, msg=lambda m: k + ": " + m)
 
 
+def test_pack_cols_forward_and_backward(hiplib):
+    """PackColsFn (prifit_pack_cols / prifit_unpack_cols): a column map with a permutation, zero padding and a source column that
+    feeds two output columns, against plain indexing and its autograd."""
+    from prifit_amd.models.pointnet_util import PackColsFn
+    gen = torch.Generator().manual_seed(3)
+    w = torch.randn(37, 9, generator=gen)
+    cols = (3, 4, 5, 0, 1, 2, -1, 8, 8, -1, 6, -1)          # column 7 unused, column 8 twice, three pad columns
+    go = torch.randn(37, len(cols), generator=gen)
+    wr = w.clone().requires_grad_(True)
+    idx = torch.tensor([max(c, 0) for c in cols])
+    mask = torch.tensor([1.0 if c >= 0 else 0.0 for c in cols])
+    ref = wr[:, idx] * mask
+    (ref * go).sum().backward()
+    wd = w.cuda().requires_grad_(True)
+    out = PackColsFn.apply(wd, cols)
+    (out * go.cuda()).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-6, atol=1e-6)
+    assert torch.equal(wd.grad[:, 7].cpu(), torch.zeros(37))
+
+
 def test_sa_msg_module(hiplib, golden):
     from prifit_amd.models import pointnet_util as pu
     g = golden("module_sa_msg")
