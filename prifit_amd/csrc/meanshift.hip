@@ -19,7 +19,7 @@ __device__ __forceinline__ float key2f(unsigned k)
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-template <int VPT>
+template <int VPT, bool VEC = false>
 __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restrict__ M, long long rows, int C,
                                                            int k, float *__restrict__ out)
 {
@@ -28,16 +28,28 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
     const int lane = threadIdx.x & 63;
     const float *r = M + row * C;
     unsigned key[VPT];
+    // which column slot j of a lane holds: the selection does not care, so 16-byte rows are read as float4 (a quarter of the
+    // load instructions: columns 4 lane + 256 (j / 4) + (j % 4)); otherwise lane + 64 j
+    auto colof = [&](int j) { return VEC ? 4 * lane + 256 * (j >> 2) + (j & 3) : lane + 64 * j; };
     // branch-free loads (clamped column), padding applied afterwards: a predicated load costs the compiler a branch and
     // a full s_waitcnt vmcnt(0) each, which serialised the VPT loads of a row
     float raw[VPT];
+    if (VEC) {
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-        const int c = lane + 64 * j;
-        raw[j] = r[c < C ? c : C - 1];
+        for (int q = 0; q < VPT / 4; ++q) {
+            const int c = 4 * lane + 256 * q;
+            const float4 v = *reinterpret_cast<const float4 *>(r + (c < C ? c : C - 4));   // C % 4 == 0
+            raw[4 * q] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            raw[j] = r[c < C ? c : C - 1];
+        }
     }
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) key[j] = (lane + 64 * j) < C ? f2key(raw[j]) : 0xffffffffu;  // padding sorts last
+    for (int j = 0; j < VPT; ++j) key[j] = colof(j) < C ? f2key(raw[j]) : 0xffffffffu;  // padding sorts last
     // Bisection on the key value instead of a masked radix step: the k-th smallest key is the largest p with
     // count(key < p) < k, found bit by bit from the top -- ONE compare-and-count per key and round (2 VALU operations)
     // where the masked digit test of the radix select took five, and no candidate bookkeeping (the padding keys
@@ -50,7 +62,7 @@ __global__ __launch_bounds__(256) void kth_smallest_kernel(const float *__restri
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         kmin = min(kmin, key[j]);
-        kmax = max(kmax, (lane + 64 * j) < C ? key[j] : 0u);
+        kmax = max(kmax, colof(j) < C ? key[j] : 0u);
     }
     kmin = ~wave_max_u32_dpp(~kmin);
     kmax = wave_max_u32_dpp(kmax);
@@ -501,10 +513,17 @@ int prifit_kth_smallest_rows(const float *M, long long rows, int C, int k, float
     if (!M || !out || rows <= 0 || C <= 0 || k < 1 || k > C || C > 4096) return PRIFIT_EINVAL;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = as_stream(stream);
-    if (C <= 512) hipLaunchKernelGGL((kth_smallest_kernel<8>), grid, block, 0, st, M, rows, C, k, out);
-    else if (C <= 1024) hipLaunchKernelGGL((kth_smallest_kernel<16>), grid, block, 0, st, M, rows, C, k, out);
-    else if (C <= 2048) hipLaunchKernelGGL((kth_smallest_kernel<32>), grid, block, 0, st, M, rows, C, k, out);
-    else hipLaunchKernelGGL((kth_smallest_kernel<64>), grid, block, 0, st, M, rows, C, k, out);
+    const bool vec = (C % 4) == 0 && ((uintptr_t)M & 15) == 0;     // 16-byte rows: float4 loads
+#define KTH(V)                                                                                              \
+    do {                                                                                                    \
+        if (vec) hipLaunchKernelGGL((kth_smallest_kernel<V, true>), grid, block, 0, st, M, rows, C, k, out); \
+        else hipLaunchKernelGGL((kth_smallest_kernel<V, false>), grid, block, 0, st, M, rows, C, k, out);    \
+    } while (0)
+    if (C <= 512) KTH(8);
+    else if (C <= 1024) KTH(16);
+    else if (C <= 2048) KTH(32);
+    else KTH(64);
+#undef KTH
     return prifit_check_launch();
 }
 
