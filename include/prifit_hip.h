@@ -301,6 +301,10 @@ int prifit_pool_reduce_groups_per_slab(void);
 
 /* slab [ceil(P/rows_per_slab)][2][C] = per-block column (sum, sum of squares) of Y. */
 int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream);
+/* out [C] += column sums of Y [P, ld] (C % 4 == 0, 16-byte rows; float atomics into a zeroed `out`): the bias gradient of a 1x1
+ * convolution that has no BatchNorm behind it (autograd of conv2 / extra_conv_emb, models/pointnet2_part_seg_msg.py:109,128, and of
+ * the DGCNN decoder's biased convolutions, src/dgcnn.py:236-259). */
+int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, void *stream);
 
 /* GroupNorm statistics (nn.GroupNorm of src/dgcnn.py:150-171,203-213: per sample and channel group) -> the same affine
  * form, per-sample tables [Bs][C].  slab [Bs * slabs_per_sample][2][C]: column (sum, sum of squares) partials, consecutive

@@ -198,6 +198,49 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const double *__res
     else dgamma[t - C] = (float)acc;
 }
 
+// out[c] += sum over the rows of Y[r][c]: the gradient of a convolution's bias (the decoders' and heads' biased 1x1 convolutions,
+// src/dgcnn.py:236-259, models/pointnet2_part_seg_msg.py:109,128, without a BatchNorm behind them).  One workgroup per 512 rows,
+// float4 columns x row lanes, partial sums combined in LDS, one float atomic per column and workgroup into the zeroed `out`
+// (torch's reduction took 17 - 23 us for 12 - 50 MB: nine launches per DGCNN step).
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ Y, long long ld, int P, int C, float *__restrict__ out)
+{
+    __shared__ float4 s_red[256];
+    const int C4 = C >> 2;
+    const int r_begin = blockIdx.x * CS_ROWS, r_end = min(P, r_begin + CS_ROWS);
+    for (int cbase = 0; cbase < C4; cbase += 256) {
+        const int cols = min(256, C4 - cbase);
+        const int lanes = 256 / cols;
+        const int c4 = cbase + threadIdx.x % cols, rl = threadIdx.x / cols;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;     // two partials per thread: independent adds
+        if (rl < lanes) {
+            int r = r_begin + rl;
+            for (; r + lanes < r_end; r += 2 * lanes) {
+                const float4 u = ld4g(Y + (size_t)r * ld + 4 * c4), v = ld4g(Y + (size_t)(r + lanes) * ld + 4 * c4);
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+            }
+            if (r < r_end) {
+                const float4 u = ld4g(Y + (size_t)r * ld + 4 * c4);
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            }
+        }
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        s_red[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            float4 t = s_red[threadIdx.x];
+            for (int l = 1; l < lanes; ++l) {
+                const float4 u = s_red[threadIdx.x + l * cols];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            float *o = out + 4 * c4;
+            unsafeAtomicAdd(o, t.x); unsafeAtomicAdd(o + 1, t.y); unsafeAtomicAdd(o + 2, t.z); unsafeAtomicAdd(o + 3, t.w);
+        }
+        __syncthreads();
+    }
+}
+
 // Column sum / sum of squares of a matrix (used when the producer was not a GEMM with fused stats).
 __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ Y, long long ld, int P, int C,
                                                         float *__restrict__ slab)
@@ -882,6 +925,13 @@ int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int 
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, Bs), dim3(256), 0, as_stream(stream), slab, slabs_per_sample, C,
                        C / groups, count, gamma, mean, invstd, coef_b, coef_d, S);
+    return prifit_check_launch();
+}
+
+int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, void *stream)
+{
+    if (bad_mat(Y, ld, C) || !out || P <= 0 || C <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(col_sum_kernel, dim3((P + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, as_stream(stream), Y, ld, P, C, out);
     return prifit_check_launch();
 }
 

@@ -776,7 +776,11 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dW = _weight_grad(gy, P, Cout, x, Kin, None)
         if ctx.needs_input_grad[2]:
-            db = gy.sum(dim=0)
+            if Cout % 4 == 0 and gy.data_ptr() % 16 == 0:
+                db = zero_pool.zeros(Cout, device=x.device)
+                call("prifit_col_sum", ptr(gy), _LL(Cout), P, Cout, ptr(db), cur_stream())
+            else:
+                db = gy.sum(dim=0)
         return dx, dW, db
 
 
