@@ -257,8 +257,14 @@ def run_rank(args):
     if trace:   # written BEFORE torch is imported (seconds on a cold box): a rank the launcher ends early has left it
         with open("%s.%d" % (trace, rank), "w") as f:
             f.write("rank %d of %d local %d" % (rank, world, local))
+    # host side of one process per GPU (prifit_amd/hostcfg.py): this rank's own cores (on its GPU's NUMA node when sysfs
+    # says which) and CPU thread pools capped at that many -- BEFORE torch starts its pools and before any GPU call
+    from prifit_amd import hostcfg
+    host = hostcfg.apply_from_env(set_torch=False)
     import torch
     import torch.distributed as dist
+    if host["threads"]:
+        torch.set_num_threads(host["threads"])
 
     if "RANK" in os.environ and args.gpus != world and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d; the environment wins" % (args.gpus, world), file=sys.stderr)
@@ -269,7 +275,8 @@ def run_rank(args):
     ndev = torch.cuda.device_count()
     share = os.environ.get("PRIFIT_BENCH_SHARE_GPU", "0") == "1"
     if local >= ndev and not share:
-        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, ndev))
+        raise SystemExit("bench.py: rank %d has LOCAL_RANK %d but only %d GPU(s) are visible (--gpus %d needs %d)"
+                         % (rank, local, ndev, args.gpus, world))
     local_dev = local % ndev
     torch.cuda.set_device(local_dev)
     device = torch.device("cuda", local_dev)
@@ -301,6 +308,7 @@ def run_rank(args):
     if use_dist:
         import socket
         mine = dict(device_identity(local_dev), rank=rank, local_rank=local, host=socket.gethostname(),
+                    cpu_cores=host["cores"], cpu_threads=host["threads"], numa_node=host["numa_node"], cpu_pinned=host["pinned"],
                     ms_per_step=1e3 * head["elapsed_local"] / head["steps"], speculation_fallbacks=head["fallbacks"],
                     allreduce_ms_per_step=head["allreduce_ms"] / head["steps"])
         report = distributed_report(mine, rehearsal=share)
@@ -761,7 +769,13 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # launcher: nothing in this branch imports torch or loads the HIP library
-        from prifit_amd import build, launch
+        from prifit_amd import build, hostcfg, launch
+        # preflight: one clear line instead of N tracebacks when the box has fewer GPUs than ranks were asked for
+        # (sysfs / *_VISIBLE_DEVICES only: the parent stays off the GPU)
+        have = hostcfg.visible_gpu_count()
+        if have is not None and have < args.gpus and os.environ.get("PRIFIT_BENCH_SHARE_GPU", "0") != "1":
+            print("bench.py: --gpus %d but only %d GPU(s) are visible on this host" % (args.gpus, have), file=sys.stderr)
+            sys.exit(2)
         build.build_library()            # once, before the ranks start (hipcc only; a no-op when up to date)
         sys.exit(launch.relaunch_self(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     run_rank(args)

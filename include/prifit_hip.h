@@ -301,10 +301,12 @@ int prifit_pool_reduce_groups_per_slab(void);
 
 /* slab [ceil(P/rows_per_slab)][2][C] = per-block column (sum, sum of squares) of Y. */
 int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, void *stream);
-/* out [C] += column sums of Y [P, ld] (C % 4 == 0, 16-byte rows; float atomics into a zeroed `out`): the bias gradient of a 1x1
- * convolution that has no BatchNorm behind it (autograd of conv2 / extra_conv_emb, models/pointnet2_part_seg_msg.py:109,128, and of
- * the DGCNN decoder's biased convolutions, src/dgcnn.py:236-259). */
-int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, void *stream);
+/* out [C] = column sums of Y [P, ld] (C % 4 == 0, 16-byte rows): the bias gradient of a 1x1 convolution that has no BatchNorm
+ * behind it (autograd of conv2 / extra_conv_emb, models/pointnet2_part_seg_msg.py:109,128, and of the DGCNN decoder's biased
+ * convolutions, src/dgcnn.py:236-259).  Per-workgroup partial rows in `workspace` (prifit_col_sum_workspace floats, 16-byte
+ * aligned), added in a fixed order by a second small launch: no atomics, the same bits from run to run. */
+long long prifit_col_sum_workspace(int P, int C);
+int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, float *workspace, void *stream);
 
 /* GroupNorm statistics (nn.GroupNorm of src/dgcnn.py:150-171,203-213: per sample and channel group) -> the same affine
  * form, per-sample tables [Bs][C].  slab [Bs * slabs_per_sample][2][C]: column (sum, sum of squares) partials, consecutive
@@ -627,6 +629,15 @@ int prifit_meanshift_split_fwd(const float *Z, const void *workspace, const floa
 int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap,
                const unsigned long long *owner_key, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids,
                int32_t *count, int32_t *labels, int32_t *used, void *stream);
+
+/* The same with centres that are not the points, src/mean_shift.py:162-202 as written: nms(centers, X, b) with
+ * centers [B,N,D] and X [B,N,D] two tables of the same row count (upstream's `cluster_nbrs[uniques] * num_mem_cluster`
+ * broadcast needs centers.shape[0] == X.shape[0]; e.g. the commented call nms(new_X, X, b) of :43).
+ * dist_xc [B,N,N] = 2 - 2 X C^T (row j: the distances of point j to every centre), dist_cc [B,N,N] = 2 - 2 C C^T.
+ * Outputs as prifit_nms; labels[j] = argmax_k <C[ids[k]], X[j]>. */
+int prifit_nms_pair(const float *dist_xc, const float *dist_cc, const float *C, const float *X, const float *bw, int B,
+                    int N, int D, int cap, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count,
+                    int32_t *labels, int32_t *used, void *stream);
 
 /* Soft membership, src/mean_shift.py:230-247.  dots [B,N,KM] = <x_j, centre_k> (raw), bw [B], gmax [B] =
  * max over live (k, j) of dots / bw^2 (detached): W [B,N,KM] = softmax-like weights, 0 for k >= count[b]. */

@@ -109,6 +109,54 @@ def run_mean_shift_variants(save, close):
     save("fit_meanshift_variants", **out)
 
 
+def run_nms_pair_and_epa_guard(save, eq, close):
+    """Two corners of the reference's call surface the loss never takes (own entry `make_golden.py nms_pair`):
+    (i) MeanShift.nms(centers, X, b) with centres that are NOT the points (src/mean_shift.py:162-202; the commented call
+    `nms(new_X, X, b)` of :43): shifted points against the original embedding; (ii) guard_mean_shift with the
+    epanechnikov kernel (src/ellipsoid_utils.py:9-27 forwards `kernel_type`, src/mean_shift.py:70-74).  Oracle vs
+    reference exactly (the same CPU arithmetic); the fixture stores K, ids and labels."""
+    ms = refshim.ref("src.mean_shift").MeanShift()
+    EU = refshim.ref("src.ellipsoid_utils")
+    seed, N, D = 9, 512, 32
+    _, _, emb = fit_inputs(2, N, D, seed, M=1000, noise=0.1)
+    out = {"seed": seed}
+    for b in range(2):
+        X = emb[b]
+        with torch.no_grad():
+            bw = ms.compute_bandwidth(X, N, 0.05)
+            Z = ms.mean_shift_(X, bw, 4)[0]              # part of the way: the modes have not collapsed to a point yet
+            cr, ir, lr = ms.nms(Z, X, bw)
+        co, io, lo = orc.nms(Z, X, bw)
+        eq(io, ir, "nms(Z, X) ids b=%d (K = %d)" % (b, ir.shape[0]))
+        eq(lo, lr, "nms(Z, X) labels b=%d" % b)
+        assert 2 <= ir.shape[0] <= 32, ir.shape
+        out["bw_%d" % b] = bw
+        out["ids_%d" % b] = ir.to(torch.int16)
+        out["labels_%d" % b] = lr.to(torch.int16)
+    # (ii) epanechnikov through guard_mean_shift, q small enough that the first pass finds more than the cap
+    X = emb[0]
+    q0, cap, iters = 0.02, 6, 5
+    calls = []
+    real = EU.meanshift.mean_shift
+
+    def counting(*a, **k):
+        calls.append(a[2])
+        return real(*a, **k)
+
+    with patched(EU.meanshift, "mean_shift", counting):
+        cr, bwr, lr = EU.guard_mean_shift(X, N, q0, iters, cap, kernel_type="epa")
+    co, bwo, lo, io, Zo, qo = orc.guard_mean_shift(X, q0, iters, cap, kernel_type="epa")
+    close(bwo, bwr, "guard_mean_shift(epa) bandwidth", rtol=1e-6)
+    assert qo == calls[-1], (qo, calls)
+    eq(lo, lr, "guard_mean_shift(epa) labels")
+    close(co, cr, "guard_mean_shift(epa) centres", rtol=1e-5, atol=1e-6)
+    print("  quantiles tried by the reference:", calls, " K =", cr.shape[0])
+    assert len(calls) >= 2, "pick q0 / cap so that a retry happens"
+    out.update(q0=q0, cap=cap, iters=iters, epa_quantiles=np.array(calls), epa_bw=bwr, epa_K=cr.shape[0],
+               epa_labels=lr.to(torch.int16))
+    save("fit_nms_pair", **out)
+
+
 def run_center_grad(save, eq, close):
     """The gradient that enters the mean-shift trajectory through `center = new_X[indices]` ALONE (src/mean_shift.py:44-46:
     `nms` runs under no_grad, the gather is the only differentiable use of the shifted points): d/dX sum(G * new_X[ids])

@@ -466,11 +466,26 @@ def knn(x, k1, k2):
         return pairwise.topk(k=k2, dim=-1)[1][:, :, keep]
 
 
-def graph_feature(x, k1, k2, idx=None):
-    """src/dgcnn.py:74-107: edge features cat(x_j - x_i, x_i) -> [B, 2C, N, k1]."""
+def knn_points_normals(x, k1, k2):
+    """src/dgcnn.py:30-71.  x [B,6,N] (xyz, normals) -> idx [B,N,k1]: the positional squared distance weighted by
+    (1 + the normals' chord distance), nearest first."""
+    keep = np.arange(0, k2, k2 // k1)
+    with torch.no_grad():
+        p, n = x[:, 0:3], x[:, 3:6]
+        inner = 2 * torch.matmul(p.transpose(2, 1), p)
+        xx = torch.sum(p ** 2, dim=1, keepdim=True)
+        p_pair = xx - inner + xx.transpose(2, 1)
+        n_pair = 2 - 2 * torch.matmul(n.transpose(2, 1), n)
+        pair = p_pair * (1 + n_pair)
+        return (-pair).topk(k=k2, dim=-1)[1][:, :, keep]
+
+
+def graph_feature(x, k1, k2, idx=None, normals=False):
+    """src/dgcnn.py:74-107 (:110-146 with normals=True: the same rows on the graph of knn_points_normals):
+    edge features cat(x_j - x_i, x_i) -> [B, 2C, N, k1]."""
     B, C, N = x.shape
     if idx is None:
-        idx = knn(x, k1, k2)
+        idx = knn_points_normals(x, k1, k2) if normals else knn(x, k1, k2)
     xt = x.transpose(2, 1).contiguous()
     nb = gather_rows(xt, idx)                                   # [B,N,k,C]
     ctr = xt.unsqueeze(2).expand(-1, -1, k1, -1)
@@ -478,8 +493,9 @@ def graph_feature(x, k1, k2, idx=None):
 
 
 class OracleDGCNGn(nn.Module):
-    """src/dgcnn.py:149-267 (input_channels=3): DGCNNEncoderGn + segmentation / embedding heads.
-    forward(points [B,3,N]) -> (embedding [B,N,emb], seg [B,3,N])."""
+    """src/dgcnn.py:149-267: DGCNNEncoderGn + segmentation / embedding heads.  num_channels=6 (:199-222): points carry
+    normals, the first graph comes from knn_points_normals, and the dilation factor is not applied (k2 = k).
+    forward(points [B,3 or 6,N]) -> (embedding [B,N,emb], seg [B,3,N])."""
 
     def __init__(self, emb_size=128, num_channels=3, nn_nb=80, dilation=1):
         super().__init__()
@@ -491,7 +507,8 @@ class OracleDGCNGn(nn.Module):
         enc.mlp1 = nn.Conv1d(256, 1024, 1)
         enc.bnmlp1 = nn.GroupNorm(8, 1024)
         self.encoder = enc
-        self.k, self.dil = nn_nb, dilation
+        self.k, self.dil = nn_nb, (dilation if num_channels == 3 else 1)
+        self.normals = num_channels == 6
         self.conv1 = nn.Conv1d(1024 + 256, 512, 1)
         self.bn1 = nn.GroupNorm(8, 512)
         self.conv2 = nn.Conv1d(512, 256, 1)
@@ -504,7 +521,7 @@ class OracleDGCNGn(nn.Module):
     def forward(self, points):
         B, _, N = points.shape
         e, k = self.encoder, self.k
-        x, _ = graph_feature(points, k, k * self.dil)
+        x, _ = graph_feature(points, k, k * self.dil, normals=self.normals)
         x1 = e.conv1(x).max(dim=-1)[0]
         x, idx = graph_feature(x1, k, k * self.dil)
         x2 = e.conv2(x).max(dim=-1)[0]
@@ -589,8 +606,8 @@ def nms(centers, X, b):
     return kept, ids, labels
 
 
-def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None, num_samples=None):
-    """src/mean_shift.py:18-48 (eff=False).
+def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None, num_samples=None, kernel_type="gaussian"):
+    """src/mean_shift.py:18-48 (eff=False); kernel_type other than "gaussian": the epanechnikov branch of :70-74.
 
     `center_ids` (harness hook): WHICH point represents a collapsed mode is decided by last-bit noise in the
     reference's own nms (the shifted points of a cluster agree to ~1e-7), yet the gradient enters the mean-shift
@@ -599,7 +616,7 @@ def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None, nu
     to be the one nms found."""
     with torch.no_grad():
         bw = compute_bandwidth(X, quantile, bandwidth_rows, num_samples)
-    Z = mean_shift_iterations(X, bw, iterations)
+    Z = mean_shift_iterations(X, bw, iterations, kernel_type)
     with torch.no_grad():
         _, ids, labels = nms(Z, Z, bw)
         if center_ids is not None:
@@ -611,10 +628,11 @@ def mean_shift(X, quantile, iterations, center_ids=None, bandwidth_rows=None, nu
     return Z[ids], bw, labels, ids, Z
 
 
-def guard_mean_shift(X, quantile, iterations, max_num_clusters, center_ids=None, bandwidth_rows=None, num_samples=None):
+def guard_mean_shift(X, quantile, iterations, max_num_clusters, center_ids=None, bandwidth_rows=None, num_samples=None,
+                     kernel_type="gaussian"):
     """src/ellipsoid_utils.py:9-27: double the quantile until <= max_num_clusters distinct labels."""
     while True:
-        centers, bw, labels, ids, Z = mean_shift(X, quantile, iterations, center_ids, bandwidth_rows, num_samples)
+        centers, bw, labels, ids, Z = mean_shift(X, quantile, iterations, center_ids, bandwidth_rows, num_samples, kernel_type)
         if torch.unique(labels).shape[0] > max_num_clusters:
             quantile *= 2
         else:

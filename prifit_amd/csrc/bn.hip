@@ -200,10 +200,11 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const double *__res
 
 // out[c] += sum over the rows of Y[r][c]: the gradient of a convolution's bias (the decoders' and heads' biased 1x1 convolutions,
 // src/dgcnn.py:236-259, models/pointnet2_part_seg_msg.py:109,128, without a BatchNorm behind them).  One workgroup per 512 rows,
-// float4 columns x row lanes, partial sums combined in LDS, one float atomic per column and workgroup into the zeroed `out`
-// (torch's reduction took 17 - 23 us for 12 - 50 MB: nine launches per DGCNN step).
+// float4 columns x row lanes, partial sums combined in LDS, one partial row per workgroup into `part` [nblocks][C]; a second
+// small launch adds the partial rows in a FIXED order (no atomics: the same bits from run to run, as torch's reduction gave;
+// torch's reduction took 17 - 23 us for 12 - 50 MB: nine launches per DGCNN step).
 constexpr int CS_ROWS = 512;
-__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ Y, long long ld, int P, int C, float *__restrict__ out)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ Y, long long ld, int P, int C, float *__restrict__ part)
 {
     __shared__ float4 s_red[256];
     const int C4 = C >> 2;
@@ -234,11 +235,25 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
                 const float4 u = s_red[threadIdx.x + l * cols];
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
-            float *o = out + 4 * c4;
-            unsafeAtomicAdd(o, t.x); unsafeAtomicAdd(o + 1, t.y); unsafeAtomicAdd(o + 2, t.z); unsafeAtomicAdd(o + 3, t.w);
+            *reinterpret_cast<float4 *>(part + (size_t)blockIdx.x * C + 4 * c4) = t;
         }
         __syncthreads();
     }
+}
+
+// out[c] = sum over the partial rows, four interleaved chains per column in a fixed order
+__global__ __launch_bounds__(256) void col_sum_reduce_kernel(const float *__restrict__ part, int nb, int C, float *__restrict__ out)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nb; b += 4) {
+        a0 += part[(size_t)b * C + c]; a1 += part[(size_t)(b + 1) * C + c];
+        a2 += part[(size_t)(b + 2) * C + c]; a3 += part[(size_t)(b + 3) * C + c];
+    }
+    for (; b < nb; ++b) a0 += part[(size_t)b * C + c];
+    out[c] = (a0 + a1) + (a2 + a3);
 }
 
 // Column sum / sum of squares of a matrix (used when the producer was not a GEMM with fused stats).
@@ -928,10 +943,18 @@ int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int 
     return prifit_check_launch();
 }
 
-int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, void *stream)
+long long prifit_col_sum_workspace(int P, int C)
 {
-    if (bad_mat(Y, ld, C) || !out || P <= 0 || C <= 0) return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(col_sum_kernel, dim3((P + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, as_stream(stream), Y, ld, P, C, out);
+    if (P <= 0 || C <= 0) return 0;
+    return (long long)((P + CS_ROWS - 1) / CS_ROWS) * C;
+}
+
+int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, float *workspace, void *stream)
+{
+    if (bad_mat(Y, ld, C) || !out || !workspace || ((uintptr_t)workspace & 15) || P <= 0 || C <= 0) return PRIFIT_EINVAL;
+    const int nb = (P + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), 0, as_stream(stream), Y, ld, P, C, workspace);
+    hipLaunchKernelGGL(col_sum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, nb, C, out);
     return prifit_check_launch();
 }
 

@@ -334,9 +334,9 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t *__restr
     for (int k = s_base + threadIdx.x; k < cap; k += 256) ids[(long long)b * cap + k] = 0;
 }
 
-// labels[j] = argmax_k <centre_k, z_j> (first max) with centre_k = Z[ids[k]]; used[b][label] = 1.
-// One wave per point; D <= 256.
-__global__ __launch_bounds__(256) void nms_labels_kernel(const float *__restrict__ Z, int N, int D,
+// labels[j] = argmax_k <centre_k, x_j> (first max) with centre_k = Zc[ids[k]], x_j = Z[j]; used[b][label] = 1.
+// One wave per point; D <= 256.  (Zc == Z: nms(Z, Z, b), the way upstream calls it.)
+__global__ __launch_bounds__(256) void nms_labels_kernel(const float *__restrict__ Zc, const float *__restrict__ Z, int N, int D,
                                                          const int32_t *__restrict__ ids,
                                                          const int32_t *__restrict__ count, int cap,
                                                          long long rows, int32_t *__restrict__ labels,
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void nms_labels_kernel(const float *__restrict
     float best = -INFINITY;
     int bk = 0;
     for (int k = 0; k < K; ++k) {
-        const float *c = Z + (b * N + ids[b * cap + k]) * D;
+        const float *c = Zc + (b * N + ids[b * cap + k]) * D;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) s += (lane + 64 * j) < D ? x[j] * c[lane + 64 * j] : 0.f;
@@ -582,7 +582,29 @@ int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N,
         hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist, N, rows, owner, counts);
     hipLaunchKernelGGL(nms_pick_kernel, grid, block, 0, st, dist, counts, bw, N, rows, flags);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(B), block, 0, st, flags, N, cap, ids, count);
-    hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, Z, N, D, ids, count, cap, rows, labels, used);
+    hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, Z, Z, N, D, ids, count, cap, rows, labels, used);
+    return prifit_check_launch();
+}
+
+int prifit_nms_pair(const float *dist_xc, const float *dist_cc, const float *C, const float *X, const float *bw, int B, int N,
+                    int D, int cap, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count,
+                    int32_t *labels, int32_t *used, void *stream)
+{
+    if (!dist_xc || !dist_cc || !C || !X || !bw || !owner || !counts || !flags || !ids || !count || !labels || !used ||
+        B <= 0 || N <= 0 || D <= 0 || D > 256 || cap <= 0)
+        return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const long long rows = (long long)B * N;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(flags, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)B * cap, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    // owner[j] = argmin_i (2 - 2 <c_i, x_j>): row j of the points x centres matrix (the column of upstream's centres x
+    // points matrix -- the same products in the same k order, so the same bits)
+    hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist_xc, N, rows, owner, counts);
+    hipLaunchKernelGGL(nms_pick_kernel, grid, block, 0, st, dist_cc, counts, bw, N, rows, flags);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(B), block, 0, st, flags, N, cap, ids, count);
+    hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, C, X, N, D, ids, count, cap, rows, labels, used);
     return prifit_check_launch();
 }
 

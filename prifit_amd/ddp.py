@@ -46,6 +46,9 @@ class FlatGradBucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.seen = [False] * len(self.params)   # has this parameter ever had a gradient ON ANY RANK (see the class docstring)
+        if strict_seen and deferred_check:
+            raise ValueError("FlatGradBucket: strict_seen=True asks for the synchronous, exact adoption of other ranks' "
+                             "gradients; deferred_check=True for the check one exchange late -- choose one")
         self.strict_seen = strict_seen
         # deferred_check: the reduced flags are read one exchange late (no host read-back in the step).  Default: device
         # buckets unless strict_seen; True forces the protocol on a host bucket (the gloo tests drive it that way)

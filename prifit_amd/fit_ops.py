@@ -357,6 +357,25 @@ def nms(Z, bw):
     return ids, count, labels, used
 
 
+def nms_pair(C, X, bw):
+    """src/mean_shift.py:162-202 with centres that are not the points: C [B,N,D], X [B,N,D] (the same row count -- upstream's
+    broadcast at :191 needs it).  Same outputs as nms()."""
+    Bt, N, D = X.shape
+    assert C.shape == X.shape, "nms(centers, X, b): upstream needs centers.shape[0] == X.shape[0] (src/mean_shift.py:191)"
+    dev = X.device
+    C, X = C.contiguous(), X.contiguous()
+    dist_xc = chord_matrix(X, C)      # row j: point j against every centre
+    dist_cc = chord_matrix(C, C)
+    i32 = dict(dtype=torch.int32, device=dev)
+    owner, counts, flags, labels = (torch.empty(Bt, N, **i32) for _ in range(4))
+    ids, used = (torch.empty(Bt, NMS_CAP, **i32) for _ in range(2))
+    count = torch.empty(Bt, **i32)
+    with profiler.span("nms", 8.0 * Bt * N * N):
+        call("prifit_nms_pair", ptr(dist_xc), ptr(dist_cc), ptr(C), ptr(X), ptr(bw), Bt, N, D, NMS_CAP, ptr(owner), ptr(counts),
+             ptr(flags), ptr(ids), ptr(count), ptr(labels), ptr(used), cur_stream())
+    return ids, count, labels, used
+
+
 class MembershipFn(torch.autograd.Function):
     """src/mean_shift.py:230-247, batched: centres [B,KM,D], X [B,N,D] -> W [B,N,KM] (0 for k >= count)."""
 

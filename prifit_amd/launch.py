@@ -31,6 +31,12 @@ def rank_env(rank, world, port, base=None, addr="127.0.0.1"):
                MASTER_ADDR=addr, MASTER_PORT=str(port))
     # dmabuf IPC is the only IPC the host driver supports (RCCL / tensor sharing across processes)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # CPU thread pools of a rank: its share of the cores this job may run on (the rank pins itself to its own cores and
+    # sets the exact figure once it knows them: prifit_amd/hostcfg.py); never every core times every rank
+    if world > 1:
+        share = max(1, len(os.sched_getaffinity(0)) // world)
+        env.setdefault("OMP_NUM_THREADS", str(share))
+        env.setdefault("MKL_NUM_THREADS", str(share))
     return env
 
 

@@ -777,8 +777,9 @@ class LinearFn(torch.autograd.Function):
             dW = _weight_grad(gy, P, Cout, x, Kin, None)
         if ctx.needs_input_grad[2]:
             if Cout % 4 == 0 and gy.data_ptr() % 16 == 0:
-                db = zero_pool.zeros(Cout, device=x.device)
-                call("prifit_col_sum", ptr(gy), _LL(Cout), P, Cout, ptr(db), cur_stream())
+                db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+                ws = torch.empty(dll().prifit_col_sum_workspace(P, Cout), dtype=torch.float32, device=x.device)
+                call("prifit_col_sum", ptr(gy), _LL(Cout), P, Cout, ptr(db), ptr(ws), cur_stream())
             else:
                 db = gy.sum(dim=0)
         return dx, dW, db

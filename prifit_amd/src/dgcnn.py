@@ -54,6 +54,38 @@ def knn(x, k1, k2):
     return idx[:, :, ::k2 // k1].long()
 
 
+def _knn_normals_cl(x, k):
+    """x [B,N,6] (xyz, normals) channels-last -> idx int32 [B,N,k] of upstream :30-71: the k smallest of
+    (|p_i|^2 - 2 <p_i, p_j> + |p_j|^2) * (1 + (2 - 2 <n_i, n_j>)).  The two Gram matrices come from the MFMA product (the
+    k-ordered fma chain of _knn_cl), the metric is formed with the reference's own operations in its own order, and the
+    selection kernel picks the largest of the negated values (G = v / 2 with zero norms makes its (-xx_i + 2 G) - xx_j
+    the value v itself, exactly).  First layer of the normals variant only: not on the benchmarked path."""
+    B, N, _ = x.shape
+    p = F.pad(x[..., 0:3], (0, 1)).contiguous()         # 16-byte rows for the product kernel
+    n = F.pad(x[..., 3:6], (0, 1)).contiguous()
+    Gp = torch.empty(B, N, N, dtype=torch.float32, device=x.device)
+    Gn = torch.empty_like(Gp)
+    gemm(NT, N, N, 4, p, 4, p, 4, Gp, N, batch=B, sA=N * 4, sB=N * 4, sC=N * N)
+    gemm(NT, N, N, 4, n, 4, n, 4, Gn, N, batch=B, sA=N * 4, sB=N * 4, sC=N * N)
+    xx = ((p[..., 0] * p[..., 0] + p[..., 1] * p[..., 1]) + p[..., 2] * p[..., 2]).unsqueeze(1)       # [B,1,N]
+    p_pair = xx - 2 * Gp + xx.transpose(2, 1)
+    n_pair = 2 - 2 * Gn
+    half = (-(p_pair * (1 + n_pair))) * 0.5
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    zero = torch.zeros(B, N, dtype=torch.float32, device=x.device)
+    with profiler.span("knn_topk", 4.0 * B * N * N + 4.0 * B * N * k):
+        call("prifit_knn_topk", ptr(half.contiguous()), ptr(zero), B, N, k, ptr(idx), cur_stream())
+    return idx
+
+
+def knn_points_normals(x, k1, k2):
+    """upstream :30-71 -- x [B,6,N] -> idx int64 [B,N,k1] (every (k2//k1)-th of the k2 nearest under the
+    normal-weighted metric)."""
+    with torch.no_grad():
+        idx = _knn_normals_cl(x.transpose(1, 2).contiguous(), k2)
+    return idx[:, :, ::k2 // k1].long()
+
+
 class EdgeGatherFn(torch.autograd.Function):
     """rows [(b,n,j), ld] = [x_j - x_i, x_i, 0-pad]  (upstream :98-105, channels-last)."""
 
@@ -86,6 +118,13 @@ def get_graph_feature(x, k1=20, k2=20, idx=None):
         idx = knn(x, k1, k2)
     rows = EdgeGatherFn.apply(xt, idx.int().contiguous(), _pad4(2 * C))
     return rows[:, :2 * C].reshape(B, N, k1, 2 * C).permute(0, 3, 1, 2), idx
+
+
+def get_graph_feature_with_normals(x, k1=20, k2=20, idx=None):
+    """upstream :110-146 -- x [B,6,N] -> feature [B,12,N,k1] on the graph of knn_points_normals."""
+    if idx is None:
+        idx = knn_points_normals(x, k1, k2)
+    return get_graph_feature(x, k1, k2, idx)[0]
 
 
 def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None):
@@ -430,8 +469,8 @@ def _w2d(conv, kp=None):
 class DGCNNEncoderGn(nn.Module):
     def __init__(self, input_channels=3, nn_nb=80, dilation=1):
         super().__init__()
-        if input_channels != 3:
-            raise NotImplementedError("the normals variant (input_channels=6) is not on the benchmarked path")
+        if input_channels not in (3, 6):
+            raise ValueError("input_channels: 3 (xyz) or 6 (xyz + normals), as upstream src/dgcnn.py:171,199")
         self.k = nn_nb
         self.dilation_factor = dilation
         self.drop = 0.0
@@ -484,13 +523,15 @@ class DGCNNEncoderGn(nn.Module):
         return ConvGNActFn.apply(rows, _w2d(conv, ld), None, gn.weight, gn.bias, cfg)   # [B*N, Cout]
 
     def forward_cl(self, pts):
-        """pts [B,N,3] -> (x4 [B,1024], x_features [B*N,256]) channels-last."""
+        """pts [B,N,3 or 6] -> (x4 [B,1024], x_features [B*N,256]) channels-last.  input_channels == 6 (upstream :199-222):
+        the first graph comes from the normal-weighted metric and no layer applies the dilation factor."""
         B, N, _ = pts.shape
-        k, k2 = self.k, self.k * self.dilation_factor
+        normals = self.input_channels == 6
+        k, k2 = self.k, self.k * (1 if normals else self.dilation_factor)
         step = k2 // k
         tables = _EDGE_TABLES and _EDGE_LINEARITY and _EDGE_FUSED_BWD
         with torch.no_grad():
-            idx1 = _knn_cl(pts, k2)[:, :, ::step].contiguous()
+            idx1 = (_knn_normals_cl(pts, k2) if normals else _knn_cl(pts, k2))[:, :, ::step].contiguous()
             csr1 = edge_csr(idx1) if tables and N <= 8192 else None
         x1 = self._edge_conv(pts, idx1, self.conv1, N, csr1)
         with torch.no_grad():
@@ -512,7 +553,7 @@ class DGCNNEncoderGn(nn.Module):
         return x4, feats
 
     def forward(self, x):
-        """x [B,3,N] -> (x4 [B,1024], x_features [B,256,N]) as upstream :171-197."""
+        """x [B,3 or 6,N] -> (x4 [B,1024], x_features [B,256,N]) as upstream :171-222."""
         B, _, N = x.shape
         x4, feats = self.forward_cl(x.transpose(1, 2).contiguous())
         return x4, feats.view(B, N, -1).permute(0, 2, 1)
@@ -576,6 +617,7 @@ class get_model(nn.Module):
             from .. import arena as zero_pool
             zero_pool.begin_step(xyz.device)
         emb, seg = self.net(xyz)
+        xyz = xyz[:, :3]                     # the loss sees positions only (normal_channel=True: rows 3..5 are normals)
         total = torch.zeros(1, device=xyz.device)
         chamfer = torch.zeros(1, device=xyz.device)
         extra = ()

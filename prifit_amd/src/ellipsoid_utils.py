@@ -16,7 +16,21 @@ def guard_mean_shift(embedding, number_samples, quantile, iterations, max_num_cl
     """upstream :9-27 for one shape: embedding [N,D] -> (center [K,D], bandwidth, labels [N]); the quantile is doubled
     until at most `max_num_clusters` distinct labels remain."""
     if kernel_type != "gaussian":
-        raise NotImplementedError("only the gaussian kernel is used by the reference's loss")
+        # the epanechnikov kernel (src/mean_shift.py:70-74): upstream's own loop over MeanShift.mean_shift -- per shape, not
+        # on the loss path (the loss never passes kernel_type); the bandwidth subset, when given, is pinned for every retry
+        from .mean_shift import MeanShift
+        ms = MeanShift()
+        while True:
+            bw = None
+            if bandwidth_rows is not None:
+                with torch.no_grad():
+                    bw = ms.compute_bandwidth(embedding, number_samples, quantile, rows=bandwidth_rows)
+            center, bandwidth, cluster_ids = ms.mean_shift(embedding, number_samples, quantile, iterations,
+                                                           kernel_type=kernel_type, bw=bw)
+            if torch.unique(cluster_ids).shape[0] > max_num_clusters:
+                quantile *= 2
+            else:
+                return center, bandwidth, cluster_ids
     rows = None if bandwidth_rows is None else torch.as_tensor(bandwidth_rows).reshape(1, -1)
     cl = fit_ops.cluster(embedding.unsqueeze(0).contiguous(), quantile, iterations, max_num_clusters,
                          num_samples=number_samples, bandwidth_rows=rows)

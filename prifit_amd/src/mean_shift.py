@@ -96,13 +96,23 @@ class MeanShift:
         return fit_ops.compute_bandwidth(X.unsqueeze(0).contiguous(), quantile, num_samples, rows)[0]
 
     def nms(self, centers, X, b):
-        """upstream :162-202 for centers is X (the only way it is called, :44)."""
-        if centers is not X and not (centers.shape == X.shape and centers.data_ptr() == X.data_ptr()):
-            raise NotImplementedError("nms(centers, X, b) is implemented for centers is X only (upstream calls it as "
-                                      "nms(new_X, new_X, b), src/mean_shift.py:44)")
+        """upstream :162-202 -> (centers[ids], ids ascending, labels [N]).  `centers is X` is how upstream calls it (:44,
+        :39); two different tables (the commented call `nms(new_X, X, b)` of :43) must have the same row count, as upstream's
+        broadcast at :191 requires."""
+        require_cuda(centers, X)
         bwb = torch.as_tensor(b, dtype=torch.float32, device=X.device).reshape(1)
-        ids, count, labels, _ = fit_ops.nms(X.unsqueeze(0).contiguous(), bwb)
+        if centers is X or (centers.shape == X.shape and centers.data_ptr() == X.data_ptr()):
+            ids, count, labels, _ = fit_ops.nms(X.unsqueeze(0).contiguous(), bwb)
+        else:
+            if centers.shape != X.shape:
+                raise RuntimeError("nms(centers, X, b): centers %s and X %s must have the same shape (upstream's "
+                                   "cluster_nbrs[uniques] * num_mem_cluster broadcast, src/mean_shift.py:191)"
+                                   % (tuple(centers.shape), tuple(X.shape)))
+            ids, count, labels, _ = fit_ops.nms_pair(centers.detach().unsqueeze(0).contiguous(),
+                                                     X.detach().unsqueeze(0).contiguous(), bwb)
         K = int(count.item())
+        if K > fit_ops.NMS_CAP:
+            raise RuntimeError("more than %d clusters" % fit_ops.NMS_CAP)
         ids = ids[0, :K].long()
         return centers[ids], ids, labels[0].long()
 

@@ -7,6 +7,8 @@ process per GPU.
     loss, acc = tr.supervised_step(points, target)              # upstream :372-399
     ss = tr.selfsup_step(chamfer_points, quantile=.05, ...)     # upstream :436-451
     tr.save(path) / tr.load(path)             # checkpoint dict of upstream :467-475
+    tr.finish()                               # REQUIRED after the last step under torch.distributed: the deferred
+                                              # has-gradient check of the final exchange (ddp.FlatGradBucket.flush)
 
 The augmentation (random per-shape scale in [0.8, 1.25] and shift in [-0.1, 0.1], provider.py:278-303) runs
 on the device.  Gradients are exchanged with `FlatGradBucket` when torch.distributed is initialised."""
@@ -50,8 +52,6 @@ class SpeculativeRunner:
         self.model = model
         self.fallbacks = 0
         self.runs = 0
-        # diagnosis (tools/step_outliers.py): treat the verdict of this run as "retry" to time the fall-back path
-        self.force_at = int(os.environ.get("PRIFIT_DEBUG_FALLBACK_AT", "-1"))
         # set by a caller that wants the NEXT run to go through the fall-back once whatever its verdict (bench.py's first
         # warm-up step: the first fall-back of a process grows the caching allocator by ~4 GB, 0.2 s of hipMalloc)
         self.force_next = False
@@ -68,7 +68,7 @@ class SpeculativeRunner:
         with fit_ops.speculative() as spec:
             out = fn()
         self.runs += 1
-        forced, self.force_next = self.force_next or self.runs - 1 == self.force_at, False
+        forced, self.force_next = self.force_next, False
         if spec.ok() and not forced:
             return out
         self.fallbacks += 1
@@ -137,6 +137,10 @@ def graph_backbone(net, xyz, cls_label, fps_start):
 class Trainer:
     def __init__(self, model, num_part=50, learning_rate=0.001, decay_rate=1e-4, lr_decay=0.5, step_size=20, lmbda=1.0,
                  fused_adam=True, strict_seen=False):
+        # one process per GPU: this rank's own cores and capped CPU thread pools (prifit_amd/hostcfg.py; a single process is
+        # left alone, and a launcher that already did it -- bench.py -- makes this a no-op)
+        from . import hostcfg
+        self.host = hostcfg.apply_from_env()
         self.model = model
         self.num_part = num_part
         self.lr0, self.lr_decay, self.step_size, self.lmbda = learning_rate, lr_decay, step_size, lmbda
@@ -209,6 +213,9 @@ class Trainer:
         workgroup per shape, and there it runs beside the matrix-bound mean-shift kernels instead of at the head of its
         own step; same indices as in-line sampling).  The following `selfsup_step()` WITHOUT `chamfer_points` consumes it.
         Models without `sample_ahead` (DGCNN) only get the batch prepared."""
+        if self._next is not None:
+            raise RuntimeError("prefetch_selfsup: the batch of an earlier prefetch has not been consumed by a "
+                               "selfsup_step() yet -- a second prefetch would drop it (its augmentation and RNG draw spent)")
         cham, points = self._selfsup_batch(chamfer_points, npoint, augment, subset)
         nxt = {"cham": cham, "points": points, "ahead": None, "fps_start": fps_start}
         self._next = nxt
@@ -260,7 +267,10 @@ class Trainer:
         self.bucket.flush()
 
     def sync_buffers(self):
-        """COLLECTIVE: rank 0's BatchNorm statistics win on every rank ("replica 0" of DataParallel)."""
+        """COLLECTIVE: rank 0's BatchNorm statistics win on every rank ("replica 0" of DataParallel).  Every rank enters it,
+        so it also runs the deferred has-gradient check of the last exchange first: the documented pattern
+        `sync_buffers(); if rank == 0: write_checkpoint()` can then not persist a model taken after a divergent step."""
+        self.bucket.flush()
         self.bucket.sync_buffers(0)
 
     def write_checkpoint(self, path):

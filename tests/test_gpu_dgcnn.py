@@ -223,52 +223,58 @@ def test_edge_tables_forward_and_backward_against_torch(D, C, stacked):
                                    msg=lambda m, name=name: name + ": " + m)
 
 
-def test_dgcnn_network(D, golden):
-    g = golden("model_dgcnn")
-    B, N, k, seed = 2, 1024, 20, int(g["seed"])
-    torch.manual_seed(31)
-    ref = orc.OracleDGCNGn(128, 3, k)
-    for m in ref.modules():
-        if isinstance(m, torch.nn.GroupNorm):
-            with torch.no_grad():
-                gen = torch.Generator().manual_seed(m.num_channels)
-                m.weight.copy_(torch.randn(m.weight.shape, generator=gen) * 0.5 + 0.75)
-                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.2)
-    net = D.DGCNGn(emb_size=128, num_channels=3, nn_nb=k)
+@pytest.mark.parametrize("name", ["model_dgcnn", "model_dgcnn_2048", "model_dgcnn_normals"])
+def test_dgcnn_network(D, golden, name):
+    """DGCNGn (src/dgcnn.py:225-267) against the reference's outputs and gradients: B = 2 x 1024, the configuration's own
+    N = 2048, and the normals variant (num_channels = 6: knn_points_normals :30-71, encoder branch :199-222)."""
+    import dgcnn_common as C
+    g = golden(name)
+    B, N, k, ch = C.CASES[name]
+    ref = C.seeded_state(orc.OracleDGCNGn, ch, k)
+    net = D.DGCNGn(emb_size=128, num_channels=ch, nn_nb=k)
     assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
-    assert sum(p.numel() for p in net.parameters()) == 1179267  # DGCNN model size
+    if ch == 3:
+        assert sum(p.numel() for p in net.parameters()) == 1179267  # SURVEY.md: DGCNN model size
     net.load_state_dict(ref.state_dict())
     net.cuda()
-    pts = _t(synth.cloud("surface", B, N, seed)).transpose(1, 2).contiguous()
-    ge = _t(synth.features(B, N, 128, seed + 1))
-    gs = _t(synth.features(B, N, 3, seed + 2)).transpose(1, 2)
+    pts, ge, gs = C.network_inputs(g, B, N, ch)
+    if ch == 6:    # the first graph under the normal-weighted metric: the reference's very neighbours
+        idx = D.knn_points_normals(pts.cuda(), k, k).cpu()
+        assert torch.equal(idx, orc.knn_points_normals(pts, k, k))
+        assert torch.equal(idx[:, :64], _t(g["knn_head"]).long()) and torch.equal(idx.sum(dim=(1, 2)), _t(g["knn_sum"]))
+        f = D.get_graph_feature_with_normals(pts.cuda(), k, k)
+        assert f.shape == (B, 12, N, k)
+        torch.testing.assert_close(f.cpu(), orc.graph_feature(pts, k, k, normals=True)[0], rtol=0, atol=0)
     emb, seg = net(pts.cuda())
     assert emb.shape == (B, N, 128) and seg.shape == (B, 3, N)
     ((emb * ge.cuda()).sum() + (seg * gs.cuda()).sum()).backward()
-    torch.testing.assert_close(emb[:, :64].detach().cpu(), _t(g["emb_head"]), rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(emb.detach().sum(dim=1).cpu(), _t(g["emb_sum"]), rtol=1e-3, atol=5e-2)
-    torch.testing.assert_close(seg.detach().cpu(), _t(g["seg"]), rtol=1e-3, atol=1e-3)
-    norms = dict(zip([str(s) for s in g["grad_names"]], g["grad_norms"]))
-    for name, p in net.named_parameters():
-        assert p.grad is not None and abs(p.grad.norm().item() - norms[name]) <= 2e-2 * norms[name] + 1e-5, (name, p.grad.norm().item(), norms[name])
-    for name, key in (("encoder.conv1.0.weight", "g_enc_conv1"), ("mlp_segmentation.weight", "g_seg"), ("mlp_seg_prob2.weight", "g_emb")):
-        got, want = dict(net.named_parameters())[name].grad.cpu(), _t(g[key])
-        assert (got - want).norm() <= 2e-2 * want.norm(), name
+    C.check_network(g, emb.detach().cpu(), seg.detach().cpu(), {n_: p.grad.cpu() for n_, p in net.named_parameters()},
+                    out_tol=1e-3, grad_tol=2e-2)
 
 
-def test_dgcnn_with_convex_loss_config5(D):
-    """configs[4]: DGCNN embedding + mean-shift + ellipsoid fit + convex loss, forward and backward."""
-    from tests_helpers import fit_inputs
+def test_dgcnn_with_convex_loss_config5(D, golden):
+    """configs[4] end to end against the reference (tests/golden/step_dgcnn_selfsup.npz: reference DGCNGn -> reference
+    convex_loss, B = 2 x 2048, q = 0.05, 10 mean-shift iterations): loss, K, the very labels, every parameter-gradient norm
+    and the embedding head's / first edge convolution's gradient vectors -- through the adapter's own forward."""
+    import dgcnn_common as C
+    g = golden("step_dgcnn_selfsup")
+    d = C.selfsup_inputs(g)
+    ref = C.selfsup_state(g, orc.OracleDGCNGn)
+    net = D.get_model(50, k=20)
+    net.net.load_state_dict(ref.state_dict())
+    net.cuda()
+    out = net(d["xyz"].cuda(), None, chamfer_points=d["cham"].cuda(), include_convex_loss=True, quantile=C.Q,
+              msc_iterations=C.ITERS, max_num_clusters=25,
+              fit_inputs=dict(rand_table=d["R"].cuda(), canonical=True, center_ids=torch.from_numpy(np.asarray(g["center_ids"])).long()))
     B, N = 2, 2048
-    pts, cham, _ = fit_inputs(B, N, 128, 3)
-    torch.manual_seed(2)
-    net = D.get_model(50, k=20).cuda()
-    out = net(pts.permute(0, 2, 1).contiguous().cuda(), None, chamfer_points=cham.permute(0, 2, 1).contiguous().cuda(),
-              include_convex_loss=True, quantile=0.05, msc_iterations=10, max_num_clusters=25)
     assert len(out) == 8 and out[0].shape == (B, N, 3) and out[2].shape == (B, 128, N)
-    out[3].mean().backward()
-    gr = net.net.mlp_seg_prob2.weight.grad
-    assert gr is not None and torch.isfinite(gr).all() and torch.isfinite(net.net.encoder.conv1[0].weight.grad).all()
+    total, chamfer, labels, params, fe = out[3], out[4], out[5], out[6], out[7]
+    total.mean().backward()
+    grads = {k_: (None if p.grad is None else p.grad.detach().cpu()) for k_, p in net.net.named_parameters()}
+    worst = C.check_selfsup(g, total.detach().cpu(), chamfer.detach().cpu(), params, [l.cpu() for l in labels],
+                            fe.detach().permute(0, 2, 1).cpu(), grads, loss_tol=1e-4)
+    print("configs[4] step vs reference: worst relative gradient deviation %.2e" % worst)
+    assert abs(net.beta - 0.99) < 1e-12
 
 
 @pytest.mark.parametrize("N,k", [(2048, 20), (1024, 40), (300, 7), (64, 64), (70, 3)])

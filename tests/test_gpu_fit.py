@@ -483,6 +483,41 @@ def test_mean_shift_variants_the_loss_never_takes(hiplib, golden):
     assert centre.shape[1] == D and labels.shape[0] == N // 2 and int(labels.max()) + 1 == centre.shape[0]
 
 
+def test_nms_with_distinct_centres_and_epanechnikov_guard(hiplib, golden):
+    """MeanShift.nms(centers, X, b) with centres that are not the points (src/mean_shift.py:162-202; shifted points against
+    the original embedding) and guard_mean_shift / kernel_type="epa" (src/ellipsoid_utils.py:9-27 -> src/mean_shift.py:70-74)
+    against the reference's ids / labels / retry sequence (tests/golden/fit_nms_pair.npz), and against the oracle on
+    2048 x 128 inputs."""
+    from prifit_amd.src.mean_shift import MeanShift
+    from prifit_amd.src import ellipsoid_utils as EU
+    g = golden("fit_nms_pair")
+    seed, N, D = int(g["seed"]), 512, 32
+    _, _, emb = fit_inputs(2, N, D, seed, M=1000, noise=0.1)
+    ms = MeanShift()
+    for b in range(2):
+        X = emb[b]
+        bw = _t(g["bw_%d" % b])
+        Z = orc.mean_shift_iterations(X, bw, 4)          # the same centres on both sides: this test is about nms
+        kept, ids, labels = ms.nms(Z.cuda(), X.cuda(), bw.cuda())
+        assert torch.equal(ids.cpu(), _t(g["ids_%d" % b]).long()) and torch.equal(labels.cpu(), _t(g["labels_%d" % b]).long())
+        torch.testing.assert_close(kept.cpu(), Z[ids.cpu()], rtol=0, atol=0)
+    # a larger case against the oracle (128-d, 2048 points: the chord kernels' tiled shapes)
+    _, _, big = fit_inputs(1, 2048, 128, 12, noise=0.05)
+    X = big[0]
+    bw = orc.compute_bandwidth(X, 0.05)
+    Z = orc.mean_shift_iterations(X, bw, 3)
+    _, io, lo = orc.nms(Z, X, bw)
+    _, ids, labels = ms.nms(Z.cuda(), X.cuda(), bw)
+    assert torch.equal(ids.cpu(), io) and torch.equal(labels.cpu(), lo)
+    with pytest.raises(RuntimeError):
+        ms.nms(Z[:100].cuda(), X.cuda(), bw)              # upstream's broadcast (:191) fails the same way
+    # epanechnikov kernel through the guard: the reference's retry sequence ends at the same quantile / K / labels
+    centre, bw, labels = EU.guard_mean_shift(emb[0].cuda(), N, float(g["q0"]), int(g["iters"]), int(g["cap"]), kernel_type="epa")
+    assert centre.shape[0] == int(g["epa_K"])
+    assert abs(float(bw) - float(g["epa_bw"])) <= 1e-5 * float(g["epa_bw"])
+    assert same_partition(labels.cpu(), _t(g["epa_labels"]).long())
+
+
 def test_nms_owner_pass_fused_into_the_chord_kernel(F, monkeypatch):
     """nms with the owner pass (argmin over every column of 2 - 2 Z Z^T, first minimum) taken in the chord kernel's epilogue
     through 64-bit atomic-min keys against the separate pass that re-reads the matrix: the very same owners, kept ids,

@@ -153,6 +153,26 @@ def test_mean_shift_variants_match_reference(golden):
         assert torch.allclose(X.grad[:64], torch.from_numpy(g["dX_" + name]), rtol=1e-4, atol=1e-6 * float(X.grad.abs().max()))
 
 
+def test_nms_with_distinct_centres_and_epanechnikov_guard_match_reference(golden):
+    """src/mean_shift.py:162-202 called as nms(shifted points, original points, b), and src/ellipsoid_utils.py:9-27 with
+    kernel_type forwarded (epanechnikov kernel, src/mean_shift.py:70-74, with quantile-doubling retries)."""
+    import tests_helpers as H
+    g = golden("fit_nms_pair")
+    seed, N, D = int(g["seed"]), 512, 32
+    _, _, emb = H.fit_inputs(2, N, D, seed, M=1000, noise=0.1)
+    for b in range(2):
+        X = emb[b]
+        bw = orc.compute_bandwidth(X, 0.05)
+        assert abs(float(bw) - float(g["bw_%d" % b])) <= 1e-6 * float(bw)
+        Z = orc.mean_shift_iterations(X, bw, 4)
+        _, ids, labels = orc.nms(Z, X, bw)
+        assert torch.equal(ids, _t(g["ids_%d" % b]).long()) and torch.equal(labels, _t(g["labels_%d" % b]).long())
+    centers, bw, labels, ids, Z, q = orc.guard_mean_shift(emb[0], float(g["q0"]), int(g["iters"]), int(g["cap"]), kernel_type="epa")
+    assert abs(q - float(g["epa_quantiles"][-1])) < 1e-12 and centers.shape[0] == int(g["epa_K"])
+    assert abs(float(bw) - float(g["epa_bw"])) <= 1e-6 * float(bw)
+    assert torch.equal(labels, _t(g["epa_labels"]).long())
+
+
 def test_center_gather_gradient_golden(golden):
     """d/dX sum(G * new_X[ids]) -- the only differentiable use of the shifted points (src/mean_shift.py:44-46) -- of the
     oracle against the reference's autograd (fit_center_grad.npz)."""
