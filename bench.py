@@ -57,6 +57,8 @@ WORKLOADS = {
 }
 
 
+# --embedding conditions beyond "clustered": name -> (equal-size spatial parts per shape as (nx, ny), prototype noise, mean-shift quantile)
+EMBEDDING_PARTS = {"clustered25": ((5, 5), 0.03, 0.02), "retry40": ((5, 8), 0.005, 0.01)}
 DEFAULT_CLOUD = {"c2": "cube", "c3": "blobs", "c5": "blobs"}   # uniform cube; blobs where clusters must exist
 METRIC = {"c2": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG seg loss only",
           "c3": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG+ellipsoid fit",
@@ -329,7 +331,9 @@ def run_rank(args):
         # (the headline is measured and stays: an exception in a side measurement is recorded in its entry, not raised)
         extra = {}
         for name, cl, emb in (("clustered_embedding", "blobs", "clustered"), ("surface_cloud", "surface", "untrained"),
-                              ("surface_cloud_clustered_embedding", "surface", "clustered")):
+                              ("surface_cloud_clustered_embedding", "surface", "clustered"),
+                              ("clusters_at_the_cap_25_parts", "blobs", "clustered25"),
+                              ("retry_every_step_40_parts_q0.01", "blobs", "retry40")):
             try:
                 r = measure(args, ctx, cl, emb, max(10, min(args.steps, 30)), 5, full=False)
                 extra[name] = condition_summary(r, cl, emb)
@@ -409,12 +413,21 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     runner = SpeculativeRunner(net)
     fit_kw = dict(chamfer_points=data.get("chamfer"), include_convex_loss=True, quantile=0.05, msc_iterations=10,
                   max_num_clusters=25)
+    if embedding != "untrained" and args.workload == "c2":
+        raise SystemExit("--embedding %s: a workload with the fit path (c3 / c5)" % embedding)
     if embedding == "clustered":
-        if args.workload == "c2":
-            raise SystemExit("--embedding clustered: a workload with the fit path (c3 / c5)")
         # what training does to the embedding, as an explicit input: 8 part prototypes per shape (synth.part_embedding_offset)
         off = torch.from_numpy(synth.part_embedding_offset(data["parts"].cpu().numpy(), 128, 1000 * rank)).to(device)
         fit_kw["fit_inputs"] = dict(embedding_offset=off)
+    elif embedding in EMBEDDING_PARTS:
+        # the fit path where it is loaded: K at the `max_num_clusters` cap (25 spatial parts per shape, README.md:62 regime), or
+        # 40 tight parts at quantile 0.01 -- more modes than the cap, so EVERY step takes guard_mean_shift's
+        # quantile-doubling retry (src/ellipsoid_utils.py:19-27: full recompute per doubling)
+        (nx, ny), noise, q = EMBEDDING_PARTS[embedding]
+        parts = synth.equal_part_labels(data["xyz"].transpose(1, 2).cpu().numpy(), nx, ny)
+        off = torch.from_numpy(synth.part_embedding_offset(parts, 128, 1000 * rank, K=nx * ny, noise=noise)).to(device)
+        fit_kw["fit_inputs"] = dict(embedding_offset=off)
+        fit_kw["quantile"] = q
 
     # Farthest-point sampling of the NEXT batch on a side stream while this step runs (ops.sample_ahead: the samples depend
     # on the coordinates alone, and the search is 640 serial rounds on one workgroup per shape: 24 of 256 CUs busy for
@@ -683,7 +696,8 @@ def condition_summary(r, cloud, embedding):
         hist[str(int(k))] = hist.get(str(int(k)), 0) + 1
     rows = family_rows(r["fams_all"], r["fams_all_steps"])
     grouping = grouping_roofline(rows)
-    return {"cloud": cloud, "embedding": embedding, "value": B_PER_GPU * r["steps"] / r["elapsed"], "unit": "shapes/s",
+    return {"cloud": cloud, "embedding": embedding, "quantile": EMBEDDING_PARTS.get(embedding, (None, None, 0.05))[2],
+            "value": B_PER_GPU * r["steps"] / r["elapsed"], "unit": "shapes/s",
             "ms_per_step": ms, "steps": r["steps"], "warmup": r["warmup"], "loss": r["loss"],
             "clusters_per_shape": {"mean": (sum(ks) / len(ks)) if ks else None, "min": min(ks) if ks else None,
                                    "max": max(ks) if ks else None, "histogram": hist},
@@ -759,7 +773,7 @@ def main():
     ap.add_argument("--cpu-baseline-shapes", type=int, default=4, help="shapes of the CPU-baseline sample (4: ~15 s)")
     # the measured condition (defaults = the headline: BASELINE.json's synthetic clouds, seeded untrained network)
     ap.add_argument("--cloud", default=None, choices=("cube", "blobs", "surface"))
-    ap.add_argument("--embedding", default="untrained", choices=("untrained", "clustered"))
+    ap.add_argument("--embedding", default="untrained", choices=("untrained", "clustered") + tuple(sorted(EMBEDDING_PARTS)))
     ap.add_argument("--no-extra", action="store_true", help="skip the training-like conditions reported under `extra`")
     ap.add_argument("--graph", action="store_true", help="replay the backbone forward + backward as HIP graphs (static shapes)")
     ap.add_argument("--ms-split", default="0", choices=("0", "bf16x3", "bf16x6", "fp16x3"),

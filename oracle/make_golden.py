@@ -739,7 +739,7 @@ def golden_dgcnn_selfsup():
     EF = refshim.ref("src.ellipsoid_fitting")
     SE = refshim.ref("src.sample_ellipsoid")
     MS = refshim.ref("src.mean_shift")
-    B, N, k, seed = 2, 2048, 20, 83
+    B, N, k, seed = 2, 2048, 20, 85      # (83 sat on a partition that flips with the CPU thread count: K 10 / 11 / 8; 84 and 85 give K = [8, 8] in fp32 at 1 and 8 threads and in fp64)
     D, ref_net, my_net = _dgcnn_pair(3, k, seed_w=37)
     cham_np, lab_np = synth.blobs_with_labels(B, 5000, seed)
     cham = torch.from_numpy(cham_np)

