@@ -818,12 +818,28 @@ def golden_dgcnn_selfsup():
         print("    grad %-32s |g| %.3e  oracle-vs-reference rel %.1e" % (kk, rg[kk].norm().item(), rel))
         worst = max(worst, rel)
         assert rel < 2e-2, (kk, rel)
-    # the measured spread oracle-vs-reference (same fp32 arithmetic, other summation orders) doubled is the bar the HIP test uses
-    save("step_dgcnn_selfsup", seed=seed, R=R, emb_W=emb_W, total_loss=rtot.detach(), chamfer_loss=rcham.detach(),
+    # Bars, MEASURED: the oracle once more in fp64 on the same inputs.  A DGCNN forward is sensitive to rounding in a way the
+    # PointNet++ one is not -- its second kNN graph is built on computed features, a 1e-7 difference flips neighbours, the
+    # embedding then moves by ~1e-3 (relative L2) and the gradients of the edge convolutions by a few per cent.  Also
+    # measured (round 5, GPU box): the SAME fp32 oracle on another host (other thread count) gives a loss 3.1e-4 away.
+    my64 = orc.OracleDGCNGn(128, 3, k).double()
+    my64.load_state_dict({kk: v.double() for kk, v in my_net.state_dict().items()})
+    e64, _ = my64(xyz.double())
+    t64 = orc.convex_loss(xyz.double(), cham_t.double(), e64.permute(0, 2, 1), quantile=q, iterations=iters, max_num_clusters=25,
+                          rand_table=[[R.double()] * 64] * B, canonical=True, center_ids=ref_ids)[0]
+    torch.mean(t64).backward()
+    g64 = {kk: p.grad.detach() for kk, p in my64.named_parameters() if p.grad is not None}
+    dev_loss = abs(float(t64.detach()) - float(rtot.detach())) / abs(float(t64.detach()))
+    dev_emb = float((e64.detach() - remb.detach().double()).norm() / e64.detach().norm())
+    dev_grad = max(float((rg[kk].double() - g64[kk]).norm() / g64[kk].norm()) for kk in names)
+    print("  fp32 reference vs fp64 oracle: loss %.2e, embedding %.2e (rel L2), worst parameter gradient %.2e" % (dev_loss, dev_emb, dev_grad))
+    loss_bar = max(1e-3, 3.0 * dev_loss)      # floor: 3 x the host-to-host spread of the fp32 oracle itself (3.1e-4)
+    grad_bar = max(2e-2, 2.0 * dev_grad, 2 * worst)
+    save("step_dgcnn_selfsup", loss_bar=np.array(loss_bar), dev_fp64=np.array([dev_loss, dev_emb, dev_grad]), seed=seed, R=R, emb_W=emb_W, total_loss=rtot.detach(), chamfer_loss=rcham.detach(),
          K=np.array(Ks), labels=torch.stack(rlabels).to(torch.int16), emb_head=remb[:, :64].detach(),
          grad_names=np.array(names), grad_norms=np.array([rg[n].norm().item() for n in names]),
          g_emb_W=rg["mlp_seg_prob2.weight"], g_enc_conv1=rg["encoder.conv1.0.weight"],
-         g_emb_head=remb.grad[:, :64].contiguous(), g_emb_norm=remb.grad.norm(), grad_bar=np.array(max(2e-2, 2 * worst)),
+         g_emb_head=remb.grad[:, :64].contiguous(), g_emb_norm=remb.grad.norm(), grad_bar=np.array(grad_bar),
          center_ids=torch.stack([torch.cat([i, torch.full((32 - i.shape[0],), -1, dtype=torch.long)]) for i in ref_ids]).to(torch.int16))
 
 

@@ -75,9 +75,22 @@ def same_partition(la, lb):
     return pairs.shape[0] == torch.unique(la).shape[0] == torch.unique(lb).shape[0]
 
 
-def check_selfsup(g, total, chamfer, params, labels, emb, grads, loss_tol=1e-4, grad_tol=None):
-    """total / chamfer [1,1], params list[B] of lists, labels list[B] of [N], emb [B,N,128] (cpu), grads name -> cpu tensor or None."""
+def partition_agreement(la, lb):
+    """Fraction of points on which two labelings agree once every cluster of `lb` is matched to the cluster of `la` it
+    overlaps most (1.0 <=> the same partition)."""
+    la, lb = la.long(), lb.long()
+    conf = torch.zeros(int(lb.max()) + 1, int(la.max()) + 1, dtype=torch.long)
+    conf.index_put_((lb, la), torch.ones_like(la), accumulate=True)
+    return float(conf.max(dim=1)[0].sum()) / la.numel()
+
+
+def check_selfsup(g, total, chamfer, params, labels, emb, grads, loss_tol=None, grad_tol=None, exact_labels=True):
+    """total / chamfer [1,1], params list[B] of lists, labels list[B] of [N], emb [B,N,128] (cpu), grads name -> cpu tensor or None.
+    Default bars: the fixture's, measured by the generator (fp32 reference against the fp64 oracle; a DGCNN forward re-builds
+    its second kNN graph on computed features, so rounding flips neighbours and moves the embedding by ~1e-3).
+    exact_labels=False (another arithmetic produced the embedding): the partitions agree on >= 99.5 % of the points."""
     grad_tol = float(g["grad_bar"]) if grad_tol is None else grad_tol
+    loss_tol = float(g["loss_bar"]) if loss_tol is None else loss_tol
     torch.testing.assert_close(total.reshape(-1), _t(g["total_loss"]).reshape(-1), rtol=loss_tol, atol=1e-7)
     torch.testing.assert_close(chamfer.reshape(-1), _t(g["chamfer_loss"]).reshape(-1), rtol=loss_tol, atol=1e-7)
     torch.testing.assert_close(emb[:, :64], _t(g["emb_head"]), rtol=1e-3, atol=1e-3)
@@ -85,8 +98,11 @@ def check_selfsup(g, total, chamfer, params, labels, emb, grads, loss_tol=1e-4, 
     assert [len(p) for p in params] == K
     ref_labels = _t(g["labels"]).long()
     for b in range(len(K)):
-        assert same_partition(labels[b], ref_labels[b]), "label partition differs, shape %d" % b
-        assert torch.equal(labels[b].long(), ref_labels[b])          # representatives pinned: the very labels
+        if exact_labels:
+            assert same_partition(labels[b], ref_labels[b]), "label partition differs, shape %d" % b
+            assert torch.equal(labels[b].long(), ref_labels[b])          # representatives pinned: the very labels
+        else:
+            assert partition_agreement(labels[b], ref_labels[b]) >= 0.995, (b, partition_agreement(labels[b], ref_labels[b]))
     names = [str(s) for s in g["grad_names"]]
     norms = dict(zip(names, g["grad_norms"]))
     for off in ("mlp_segmentation.weight", "mlp_segmentation.bias"):   # the seg head is off this path

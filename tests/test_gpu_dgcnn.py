@@ -272,9 +272,27 @@ def test_dgcnn_with_convex_loss_config5(D, golden):
     total.mean().backward()
     grads = {k_: (None if p.grad is None else p.grad.detach().cpu()) for k_, p in net.net.named_parameters()}
     worst = C.check_selfsup(g, total.detach().cpu(), chamfer.detach().cpu(), params, [l.cpu() for l in labels],
-                            fe.detach().permute(0, 2, 1).cpu(), grads, loss_tol=1e-4)
-    print("configs[4] step vs reference: worst relative gradient deviation %.2e" % worst)
+                            fe.detach().permute(0, 2, 1).cpu(), grads, exact_labels=False)
+    print("configs[4] step vs reference: worst relative gradient deviation %.2e (bar %.2e), loss bar %.1e"
+          % (worst, float(g["grad_bar"]), float(g["loss_bar"])))
     assert abs(net.beta - 0.99) < 1e-12
+    # The loss bar above is the backbone's (rounding flips kNN neighbours: generator docstring).  The FIT path itself is held
+    # to the north star's 1e-4: both sides on the SAME embedding -- the oracle's DGCNN run on this box's CPU
+    from prifit_amd.convex_loss import convex_loss
+    with torch.no_grad():
+        emb_o, _ = ref(d["xyz"])
+    kw = dict(quantile=C.Q, iterations=C.ITERS, max_num_clusters=25, canonical=True)
+    Xo = emb_o.permute(0, 2, 1).contiguous().requires_grad_(True)
+    to, _, po, lo = orc.convex_loss(d["xyz"], d["cham"], Xo, rand_table=[[d["R"]] * 64] * 2, center_ids=d["center_ids"], **kw)
+    to.mean().backward()
+    Xh = emb_o.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    th, _, ph, lh = convex_loss(d["xyz"].cuda(), d["cham"].cuda(), Xh, rand_table=d["R"].cuda(),
+                                center_ids=torch.from_numpy(np.asarray(g["center_ids"])).long(), **kw)
+    th.mean().backward()
+    assert [len(p) for p in ph] == [len(p) for p in po]
+    assert abs(float(th.detach()) - float(to.detach())) <= 1e-4 * abs(float(to.detach())), (float(th.detach()), float(to.detach()))
+    assert all(torch.equal(a.cpu().long(), b_) for a, b_ in zip(lh, lo))
+    assert (Xh.grad.cpu() - Xo.grad).norm() <= 2e-2 * Xo.grad.norm()
 
 
 @pytest.mark.parametrize("N,k", [(2048, 20), (1024, 40), (300, 7), (64, 64), (70, 3)])

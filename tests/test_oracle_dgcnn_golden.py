@@ -33,4 +33,5 @@ def test_dgcnn_selfsup_step_matches_reference(golden):
                                                      center_ids=d["center_ids"])
     torch.mean(total).backward()
     grads = {k: (None if p.grad is None else p.grad.detach()) for k, p in net.named_parameters()}
-    C.check_selfsup(g, total.detach(), chamfer.detach(), params, labels, emb.detach(), grads, loss_tol=1e-5, grad_tol=5e-3)
+    # (the fixture's own bars: even the same fp32 arithmetic with another thread count flips kNN neighbours, dgcnn_common)
+    C.check_selfsup(g, total.detach(), chamfer.detach(), params, labels, emb.detach(), grads)
