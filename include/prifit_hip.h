@@ -772,6 +772,12 @@ int prifit_cuboid_sample_nn_bwd(const float *r, const float *V, const float *c, 
  * prifit_gemm_f32), xx [B,N] = |x|^2; idx [B,N,k] = top-k of (-xx_i - (-2 G_ij)) - xx_j, descending,
  * ties to the lower index.  N <= 4096. */
 int prifit_knn_topk(const float *G, const float *xx, int B, int N, int k, int32_t *idx, void *stream);
+/* The same selection for the network's FIRST graph (src/dgcnn.py:171-175: knn on the xyz coordinates), straight from the
+ * cloud x [B,N,3]: the values -|x_i|^2 + 2 <x_i, x_j> - |x_j|^2 are formed from an LDS copy of the cloud with the product
+ * kernel's own fma chain and rounding (the same indices bit for bit as prifit_gemm_f32 + prifit_knn_topk), and the [B,N,N]
+ * pairwise matrix is never written.  64 <= N <= 2048, k <= 64 (prifit_knn3_supported). */
+int prifit_knn3_supported(int N, int k);
+int prifit_knn3_topk(const float *x, int B, int N, int k, int32_t *idx, void *stream);
 
 /* Edge features, src/dgcnn.py:74-107: out[(b,n,j), :] = [x[b,idx[b,n,j]] - x[b,n], x[b,n], 0-pad],
  * x [B,N,C] channels-last, out rows of ld_out >= 2C floats. */

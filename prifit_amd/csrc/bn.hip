@@ -451,25 +451,30 @@ __global__ __launch_bounds__(256) void gather_linear_bwd_kernel(const float *__r
 //     dU[b, idx, :] += dY,   dVc[g, :] -= sum_k dY[(g,k), :]
 // One workgroup = (shape, a range of GLB_PTS points, a range of centres): it keeps dU of its points in LDS ([GLB_PTS][C]
 // floats), walks the index lists of its centres, loads the rows whose index falls into its range -- whole rows: one wave
-// instruction = the 4 C contiguous bytes of a row, lane = 2 channels -- forms dY and adds it there (each wave owns a quarter
+// instruction = the 4 C contiguous bytes of a row, lane = 2 channels -- forms dY and adds it there (each wave owns an eighth
 // of the points: plain read-modify-write); at the end the non-zero entries go to global memory with float atomics.  Every row is loaded by exactly one workgroup, the global
 // atomics drop from one per element of dY (B S K C: 75 M at SA2) to at most one per element of dU and centre range, and
 // the pass that wrote dY (read G, read Y, write dY) is gone.  (Splitting the CHANNELS over workgroups instead -- 128-byte
 // pieces of every row read by four different workgroups -- measured slower than the pass it replaces.)
-constexpr int GLB_PTS = 128, GLB_CMAX = 128;
-__global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
+// (Round 5, measured and NOT kept: eight waves per workgroup instead of four -- twice the rows in flight per CU -- 96 -> 117 us
+// at K = 64, 163 -> 154 us at K = 128, stand-alone, alternating builds: -DGLB_WAVES_N=8.)
+#ifndef GLB_WAVES_N
+#define GLB_WAVES_N 4
+#endif
+constexpr int GLB_PTS = 128, GLB_CMAX = 128, GLB_WAVES = GLB_WAVES_N, GLB_NTH = 64 * GLB_WAVES;
+__global__ __launch_bounds__(GLB_NTH, 2) void gather_linear_bwd_bn_kernel(
     const float *__restrict__ G, const float *__restrict__ Y, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ ca, const float *__restrict__ cb,
     const float *__restrict__ cd, const int32_t *__restrict__ idx, int N, int S, int K, int C, int splits,
     float *__restrict__ dU, float *__restrict__ dVc)
 {
     __shared__ float s_acc[GLB_PTS * GLB_CMAX];
-    __shared__ int s_rows[4][128];          // per wave: the rows of the current batch of the index list that are ours
+    __shared__ int s_rows[GLB_WAVES][128];  // per wave: the rows of the current batch of the index list that are ours
     const int n0 = blockIdx.x * GLB_PTS, split = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = 2 * lane;                 // this lane's channel pair
     const bool cok = c < C;
-    for (int i = threadIdx.x; i < GLB_PTS * C; i += 256) s_acc[i] = 0.f;
+    for (int i = threadIdx.x; i < GLB_PTS * C; i += GLB_NTH) s_acc[i] = 0.f;
     float2 sc = {0.f, 0.f}, sh = sc, a = sc, bb = sc, d = sc;
     if (cok) {
         sc = *reinterpret_cast<const float2 *>(scale + c); sh = *reinterpret_cast<const float2 *>(shift + c);
@@ -480,52 +485,71 @@ __global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
     const int per = (S + splits - 1) / splits;
     const int s_begin = split * per, s_end = min(S, s_begin + per);
     int *rows = s_rows[wave];
-    // every wave walks ALL index lists of the workgroup's centres and takes the rows of ITS points (point & 3 == wave): a point's
+    // every wave walks ALL index lists of the workgroup's centres and takes the rows of ITS points (point % GLB_WAVES == wave): a point's
     // accumulator is then touched by one wave only and the LDS update needs no atomic (LDS float atomics measured ~2 cycles
-    // per LANE: 75 M of them were 3 x the time of the loads)
-    for (int sidx = s_begin; sidx < s_end; ++sidx) {
-        const long long g = (long long)b * S + sidx;
-        const float *gp = G + (size_t)g * K * C + c, *yp = Y + (size_t)g * K * C + c;
-        const int32_t *ix = idx + (size_t)g * K;
-        float2 acc = {0.f, 0.f}, pacc = {0.f, 0.f};
-        // Padding: a ball with fewer than K points repeats its FIRST index (models/pointnet_util.py:104-106), on sparse clouds
-        // in most of the slots -- all of them rows of one point, i.e. of one wave.  The workgroup that owns that point deals
-        // the padded slots round-robin over its four waves instead; their sum stays in registers and goes to dU with one
-        // global atomic per channel and group.
-        const int first = ix[0];
-        const bool pads_here = first >= n0 && first < n0 + GLB_PTS && first < N;
-        int pad_seen = 0;
-        for (int k0 = 0; k0 < K; k0 += 64) {
-            // the rows of this batch that are this wave's: compacted in slot order (ballot + prefix count)
+    // per LANE: 75 M of them were 3 x the time of the loads).
+    // Round 5: the walk is over CHUNKS of 64 slots (centre, k0) with the index chunk of step t + 1 requested before the rows of
+    // step t are processed -- a centre used to cost two dependent memory round trips (its indices, then the ~4..8 rows that
+    // turn out to be this wave's), and with ~26 centres per workgroup that chain WAS the kernel's time.
+    const int nblk = (K + 63) >> 6;
+    const int T = (s_end - s_begin) * nblk;
+    auto load_chunk = [&](int t) -> int {
+        const int sidx = s_begin + t / nblk, r = ((t % nblk) << 6) + lane;
+        return (t < T && r < K) ? idx[((size_t)b * S + sidx) * K + r] : -1;
+    };
+    int n_cur = T > 0 ? load_chunk(0) : -1;
+    float2 acc = {0.f, 0.f}, pacc = {0.f, 0.f};
+    int first = 0, pad_seen = 0;
+    bool pads_here = false;
+    const float *gp = G, *yp = Y;
+    long long g = 0;
+    for (int t = 0; t < T; ++t) {
+        const int n_nxt = load_chunk(t + 1);
+        __builtin_amdgcn_sched_barrier(0);      // (the request stays HERE: left alone the scheduler sinks it to its use)
+        const int k0 = (t % nblk) << 6;
+        if (k0 == 0) {
+            g = (long long)b * S + s_begin + t / nblk;
+            gp = G + (size_t)g * K * C + c; yp = Y + (size_t)g * K * C + c;
+            acc = make_float2(0.f, 0.f); pacc = make_float2(0.f, 0.f);
+            // Padding: a ball with fewer than K points repeats its FIRST index (models/pointnet_util.py:104-106), on sparse clouds
+            // in most of the slots -- all of them rows of one point, i.e. of one wave.  The workgroup that owns that point deals
+            // the padded slots round-robin over its waves instead; their sum stays in registers and goes to dU with one
+            // global atomic per channel and group.
+            first = __builtin_amdgcn_readfirstlane(n_cur);
+            pads_here = first >= n0 && first < n0 + GLB_PTS && first < N;
+            pad_seen = 0;
+        }
+        {
+            // the rows of this chunk that are this wave's: compacted in slot order (ballot + prefix count)
             const int r = k0 + lane;
-            const int n = r < K ? ix[r] : -1;
-            const bool pad = pads_here && r > 0 && n == first;
+            const int n = n_cur;
+            const bool pad = pads_here && r > 0 && r < K && n == first;
             const unsigned long long pm = __ballot(pad);
-            const bool my_pad = pad && ((pad_seen + __popcll(pm & ((1ull << lane) - 1ull))) & 3) == wave;
+            const bool my_pad = pad && ((pad_seen + __popcll(pm & ((1ull << lane) - 1ull))) & (GLB_WAVES - 1)) == wave;
             pad_seen += __popcll(pm);
-            const bool mine = my_pad || (!pad && n >= n0 && n < n0 + GLB_PTS && n < N && (n & 3) == wave);
+            const bool mine = my_pad || (!pad && n >= n0 && n < n0 + GLB_PTS && n < N && (n & (GLB_WAVES - 1)) == wave);
             const unsigned long long m = __ballot(mine);
             if (mine) rows[__popcll(m & ((1ull << lane) - 1ull))] = (r << 8) | (my_pad ? 0x80 : 0) | ((n - n0) & 0x7f);
             const int cnt = __popcll(m);
             // (wave-private LDS: the writes above are visible to the wave's own later reads without a barrier)
             __builtin_amdgcn_wave_barrier();
-            constexpr int UNR = 4;
-            for (int t = 0; t < cnt; t += UNR) {
+            constexpr int UNR = 8;
+            for (int q = 0; q < cnt; q += UNR) {
                 float2 gv[UNR], yv[UNR];
                 int pk[UNR];
 #pragma unroll
                 for (int j = 0; j < UNR; ++j) {
-                    pk[j] = rows[min(t + j, cnt - 1)];
+                    pk[j] = rows[min(q + j, cnt - 1)];
                     const size_t off = (size_t)(pk[j] >> 8) * C;
-                    gv[j] = cok ? *reinterpret_cast<const float2 *>(gp + off) : make_float2(0.f, 0.f);
-                    yv[j] = cok ? *reinterpret_cast<const float2 *>(yp + off) : make_float2(0.f, 0.f);
+                    gv[j] = (cok && GLB_PROBE != 2) ? *reinterpret_cast<const float2 *>(gp + off) : make_float2(0.f, 0.f);
+                    yv[j] = (cok && GLB_PROBE != 2) ? *reinterpret_cast<const float2 *>(yp + off) : make_float2(0.f, 0.f);
                 }
 #pragma unroll
                 for (int j = 0; j < UNR; ++j) {
-                    if (t + j < cnt && cok) {
+                    if (q + j < cnt && cok) {
                         const float dx = fmaf(a.x, fmaf(yv[j].x, sc.x, sh.x) > 0.f ? gv[j].x : 0.f, fmaf(bb.x, yv[j].x, d.x));
                         const float dyy = fmaf(a.y, fmaf(yv[j].y, sc.y, sh.y) > 0.f ? gv[j].y : 0.f, fmaf(bb.y, yv[j].y, d.y));
-                        if (pk[j] & 0x80) {   // (wave-uniform) a padded slot: summed in registers
+                        if ((pk[j] & 0x80) || GLB_PROBE == 3) {   // (wave-uniform) a padded slot: summed in registers
                             pacc.x += dx; pacc.y += dyy;
                         } else {
                             // plain read-modify-write: the point is this wave's alone, and a wave's LDS accesses execute in order
@@ -540,21 +564,27 @@ __global__ __launch_bounds__(256, 2) void gather_linear_bwd_bn_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (cok && (acc.x != 0.f || acc.y != 0.f)) {
-            unsafeAtomicAdd(dVc + (size_t)g * C + c, -acc.x);
-            unsafeAtomicAdd(dVc + (size_t)g * C + c + 1, -acc.y);
+#ifndef GLB_PROBE
+#define GLB_PROBE 0     // timing-only diagnosis builds (wrong results): 1 no global atomics, 2 no row loads, 3 no LDS update
+#endif
+        if (k0 + 64 >= K && GLB_PROBE != 1) {      // the centre's last chunk: its sums leave
+            if (cok && (acc.x != 0.f || acc.y != 0.f)) {
+                unsafeAtomicAdd(dVc + (size_t)g * C + c, -acc.x);
+                unsafeAtomicAdd(dVc + (size_t)g * C + c + 1, -acc.y);
+            }
+            if (cok && (pacc.x != 0.f || pacc.y != 0.f)) {
+                unsafeAtomicAdd(dU + ((size_t)b * N + first) * C + c, pacc.x);
+                unsafeAtomicAdd(dU + ((size_t)b * N + first) * C + c + 1, pacc.y);
+            }
         }
-        if (cok && (pacc.x != 0.f || pacc.y != 0.f)) {
-            unsafeAtomicAdd(dU + ((size_t)b * N + first) * C + c, pacc.x);
-            unsafeAtomicAdd(dU + ((size_t)b * N + first) * C + c + 1, pacc.y);
-        }
+        n_cur = n_nxt;
     }
     __syncthreads();
     const int npts = min(GLB_PTS, N - n0);
     float *dst = dU + ((size_t)b * N + n0) * C;
-    for (int i = threadIdx.x; i < npts * C; i += 256) {
+    for (int i = threadIdx.x; i < npts * C; i += GLB_NTH) {
         const float v = s_acc[i];
-        if (v != 0.f) unsafeAtomicAdd(dst + i, v);
+        if (v != 0.f && GLB_PROBE != 1) unsafeAtomicAdd(dst + i, v);
     }
 }
 
@@ -1022,7 +1052,7 @@ int prifit_gather_linear_bwd_bn(const float *G, const float *Y, const float *sca
     const int ranges = (N + GLB_PTS - 1) / GLB_PTS;
     int splits = (2 * 256) / (B * ranges);                 // one round of resident workgroups (two per CU), no tail
     splits = splits < 1 ? 1 : (splits > (S + 7) / 8 ? (S + 7) / 8 : splits);
-    hipLaunchKernelGGL(gather_linear_bwd_bn_kernel, dim3(ranges, splits, B), dim3(256), 0, as_stream(stream), G, Y, scale,
+    hipLaunchKernelGGL(gather_linear_bwd_bn_kernel, dim3(ranges, splits, B), dim3(GLB_NTH), 0, as_stream(stream), G, Y, scale,
                        shift, coef_a, coef_b, coef_d, idx, N, S, K, C, splits, dU, dVc);
     return prifit_check_launch();
 }

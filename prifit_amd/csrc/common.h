@@ -73,6 +73,23 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// Workgroup -> (shape, block inside the shape) with all blocks of a shape on ONE XCD (workgroups go to the XCDs round-robin):
+// the gather passes re-read a shape's per-point tables k times, 0.5 - 1 MB per shape and table against 4 MB of L2 per XCD --
+// in launch order every XCD sees every shape and the re-reads miss.  W = blocks per shape; the last B % 8 shapes stay linear.
+__device__ __forceinline__ void xcd_shape_block(int wg, int W, int B, int &b, int &within)
+{
+    const int full = (B >> 3) << 3;
+    if (wg < full * W) {
+        const int s = wg >> 3;
+        b = (wg & 7) + 8 * (s / W);
+        within = s % W;
+    } else {
+        const int r = wg - full * W;
+        b = full + r / W;
+        within = r % W;
+    }
+}
+
 // A [P, C] operand that is NOT stored: row r of it is the first-layer pre-activation of a set-abstraction MLP written by
 // linearity (models/pointnet_util.py:243-252: conv1([feat_j | xyz_j - c_g]) = U_j - Vc_g with U per point, Vc per centre
 // and the bias folded into U), re-formed on load as U[shape(r) * N + idx[r]] - Vc[r / Kg].  U is small (B N C floats, L2 /

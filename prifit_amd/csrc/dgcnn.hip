@@ -56,28 +56,12 @@ __device__ __forceinline__ unsigned knn_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Selection of the k largest of a row's keys (order-preserving images of the values, 0 = padding), VPT per lane, column of
+// key[j] = lane + 64 j.  out[0..k) = their columns, descending value, ties to the lower column.  `sel`: 64 wave-private LDS slots.
 template <int VPT>
-__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ G, const float *__restrict__ xx,
-                                                         int N, long long rows, int k, int32_t *__restrict__ idx)
+__device__ __forceinline__ void knn_select_keys(unsigned (&key)[VPT], int N, int k, unsigned long long *sel, int lane,
+                                                int32_t *__restrict__ out)
 {
-    __shared__ unsigned long long s_sel[4][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    const long long b = row / N;
-    const float *g = G + row * N;
-    const float *xb = xx + b * N;
-    const float nxi = -xb[row - b * N];
-    float gv[VPT], xv[VPT];
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-        const int c = lane + 64 * j;
-        gv[j] = g[c < N ? c : N - 1];
-        xv[j] = xb[c < N ? c : N - 1];
-    }
-    unsigned key[VPT];   // padding columns: key 0 (below every real value, -inf included: its key is 0x007fffff)
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) key[j] = (lane + 64 * j) < N ? knn_key((nxi - (-2.0f * gv[j])) - xv[j]) : 0u;
     // (0) fast path (round 4).  The k-th largest of the 64 per-lane maxima, t0, is a conservative threshold: at least k keys
     // (those maxima) are >= t0, so the k largest keys of the row are all >= t0 -- and usually little more than k keys are.
     // When at most 64 keys pass, they are compacted and sorted right away: the composite (key, ~index) order of the sort IS
@@ -110,14 +94,14 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
             const unsigned long long mt = __ballot(take);
             const int pos = n0 + __builtin_popcountll(mt & ltm);
             if (take && pos < 64)
-                s_sel[wave][pos] = ((unsigned long long)key[j] << 32) | (unsigned)(~(unsigned)(lane + 64 * j));
+                sel[pos] = ((unsigned long long)key[j] << 32) | (unsigned)(~(unsigned)(lane + 64 * j));
             n0 += __builtin_popcountll(mt);
         }
         if (n0 >= k && n0 <= 64) {   // wave-uniform
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned long long v = lane < n0 ? s_sel[wave][lane] : 0ull;
+            unsigned long long v = lane < n0 ? sel[lane] : 0ull;
 #pragma unroll
             for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
@@ -130,7 +114,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
                     v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
                 }
             }
-            if (lane < k) idx[row * k + lane] = (int)(~(unsigned)v);
+            if (lane < k) out[lane] = (int)(~(unsigned)v);
             return;
         }
         __builtin_amdgcn_wave_barrier();   // (the general path below rewrites s_sel)
@@ -170,7 +154,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
         const bool take = gt || (eq && seen_eq + __builtin_popcountll(meq & lt) < ties);
         const unsigned long long mt = __ballot(take);
         if (take)
-            s_sel[wave][nsel + __builtin_popcountll(mt & lt)] =
+            sel[nsel + __builtin_popcountll(mt & lt)] =
                 ((unsigned long long)key[j] << 32) | (unsigned)(~(unsigned)(lane + 64 * j));
         nsel += __builtin_popcountll(mt);
         seen_eq += __builtin_popcountll(meq);
@@ -179,7 +163,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // (3) bitonic sort of 64 pairs, descending (empty slots: 0, below every pair: an index complement is never 0 here)
-    unsigned long long v = lane < k ? s_sel[wave][lane] : 0ull;
+    unsigned long long v = lane < k ? sel[lane] : 0ull;
 #pragma unroll
     for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
@@ -192,7 +176,69 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict
             v = keep_max ? (v > o ? v : o) : (v < o ? v : o);
         }
     }
-    if (lane < k) idx[row * k + lane] = (int)(~(unsigned)v);
+    if (lane < k) out[lane] = (int)(~(unsigned)v);
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ G, const float *__restrict__ xx,
+                                                         int N, long long rows, int k, int32_t *__restrict__ idx)
+{
+    __shared__ unsigned long long s_sel[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const long long b = row / N;
+    const float *g = G + row * N;
+    const float *xb = xx + b * N;
+    const float nxi = -xb[row - b * N];
+    float gv[VPT], xv[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int c = lane + 64 * j;
+        gv[j] = g[c < N ? c : N - 1];
+        xv[j] = xb[c < N ? c : N - 1];
+    }
+    unsigned key[VPT];   // padding columns: key 0 (below every real value, -inf included: its key is 0x007fffff)
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) key[j] = (lane + 64 * j) < N ? knn_key((nxi - (-2.0f * gv[j])) - xv[j]) : 0u;
+    knn_select_keys<VPT>(key, N, k, s_sel[wave], lane, idx + row * k);
+}
+
+// The first graph of the network (C = 3: the coordinates themselves) with NO pairwise matrix: the cloud sits in LDS as
+// (x, y, z, |p|^2), a wave forms the 2048 values of its row from it -- the k-ordered fma chain of the matrix kernel's K = 3
+// product, term by term: x x', then fma(y, y', .), then fma(z, z', .) -- and selects.  The [B, N, N] Gram matrix (403 MB
+// written at 2.9 TB/s by a K = 3 "product" at 0.03 of the matrix peak, then read back) never exists.  One workgroup = 64 rows.
+constexpr int KNN3_ROWS = 64;
+template <int VPT>
+__global__ __launch_bounds__(256) void knn3_select_kernel(const float *__restrict__ x, int N, int k, int32_t *__restrict__ idx)
+{
+    __shared__ float4 s_pts[64 * VPT];
+    __shared__ unsigned long long s_sel[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y, r0 = blockIdx.x * KNN3_ROWS;
+    const float *xb = x + (size_t)b * N * 3;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float px = xb[3 * i], py = xb[3 * i + 1], pz = xb[3 * i + 2];
+        s_pts[i] = make_float4(px, py, pz, (px * px + py * py) + pz * pz);      // (the torch expression of _knn_cl, op by op)
+    }
+    __syncthreads();
+    const int r1 = min(N, r0 + KNN3_ROWS);
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float4 q = s_pts[r];
+        const float nxi = -q.w;
+        unsigned key[VPT];
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const int c = lane + 64 * j;
+            const float4 p = s_pts[c < N ? c : N - 1];
+            float g = q.x * p.x;
+            g = fmaf(q.y, p.y, g);
+            g = fmaf(q.z, p.z, g);
+            key[j] = c < N ? knn_key((nxi - (-2.0f * g)) - p.w) : 0u;
+        }
+        knn_select_keys<VPT>(key, N, k, s_sel[wave], lane, idx + ((size_t)b * N + r) * k);
+        __builtin_amdgcn_wave_barrier();   // (the next row rewrites s_sel)
+    }
 }
 
 // rows (b, n, j): [x[b, idx[b,n,j]] - x[b,n] (C), x[b,n] (C), 0-pad]   (src/dgcnn.py:98-105)
@@ -299,6 +345,18 @@ int prifit_knn_topk(const float *G, const float *xx, int B, int N, int k, int32_
     if (N <= 1024) hipLaunchKernelGGL((knn_topk_kernel<16>), grid, block, 0, st, G, xx, N, rows, k, idx);
     else if (N <= 2048) hipLaunchKernelGGL((knn_topk_kernel<32>), grid, block, 0, st, G, xx, N, rows, k, idx);
     else hipLaunchKernelGGL((knn_topk_kernel<64>), grid, block, 0, st, G, xx, N, rows, k, idx);
+    return prifit_check_launch();
+}
+
+int prifit_knn3_supported(int N, int k) { return (N >= 64 && N <= 2048 && k >= 1 && k <= 64) ? 1 : 0; }
+
+int prifit_knn3_topk(const float *x, int B, int N, int k, int32_t *idx, void *stream)
+{
+    if (!x || !idx || B <= 0 || B > 65535 || !prifit_knn3_supported(N, k)) return PRIFIT_EINVAL;
+    dim3 grid((unsigned)((N + KNN3_ROWS - 1) / KNN3_ROWS), (unsigned)B), block(256);
+    hipStream_t st = as_stream(stream);
+    if (N <= 1024) hipLaunchKernelGGL((knn3_select_kernel<16>), grid, block, 0, st, x, N, k, idx);
+    else hipLaunchKernelGGL((knn3_select_kernel<32>), grid, block, 0, st, x, N, k, idx);
     return prifit_check_launch();
 }
 

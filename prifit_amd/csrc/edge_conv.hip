@@ -25,23 +25,6 @@ constexpr int EC_MAXN = 8192;    // CSR build: one workgroup per shape, histogra
 
 __device__ __forceinline__ float act_grad(float z, float g, float slope) { return z > 0.f ? g : g * slope; }
 
-// Workgroup -> (shape, block inside the shape) with all blocks of a shape on ONE XCD (workgroups go to the XCDs round-robin):
-// the gather passes re-read a shape's per-point tables k times, 0.5 - 1 MB per shape and table against 4 MB of L2 per XCD --
-// in launch order every XCD sees every shape and the re-reads miss.  W = blocks per shape; the last B % 8 shapes stay linear.
-__device__ __forceinline__ void xcd_shape_block(int wg, int W, int B, int &b, int &within)
-{
-    const int full = (B >> 3) << 3;
-    if (wg < full * W) {
-        const int s = wg >> 3;
-        b = (wg & 7) + 8 * (s / W);
-        within = s % W;
-    } else {
-        const int r = wg - full * W;
-        b = full + r / W;
-        within = r % W;
-    }
-}
-
 // ---- CSR of the neighbour lists: offs[b][n] .. offs[b][n+1] = positions in lst[b] of the edges (i k + j) with idx[b,i,j] = n;
 // pos[b][e] = the position of edge e in lst[b] ----
 __global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restrict__ idx, int N, int k,

@@ -906,23 +906,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // The matrix is symmetric and so is its arithmetic -- C[i][j] and C[j][i] are the same products added in the same
 // k order -- so only the tiles on and above the diagonal are computed (136 of 256 at n = 2048); an off-diagonal tile
 // is also written transposed, through LDS, as whole coalesced rows.  Bit-identical to the full product.
+#ifndef CHORD_XCD
+#define CHORD_XCD 1     // (A/B builds: -DCHORD_XCD=0 is round 4's (tile, shape) launch order)
+#endif
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chord_sym_kernel(
     const float *__restrict__ A, long long lda, long long sA, float *__restrict__ C, long long ldc, long long sC, int n, int K,
-    unsigned long long *__restrict__ okey)
+    int batch, unsigned long long *__restrict__ okey)
 {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int SZ = BM * (BK + PAD);
     constexpr int TLD = BM + 4;   // transposed staging: [column of the tile][row], 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) float lds[4 * SZ];   // two stages of (row panel, column panel); 73.7 KB >= 128 * TLD * 4
     static_assert(4 * SZ >= BN * TLD, "the transposed tile fits the staging buffers");
-    // upper-triangular tile index -> (tile_m <= tile_n)
+    // upper-triangular tile index -> (tile_m <= tile_n).  Round 5: all tiles of a shape on ONE XCD (xcd_shape_block; the
+    // grid is linear) -- in (tile, shape) launch order every XCD's L2 fetched every shape's rows: 217 MB of reads for a 25 MB
+    // input by the PMC counters (1.48 x the algorithmic bytes of the launch)
     const int T = n / BM;
-    int t = blockIdx.x, tile_m = 0;
+    int t, zb;
+#if CHORD_XCD
+    xcd_shape_block((int)blockIdx.x, T * (T + 1) / 2, batch, zb, t);
+#else
+    t = (int)blockIdx.x % (T * (T + 1) / 2); zb = (int)blockIdx.x / (T * (T + 1) / 2);
+#endif
+    int tile_m = 0;
     while (t >= T - tile_m) { t -= T - tile_m; ++tile_m; }
     const int tile_n = tile_m + t;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const float *Az = A + (long long)blockIdx.z * sA;
-    float *Cz = C + (long long)blockIdx.z * sC;
+    const float *Az = A + (long long)zb * sA;
+    float *Cz = C + (long long)zb * sC;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -972,7 +983,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // block, the candidates of its row block (a column minimum, from the accumulator registers) and -- off the diagonal --
     // for the points of its row block the candidates of its column block (from the transposed copy in LDS).  The matrix is
     // bitwise symmetric, so a column's minimum over rows is that point's row minimum over columns.
-    unsigned long long *okz = okey ? okey + (long long)blockIdx.z * n : nullptr;
+    unsigned long long *okz = okey ? okey + (long long)zb * n : nullptr;
     auto fkey = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -1417,8 +1428,8 @@ int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float
         (long long)n * lda * 4 >= 0x7ff00000LL)
         return PRIFIT_EINVAL;
     const int T = n / 128;
-    hipLaunchKernelGGL(chord_sym_kernel, dim3(T * (T + 1) / 2, 1, batch), dim3(512), 0, as_stream(stream), A, lda, strideA, C, ldc,
-                       strideC, n, K, owner_key);
+    hipLaunchKernelGGL(chord_sym_kernel, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda, strideA,
+                       C, ldc, strideC, n, K, batch, owner_key);
     return prifit_check_launch();
 }
 

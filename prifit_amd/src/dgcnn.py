@@ -31,10 +31,19 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+# the first graph (C = 3) straight from the cloud, no [B,N,N] pairwise matrix (prifit_knn3_topk; 0: product + selection, A/B arm)
+_KNN3_FUSED = __import__("os").environ.get("PRIFIT_KNN3_FUSED", "1") != "0"
+
+
 def _knn_cl(x, k):
     """x [B,N,C] channels-last -> idx int32 [B,N,k]."""
     x = x.contiguous()
     B, N, C = x.shape
+    if C == 3 and _KNN3_FUSED and dll().prifit_knn3_supported(N, k):
+        idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+        with profiler.span("knn3_topk", 12.0 * B * N + 4.0 * B * N * k):      # HBM: the cloud once, the lists once
+            call("prifit_knn3_topk", ptr(x), B, N, k, ptr(idx), cur_stream())
+        return idx
     G = torch.empty(B, N, N, dtype=torch.float32, device=x.device)
     gemm(NT, N, N, C, x, C, x, C, G, N, batch=B, sA=N * C, sB=N * C, sC=N * N)
     if C == 3:

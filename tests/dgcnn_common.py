@@ -93,7 +93,10 @@ def check_selfsup(g, total, chamfer, params, labels, emb, grads, loss_tol=None, 
     loss_tol = float(g["loss_bar"]) if loss_tol is None else loss_tol
     torch.testing.assert_close(total.reshape(-1), _t(g["total_loss"]).reshape(-1), rtol=loss_tol, atol=1e-7)
     torch.testing.assert_close(chamfer.reshape(-1), _t(g["chamfer_loss"]).reshape(-1), rtol=loss_tol, atol=1e-7)
-    torch.testing.assert_close(emb[:, :64], _t(g["emb_head"]), rtol=1e-3, atol=1e-3)
+    # (relative L2: a neighbour flipping in the second kNN graph moves single entries by more than any elementwise bar;
+    # the fp32 reference and the fp64 oracle are dev_fp64[1] = 3.5e-3 apart by this measure)
+    eh = _t(g["emb_head"])
+    assert float((emb[:, :64] - eh).norm() / eh.norm()) <= 2.0 * float(g["dev_fp64"][1])
     K = [int(k) for k in g["K"]]
     assert [len(p) for p in params] == K
     ref_labels = _t(g["labels"]).long()

@@ -295,6 +295,25 @@ def test_dgcnn_with_convex_loss_config5(D, golden):
     assert (Xh.grad.cpu() - Xo.grad).norm() <= 2e-2 * Xo.grad.norm()
 
 
+@pytest.mark.parametrize("N,k", [(2048, 20), (1024, 40), (300, 7), (64, 64), (70, 3), (2048, 40)])
+def test_knn3_from_the_cloud_equals_product_plus_selection(D, N, k, monkeypatch):
+    """prifit_knn3_topk (the first graph straight from the xyz cloud, no pairwise matrix) against the product kernel +
+    prifit_knn_topk it replaces: the same indices bit for bit -- on surface clouds, on clouds with every point twice and a
+    ten-fold point (exact ties across the k-th place), ragged N."""
+    B = 3
+    rng = np.random.default_rng(7 * N + k)
+    xs = [synth.cloud("surface", B, N, N + k), rng.normal(size=(B, N, 3)).astype(np.float32)]
+    xs[1][:, N // 2:] = xs[1][:, :N - N // 2]
+    xs[1][0, :10] = xs[1][0, 0]
+    for x in xs:
+        xt = torch.from_numpy(x).cuda()
+        monkeypatch.setattr(D, "_KNN3_FUSED", True)
+        got = D._knn_cl(xt, k)
+        monkeypatch.setattr(D, "_KNN3_FUSED", False)
+        want = D._knn_cl(xt, k)
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("N,k", [(2048, 20), (1024, 40), (300, 7), (64, 64), (70, 3)])
 def test_knn_selection_order_and_ties(hiplib, N, k):
     """prifit_knn_topk (selection + one sort per wave) against a stable sort of the same values: descending value, exact ties
