@@ -461,6 +461,9 @@ __global__ __launch_bounds__(256) void gather_linear_bwd_kernel(const float *__r
 #ifndef GLB_WAVES_N
 #define GLB_WAVES_N 4
 #endif
+#ifndef GLB_PROBE
+#define GLB_PROBE 0     // timing-only diagnosis builds (wrong results): 1 no global atomics, 2 no row loads, 3 no LDS update
+#endif
 constexpr int GLB_PTS = 128, GLB_CMAX = 128, GLB_WAVES = GLB_WAVES_N, GLB_NTH = 64 * GLB_WAVES;
 __global__ __launch_bounds__(GLB_NTH, 2) void gather_linear_bwd_bn_kernel(
     const float *__restrict__ G, const float *__restrict__ Y, const float *__restrict__ scale,
@@ -564,9 +567,6 @@ __global__ __launch_bounds__(GLB_NTH, 2) void gather_linear_bwd_bn_kernel(
             }
             __builtin_amdgcn_wave_barrier();
         }
-#ifndef GLB_PROBE
-#define GLB_PROBE 0     // timing-only diagnosis builds (wrong results): 1 no global atomics, 2 no row loads, 3 no LDS update
-#endif
         if (k0 + 64 >= K && GLB_PROBE != 1) {      // the centre's last chunk: its sums leave
             if (cok && (acc.x != 0.f || acc.y != 0.f)) {
                 unsafeAtomicAdd(dVc + (size_t)g * C + c, -acc.x);
