@@ -190,7 +190,7 @@ def _traffic_per_launch(dom):
     # (the PMC tool names kernels, the spans name call sites)
     alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false", "ms_fused_bwd": "ms_fused_kernel<1, true, true",
              "gemm_dual_nn": "gemm_dual_sk_kernel"}
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 fams_pmc = json.load(fh)["families"]
@@ -428,7 +428,10 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
         # quantile-doubling retry (src/ellipsoid_utils.py:19-27: full recompute per doubling)
         (nx, ny), noise, q = EMBEDDING_PARTS[embedding]
         parts = synth.equal_part_labels(data["xyz"].transpose(1, 2).cpu().numpy(), nx, ny)
-        off = torch.from_numpy(synth.part_embedding_offset(parts, 128, 1000 * rank, K=nx * ny, noise=noise)).to(device)
+        # (scale 100, not the 30 of "clustered": at 30 the network's own output is 0.15 of a prototype's length, as much as the
+        # prototype noise, and as Adam moves it over the measurement's 35 steps a part splits into two modes every few steps:
+        # 26 modes = a retry; measured round 5: 10 of 30 steps)
+        off = torch.from_numpy(synth.part_embedding_offset(parts, 128, 1000 * rank, K=nx * ny, noise=noise, scale=100.0)).to(device)
         fit_kw["fit_inputs"] = dict(embedding_offset=off)
         fit_kw["quantile"] = q
 
