@@ -654,7 +654,7 @@ def family_rows(fams, steps):
             per.update(bound="mfma", achieved=terms * work / (ms * 1e-3) / 1e12, peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=terms * work / steps, flops_per_launch=terms * work / max(n, 1),
                        fp32_equivalent_tflops=work / (ms * 1e-3) / 1e12, plane_products=terms)
-        elif base == "sample_nn":    # exact nearest-target search: fp32 vector ALU (its peak = the fp32 MFMA peak on gfx950)
+        elif base in ("sample_nn", "knn3_topk"):    # pairwise searches on the fp32 vector ALU (its peak = the fp32 MFMA peak on gfx950)
             per.update(bound="valu", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=work / steps, flops_per_launch=work / max(n, 1))
         elif (base.startswith("gemm") and not base.startswith("gemm_stream")) or base.startswith(("ms_fused", "chord_sym")):

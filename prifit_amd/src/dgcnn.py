@@ -41,7 +41,8 @@ def _knn_cl(x, k):
     B, N, C = x.shape
     if C == 3 and _KNN3_FUSED and dll().prifit_knn3_supported(N, k):
         idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
-        with profiler.span("knn3_topk", 12.0 * B * N + 4.0 * B * N * k):      # HBM: the cloud once, the lists once
+        # a VALU row: per pair one multiply, two fmas and the three operations of the value (8 flop), then the selection
+        with profiler.span("knn3_topk", 8.0 * B * N * N):
             call("prifit_knn3_topk", ptr(x), B, N, k, ptr(idx), cur_stream())
         return idx
     G = torch.empty(B, N, N, dtype=torch.float32, device=x.device)
