@@ -193,6 +193,29 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
                                 void *stream);
+/* EXPERIMENT (round 5; not on the default path): the row-dense part of a max-pooled last layer's backward in
+ * the algebraic form (models/pointnet_util.py:252-256 through autograd).  With dY = T [row == winner] + b Y + d and
+ * Y = A W^T + bias, A = relu(bn(Yp)): dA = A M + 1 v^T + (winners' rows), dW = diag(b) W (A^T A) + ... -- two products over
+ * Cin x Cin that read only Yp [P, Cin].  Gp [P, Cin] = A M + v; red_slab [slabs][2][Cin] = the (m1, m2) BatchNorm-backward sums
+ * of the layer below from Gp; gram [Cin, Cin] = A^T A, asum [Cin] = 1^T A.  Cin in {64, 96, 128}; workspace: _workspace floats.
+ * prifit_pool_alg_sparse_f32 (run AFTER the dense pass, same stream): the winners' rows -- Gp[winner row] += sum T_c W[c, :]
+ * with their share of the (m1, m2) sums (red_slab [_sparse_slabs][2][Cin], to be handed to prifit_bn_bwd_finalize together
+ * with the dense pass's slabs), and dWs [Cout, Cin] = S^T A.  arg / T [G, Cout]: winning row inside each group of K rows and
+ * the pooled gradient there (prifit_pool_bwd_table).  (Cout, Cin) in {(128, 96), (128, 64), (256, 128), (64, 32)}. */
+int prifit_pool_alg_supported(long long P, int Cin);
+int prifit_pool_alg_slabs(long long P, int Cin);
+long long prifit_pool_alg_workspace(long long P, int Cin);
+int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
+                              const float *p_mean, const float *p_invstd, const float *M, long long ldm, const float *v, float *Gp,
+                              long long ldgp, float *red_slab, float *gram, float *asum, float *workspace, void *stream);
+int prifit_pool_alg_sparse_supported(int G, int K, int Cout, int Cin);
+int prifit_pool_alg_sparse_slabs(int G);
+long long prifit_pool_alg_sparse_workspace(int G, int Cout, int Cin);
+int prifit_pool_alg_sparse_f32(int G, int K, int Cout, int Cin, const int32_t *arg, const float *T, const float *W,
+                               const float *Yp, long long ldyp, const float *p_scale, const float *p_shift, const float *p_mean,
+                               const float *p_invstd, float *Gp, long long ldgp, float *red_slab, float *dWs, float *workspace,
+                               void *stream);
+
 /* Rows that are never stored (round 4).  The first layer of a set-abstraction MLP written by linearity --
  * y1[row] = U[b, idx[row]] - Vc[b, s], U [B,N,64] per point (bias folded in), Vc [B,S,64] per centre, models/pointnet_util.py
  * :243-252 -- has ~10^6 rows of 256 bytes that its three consumers used to read back from HBM (0.6 GB written + 3 reads per

@@ -25,6 +25,7 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_stream.hip": [],
     "gemm_stream_bwd.hip": [],
+    "pool_alg.hip": [],
     "bn.hip": [],
     "meanshift.hip": [],
     "meanshift_fused.hip": [],

@@ -385,6 +385,251 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5 (EXPERIMENT, measured in DESIGN 5.3): the DENSE part of a max-pooled last layer's backward in the algebraic form.
+// With dY = T [row == winner] + b Y + d and Y = A W^T + bias (A = relu(bn(Yp)), the layer's input):
+//     dA = A M + 1 v^T + (winners' rows)        M = W^T diag(b) W  [Cin, Cin],  v = W^T (d + b * bias)
+//     dW = diag(b) W (A^T A) + (d + b * bias) (1^T A) + (winners' rows)
+// so the row-dense work is two products over Cin x Cin -- A M and the Gram matrix A^T A (symmetric: blocks on and above the
+// diagonal) -- that read ONLY Yp; the pooled layer's own pre-activation Y is not needed at all.  This kernel is that pass:
+// the one-pass structure above with the "dY tile" := the activated copy of the Yp tile.  Gp = A M + v, the (m1, m2) sums of the
+// layer below from Gp (yhat re-formed from A where the mask is on: yhat = A e + f), the Gram blocks per workgroup.
+template <int CIN> struct AlgRoles;
+// wave -> list of Gram blocks (row block * NA + column block); A-waves first (one per 32 columns)
+template <> struct AlgRoles<96> { static constexpr int NW = 7; static constexpr int nblk[7] = {0, 0, 0, 3, 1, 1, 1};
+                                  static constexpr int blk[7][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 4, 8}, {1, 0, 0}, {2, 0, 0}, {5, 0, 0}}; };
+template <> struct AlgRoles<64> { static constexpr int NW = 4; static constexpr int nblk[4] = {0, 0, 2, 1};
+                                  static constexpr int blk[4][2] = {{0, 0}, {0, 0}, {0, 3}, {1, 0}}; };
+template <> struct AlgRoles<128> { static constexpr int NW = 8; static constexpr int nblk[8] = {0, 0, 0, 0, 3, 3, 2, 2};
+                                   static constexpr int blk[8][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 5, 10}, {15, 1, 2}, {3, 6, 0}, {7, 11, 0}}; };
+
+struct AlgArgs {
+    long long P;
+    const float *Yp; long long ldyp;          // [P, Cin]
+    const float *ps, *pt, *pmu, *pis;         // the layer below: scale, shift, mean, invstd [Cin]
+    const float *M; long long ldm;            // [Cin, Cin]
+    const float *v;                           // [Cin]
+    float *Gp; long long ldgp;                // [P, Cin]
+    float *red_slab;                          // [grid][2][Cin]
+    float *gram_part;                         // [grid][Cin][Cin] (blocks on and above the diagonal written)
+    float *asum_part;                         // [grid][Cin] column sums of A over the workgroup's rows
+};
+
+template <int CIN>
+__global__ __launch_bounds__((64 * AlgRoles<CIN>::NW), 1) void pool_alg_dense_kernel(const AlgArgs g)
+{
+    using R = AlgRoles<CIN>;
+    constexpr int NA = CIN / 32, NTH = 64 * R::NW;
+    constexpr int LDA = CIN + 4;
+    constexpr int KG = CIN / 8, P4 = CIN / 4, NP4 = SBM * P4, NVP = (NP4 + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) float s_a[2][SBM * LDA];
+    __shared__ __attribute__((aligned(16))) float s_co[2][CIN];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool a_wave = wave < NA;
+    const int wa = a_wave ? wave : 0;
+    for (int t = threadIdx.x; t < CIN; t += NTH) { s_co[0][t] = g.ps[t]; s_co[1][t] = g.pt[t]; }
+    const int tiles = (int)((g.P + SBM - 1) / SBM);
+    float4 stp[NVP];
+    int poff[NVP];
+#pragma unroll
+    for (int p = 0; p < NVP; ++p) {
+        const int id = threadIdx.x + NTH * p;
+        poff[p] = id < NP4 ? ((id / P4) * (int)g.ldyp + 4 * (id % P4)) * 4 : 0x7fffffff;
+    }
+    auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
+        const long long left = g.P - m0;
+        const int rows = left < SBM ? (int)left : SBM;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0, ((rows - 1) * (int)ld + width) * 4, 0x00020000);
+    };
+    auto load_tile = [&](int tile) {
+        const __amdgpu_buffer_rsrc_t rp = tile_rsrc(g.Yp, g.ldyp, tile * SBM, CIN);
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, poff[p], 0, 0));
+            stp[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto store_tile = [&](int tile, int buf) {
+        const int m0 = tile * SBM;
+        const bool full = (long long)m0 + SBM <= g.P;
+#pragma unroll
+        for (int p = 0; p < NVP; ++p) {
+            const int id = threadIdx.x + NTH * p;
+            if (NVP * NTH != NP4 && id >= NP4) continue;
+            const int row = id / P4, c4 = id - row * P4;
+            const float4 cs = *reinterpret_cast<const float4 *>(&s_co[0][4 * c4]);
+            const float4 ct = *reinterpret_cast<const float4 *>(&s_co[1][4 * c4]);
+            float4 x = stp[p];
+            x.x = fmaxf(fmaf(x.x, cs.x, ct.x), 0.f); x.y = fmaxf(fmaf(x.y, cs.y, ct.y), 0.f);
+            x.z = fmaxf(fmaf(x.z, cs.z, ct.z), 0.f); x.w = fmaxf(fmaf(x.w, cs.w, ct.w), 0.f);
+            if (!full && (long long)m0 + row >= g.P) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&s_a[buf][row * LDA + 4 * c4]) = x;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= tiles) tile = tiles - 1;
+    load_tile(tile);
+    __syncthreads();
+    store_tile(tile, 0);
+    __syncthreads();
+    if (a_wave) {
+        const int col = 32 * wa + li;
+        float4 bf[KG];
+#pragma unroll
+        for (int q = 0; q < KG; ++q) {
+            const int k0 = 8 * q + 4 * lh;
+            bf[q] = make_float4(g.M[(long long)k0 * g.ldm + col], g.M[(long long)(k0 + 1) * g.ldm + col],
+                                g.M[(long long)(k0 + 2) * g.ldm + col], g.M[(long long)(k0 + 3) * g.ldm + col]);
+        }
+        // yhat of the layer below from its activation where the mask is on: y = (A - t) / s  ->  yhat = A e + f
+        const float rs = g.ps[col], rt = g.pt[col];
+        const float inv_s = rs != 0.f ? 1.0f / rs : 0.f;
+        float r_e = inv_s * g.pis[col], r_f = (-rt * inv_s - g.pmu[col]) * g.pis[col], r_v = g.v[col];
+#pragma unroll
+        for (int q = 0; q < KG; ++q) asm volatile("" : "+v"(bf[q].x), "+v"(bf[q].y), "+v"(bf[q].z), "+v"(bf[q].w));
+        asm volatile("" : "+v"(r_e), "+v"(r_f), "+v"(r_v));
+        float m1 = 0.f, m2 = 0.f, sa = 0.f;
+        const int ldgp4 = (int)g.ldgp * 4;
+        const int c_voff = ((4 * lh) * (int)g.ldgp + col) * 4;
+        for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+            const int cur = it & 1;
+            const int next = tile + gridDim.x;
+            const int ntile = next < tiles ? next : tile;
+            load_tile(ntile);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+            const float *ap = &s_a[cur][li * LDA + 4 * lh];
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                float4 fa[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LDA + 8 * q);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, bf[q].y, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, bf[q].z, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, bf[q].w, acc[a], 0, 0, 0);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t crs = tile_rsrc(g.Gp, g.ldgp, tile * SBM, CIN);
+            const float *yp = &s_a[cur][(4 * lh) * LDA + col];
+            const long long left = g.P - (long long)tile * SBM;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 32 * a + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[a][r] + r_v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, rl * ldgp4, 0);
+                    const float av = yp[rl * LDA];            // (rows beyond P hold zeros)
+                    const float gm = (av > 0.f && rl + 4 * lh < left) ? v : 0.f;
+                    m1 += gm;
+                    m2 += gm * fmaf(av, r_e, r_f);
+                    sa += av;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            store_tile(ntile, cur ^ 1);
+            __syncthreads();
+        }
+        m1 += __shfl_xor(m1, 32, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        sa += __shfl_xor(sa, 32, 64);
+        if (lh == 0) {
+            g.red_slab[((long long)blockIdx.x * 2 + 0) * CIN + col] = m1;
+            g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
+            g.asum_part[(long long)blockIdx.x * CIN + col] = sa;
+        }
+    } else {
+        auto w_role = [&](auto wv) {
+            constexpr int WV = decltype(wv)::value, WCNT = R::nblk[WV];
+            f32x16 accw[WCNT];
+#pragma unroll
+            for (int i = 0; i < WCNT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+            for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+                const int cur = it & 1;
+                const int next = tile + gridDim.x;
+                const int ntile = next < tiles ? next : tile;
+                load_tile(ntile);
+                __builtin_amdgcn_sched_barrier(0);
+                const float *base = &s_a[cur][lh * LDA + li];
+                constexpr int GS = WCNT >= 3 ? 2 : 4, NG = SBM / 2 / GS;
+                float av[2][GS][WCNT], pv[2][GS][WCNT];
+                auto fetch = [&](int buf, int grp) {
+#pragma unroll
+                    for (int u = 0; u < GS; ++u)
+#pragma unroll
+                        for (int i = 0; i < WCNT; ++i) {
+                            av[buf][u][i] = base[2 * (grp * GS + u) * LDA + 32 * (R::blk[WV][i] / NA)];
+                            pv[buf][u][i] = base[2 * (grp * GS + u) * LDA + 32 * (R::blk[WV][i] % NA)];
+                        }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp) {
+                    if (grp + 1 < NG) fetch((grp + 1) & 1, grp + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < GS; ++u)
+#pragma unroll
+                        for (int i = 0; i < WCNT; ++i)
+                            accw[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[grp & 1][u][i], pv[grp & 1][u][i], accw[i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                store_tile(ntile, cur ^ 1);
+                __syncthreads();
+            }
+            float *dst = g.gram_part + (long long)blockIdx.x * CIN * CIN;
+#pragma unroll
+            for (int i = 0; i < WCNT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * (R::blk[WV][i] / NA) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    dst[row * CIN + 32 * (R::blk[WV][i] % NA) + li] = accw[i][r];
+                }
+        };
+        if constexpr (R::NW > NA + 0) { if (wave == NA + 0) w_role(IC<NA + 0>{}); }
+        if constexpr (R::NW > NA + 1) { if (wave == NA + 1) w_role(IC<NA + 1>{}); }
+        if constexpr (R::NW > NA + 2) { if (wave == NA + 2) w_role(IC<NA + 2>{}); }
+        if constexpr (R::NW > NA + 3) { if (wave == NA + 3) w_role(IC<NA + 3>{}); }
+    }
+}
+
+// Gram[i][j] = sum over workgroups of their partial blocks (upper triangle of 32 x 32 blocks), mirrored into the lower one
+__global__ __launch_bounds__(256) void pool_alg_gram_reduce_kernel(const float *__restrict__ part, const float *__restrict__ apart, int nwg,
+                                                                   int cin, float *__restrict__ Gm, float *__restrict__ asum)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cin) {       // column sums of A: the partial rows in a fixed order
+        float s0 = 0.f, s1 = 0.f;
+        int w = 0;
+        for (; w + 1 < nwg; w += 2) { s0 += apart[(long long)w * cin + i]; s1 += apart[(long long)(w + 1) * cin + i]; }
+        if (w < nwg) s0 += apart[(long long)w * cin + i];
+        asum[i] = s0 + s1;
+    }
+    if (i >= cin * cin) return;
+    const int r = i / cin, c = i - r * cin;
+    if ((r >> 5) > (c >> 5)) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int w = 0;
+    for (; w + 3 < nwg; w += 4) {
+        a0 += part[(long long)w * cin * cin + i]; a1 += part[(long long)(w + 1) * cin * cin + i];
+        a2 += part[(long long)(w + 2) * cin * cin + i]; a3 += part[(long long)(w + 3) * cin * cin + i];
+    }
+    for (; w < nwg; ++w) a0 += part[(long long)w * cin * cin + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    Gm[i] = v;
+    if ((r >> 5) != (c >> 5)) Gm[c * cin + r] = v;
+}
+
 // dW[c] = sum over workgroups of their partial slabs, in a fixed order: 64 outputs per workgroup, four threads per output
 // take every fourth slab (four independent loads in flight each), combined through LDS.  (One thread per output walking all
 // 256 slabs was a 61 us launch of 24 workgroups: a serial chain of dependent adds on L2 latency.)
@@ -499,6 +744,40 @@ static int stream_bwd_impl(long long P, int Cout, int Cin, const float *G, const
     else bwd_launch<64, 64>(g, pool, grid, st);
     const int n = Cout * Cin;
     hipLaunchKernelGGL(stream_bwd_dw_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, workspace, grid, n, Cin, lddw, dW);
+    return prifit_check_launch();
+}
+
+int prifit_pool_alg_supported(long long P, int Cin) { return (P >= SBM && P <= 0x7fffffffLL * 32 && (Cin == 64 || Cin == 96 || Cin == 128)) ? 1 : 0; }
+
+static int pool_alg_grid(long long P, int Cin)
+{
+    const long long tiles = (P + SBM - 1) / SBM;
+    const long long want = 256LL;     // (one workgroup per CU: 203-256 VGPRs at 7-8 waves)
+    return (int)(tiles < want ? tiles : want);
+}
+
+int prifit_pool_alg_slabs(long long P, int Cin) { return prifit_pool_alg_supported(P, Cin) ? pool_alg_grid(P, Cin) : 0; }
+long long prifit_pool_alg_workspace(long long P, int Cin) { return prifit_pool_alg_supported(P, Cin) ? (long long)pool_alg_grid(P, Cin) * (Cin * Cin + Cin) : 0; }
+
+int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
+                              const float *p_mean, const float *p_invstd, const float *M, long long ldm, const float *v, float *Gp,
+                              long long ldgp, float *red_slab, float *gram, float *asum, float *workspace, void *stream)
+{
+    if (!Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !M || !v || !Gp || !red_slab || !gram || !asum || !workspace ||
+        !prifit_pool_alg_supported(P, Cin) || ldyp < Cin || (ldyp & 3) || ldm < Cin || ldgp < Cin || ((uintptr_t)Yp & 15) ||
+        (long long)SBM * ldyp * 4 >= 0x7ff00000LL || (long long)SBM * ldgp * 4 >= 0x7ff00000LL)
+        return PRIFIT_EINVAL;
+    AlgArgs g;
+    g.P = P; g.Yp = Yp; g.ldyp = ldyp; g.ps = p_scale; g.pt = p_shift; g.pmu = p_mean; g.pis = p_invstd; g.M = M; g.ldm = ldm;
+    const int grid = pool_alg_grid(P, Cin);
+    g.v = v; g.Gp = Gp; g.ldgp = ldgp; g.red_slab = red_slab; g.gram_part = workspace;
+    g.asum_part = workspace + (long long)grid * Cin * Cin;
+    hipStream_t st = as_stream(stream);
+    if (Cin == 96) hipLaunchKernelGGL((pool_alg_dense_kernel<96>), dim3(grid), dim3(64 * AlgRoles<96>::NW), 0, st, g);
+    else if (Cin == 64) hipLaunchKernelGGL((pool_alg_dense_kernel<64>), dim3(grid), dim3(64 * AlgRoles<64>::NW), 0, st, g);
+    else hipLaunchKernelGGL((pool_alg_dense_kernel<128>), dim3(grid), dim3(64 * AlgRoles<128>::NW), 0, st, g);
+    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3((Cin * Cin + 255) / 256), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
+                       gram, asum);
     return prifit_check_launch();
 }
 

@@ -37,6 +37,11 @@ _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_a
 # where it measured faster -- the unpooled middle layers (_FUSE_BWD_AUTO below; round 3 had only the 96 -> 64 one);
 # "1": every supported shape (slower on the others: the kernel's dW role is latency-bound); "0": never.
 _FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "auto")
+# Max-pooled last layer, backward in the algebraic form (round 5; csrc/pool_alg.hip, prifit_pool_alg_dense_f32): with
+# dY = T [row == winner] + b Y + d and Y = A W^T + bias the row-dense work is A M (M = W^T diag(b) W) and the Gram matrix
+# A^T A -- products over Cin x Cin that read only the layer's INPUT -- plus index work on the winners' rows.  0: the streaming
+# dA / dW pair over Cout x Cin that reads the pooled layer's pre-activation (A/B runs; both arms tested).
+_POOL_ALG = os.environ.get("PRIFIT_POOL_ALG", "1") != "0"
 
 
 # (round 4, tools/fam_table.py on one box: one-pass kernel against the separate dA + dW pair)
@@ -146,6 +151,44 @@ def _fused_bwd(P, Cout, Kin, G, Y, scale, shift, ca, cb, cd, arg, Ttab, pool_K, 
              ptr(W), _LL(Kin), ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(rslab),
              ptr(dW), _LL(Kin), ptr(ws), cur_stream())
     return Gp, rslab, ns
+
+
+def fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys):
+    """The algebraic backward of a max-pooled last layer (_POOL_ALG) takes this layer."""
+    if not (pooled and _POOL_ALG and _FUSE_RED and training and l > 0 and W is not None and ctx.needs_input_grad[2 + 6 * l]):
+        return False
+    K = cfg["pool_K"]
+    return bool(K % 64 == 0 and P % K == 0 and Ys[l - 1] is not None and Ys[l - 1].stride(0) % 4 == 0 and
+                Ys[l - 1].data_ptr() % 16 == 0 and dll().prifit_pool_alg_supported(_LL(P), Kin) and
+                dll().prifit_pool_alg_sparse_supported(P // K, K, Cout, Kin))
+
+
+def _pool_alg_bwd(P, G, K, Cout, Kin, W, bias, cb, cd, arg, Ttab, Yp, aff_p, stats_p, dW, dev):
+    """Gp [P, Kin], the (m1, m2) slabs of the layer below and dW (written into `dW`) of a max-pooled last layer from its INPUT
+    alone: dense pass (A M + v, Gram matrix, column sums of A) + the winners' rows (csrc/pool_alg.hip)."""
+    (sc1, sh1), (mu1, is1) = aff_p, stats_p
+    e = cd if bias is None else torch.addcmul(cd, cb, bias)             # d + b * bias  [Cout]
+    Wb = W * cb.unsqueeze(1)
+    M = torch.mm(W.t(), Wb)                                             # W^T diag(b) W  [Kin, Kin]
+    v = torch.mv(W.t(), e)
+    nd, nsp = dll().prifit_pool_alg_slabs(_LL(P), Kin), dll().prifit_pool_alg_sparse_slabs(G)
+    rslab = torch.empty(nd + nsp, 2, Kin, dtype=torch.float32, device=dev)
+    Gp = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+    gram = torch.empty(Kin, Kin, dtype=torch.float32, device=dev)
+    asum = torch.empty(Kin, dtype=torch.float32, device=dev)
+    ws = torch.empty(dll().prifit_pool_alg_workspace(_LL(P), Kin), dtype=torch.float32, device=dev)
+    with profiler.span(profiler.tag("pool_alg_dense", P, Kin, Kin), 2.0 * P * Kin * Kin * 1.5):
+        call("prifit_pool_alg_dense_f32", _LL(P), Kin, ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(M),
+             _LL(Kin), ptr(v), ptr(Gp), _LL(Kin), ptr(rslab), ptr(gram), ptr(asum), ptr(ws), cur_stream())
+    dWs = torch.empty(Cout, Kin, dtype=torch.float32, device=dev)
+    ws2 = torch.empty(dll().prifit_pool_alg_sparse_workspace(G, Cout, Kin), dtype=torch.float32, device=dev)
+    with profiler.span(profiler.tag("pool_alg_sparse", P, Cout, Kin), 4.0 * G * Cout * (3.0 * Kin + 2)):
+        call("prifit_pool_alg_sparse_f32", G, K, Cout, Kin, ptr(arg), ptr(Ttab), ptr(W), ptr(Yp), _LL(Yp.stride(0)), ptr(sc1),
+             ptr(sh1), ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(rslab[nd:]), ptr(dWs), ptr(ws2), cur_stream())
+    # dW = S^T A + diag(b) W (A^T A) + (d + b * bias) (1^T A)
+    torch.addmm(dWs, Wb, gram, out=dW)
+    dW.addr_(e, asum)
+    return Gp, rslab, nd + nsp
 
 
 class SharedMLPFn(torch.autograd.Function):
@@ -279,6 +322,7 @@ class SharedMLPFn(torch.autograd.Function):
         ctx.P, ctx.dev = P, dev
         assert nr is None or (training and L >= 3 and Ys[0] is None)
         ctx.saved = (x, Ys, Ws, affines, stats_saved, arg)
+        ctx.biases = [tensors[6 * l + 1] for l in range(L)]
         return out
 
     @staticmethod
@@ -330,7 +374,8 @@ class SharedMLPFn(torch.autograd.Function):
             fuse_bn = bool(_FUSE_BN_APPLY and _FUSE_RED and not pooled and not direct0 and training and l > 0 and W is not None and
                            ctx.needs_input_grad[2 + 6 * l] and G_in.stride(0) == Cout and G_in.data_ptr() % 16 == 0 and
                            _stream_ok(NN, P, Kin, Cout) and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
-            dY = None if (fuse_pool or direct0 or gather0 or fuse_bn) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            dY = None if (fuse_pool or direct0 or gather0 or fuse_bn or fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys)) \
+                else torch.empty(P, Cout, dtype=torch.float32, device=dev)
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
@@ -349,6 +394,25 @@ class SharedMLPFn(torch.autograd.Function):
             fused_red = None
             call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
                  ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
+            alg_pool = bool(fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys))
+            if alg_pool:
+                K = cfg["pool_K"]
+                G = P // K
+                Ttab = torch.empty(G, Cout, dtype=torch.float32, device=dev)
+                call("prifit_pool_bwd_table", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
+                     ptr(shift), ptr(ca), G, K, Cout, _F(0.0), ptr(Ttab), cur_stream())
+                wo, wn, bo, bn_ = wslots[l]
+                dW = arena[wo:wo + wn].view(Cout, Kin)
+                G_prev, rslab, ns = _pool_alg_bwd(P, G, K, Cout, Kin, W, ctx.biases[l], cb, cd, arg, Ttab, Ys[l - 1], affines[l - 1],
+                                                  stats_saved[l - 1], dW, dev)
+                grads[6 * l] = dW
+                if ctx.needs_input_grad[2 + 6 * l + 1]:
+                    grads[6 * l + 1] = arena[bo:bo + bn_]
+                grads[6 * l + 2] = dgamma
+                grads[6 * l + 3] = dbeta
+                fused_red = (rslab, ns)
+                G_in = G_prev
+                continue
             if fuse_pool:
                 Ttab = torch.empty(G, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_table", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),

@@ -247,6 +247,47 @@ def test_shared_mlp_fused_da_dw_matches_separate_kernels(nn_ops, P, K, dims):
         assert (a - b).norm() <= 2e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
 
 
+@pytest.mark.parametrize("P,K,dims", [(98304, 128, ((64, 64), (64, 96), (96, 128))),       # SA1 scale 3's widths
+                                      (65536, 64, ((64, 64), (64, 64), (64, 128))),        # SA1 scale 2
+                                      (32768, 64, ((128, 128), (128, 128), (128, 256))),   # SA2 scale 1: tiled kernels in the other arm
+                                      (65600 // 64 * 64, 64, ((32, 64), (64, 128)))])      # two layers, ragged tile count
+def test_pooled_layer_backward_in_algebraic_form_matches_the_products_over_cout(nn_ops, P, K, dims):
+    """SharedMLPFn with the max-pooled last layer's backward in the algebraic form (default: A M and the Gram matrix A^T A over
+    Cin x Cin from the layer's INPUT, the winners' rows as index work; csrc/pool_alg.hip) against the arm that multiplies over
+    Cout x Cin and reads the pooled layer's pre-activation: same forward bit for bit, every gradient to fp32 rounding --
+    with conv biases that are NOT zero (they enter v = W^T (d + b * bias) and the weight gradient)."""
+    x = _rand((P, dims[0][0]), 31).cuda()
+    g = torch.Generator().manual_seed(32)
+    tens = []
+    for cin, cout in dims:
+        tens += [(torch.randn(cout, cin, generator=g) * (2.0 / cin ** 0.5)).cuda().requires_grad_(True),
+                 (torch.randn(cout, generator=g) * 0.3).cuda().requires_grad_(True),
+                 (torch.rand(cout, generator=g) + 0.5).cuda().requires_grad_(True), (torch.randn(cout, generator=g) * 0.1).cuda().requires_grad_(True),
+                 torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")]
+    gout = _rand((P // K, dims[-1][1]), 33).cuda()
+    res = {}
+    for alg in (True, False):
+        old = nn_ops._POOL_ALG
+        nn_ops._POOL_ALG = alg
+        try:
+            xi = x.clone().requires_grad_(True)
+            cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
+            out = nn_ops.SharedMLPFn.apply(xi, cfg, *[t.clone() if not t.requires_grad else t for t in tens])
+            grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
+            res[alg] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
+        finally:
+            nn_ops._POOL_ALG = old
+    assert torch.equal(res[True][0], res[False][0])
+    worst = 0.0
+    for a, b in zip(res[True][1:], res[False][1:]):
+        if b is None:
+            assert a is None
+            continue
+        worst = max(worst, ((a - b).norm() / (b.norm() + 1e-30)).item())
+        assert (a - b).norm() <= 5e-5 * b.norm() + 1e-6, ((a - b).norm().item(), b.norm().item())
+    print("algebraic pooled backward vs products over Cout: worst relative deviation %.2e" % worst)
+
+
 @pytest.mark.parametrize("P,Cout,Kin", [(40008, 96, 64), (65536, 64, 64), (33000, 128, 128), (50000, 128, 96)])
 def test_bn_apply_on_load_matches_apply_pass(nn_ops, P, Cout, Kin):
     """prifit_gemm_stream_tn_bn_f32 / prifit_gemm_stream_dgrad_bn_f32 (a middle layer's dY formed from G and Y inside the
