@@ -208,6 +208,15 @@ long long prifit_pool_alg_workspace(long long P, int Cin);
 int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
                               const float *p_mean, const float *p_invstd, const float *M, long long ldm, const float *v, float *Gp,
                               long long ldgp, float *red_slab, float *gram, float *asum, float *workspace, void *stream);
+/* Both in ONE pass (the default where it exists: Cout == 128, Cin in {64, 96}, K % 64 == 0): the winners' rows are added inside
+ * the dense pass by one more wave (S tile in LDS from W in LDS; dWs accumulated in registers) -- Gp, red_slab [_slabs][2][Cin],
+ * gram, asum and dWs [Cout, Cin] complete, no second pass over Gp or Yp.  workspace: _fused_workspace floats. */
+int prifit_pool_alg_fused_supported(long long P, int K, int Cout, int Cin);
+long long prifit_pool_alg_fused_workspace(long long P, int Cout, int Cin);
+int prifit_pool_alg_fused_f32(long long P, int K, int Cout, int Cin, const float *Yp, long long ldyp, const float *p_scale,
+                              const float *p_shift, const float *p_mean, const float *p_invstd, const float *M, long long ldm,
+                              const float *v, const int32_t *arg, const float *T, const float *W, float *Gp, long long ldgp,
+                              float *red_slab, float *gram, float *asum, float *dWs, float *workspace, void *stream);
 int prifit_pool_alg_sparse_supported(int G, int K, int Cout, int Cin);
 int prifit_pool_alg_sparse_slabs(int G);
 long long prifit_pool_alg_sparse_workspace(int G, int Cout, int Cin);

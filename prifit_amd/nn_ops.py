@@ -37,11 +37,16 @@ _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_a
 # where it measured faster -- the unpooled middle layers (_FUSE_BWD_AUTO below; round 3 had only the 96 -> 64 one);
 # "1": every supported shape (slower on the others: the kernel's dW role is latency-bound); "0": never.
 _FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "auto")
-# Max-pooled last layer, backward in the algebraic form (round 5; csrc/pool_alg.hip, prifit_pool_alg_dense_f32): with
+# Max-pooled last layer, backward in the algebraic form (round 5 EXPERIMENT; csrc/pool_alg.hip, prifit_pool_alg_dense_f32): with
 # dY = T [row == winner] + b Y + d and Y = A W^T + bias the row-dense work is A M (M = W^T diag(b) W) and the Gram matrix
-# A^T A -- products over Cin x Cin that read only the layer's INPUT -- plus index work on the winners' rows.  0: the streaming
-# dA / dW pair over Cout x Cin that reads the pooled layer's pre-activation (A/B runs; both arms tested).
-_POOL_ALG = os.environ.get("PRIFIT_POOL_ALG", "1") != "0"
+# A^T A -- products over Cin x Cin that read only the layer's INPUT -- plus index work on the winners' rows.  Parity with the
+# default arm at 1.5e-6 (tests/test_gpu_backbone.py), and the dense pass alone is 30-55 % faster than the pair it replaces
+# (575 against 843 us at [1.57 M x 128 x 96]); but the winners' rows cost more than that saves, inside the pass or behind it
+# (745-1109 us fused, 1254 us as a second launch: DESIGN.md 5.3), so the DEFAULT stays the streaming dA / dW pair over
+# Cout x Cin that reads the pooled layer's pre-activation.  1: the algebraic arm.
+_POOL_ALG = os.environ.get("PRIFIT_POOL_ALG", "0") != "0"
+# ... with the winners' rows inside the dense pass where that kernel exists (0: dense pass + separate index kernel; A/B, tested)
+_POOL_ALG_FUSED = os.environ.get("PRIFIT_POOL_ALG_FUSED", "1") != "0"
 
 
 # (round 4, tools/fam_table.py on one box: one-pass kernel against the separate dA + dW pair)
@@ -171,16 +176,28 @@ def _pool_alg_bwd(P, G, K, Cout, Kin, W, bias, cb, cd, arg, Ttab, Yp, aff_p, sta
     Wb = W * cb.unsqueeze(1)
     M = torch.mm(W.t(), Wb)                                             # W^T diag(b) W  [Kin, Kin]
     v = torch.mv(W.t(), e)
-    nd, nsp = dll().prifit_pool_alg_slabs(_LL(P), Kin), dll().prifit_pool_alg_sparse_slabs(G)
-    rslab = torch.empty(nd + nsp, 2, Kin, dtype=torch.float32, device=dev)
+    nd = dll().prifit_pool_alg_slabs(_LL(P), Kin)
     Gp = torch.empty(P, Kin, dtype=torch.float32, device=dev)
     gram = torch.empty(Kin, Kin, dtype=torch.float32, device=dev)
     asum = torch.empty(Kin, dtype=torch.float32, device=dev)
+    dWs = torch.empty(Cout, Kin, dtype=torch.float32, device=dev)
+    if _POOL_ALG_FUSED and dll().prifit_pool_alg_fused_supported(_LL(P), K, Cout, Kin):
+        rslab = torch.empty(nd, 2, Kin, dtype=torch.float32, device=dev)
+        ws = torch.empty(dll().prifit_pool_alg_fused_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
+        # one pass: Yp read once, Gp written once (the two products over Cin x Cin ride on it)
+        with profiler.span(profiler.tag("pool_alg_fused", P, Cout, Kin), 8.0 * P * Kin):
+            call("prifit_pool_alg_fused_f32", _LL(P), K, Cout, Kin, ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1),
+                 ptr(is1), ptr(M), _LL(Kin), ptr(v), ptr(arg), ptr(Ttab), ptr(W), ptr(Gp), _LL(Kin), ptr(rslab), ptr(gram),
+                 ptr(asum), ptr(dWs), ptr(ws), cur_stream())
+        torch.addmm(dWs, Wb, gram, out=dW)
+        dW.addr_(e, asum)
+        return Gp, rslab, nd
+    nsp = dll().prifit_pool_alg_sparse_slabs(G)
+    rslab = torch.empty(nd + nsp, 2, Kin, dtype=torch.float32, device=dev)
     ws = torch.empty(dll().prifit_pool_alg_workspace(_LL(P), Kin), dtype=torch.float32, device=dev)
-    with profiler.span(profiler.tag("pool_alg_dense", P, Kin, Kin), 2.0 * P * Kin * Kin * 1.5):
+    with profiler.span(profiler.tag("pool_alg_dense", P, Kin, Kin), 8.0 * P * Kin):
         call("prifit_pool_alg_dense_f32", _LL(P), Kin, ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(M),
              _LL(Kin), ptr(v), ptr(Gp), _LL(Kin), ptr(rslab), ptr(gram), ptr(asum), ptr(ws), cur_stream())
-    dWs = torch.empty(Cout, Kin, dtype=torch.float32, device=dev)
     ws2 = torch.empty(dll().prifit_pool_alg_sparse_workspace(G, Cout, Kin), dtype=torch.float32, device=dev)
     with profiler.span(profiler.tag("pool_alg_sparse", P, Cout, Kin), 4.0 * G * Cout * (3.0 * Kin + 2)):
         call("prifit_pool_alg_sparse_f32", G, K, Cout, Kin, ptr(arg), ptr(Ttab), ptr(W), ptr(Yp), _LL(Yp.stride(0)), ptr(sc1),

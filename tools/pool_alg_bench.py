@@ -25,9 +25,10 @@ for P, Cout, Cin, pool_K in [(1572864, 128, 96, 128), (786432, 128, 64, 64), (19
     Gp = torch.empty(P, Cin, device="cuda"); gram = torch.empty(Cin, Cin, device="cuda")
     ns = dll().prifit_pool_alg_slabs(LL(P), Cin)
     sl = torch.empty(ns, 2, Cin, device="cuda"); ws = torch.empty(dll().prifit_pool_alg_workspace(LL(P), Cin), device="cuda")
+    asum0 = torch.empty(Cin, device="cuda")
     def alg():
         call("prifit_pool_alg_dense_f32", LL(P), Cin, ptr(Yp), LL(Cin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(M), LL(Cin), ptr(v),
-             ptr(Gp), LL(Cin), ptr(sl), ptr(gram), ptr(ws), cur_stream())
+             ptr(Gp), LL(Cin), ptr(sl), ptr(gram), ptr(asum0), ptr(ws), cur_stream())
     alg(); torch.cuda.synchronize()
     n = min(P, 65536)
     A = torch.relu(Yp * s1 + t1)
@@ -56,6 +57,19 @@ for P, Cout, Cin, pool_K in [(1572864, 128, 96, 128), (786432, 128, 64, 64), (19
             call("prifit_gemm_stream_tn_pool_f32", Cout, Cin, LL(P), ptr(Y), LL(Cout), ptr(Yp), LL(Cin), ptr(dW), LL(Cin), ptr(s1), ptr(t1), ptr(arg), ptr(T), ptr(cb), ptr(cd), pool_K, ptr(ws2), cur_stream())
             call("prifit_gemm_stream_dgrad_pool_f32", P, Cin, Cout, ptr(Y), LL(Cout), ptr(W), LL(Cin), ptr(Gp), LL(Cin), ptr(bias_dw), ptr(arg), ptr(T), ptr(cb), pool_K, ptr(Yp), LL(Cin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl2), cur_stream())
         t_pair = timeit(pair)
+    t_fused = float("nan")
+    if dll().prifit_pool_alg_fused_supported(LL(P), pool_K, Cout, Cin):
+        G_ = P // pool_K
+        arg2 = torch.randint(0, pool_K, (G_, Cout), device="cuda", generator=g, dtype=torch.int32)
+        T2 = rnd(G_, Cout) * (torch.rand(G_, Cout, device="cuda", generator=g) > 0.4)      # ~40 % of the pooled gradients masked
+        W2 = rnd(Cout, Cin)
+        dWs = torch.empty(Cout, Cin, device="cuda"); asum = torch.empty(Cin, device="cuda")
+        wsf = torch.empty(dll().prifit_pool_alg_fused_workspace(LL(P), Cout, Cin), device="cuda")
+        def fused():
+            call("prifit_pool_alg_fused_f32", LL(P), pool_K, Cout, Cin, ptr(Yp), LL(Cin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(M), LL(Cin),
+                 ptr(v), ptr(arg2), ptr(T2), ptr(W2), ptr(Gp), LL(Cin), ptr(sl), ptr(gram), ptr(asum), ptr(dWs), ptr(wsf), cur_stream())
+        t_fused = timeit(fused)
+    print("   with the winners' rows inside the pass: %7.1f us" % t_fused)
     print("[%8d rows, Cout %3d, Cin %3d] algebraic dense pass %7.1f us (%.0f GB/s of 8 P Cin B, %.1f TFLOP/s of its %.1f GFLOP)   today's pooled pair %7.1f us   errors %.1e %.1e %.1e %.1e"
           % (P, Cout, Cin, t_alg, 8.0 * P * Cin / t_alg / 1e3, 2.0 * P * Cin * Cin * 1.0 * (1 + (Cin // 32 + 1) / (2.0 * (Cin // 32))) / t_alg / 1e6,
              2.0 * P * Cin * Cin * (1 + (Cin // 32 + 1) / (2.0 * (Cin // 32))) / 1e9, t_pair, eg, ew, e1, e2), flush=True)
