@@ -114,6 +114,30 @@ def test_rank_env_caps_the_thread_pools_and_ranks_pin_themselves():
     assert all(int(r[2]) == len(s) == int(r[3]) for r, s in zip(rows, sets))
 
 
+def test_gpu_numa_node_from_a_faked_sysfs(tmp_path, monkeypatch):
+    """The GPU -> NUMA node lookup on a faked KFD / DRM tree: nodes 0-1 are CPUs (simd_count 0), nodes 2-3 GPUs with render
+    minors 128 / 129 on NUMA nodes 0 / 1; a *_VISIBLE_DEVICES variable (devices reordered) switches the lookup off."""
+    from prifit_amd import hostcfg
+    kfd, drm = tmp_path / "kfd", tmp_path / "drm"
+    for n, (simd, minor) in enumerate([(0, -1), (0, -1), (1216, 128), (1216, 129)]):
+        d = kfd / str(n)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n" % (64 if simd == 0 else 0, simd, minor))
+    for minor, node in ((128, 0), (129, 1)):
+        d = drm / ("renderD%d" % minor) / "device"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    real = hostcfg.kfd_gpu_nodes
+    monkeypatch.setattr(hostcfg, "kfd_gpu_nodes", lambda root=str(kfd): real(root))
+    assert [g["drm_render_minor"] for g in hostcfg.kfd_gpu_nodes()] == [128, 129]
+    assert hostcfg.gpu_numa_node(0, drm_root=str(drm)) == 0 and hostcfg.gpu_numa_node(1, drm_root=str(drm)) == 1
+    assert hostcfg.gpu_numa_node(2, drm_root=str(drm)) is None                      # no such GPU
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    assert hostcfg.gpu_numa_node(0, drm_root=str(drm)) is None
+
+
 def test_visible_gpu_count_and_preflight(monkeypatch):
     from prifit_amd import hostcfg
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
