@@ -626,10 +626,12 @@ int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, c
  * (Zin[t] [B,N,D]) and produced (Zout[t] [B,N,D], O[t] [B,N,D], rowsum[t] [B,N], nrm[t] [B,N]; Zin[t+1] == Zout[t]);
  * ids [B,R] int64 row indices (clamped to [0,N)), nrows [B] live slots per shape (NULL: all R), R <= 32;
  * g_rows [B,R,D] = dL/d(Zout[T-1][b, ids[b,r]]); dX [B,N,D] is ACCUMULATED into (both uses of the dictionary and the
- * Z_0 = X.clone() of :60).  workspace: prifit_meanshift_rows_bwd_workspace floats, 16-byte aligned.
- * D in {32, 64, 128} (prifit_meanshift_rows_supported).  Deterministic except where two live slots name one point. */
+ * Z_0 = X.clone() of :60) -- read-modified-written ONCE, by the last of the T + 2 launches: the iterations leave their K and
+ * gS values in tables [T][B][R][N] inside the workspace.  workspace: prifit_meanshift_rows_bwd_workspace(B, N, D, R, T)
+ * floats, 16-byte aligned.  D in {32, 64, 128} (prifit_meanshift_rows_supported).  Deterministic (fixed summation orders;
+ * two live slots that name one point are added in slot order). */
 int prifit_meanshift_rows_supported(int N, int D, int R);
-long long prifit_meanshift_rows_bwd_workspace(int B, int N, int D, int R);
+long long prifit_meanshift_rows_bwd_workspace(int B, int N, int D, int R, int T);
 int prifit_meanshift_rows_bwd(const float *X, const float *bw, int B, int N, int D, int T, const float *const *Zin,
                               const float *const *Zout, const float *const *O, const float *const *rowsum,
                               const float *const *nrm, const long long *ids, const int *nrows, int R,

@@ -230,11 +230,11 @@ class MeanShiftRowsFn(torch.autograd.Function):
         R = ids.shape[1]
         g = g.contiguous()
         gX = zero_pool.zeros(Bt, N, D, device=X.device)
-        ws = torch.empty(dll().prifit_meanshift_rows_bwd_workspace(Bt, N, D, R), dtype=torch.float32, device=X.device)
         T = len(traj)
+        ws = torch.empty(dll().prifit_meanshift_rows_bwd_workspace(Bt, N, D, R, T), dtype=torch.float32, device=X.device)
         arr = lambda k: (ctypes.c_void_p * max(T, 1))(*[it[k].data_ptr() for it in traj])
-        # HBM-bound: per iteration the dictionary is read once and dX read-modified-written once (12 B per element)
-        with profiler.span("ms_rows_bwd", 12.0 * Bt * N * D * T):
+        # HBM-bound: per iteration the dictionary is read once (4 B per element); dX read-modified-written once in all (8 B)
+        with profiler.span("ms_rows_bwd", 4.0 * Bt * N * D * (T + 2)):
             call("prifit_meanshift_rows_bwd", ptr(X), ptr(bw), Bt, N, D, T, arr(0), arr(4), arr(2), arr(3), arr(5), ptr(ids),
                  ptr(nrows), R, ptr(g), ptr(ws), ptr(gX), cur_stream())
         return gX, None, None, None, None

@@ -599,6 +599,12 @@ def test_mean_shift_row_sparse_backward_equals_dense(F, N, D, T, nrows):
     assert torch.isfinite(Xr.grad).all()
     torch.testing.assert_close(Xr.grad, ref, rtol=2e-4, atol=2e-5 * ref.abs().max().item())
     assert abs(Xr.grad.norm().item() - ref.norm().item()) <= 1e-4 * ref.norm().item()
+    # fixed summation orders (the workgroup that happens to finish last in a shape sums the tile slabs in tile order): same bits
+    X2 = X.cuda().requires_grad_(True)
+    with torch.no_grad():
+        _, traj2 = F.mean_shift_trajectory(X2.detach(), bw.cuda(), T, keep_kernel=False)
+    (F.MeanShiftRowsFn.apply(X2, bw.cuda(), ids.cuda(), nr.cuda(), traj2) * G.cuda()).sum().backward()
+    assert torch.equal(X2.grad, Xr.grad)
 
 
 def test_cluster_gradient_same_with_both_mean_shift_engines(F, monkeypatch):
