@@ -345,13 +345,19 @@ int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, float
  * slabs of one sample; count = rows per sample x channels per group; fp64 accumulation.  C / groups divides 256
  * (prifit_gn_finalize_supported).  _bwd_: from the (sum Gm, sum Gm yhat) partials of the backward reduce kernels the apply
  * pass's coefficients coef_b, coef_d [Bs][C] (coef_a = scale) and the per-sample channel totals S [Bs][2][C] in fp64
- * (dgamma = sum_b S[b][1], dbeta = sum_b S[b][0]). */
+ * (dgamma = sum_b S[b][1], dbeta = sum_b S[b][0]).
+ * chsum (forward: optional output, backward: optional input) [Bs][C] fp64 = the column sums of Y per sample.  With it the
+ * backward also writes dsum [Bs][C] = the column sums of dY per sample -- from dY = coef_a Gm + coef_b Y + coef_d row by row,
+ * sum_rows dY = coef_a sum Gm + coef_b sum Y + coef_d rows_per_sample -- i.e. the gradient of a per-sample offset
+ * (prifit_gn_finalize_offset) and, summed over the samples (prifit_gn_param_grads), of the bias of the convolution in front
+ * (nn.Conv1d(.., bias=True), src/dgcnn.py:188,236-240), without a pass over the [B N, C] tensor dY. */
 int prifit_gn_finalize_supported(int C, int groups);
 int prifit_gn_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count, const float *gamma,
-                       const float *beta, double eps, float *scale, float *shift, float *mean, float *invstd, void *stream);
+                       const float *beta, double eps, float *scale, float *shift, float *mean, float *invstd, double *chsum,
+                       void *stream);
 int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
                            const float *gamma, const float *mean, const float *invstd, float *coef_b, float *coef_d,
-                           double *S, void *stream);
+                           double *S, const double *chsum, double rows_per_sample, float *dsum, void *stream);
 /* The same for a tensor Y + offset[b][c] whose per-sample, per-channel constant `offset` [Bs][C] the producer left out of
  * Y (the decoder's first convolution, src/dgcnn.py:253-257: the 1024 global-feature channels of its input are the same for
  * every point of a sample, so their product with the weight is ONE row per sample instead of N): slab = statistics of Y
@@ -359,10 +365,12 @@ int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int 
  * affine / pool / backward kernels then run on Y unchanged and the offset never has to be added to N rows. */
 int prifit_gn_finalize_offset(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
                               const float *gamma, const float *beta, double eps, const float *offset, double rows_per_sample,
-                              float *scale, float *shift, float *mean, float *invstd, void *stream);
+                              float *scale, float *shift, float *mean, float *invstd, double *chsum, void *stream);
 /* dgamma [C], dbeta [C] = the sums over the samples of S[b][1][:], S[b][0][:] (src/dgcnn.py:150-171: the affine parameters of
- * nn.GroupNorm are shared by all samples). */
-int prifit_gn_param_grads(const double *S, int Bs, int C, float *dgamma, float *dbeta, void *stream);
+ * nn.GroupNorm are shared by all samples); dsum (may be NULL) [Bs][C] from prifit_gn_bwd_finalize: db [C] = its sum over the
+ * samples. */
+int prifit_gn_param_grads(const double *S, int Bs, int C, float *dgamma, float *dbeta, const float *dsum, float *db,
+                          void *stream);
 
 /* Batch statistics -> affine form of BatchNorm (torch.nn.BatchNorm{1,2}d in train mode, as used at
  * models/pointnet_util.py:198,254,312): mean/var over `count` positions from the partial slabs,

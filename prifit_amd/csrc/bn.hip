@@ -133,13 +133,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           double eps, const float *__restrict__ offset, double rows,
                                                           float *__restrict__ scale, float *__restrict__ shift,
-                                                          float *__restrict__ mean_o, float *__restrict__ invstd_o)
+                                                          float *__restrict__ mean_o, float *__restrict__ invstd_o,
+                                                          double *__restrict__ chsum)
 {
     __shared__ double s_part[2][256];
     __shared__ double s_red[4];
     const int g = blockIdx.x, b = blockIdx.y, c0 = g * cpg;
     double t0, t1;
     gn_channel_sums(slab, b, sps, C, c0, cpg, s_part, t0, t1);
+    if (chsum && threadIdx.x < cpg) chsum[(size_t)b * C + c0 + threadIdx.x] = t0;     // of Y alone (before the offset)
     double off = 0.0;
     if (offset && threadIdx.x < cpg) {
         off = (double)offset[(size_t)b * C + c0 + threadIdx.x];
@@ -163,10 +165,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 
 // slab: (sum Gm, sum Gm * yhat) partials.  Out: cb, cd [Bs][C] (ca = scale), and the per-sample channel totals
 // S [Bs][2][C] in fp64 (dgamma = sum_b S[b][1], dbeta = sum_b S[b][0]: two small reductions left to the caller).
+// chsum (may be NULL) [Bs][C]: the forward's column sums of Y; then dsum [Bs][C] = the column sums of dY per sample WITHOUT
+// reading dY: dY = ca Gm + cb Y + cd row by row, so sum_rows dY = ca sum Gm + cb sum Y + cd rows (the bias / offset gradient of
+// the convolution in front: torch's reduction over the [B N, C] tensor took 16-32 us per layer).
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *__restrict__ slab, int sps, int C, int cpg, double m,
                                                               const float *__restrict__ gamma, const float *__restrict__ mean,
                                                               const float *__restrict__ invstd, float *__restrict__ cb,
-                                                              float *__restrict__ cd, double *__restrict__ S)
+                                                              float *__restrict__ cd, double *__restrict__ S,
+                                                              const double *__restrict__ chsum, double rows,
+                                                              float *__restrict__ dsum)
 {
     __shared__ double s_part[2][256];
     __shared__ double s_red[4];
@@ -178,8 +185,13 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *__res
     if (threadIdx.x < cpg) {
         const size_t o = (size_t)b * C + c0 + threadIdx.x;
         const double isd = (double)invstd[o], mu = (double)mean[o];
-        cb[o] = (float)(-(isd * isd) * m2);
-        cd[o] = (float)(-isd * m1 + mu * isd * isd * m2);
+        const float cbf = (float)(-(isd * isd) * m2), cdf = (float)(-isd * m1 + mu * isd * isd * m2);
+        cb[o] = cbf;
+        cd[o] = cdf;
+        if (chsum) {                                         // with the ROUNDED coefficients the apply pass multiplies by
+            const float caf = __fmul_rn(gamma[c0 + threadIdx.x], invstd[o]);
+            dsum[o] = (float)((double)caf * t0 + (double)cbf * chsum[o] + (double)cdf * rows);
+        }
         S[((size_t)b * 2 + 0) * C + c0 + threadIdx.x] = t0;
         S[((size_t)b * 2 + 1) * C + c0 + threadIdx.x] = t1;
     }
@@ -187,11 +199,20 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float *__res
 
 // dbeta[c] = sum_b S[b][0][c], dgamma[c] = sum_b S[b][1][c] (fp64 sums of prifit_gn_bwd_finalize's per-sample pairs): one
 // launch in place of torch's reduction + cast pair (~20 us for 2 C numbers, seven GroupNorm layers per step).
+// dsum (may be NULL) [Bs][C]: db [C] = its sum over the samples (the bias gradient), threads 2 C .. 3 C
 __global__ __launch_bounds__(256) void gn_param_grads_kernel(const double *__restrict__ S, int Bs, int C, float *__restrict__ dgamma,
-                                                             float *__restrict__ dbeta)
+                                                             float *__restrict__ dbeta, const float *__restrict__ dsum,
+                                                             float *__restrict__ db)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= 2 * C) return;
+    if (t >= 2 * C) {
+        if (dsum && t < 3 * C) {
+            double acc = 0.0;
+            for (int b = 0; b < Bs; ++b) acc += (double)dsum[(size_t)b * C + (t - 2 * C)];
+            db[t - 2 * C] = (float)acc;
+        }
+        return;
+    }
     double acc = 0.0;
     for (int b = 0; b < Bs; ++b) acc += S[(size_t)b * 2 * C + t];
     if (t < C) dbeta[t] = (float)acc;
@@ -939,37 +960,38 @@ int prifit_gn_finalize_supported(int C, int groups)
 }
 
 int prifit_gn_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count, const float *gamma,
-                       const float *beta, double eps, float *scale, float *shift, float *mean, float *invstd, void *stream)
+                       const float *beta, double eps, float *scale, float *shift, float *mean, float *invstd, double *chsum,
+                       void *stream)
 {
     if (!slab || !gamma || !beta || !scale || !shift || !mean || !invstd || Bs <= 0 || slabs_per_sample <= 0 || count <= 0 ||
         !prifit_gn_finalize_supported(C, groups))
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, Bs), dim3(256), 0, as_stream(stream), slab, slabs_per_sample, C,
-                       C / groups, count, gamma, beta, eps, (const float *)nullptr, 0.0, scale, shift, mean, invstd);
+                       C / groups, count, gamma, beta, eps, (const float *)nullptr, 0.0, scale, shift, mean, invstd, chsum);
     return prifit_check_launch();
 }
 
 int prifit_gn_finalize_offset(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
                               const float *gamma, const float *beta, double eps, const float *offset, double rows_per_sample,
-                              float *scale, float *shift, float *mean, float *invstd, void *stream)
+                              float *scale, float *shift, float *mean, float *invstd, double *chsum, void *stream)
 {
     if (!slab || !gamma || !beta || !offset || !scale || !shift || !mean || !invstd || Bs <= 0 || slabs_per_sample <= 0 ||
         count <= 0 || rows_per_sample <= 0 || !prifit_gn_finalize_supported(C, groups))
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, Bs), dim3(256), 0, as_stream(stream), slab, slabs_per_sample, C,
-                       C / groups, count, gamma, beta, eps, offset, rows_per_sample, scale, shift, mean, invstd);
+                       C / groups, count, gamma, beta, eps, offset, rows_per_sample, scale, shift, mean, invstd, chsum);
     return prifit_check_launch();
 }
 
 int prifit_gn_bwd_finalize(const float *slab, int Bs, int slabs_per_sample, int C, int groups, double count,
                            const float *gamma, const float *mean, const float *invstd, float *coef_b, float *coef_d,
-                           double *S, void *stream)
+                           double *S, const double *chsum, double rows_per_sample, float *dsum, void *stream)
 {
     if (!slab || !gamma || !mean || !invstd || !coef_b || !coef_d || !S || Bs <= 0 || slabs_per_sample <= 0 || count <= 0 ||
-        !prifit_gn_finalize_supported(C, groups))
+        !prifit_gn_finalize_supported(C, groups) || (chsum && (!dsum || rows_per_sample <= 0)))
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, Bs), dim3(256), 0, as_stream(stream), slab, slabs_per_sample, C,
-                       C / groups, count, gamma, mean, invstd, coef_b, coef_d, S);
+                       C / groups, count, gamma, mean, invstd, coef_b, coef_d, S, chsum, rows_per_sample, dsum);
     return prifit_check_launch();
 }
 
@@ -988,10 +1010,11 @@ int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, float
     return prifit_check_launch();
 }
 
-int prifit_gn_param_grads(const double *S, int Bs, int C, float *dgamma, float *dbeta, void *stream)
+int prifit_gn_param_grads(const double *S, int Bs, int C, float *dgamma, float *dbeta, const float *dsum, float *db, void *stream)
 {
-    if (!S || !dgamma || !dbeta || Bs <= 0 || C <= 0) return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, as_stream(stream), S, Bs, C, dgamma, dbeta);
+    if (!S || !dgamma || !dbeta || Bs <= 0 || C <= 0 || (dsum && !db)) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3(((dsum ? 3 : 2) * C + 255) / 256), dim3(256), 0, as_stream(stream), S, Bs, C,
+                       dgamma, dbeta, dsum, db);
     return prifit_check_launch();
 }
 

@@ -25,6 +25,8 @@ _F = ctypes.c_float
 _D = ctypes.c_double
 # GroupNorm statistics -> coefficient tables in one launch each way (0: the torch fp64 form, ~35 tiny launches per layer; A/B)
 _GN_KERNELS = __import__("os").environ.get("PRIFIT_GN_KERNELS", "1") != "0"
+# bias / offset gradients of a convolution in front of a GroupNorm from the statistics (0: torch's column sums over dY; A/B arm, tested)
+_GN_COLSUMS = __import__("os").environ.get("PRIFIT_GN_COLSUMS", "1") != "0"
 
 
 def _pad4(c):
@@ -137,9 +139,11 @@ def get_graph_feature_with_normals(x, k1=20, k2=20, idx=None):
     return get_graph_feature(x, k1, k2, idx)[0]
 
 
-def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None):
+def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None, chsum=None):
     """Per-sample coefficient tables (scale, shift, mean, invstd), each [Bs, C], from the column-statistics slabs
-    [Bs * sps][2][C] of a tensor with `rows` rows per sample (`sps` consecutive slabs belong to one sample)."""
+    [Bs * sps][2][C] of a tensor with `rows` rows per sample (`sps` consecutive slabs belong to one sample).
+    chsum (optional, float64 [Bs, C], filled by the kernels): the tensor's column sums per sample -- what the backward needs to
+    give the column sums of dY without reading dY (prifit_gn_bwd_finalize)."""
     G, eps = cfg["groups"], cfg["eps"]
     dev = slab.device
     m = float(rows * (Cout // G))
@@ -148,13 +152,14 @@ def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None):
         scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
         call("prifit_gn_finalize_offset", ptr(slab), Bs, sps, Cout, G, _D(m), ptr(gamma.contiguous()),
              ptr(beta.contiguous()), _D(float(eps)), ptr(offset.contiguous()), _D(float(rows)), ptr(scale), ptr(shift), ptr(mean),
-             ptr(invstd), cur_stream())
+             ptr(invstd), ptr(chsum), cur_stream())
     elif _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
         # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
         scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
         call("prifit_gn_finalize", ptr(slab), Bs, sps, Cout, G, _D(m), ptr(gamma.contiguous()),
-             ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), cur_stream())
+             ptr(beta.contiguous()), _D(float(eps)), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(chsum), cur_stream())
     else:
+        assert chsum is None
         sums = slab.view(Bs, sps, 2, Cout).double().sum(dim=1)               # [Bs, 2, C] per-sample column sums
         s1 = sums[:, 0].view(Bs, G, -1).sum(-1) / m
         s2 = sums[:, 1].view(Bs, G, -1).sum(-1) / m
@@ -167,7 +172,7 @@ def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None):
     return scale, shift, mean, invstd
 
 
-def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None):
+def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None, chsum=None):
     """GroupNorm statistics from the 128-row (or `tile`-row) column-statistics slabs of Y [P, C] -> per-sample coefficient
     tables, then LeakyReLU [+ max over the pool_K rows of each group].  Returns (out, scale, shift, mean, invstd, arg).
     offset [Bs, C] (optional): the normalised tensor is Y + offset[sample] (prifit_gn_finalize_offset: the tables come out
@@ -177,7 +182,7 @@ def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None):
     assert P % rps == 0 and rps % tile == 0 and Cout % G == 0
     Bs = P // rps
     dev = Y.device
-    scale, shift, mean, invstd = _gn_tables(slab, Bs, rps // tile, Cout, rps, gamma, beta, cfg, offset)
+    scale, shift, mean, invstd = _gn_tables(slab, Bs, rps // tile, Cout, rps, gamma, beta, cfg, offset, chsum)
     arg = None
     if pool_K:
         Gp = P // pool_K
@@ -196,9 +201,10 @@ def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None):
     return out, scale, shift, mean, invstd, arg
 
 
-def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
-    """Gradient of _gn_forward w.r.t. Y (written as dY [P, C]), gamma and beta."""
-    gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg)
+def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chsum=None, sums=None):
+    """Gradient of _gn_forward w.r.t. Y (written as dY [P, C]), gamma and beta.  chsum (the forward's, _gn_tables) and a dict
+    `sums`: sums["dsum"] [Bs, C] = the column sums of dY per sample, sums["db"] [C] = over all rows."""
+    gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chsum, sums)
     P, Cout = Y.shape
     rps, slope, pool_K = cfg["rps"], cfg["slope"], cfg["pool_K"]
     dY = torch.empty(P, Cout, dtype=torch.float32, device=Y.device)
@@ -212,7 +218,7 @@ def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
     return dY, dgamma, dbeta
 
 
-def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
+def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chsum=None, sums=None):
     """The reduction half of the GroupNorm backward: (gout contiguous, ca, cb, cd [Bs, C], dgamma, dbeta) with
     dY = ca * act'(.) * g + cb * Y + cd."""
     P, Cout = Y.shape
@@ -246,10 +252,15 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg):
     if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
         cb, cd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(2))
         S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
+        dsum = db = None
+        if chsum is not None:
+            dsum = torch.empty(Bs, Cout, dtype=torch.float32, device=dev)
+            db = torch.empty(Cout, dtype=torch.float32, device=dev)
+            sums["dsum"], sums["db"] = dsum, db
         call("prifit_gn_bwd_finalize", ptr(slab), Bs, nslab // Bs, Cout, G, _D(m), ptr(gamma.contiguous()), ptr(mean),
-             ptr(invstd), ptr(cb), ptr(cd), ptr(S), cur_stream())
+             ptr(invstd), ptr(cb), ptr(cd), ptr(S), ptr(chsum), _D(float(rps)), ptr(dsum), cur_stream())
         dgamma, dbeta = (torch.empty(Cout, dtype=torch.float32, device=dev) for _ in range(2))
-        call("prifit_gn_param_grads", ptr(S), Bs, Cout, ptr(dgamma), ptr(dbeta), cur_stream())
+        call("prifit_gn_param_grads", ptr(S), Bs, Cout, ptr(dgamma), ptr(dbeta), ptr(dsum), ptr(db), cur_stream())
     else:
         S = slab.view(Bs, nslab // Bs, 2, Cout).double().sum(dim=1)          # [Bs, 2, C]: sum Gm, sum Gm*yhat
         dgamma = S[:, 1].sum(0).float()
@@ -299,10 +310,16 @@ class ConvGNActFn(torch.autograd.Function):
                  ptr(bias), ptr(slab), ptr(cand), cur_stream())
         else:
             gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
-        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset, cand)
+        # a bias or an offset in front of the normalisation: their gradients are column sums of dY, which the backward's
+        # finalize gives from the statistics alone if the forward keeps the column sums of Y (24 x C numbers)
+        chsum = None
+        if (bias is not None or offset is not None) and _GN_COLSUMS and _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, cfg["groups"]):
+            chsum = torch.empty(P // cfg["rps"], Cout, dtype=torch.float64, device=dev)
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset, cand, chsum)
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_offset = offset is not None
+        ctx.chsum = chsum
         ctx.save_for_backward(x, W, gamma, Y, scale, shift, mean, invstd, *([arg] if arg is not None else []))
         return out
 
@@ -314,13 +331,15 @@ class ConvGNActFn(torch.autograd.Function):
         P, Kin = x.shape
         Cout = W.shape[0]
         dev = x.device
-        dY, dgamma, dbeta = _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg)
+        sums = {}
+        dY, dgamma, dbeta = _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, ctx.chsum, sums)
         dW = nn_ops._weight_grad(dY, P, Cout, x, Kin, None) if ctx.needs_input_grad[1] else None
         doff = None
         if ctx.has_offset and ctx.needs_input_grad[6]:
-            doff = dY.view(P // cfg["rps"], cfg["rps"], Cout).sum(dim=1)          # the offset reaches every row of its sample
+            # the offset reaches every row of its sample: its gradient is the column sum of dY over the sample
+            doff = sums["dsum"] if "dsum" in sums else dY.view(P // cfg["rps"], cfg["rps"], Cout).sum(dim=1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = doff.sum(dim=0) if doff is not None else dY.sum(dim=0)
+            db = sums["db"] if "db" in sums else (doff.sum(dim=0) if doff is not None else dY.sum(dim=0))
         else:
             db = None
         dx = None

@@ -103,6 +103,39 @@ def test_conv_groupnorm_block_with_per_sample_offset(D):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-3, atol=2e-4 * b.grad.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
 
 
+@pytest.mark.parametrize("case", ["bias", "offset", "bias_and_offset", "global_pool_bias"])
+def test_bias_and_offset_gradients_come_from_the_statistics(D, case, monkeypatch):
+    """d loss / d bias and d loss / d offset of a convolution in front of a GroupNorm are column sums of dY.  By default they
+    come out of prifit_gn_bwd_finalize (sum_rows dY = ca sum Gm + cb sum Y + cd rows, the column sums of Y kept by the forward)
+    with no pass over dY; PRIFIT_GN_COLSUMS=0 sums dY with torch.  Same numbers to fp32 rounding."""
+    B, N, Cin, Cout, G = 4, 2048, 64, 256, 4
+    pool = case == "global_pool_bias"
+    x = _t(synth.features(1, B * N, Cin, 41))[0]
+    W = _t(synth.features(1, Cout, Cin, 42))[0] * 0.2
+    bias = _t(synth.features(1, 1, Cout, 43))[0, 0] if "bias" in case else None
+    off = _t(synth.features(1, B, Cout, 44))[0] * 1.5 if "offset" in case else None
+    gamma = _t(synth.features(1, 1, Cout, 45))[0, 0] * 0.5 + 0.8
+    beta = _t(synth.features(1, 1, Cout, 46))[0, 0] * 0.2
+    go = _t(synth.features(1, B if pool else B * N, Cout, 47))[0].cuda()
+    cfg = {"groups": G, "rps": N, "slope": 0.0, "pool_K": N if pool else 0, "eps": 1e-5}
+    grads = []
+    for colsums in (True, False):
+        monkeypatch.setattr(D, "_GN_COLSUMS", colsums)
+        dl = [None if t is None else t.detach().cuda().requires_grad_(True) for t in (x, W, bias, gamma, beta, off)]
+        out = D.ConvGNActFn.apply(dl[0], dl[1], dl[2], dl[3], dl[4], cfg, dl[5])
+        (out * go).sum().backward()
+        grads.append([None if t is None else t.grad.clone() for t in dl])
+    for a, b, name in zip(grads[0], grads[1], ["x", "W", "bias", "gamma", "beta", "offset"]):
+        if a is None:
+            assert b is None
+            continue
+        if name in ("bias", "offset"):
+            assert a.abs().max().item() > 0
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * b.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
+        else:            # (the other gradients do not depend on the switch; the weight gradient's split-K sums are not bit-stable)
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
+
+
 def test_global_max_pool_fused_into_the_block(D):
     """relu(gn(conv(.))) followed by the max over the whole cloud (src/dgcnn.py:194-197) as one pooled block with K = N
     (candidates from the product's epilogue, gradient routed through the winners) against plain torch."""
