@@ -208,6 +208,18 @@ long long prifit_pool_alg_workspace(long long P, int Cin);
 int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
                               const float *p_mean, const float *p_invstd, const float *M, long long ldm, const float *v, float *Gp,
                               long long ldgp, float *red_slab, float *gram, float *asum, float *workspace, void *stream);
+/* The winners' terms of a layer max-pooled over the WHOLE cloud (src/dgcnn.py:194-197: x.max(dim=-1) behind conv + GroupNorm +
+ * ReLU; one pooling group per sample, K rows, Cout winners), backward in the algebraic form (csrc/pool_alg.hip):
+ *   dX[b, arg[b,c], :] += T[b,c] W[c, :]   (rows; channels in ascending order)      dX [Bs K, lddx], NULL: skipped
+ *   dW[c, :] += sum_b T[b,c] X[b K + arg[b,c], :]   (samples in ascending order)    dW [Cout, lddw], NULL: skipped
+ * arg [Bs, Cout] the winning row inside the sample, T [Bs, Cout] the pooled gradient through the activation (0: no term).  The
+ * dense terms (X_b M_b, Gram matrices) are batched prifit_gemm_f32 products on the caller's side.  Cout % 64 == 0, <= 1024; Cin in
+ * {64, 128, 256}.  Deterministic. */
+int prifit_global_pool_winners_supported(int Cout, int Cin);
+int prifit_global_pool_winners_f32(int Bs, int K, int Cout, int Cin, const int32_t *arg, const float *T, const float *W,
+                                   long long ldw, const float *X, long long ldx, float *dX, long long lddx, float *dW,
+                                   long long lddw, void *stream);
+
 /* Both in ONE pass (the default where it exists: Cout == 128, Cin in {64, 96}, K % 64 == 0): the winners' rows are added inside
  * the dense pass by one more wave (S tile in LDS from W in LDS; dWs accumulated in registers) -- Gp, red_slab [_slabs][2][Cin],
  * gram, asum and dWs [Cout, Cin] complete, no second pass over Gp or Yp.  workspace: _fused_workspace floats. */
@@ -339,6 +351,10 @@ int prifit_col_stats(const float *Y, long long ld, int P, int C, float *slab, vo
  * aligned), added in a fixed order by a second small launch: no atomics, the same bits from run to run. */
 long long prifit_col_sum_workspace(int P, int C);
 int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, float *workspace, void *stream);
+/* The same per sample: out [P / rows_per_sample, C] = the column sums of each sample's rows (rows_per_sample % 512 == 0; the
+ * 1^T x_b of a per-sample rank-one term, csrc/pool_alg.hip's global-pool backward). */
+int prifit_col_sum_samples(const float *Y, long long ld, int P, int C, int rows_per_sample, float *out, float *workspace,
+                           void *stream);
 
 /* GroupNorm statistics (nn.GroupNorm of src/dgcnn.py:150-171,203-213: per sample and channel group) -> the same affine
  * form, per-sample tables [Bs][C].  slab [Bs * slabs_per_sample][2][C]: column (sum, sum of squares) partials, consecutive

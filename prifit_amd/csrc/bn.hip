@@ -262,11 +262,14 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
     }
 }
 
-// out[c] = sum over the partial rows, four interleaved chains per column in a fixed order
+// out[c] = sum over the partial rows, four interleaved chains per column in a fixed order (blockIdx.y: one output row per nb
+// consecutive partial rows -- the per-sample sums of prifit_col_sum_samples)
 __global__ __launch_bounds__(256) void col_sum_reduce_kernel(const float *__restrict__ part, int nb, int C, float *__restrict__ out)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    part += (size_t)blockIdx.y * nb * C;
+    out += (size_t)blockIdx.y * C;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int b = 0;
     for (; b + 3 < nb; b += 4) {
@@ -1007,6 +1010,19 @@ int prifit_col_sum(const float *Y, long long ld, int P, int C, float *out, float
     const int nb = (P + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), 0, as_stream(stream), Y, ld, P, C, workspace);
     hipLaunchKernelGGL(col_sum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, nb, C, out);
+    return prifit_check_launch();
+}
+
+int prifit_col_sum_samples(const float *Y, long long ld, int P, int C, int rows_per_sample, float *out, float *workspace,
+                           void *stream)
+{
+    if (bad_mat(Y, ld, C) || !out || !workspace || ((uintptr_t)workspace & 15) || P <= 0 || C <= 0 || rows_per_sample <= 0 ||
+        rows_per_sample % CS_ROWS || P % rows_per_sample || P / rows_per_sample > 65535)
+        return PRIFIT_EINVAL;
+    const int nb = P / CS_ROWS, per = rows_per_sample / CS_ROWS;
+    hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), 0, as_stream(stream), Y, ld, P, C, workspace);
+    hipLaunchKernelGGL(col_sum_reduce_kernel, dim3((C + 255) / 256, P / rows_per_sample), dim3(256), 0, as_stream(stream), workspace,
+                       per, C, out);
     return prifit_check_launch();
 }
 

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import arena as zero_pool
 from .. import nn_ops
 from .. import profiler
 from .._lib import call, cur_stream, dll, ptr
@@ -235,6 +236,8 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chs
         gm = torch.where(yw * scale + shift > 0, gout, gout * slope)
         slab = torch.stack([gm, gm * ((yw - mean) * invstd)], dim=1).contiguous()                # [Bs, 2, C]
         nslab = Gp
+        if sums is not None:
+            sums["gm"] = gm
     elif pool_K:
         Gp = P // pool_K
         rows = dll().prifit_pool_reduce_groups_per_slab()
@@ -281,6 +284,49 @@ def pool_product_ok(P, Cout, Kin):
     return Kin % 4 == 0 and bool(dll().prifit_gemm_pool_supported(P, Cout, Kin))
 
 
+def _global_pool_alg_ok(P, rps, Cout, Kin, x):
+    return bool(_GLOBAL_POOL_ALG and dll().prifit_global_pool_winners_supported(Cout, Kin) and rps % 512 == 0 and
+                x.data_ptr() % 16 == 0)
+
+
+def _global_pool_alg_bwd(x, W, bias, ca, cb, cd, gm, arg, rps, need_dx, need_dW):
+    """dx [P, Kin] and dW [Cout, Kin] of conv -> GroupNorm -> ReLU -> max over the whole cloud (upstream :194-197) WITHOUT the
+    [P, Cout] tensor dY.  Row by row dY = T [row == winner] + cb * Y + cd with Y = x W^T + bias and per-sample tables
+    T = ca * gm, cb, cd [Bs, Cout], so with A_b = diag(cb_b) W and e_b = cd_b + cb_b * bias:
+        dx_b = x_b (W^T A_b) + 1 (e_b W)^T + (winners: dx[b, arg[b,c]] += T[b,c] W[c])
+        dW   = sum_b A_b (x_b^T x_b) + e_b^T (1^T x_b) + (winners: dW[c] += T[b,c] x[b, arg[b,c]])
+    -- per-sample [Kin, Kin] products (6.4 + 3.2 GFLOP each way at B = 24 x 2048, Kin = 256, Cout = 1024) in place of two
+    25.8 GFLOP products over dY, and the 403 MB that writing and reading dY moved."""
+    P, Kin = x.shape
+    Cout = W.shape[0]
+    Bs = P // rps
+    dev = x.device
+    T = (ca * gm).contiguous()
+    e = cd if bias is None else torch.addcmul(cd, cb, bias)                      # [Bs, Cout]
+    Acat = torch.empty(Cout, Bs, Kin, dtype=torch.float32, device=dev)              # A_b = Acat[:, b, :]
+    torch.mul(cb.t().unsqueeze(-1), W.unsqueeze(1), out=Acat)
+    dx = dW = None
+    if need_dx:
+        M = zero_pool.zeros(Bs, Kin, Kin, device=dev)
+        gemm(TN, Kin, Kin, Cout, W, Kin, Acat, Bs * Kin, M, Kin, batch=Bs, sA=0, sB=Kin, sC=Kin * Kin, splitk=4)    # W^T A_b
+        v = torch.mm(e, W)                                                         # [Bs, Kin]
+        dx = torch.empty(P, Kin, dtype=torch.float32, device=dev)
+        gemm(NN, rps, Kin, Kin, x, Kin, M, Kin, dx, Kin, batch=Bs, sA=rps * Kin, sB=Kin * Kin, sC=rps * Kin, bias=v, bias_stride=Kin)
+    if need_dW:
+        G = zero_pool.zeros(Bs, Kin, Kin, device=dev)
+        gemm(TN, Kin, Kin, rps, x, Kin, x, Kin, G, Kin, batch=Bs, sA=rps * Kin, sB=rps * Kin, sC=Kin * Kin, splitk=4)  # x_b^T x_b
+        s = torch.empty(Bs, Kin, dtype=torch.float32, device=dev)                  # 1^T x_b
+        ws = torch.empty(dll().prifit_col_sum_workspace(P, Kin), dtype=torch.float32, device=dev)
+        call("prifit_col_sum_samples", ptr(x), _LL(Kin), P, Kin, rps, ptr(s), ptr(ws), cur_stream())
+        dW = zero_pool.zeros(Cout, Kin, device=dev)
+        gemm(NN, Cout, Kin, Bs * Kin, Acat, Bs * Kin, G, Kin, dW, Kin, splitk=32)   # sum_b A_b G_b as ONE product, K = Bs Kin
+        dW.addmm_(e.t(), s)
+    with profiler.span("global_pool_winners", 4.0 * Bs * Cout * (2.0 * Kin + 2.0)):
+        call("prifit_global_pool_winners_f32", Bs, rps, Cout, Kin, ptr(arg), ptr(T), ptr(W), _LL(Kin), ptr(x), _LL(Kin), ptr(dx),
+             _LL(Kin), ptr(dW), _LL(Kin), cur_stream())
+    return dx, dW
+
+
 class ConvGNActFn(torch.autograd.Function):
     """conv1x1 (+bias) -> GroupNorm(groups) -> LeakyReLU(slope) [-> max over the K rows of each group].
 
@@ -320,6 +366,7 @@ class ConvGNActFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_offset = offset is not None
         ctx.chsum = chsum
+        ctx.bias = bias
         ctx.save_for_backward(x, W, gamma, Y, scale, shift, mean, invstd, *([arg] if arg is not None else []))
         return out
 
@@ -332,6 +379,14 @@ class ConvGNActFn(torch.autograd.Function):
         Cout = W.shape[0]
         dev = x.device
         sums = {}
+        if (cfg["pool_K"] and cfg["pool_K"] == cfg["rps"] and ctx.chsum is not None and not ctx.has_offset and
+                _global_pool_alg_ok(P, cfg["rps"], Cout, Kin, x)):
+            # the layer pooled over the whole cloud: everything from the statistics, the input and B x Cout winners
+            gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, ctx.chsum, sums)
+            dx, dW = _global_pool_alg_bwd(x, W, ctx.bias, ca, cb, cd, sums["gm"], arg, cfg["rps"], ctx.needs_input_grad[0],
+                                          ctx.needs_input_grad[1])
+            db = sums["db"] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dx, dW, db, dgamma, dbeta, None, None
         dY, dgamma, dbeta = _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, ctx.chsum, sums)
         dW = nn_ops._weight_grad(dY, P, Cout, x, Kin, None) if ctx.needs_input_grad[1] else None
         doff = None
@@ -486,6 +541,9 @@ _EDGE_FUSED_BWD = __import__("os").environ.get("PRIFIT_EDGE_FUSED_BWD", "1") != 
 _EDGE_TABLES = __import__("os").environ.get("PRIFIT_EDGE_TABLES", "1") != "0"
 # the global max over the cloud fused into the mlp1 block (0: activation pass + torch max; A/B arm, tested)
 _GLOBAL_POOL_FUSED = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_FUSED", "1") != "0"
+# ... and its backward in the algebraic form: no [B N, Cout] tensor dY, the two products over it replaced by per-sample
+# [Cin, Cin] products and B x Cout winners' rows (0: pool_bwd_apply + the dense dA / dW products; A/B arm, tested)
+_GLOBAL_POOL_ALG = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_ALG", "1") != "0"
 
 
 def _w2d(conv, kp=None):
