@@ -156,6 +156,10 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
  * (src/mean_shift.py:168-170) without a second read of the matrix; hand it to prifit_nms. */
 int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
                          int n, int K, int batch, unsigned long long *owner_key, void *stream);
+/* The plain product C[z] = A[z] A[z]^T on the same kernel (the `inner` of src/dgcnn.py:13 for a neighbour graph over features,
+ * K = 64): the same bits as prifit_gemm_f32(NT, A, A), 136 of 256 tiles computed at n = 2048. */
+int prifit_gram_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC, int n, int K,
+                        int batch, void *stream);
 
 /* Forward of a max-pooled last layer on the tiled (persistent 128 x 128) kernel, as prifit_gemm_stream_pool_f32 does on
  * the streaming shapes (models/pointnet_util.py:252-257): Y = relu(bn(A)) W^T + bias with the column statistics AND the

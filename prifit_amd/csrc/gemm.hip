@@ -909,6 +909,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifndef CHORD_XCD
 #define CHORD_XCD 1     // (A/B builds: -DCHORD_XCD=0 is round 4's (tile, shape) launch order)
 #endif
+// GRAM: the plain product A A^T instead (the pairwise matrix of src/dgcnn.py:13 for the second neighbour graph, K = 64).
+template <bool GRAM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chord_sym_kernel(
     const float *__restrict__ A, long long lda, long long sA, float *__restrict__ C, long long ldc, long long sC, int n, int K,
     int batch, unsigned long long *__restrict__ okey)
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = 2.0f - 2.0f * acc[b][r];   // src/mean_shift.py:154 / :168
+            const float v = GRAM ? acc[b][r] : 2.0f - 2.0f * acc[b][r];   // src/mean_shift.py:154 / :168
             Cz[(long long)(m0 + row) * ldc + n0 + col] = v;
             if (mirror) lds[col * TLD + row] = v;
             if (v < cmin) { cmin = v; cidx = row; }     // rows ascend with r inside a lane: strict keeps the first
@@ -1428,8 +1430,21 @@ int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float
         (long long)n * lda * 4 >= 0x7ff00000LL)
         return PRIFIT_EINVAL;
     const int T = n / 128;
-    hipLaunchKernelGGL(chord_sym_kernel, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda, strideA,
-                       C, ldc, strideC, n, K, batch, owner_key);
+    hipLaunchKernelGGL(chord_sym_kernel<false>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
+                       strideA, C, ldc, strideC, n, K, batch, owner_key);
+    return prifit_check_launch();
+}
+
+int prifit_gram_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC, int n, int K,
+                        int batch, void *stream)
+{
+    if (!A || !C || n <= 0 || (n % 128) || K <= 0 || (K % BK) || batch <= 0 || batch > 65535 || lda < K || ldc < n || (lda & 3) ||
+        (ldc & 3) || (strideA & 3) || (strideC & 3) || ((uintptr_t)A & 15) || ((uintptr_t)C & 15) ||
+        (long long)n * lda * 4 >= 0x7ff00000LL)
+        return PRIFIT_EINVAL;
+    const int T = n / 128;
+    hipLaunchKernelGGL(chord_sym_kernel<true>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
+                       strideA, C, ldc, strideC, n, K, batch, (unsigned long long *)nullptr);
     return prifit_check_launch();
 }
 

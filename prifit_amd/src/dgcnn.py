@@ -38,6 +38,10 @@ def _pad4(c):
 _KNN3_FUSED = __import__("os").environ.get("PRIFIT_KNN3_FUSED", "1") != "0"
 
 
+# the pairwise matrix of a feature graph on the symmetric kernel (0: the general product; A/B arm, tested bit-equal)
+_KNN_GRAM_SYM = __import__("os").environ.get("PRIFIT_KNN_GRAM_SYM", "1") != "0"
+
+
 def _knn_cl(x, k):
     """x [B,N,C] channels-last -> idx int32 [B,N,k]."""
     x = x.contiguous()
@@ -49,7 +53,12 @@ def _knn_cl(x, k):
             call("prifit_knn3_topk", ptr(x), B, N, k, ptr(idx), cur_stream())
         return idx
     G = torch.empty(B, N, N, dtype=torch.float32, device=x.device)
-    gemm(NT, N, N, C, x, C, x, C, G, N, batch=B, sA=N * C, sB=N * C, sC=N * N)
+    if _KNN_GRAM_SYM and N % 128 == 0 and C % 32 == 0 and x.data_ptr() % 16 == 0:
+        # x x^T is symmetric and so is its arithmetic: the tiles on and above the diagonal, the others as their transposes
+        with profiler.span(profiler.tag("gram_sym", N, C, B), 2.0 * B * N * N * C):
+            call("prifit_gram_sym_f32", ptr(x), _LL(C), _LL(N * C), ptr(G), _LL(N), _LL(N * N), N, C, B, cur_stream())
+    else:
+        gemm(NT, N, N, C, x, C, x, C, G, N, batch=B, sA=N * C, sB=N * C, sC=N * N)
     if C == 3:
         xx = (x[..., 0] * x[..., 0] + x[..., 1] * x[..., 1]) + x[..., 2] * x[..., 2]
     else:

@@ -351,6 +351,28 @@ def test_knn3_from_the_cloud_equals_product_plus_selection(D, N, k, monkeypatch)
         assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("N,C,k", [(2048, 64, 20), (1024, 64, 40), (256, 128, 16)])
+def test_feature_graph_on_the_symmetric_product_kernel(D, N, C, k, monkeypatch):
+    """The pairwise matrix of a neighbour graph over FEATURES (the second graph of the encoder, src/dgcnn.py:189-191, C = 64) on
+    the symmetric kernel (prifit_gram_sym_f32: tiles on and above the diagonal, the others as transposes) against the general
+    product: the same matrix and the same neighbour lists bit for bit, duplicated points included."""
+    B = 3
+    x = torch.from_numpy(np.random.default_rng(N + C).normal(size=(B, N, C)).astype(np.float32)).cuda()
+    x[:, N // 2:N // 2 + 8] = x[:, :8]
+    import ctypes
+    from prifit_amd._lib import call, cur_stream, ptr
+    from prifit_amd.nn_ops import NT, gemm
+    LL = ctypes.c_longlong
+    G0, G1 = (torch.empty(B, N, N, device="cuda") for _ in range(2))
+    gemm(NT, N, N, C, x, C, x, C, G0, N, batch=B, sA=N * C, sB=N * C, sC=N * N)
+    call("prifit_gram_sym_f32", ptr(x), LL(C), LL(N * C), ptr(G1), LL(N), LL(N * N), N, C, B, cur_stream())
+    assert torch.equal(G0, G1)
+    monkeypatch.setattr(D, "_KNN_GRAM_SYM", True)
+    got = D._knn_cl(x, k)
+    monkeypatch.setattr(D, "_KNN_GRAM_SYM", False)
+    assert torch.equal(got, D._knn_cl(x, k))
+
+
 @pytest.mark.parametrize("N,k", [(2048, 20), (1024, 40), (300, 7), (64, 64), (70, 3)])
 def test_knn_selection_order_and_ties(hiplib, N, k):
     """prifit_knn_topk (selection + one sort per wave) against a stable sort of the same values: descending value, exact ties
