@@ -219,6 +219,9 @@ int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long l
  * arg [Bs, Cout] the winning row inside the sample, T [Bs, Cout] the pooled gradient through the activation (0: no term).  The
  * dense terms (X_b M_b, Gram matrices) are batched prifit_gemm_f32 products on the caller's side.  Cout % 64 == 0, <= 1024; Cin in
  * {64, 128, 256}.  Deterministic. */
+/* out[i] = sum over the nslab slabs of part[slab][i], i < n: per-workgroup partial results (a weight gradient's partial
+ * [Cout, Cin] blocks) added in a fixed order, four interleaved chains -- the same bits from run to run. */
+int prifit_slab_sum(const float *part, int nslab, long long n, float *out, void *stream);
 int prifit_global_pool_winners_supported(int Cout, int Cin);
 int prifit_global_pool_winners_f32(int Bs, int K, int Cout, int Cin, const int32_t *arg, const float *T, const float *W,
                                    long long ldw, const float *X, long long ldx, float *dX, long long lddx, float *dW,

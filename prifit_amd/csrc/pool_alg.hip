@@ -306,4 +306,11 @@ int prifit_global_pool_winners_f32(int Bs, int K, int Cout, int Cin, const int32
     return prifit_check_launch();
 }
 
+int prifit_slab_sum(const float *part, int nslab, long long n, float *out, void *stream)
+{
+    if (!part || !out || nslab <= 0 || n <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), part, nslab, n, out);
+    return prifit_check_launch();
+}
+
 }  // extern "C"

@@ -70,6 +70,14 @@ def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, 
             bool(dll().prifit_gemm_stream_supported(layout, M, N, K)))
 
 
+def slab_sum(part):
+    """part [nslab, ...] -> its sum over the slabs in a fixed order (prifit_slab_sum; torch's reduction: 10-13 us + a memset)."""
+    part = part.contiguous()
+    out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    call("prifit_slab_sum", ptr(part), part.shape[0], _LL(out.numel()), ptr(out), cur_stream())
+    return out
+
+
 def gemm_stats_slabs(M, N, K):
     """Number of column-statistics slabs a forward (NT) product of this shape writes."""
     if _stream_ok(NT, M, N, K):
@@ -492,7 +500,7 @@ class SharedMLPFn(torch.autograd.Function):
                             call("prifit_sa_first_layer_dw_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
                                  ptr(info["idx"]), ptr(info["xyz"]), ptr(info["new_xyz"]), ptr(info["feat"]), Bq, Nq, Sq, Kq, Cout,
                                  Dq, int(info["feat_first"]), nblk, ptr(part), cur_stream())
-                    grads[0] = part.sum(dim=0)
+                    grads[0] = slab_sum(part)
                 if ctx.needs_input_grad[3]:
                     grads[1] = zero_pool.zeros(Cout, device=dev)  # bias in front of a batch-stat BatchNorm
                 G_in = None
@@ -761,7 +769,7 @@ class SAGroupDirectFn(torch.autograd.Function):
                 with profiler.span("sa_first_layer_dw", 4.0 * P * (C + 1)):
                     call("prifit_sa_first_layer_dw", ptr(gY), ptr(idxs[r]), ptr(xyz), ptr(new_xyz), ptr(feat), B, N, S,
                          K, C, D, int(feat_first), nblk, ptr(part), cur_stream())
-                dW = part.sum(dim=0)
+                dW = slab_sum(part)
                 if has_bias[r]:
                     # a bias in front of a batch-statistics BatchNorm has zero gradient
                     db = zero_pool.zeros(C, device=gY.device) if training else gY.sum(dim=0)
