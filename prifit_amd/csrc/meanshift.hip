@@ -562,6 +562,17 @@ __global__ __launch_bounds__(256) void nms_owner_from_keys_kernel(const unsigned
     atomicAdd(counts + (row / N) * N + bi, 1);
 }
 
+// counts, flags [rows] and used [B cap] start at zero: one memset when the caller allocated them back to back
+static int nms_zero(int32_t *counts, int32_t *flags, int32_t *used, long long rows, size_t nused, hipStream_t st)
+{
+    if (flags == counts + rows && used == flags + rows)
+        return hipMemsetAsync(counts, 0, sizeof(int32_t) * (2 * (size_t)rows + nused), st) == hipSuccess ? PRIFIT_OK : PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(flags, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (hipMemsetAsync(used, 0, sizeof(int32_t) * nused, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    return PRIFIT_OK;
+}
+
 int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap,
                const unsigned long long *owner_key, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids,
                int32_t *count, int32_t *labels, int32_t *used, void *stream)
@@ -572,9 +583,7 @@ int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N,
     hipStream_t st = as_stream(stream);
     const long long rows = (long long)B * N;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    if (hipMemsetAsync(flags, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    if (hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)B * cap, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (nms_zero(counts, flags, used, rows, (size_t)B * cap, st) != PRIFIT_OK) return PRIFIT_ELAUNCH;
     if (owner_key)
         hipLaunchKernelGGL(nms_owner_from_keys_kernel, dim3((unsigned)((rows + 255) / 256)), block, 0, st, owner_key, N, rows,
                            owner, counts);
@@ -596,9 +605,7 @@ int prifit_nms_pair(const float *dist_xc, const float *dist_cc, const float *C, 
     hipStream_t st = as_stream(stream);
     const long long rows = (long long)B * N;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    if (hipMemsetAsync(flags, 0, sizeof(int32_t) * rows, st) != hipSuccess) return PRIFIT_ELAUNCH;
-    if (hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)B * cap, st) != hipSuccess) return PRIFIT_ELAUNCH;
+    if (nms_zero(counts, flags, used, rows, (size_t)B * cap, st) != PRIFIT_OK) return PRIFIT_ELAUNCH;
     // owner[j] = argmin_i (2 - 2 <c_i, x_j>): row j of the points x centres matrix (the column of upstream's centres x
     // points matrix -- the same products in the same k order, so the same bits)
     hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist_xc, N, rows, owner, counts);

@@ -154,7 +154,9 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
     Bt, N, D = X.shape
     dev = X.device
     fused = D == 128  # flash-style kernel (csrc/meanshift_fused.hip); other widths take the GEMM chain
-    Z = X.clone()
+    # Z_0 = X.clone() (:60): no kernel writes its input iterate, so the first one IS X (a 25 MB copy saved; with no iteration
+    # the caller gets its own tensor)
+    Z = X if iterations > 0 else X.clone()
     saved = []
     scratch = None
     split = split_mode(N, D, keep_kernel) if fused else 0
@@ -344,12 +346,13 @@ def nms(Z, bw):
     okey = keys[0] if keys else None
     i32 = dict(dtype=torch.int32, device=dev)
     owner = torch.empty(Bt, N, **i32)
-    counts = torch.empty(Bt, N, **i32)
-    flags = torch.empty(Bt, N, **i32)
+    # (counts | flags | used in ONE allocation: prifit_nms zeroes them with one memset when they are adjacent)
+    zeroed = torch.empty(2 * Bt * N + Bt * NMS_CAP, **i32)
+    counts, flags = zeroed[:Bt * N].view(Bt, N), zeroed[Bt * N:2 * Bt * N].view(Bt, N)
+    used = zeroed[2 * Bt * N:].view(Bt, NMS_CAP)
     ids = torch.empty(Bt, NMS_CAP, **i32)
     count = torch.empty(Bt, **i32)
     labels = torch.empty(Bt, N, **i32)
-    used = torch.empty(Bt, NMS_CAP, **i32)
     # the chord matrix is read once (neighbour pick) when the owner pass ran in the chord kernel's epilogue, else twice
     with profiler.span("nms", (4.0 if okey is not None else 8.0) * Bt * N * N):
         call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(okey), ptr(owner), ptr(counts), ptr(flags), ptr(ids),
@@ -618,7 +621,7 @@ def _shift(X, bw, iterations):
 def _centres(X, bw, handle, ids, count):
     """center = new_X[indices] (src/mean_shift.py:46), [B,KM,D], differentiable w.r.t. X."""
     if isinstance(handle, list):
-        return MeanShiftRowsFn.apply(X, bw, ids, count.clamp(max=KM), handle)
+        return MeanShiftRowsFn.apply(X, bw, ids, count, handle)      # (the kernels clamp the live count to the KM slots)
     return torch.gather(handle, 1, ids.unsqueeze(-1).expand(-1, -1, X.shape[2]))
 
 
