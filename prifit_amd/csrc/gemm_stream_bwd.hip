@@ -927,31 +927,44 @@ __global__ __launch_bounds__(256) void pool_alg_slab_sum_kernel(const float *__r
     out[i] = (a0 + a1) + (a2 + a3);
 }
 
-// Gram[i][j] = sum over workgroups of their partial blocks (upper triangle of 32 x 32 blocks), mirrored into the lower one
+// Gram[i][j] = sum over workgroups of their partial blocks (upper triangle of 32 x 32 blocks), mirrored into the lower one.
+// 32 outputs per workgroup, eight threads per output take every eighth slab (four chains each), combined through LDS in a fixed
+// order.  (One thread per output walking all 256 slabs: a serial chain of dependent adds on L2 latency, 51 us per launch.)
 __global__ __launch_bounds__(256) void pool_alg_gram_reduce_kernel(const float *__restrict__ part, const float *__restrict__ apart, int nwg,
                                                                    int cin, float *__restrict__ Gm, float *__restrict__ asum)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < cin) {       // column sums of A: the partial rows in a fixed order
-        float s0 = 0.f, s1 = 0.f;
-        int w = 0;
-        for (; w + 1 < nwg; w += 2) { s0 += apart[(long long)w * cin + i]; s1 += apart[(long long)(w + 1) * cin + i]; }
-        if (w < nwg) s0 += apart[(long long)w * cin + i];
-        asum[i] = s0 + s1;
-    }
-    if (i >= cin * cin) return;
-    const int r = i / cin, c = i - r * cin;
-    if ((r >> 5) > (c >> 5)) return;
+    __shared__ float s_p[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int nn = cin * cin;
+    // blocks 0 .. nn / 32 - 1: the Gram entries; the blocks after them: the column sums of A
+    const bool gram = (int)blockIdx.x < nn / 32;
+    const int i = gram ? blockIdx.x * 32 + o : ((int)blockIdx.x - nn / 32) * 32 + o;
+    const int n = gram ? nn : cin;
+    const float *src = gram ? part : apart;
+    bool live = i < n;
+    int r = 0, c = 0;
+    if (gram) { r = i / cin; c = i - r * cin; live = live && (r >> 5) <= (c >> 5); }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nwg; w += 4) {
-        a0 += part[(long long)w * cin * cin + i]; a1 += part[(long long)(w + 1) * cin * cin + i];
-        a2 += part[(long long)(w + 2) * cin * cin + i]; a3 += part[(long long)(w + 3) * cin * cin + i];
+    if (live) {
+        int w = sl;
+        for (; w + 24 < nwg; w += 32) {
+            a0 += src[(long long)w * n + i]; a1 += src[(long long)(w + 8) * n + i];
+            a2 += src[(long long)(w + 16) * n + i]; a3 += src[(long long)(w + 24) * n + i];
+        }
+        for (; w < nwg; w += 8) a0 += src[(long long)w * n + i];
     }
-    for (; w < nwg; ++w) a0 += part[(long long)w * cin * cin + i];
-    const float v = (a0 + a1) + (a2 + a3);
-    Gm[i] = v;
-    if ((r >> 5) != (c >> 5)) Gm[c * cin + r] = v;
+    s_p[sl][o] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl != 0 || !live) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += s_p[q][o];
+    if (gram) {
+        Gm[i] = v;
+        if ((r >> 5) != (c >> 5)) Gm[c * cin + r] = v;
+    } else {
+        asum[i] = v;
+    }
 }
 
 // dW[c] = sum over workgroups of their partial slabs, in a fixed order: 64 outputs per workgroup, four threads per output
@@ -1100,7 +1113,7 @@ int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long l
     if (Cin == 96) hipLaunchKernelGGL((pool_alg_dense_kernel<96>), dim3(grid), dim3(64 * AlgRoles<96>::NW), 0, st, g);
     else if (Cin == 64) hipLaunchKernelGGL((pool_alg_dense_kernel<64>), dim3(grid), dim3(64 * AlgRoles<64>::NW), 0, st, g);
     else hipLaunchKernelGGL((pool_alg_dense_kernel<128>), dim3(grid), dim3(64 * AlgRoles<128>::NW), 0, st, g);
-    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3((Cin * Cin + 255) / 256), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
+    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3(Cin * Cin / 32 + (Cin + 31) / 32), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
                        gram, asum);
     return prifit_check_launch();
 }
@@ -1135,7 +1148,7 @@ int prifit_pool_alg_fused_f32(long long P, int K, int Cout, int Cin, const float
     hipStream_t st = as_stream(stream);
     if (Cin == 96) hipLaunchKernelGGL((pool_alg_fused_kernel<96, 128>), dim3(grid), dim3(64 * FusedWaves<96>::value), 0, st, a);
     else hipLaunchKernelGGL((pool_alg_fused_kernel<64, 128>), dim3(grid), dim3(64 * FusedWaves<64>::value), 0, st, a);
-    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3((Cin * Cin + 255) / 256), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
+    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3(Cin * Cin / 32 + (Cin + 31) / 32), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
                        gram, asum);
     hipLaunchKernelGGL(pool_alg_slab_sum_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, a.dws_part, grid, Cout * Cin, dWs);
     return prifit_check_launch();

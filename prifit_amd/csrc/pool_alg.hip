@@ -10,7 +10,7 @@
 //   rows:     for every row of a group that won channels {c}:  Gp[row] += sum_c T_c W[c, :]  (and its share of the
 //             BatchNorm-backward sums (m1, m2) of the layer below: those are linear in Gp);
 //   channels: dWs[c, :] += T_c A[winner row of c, :]  accumulated over the groups of a persistent workgroup in registers.
-// Fixed orders everywhere (rows by ascending channel, groups by ascending index, partial slabs summed by a second launch): no
+// Fixed orders everywhere (rows by ascending channel, groups by ascending index, partial blocks summed in split order): no
 // atomics, the same bits from run to run.
 #include "common.h"
 
@@ -24,27 +24,42 @@ struct SparseArgs {
     const float *Yp; long long ldyp;          // [G K, Cin]
     const float *ps, *pt, *pmu, *pis;         // the layer below: scale, shift, mean, invstd [Cin]
     float *Gp; long long ldgp;                // [G K, Cin]: read-modify-written on the winners' rows
-    float *red_slab;                          // [grid][2][Cin]
-    float *dws_part;                          // [grid][Cout][Cin]
+    float *red_slab;                          // [row grid][2][Cin]
+    float *dws_part;                          // [channel splits][Cout][Cin]
+    int nsplit;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-template <int COUT, int CIN, int NTH>
-__global__ __launch_bounds__(NTH) void pool_alg_sparse_kernel(const SparseArgs a)
+// Two launches (round 5, late): the first form did rows and channels in ONE persistent kernel of 256 workgroups -- a group
+// after the other per workgroup, two barriers per group, every load at the end of a dependent chain: 174 us for 3072 groups
+// of 64 rows (SA2 scale 1), 1254 us for 12288 groups of 128 (SA1 scale 3), more than the dense pass saved.  Rows and
+// channels share nothing but their inputs:
+//   rows     one workgroup per group (a grid-stride loop when there are more than SPARSE_ROW_GRID groups): (arg, T) of the group
+//            in LDS, 8 waves, a wave per row, the channels that won a row from ballots in ascending order (8 rows of W in flight); the row's sum of T_c W[c, :]
+//            is added to Gp[row] and enters the (m1, m2) sums of the layer below, one slab per workgroup.
+//   channels one wave per channel and SPLIT of the groups: T_c A[winner row] over its groups in ascending order, 8 row loads in
+//            flight (the (arg, T) pairs of 64 groups sit in the lanes); the per-split partial [Cout, Cin] blocks are added
+//            by slab_sum_kernel in split order.
+constexpr int SPARSE_ROW_GRID = 2048;
+
+#ifndef PA_NW
+#define PA_NW 4
+#endif
+#ifndef PA_UNR
+#define PA_UNR 2
+#endif
+template <int COUT, int CIN>
+__global__ __launch_bounds__(64 * PA_NW) void pool_alg_rows_kernel(const SparseArgs a)
 {
-    constexpr int NW = NTH / 64;
-    constexpr int PARTS = NTH / COUT, CPT = CIN / PARTS;     // threads per channel, columns per thread (channel phase)
-    constexpr int J = (CIN + 63) / 64;                       // columns per lane (row phase)
+    constexpr int NW = PA_NW, NTH = 64 * NW;
+    constexpr int J = (CIN + 63) / 64;                       // columns per lane
     constexpr int NCH = COUT / 64;
-    static_assert(NTH % COUT == 0 && CIN % PARTS == 0 && CPT % 4 == 0 && COUT % 64 == 0, "thread mapping");
+    constexpr int UNR = PA_UNR;                              // W rows in flight per wave
     __shared__ int s_arg[COUT];
     __shared__ float s_T[COUT];
-    __shared__ __attribute__((aligned(16))) float s_ps[CIN], s_pt[CIN];
     __shared__ float s_red[NW][2][CIN];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    for (int t = threadIdx.x; t < CIN; t += NTH) { s_ps[t] = a.ps[t]; s_pt[t] = a.pt[t]; }
-    // row phase: this lane's columns and their BatchNorm constants
     float cps[J], cpt[J], cmu[J], cis[J], m1[J], m2[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -52,20 +67,13 @@ __global__ __launch_bounds__(NTH) void pool_alg_sparse_kernel(const SparseArgs a
         cps[j] = a.ps[cc]; cpt[j] = a.pt[cc]; cmu[j] = a.pmu[cc]; cis[j] = a.pis[cc];
         m1[j] = 0.f; m2[j] = 0.f;
     }
-    // channel phase: this thread's channel and column range, its accumulators
-    const int ch = threadIdx.x % COUT, part = threadIdx.x / COUT;
-    float4 accw[CPT / 4];
-#pragma unroll
-    for (int i = 0; i < CPT / 4; ++i) accw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
     for (int g = blockIdx.x; g < a.G; g += gridDim.x) {
-        __syncthreads();                                     // (the previous group's channel phase has read s_arg / s_T)
+        __syncthreads();                                     // (the previous group's rows have read s_arg / s_T)
         for (int t = threadIdx.x; t < COUT; t += NTH) {
             s_arg[t] = a.arg[(size_t)g * COUT + t];
             s_T[t] = a.T[(size_t)g * COUT + t];
         }
         __syncthreads();
-        // ---- rows: wave w takes rows w, w + NW, ...; the channels that won a row come out of ballots, ascending
         int myarg[NCH];
 #pragma unroll
         for (int q = 0; q < NCH; ++q) myarg[q] = (s_T[64 * q + lane] != 0.f) ? s_arg[64 * q + lane] : -1;
@@ -75,59 +83,61 @@ __global__ __launch_bounds__(NTH) void pool_alg_sparse_kernel(const SparseArgs a
 #pragma unroll
             for (int q = 0; q < NCH; ++q) { mk[q] = __ballot(myarg[q] == r); any = any || mk[q] != 0ull; }
             if (!any) continue;                              // (wave-uniform)
+            const size_t row = (size_t)g * a.K + r;
+            float y[J], old[J];                              // the row's own loads first: they fly under the channel walk
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int col = lane + 64 * j;
+                y[j] = col < CIN ? a.Yp[row * a.ldyp + col] : 0.f;
+                old[j] = col < CIN ? a.Gp[row * a.ldgp + col] : 0.f;
+            }
             float acc[J];
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[j] = 0.f;
+            // the channels that won this row in ascending order, UNR rows of W in flight at a time (one after the other each
+            // costs an L2 round trip: a row of a 64-row group wins ~4 of 256 channels); the masks are wave-uniform, so the walk
+            // over their bits is scalar work; a dead slot multiplies W's first row by zero
+            while (any) {
+                int cs[UNR];
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                unsigned long long m = mk[q];
-                while (m) {
-                    const int c = 64 * q + __builtin_ctzll(m);
-                    m &= m - 1ull;
-                    const float t = s_T[c];
+                for (int u = 0; u < UNR; ++u) {
+                    int c = -1;
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q)
+                        if (c < 0 && mk[q]) { c = 64 * q + __builtin_ctzll(mk[q]); mk[q] &= mk[q] - 1ull; }
+                    cs[u] = c;
+                }
+                float w[UNR][J], ts[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int cc = cs[u] >= 0 ? cs[u] : 0;
+                    ts[u] = cs[u] >= 0 ? s_T[cc] : 0.f;
 #pragma unroll
                     for (int j = 0; j < J; ++j) {
                         const int col = lane + 64 * j;
-                        if (col < CIN) acc[j] = fmaf(t, a.W[(size_t)c * CIN + col], acc[j]);
+                        w[u][j] = col < CIN ? a.W[(size_t)cc * CIN + col] : 0.f;
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) acc[j] = fmaf(ts[u], w[u][j], acc[j]);
+                any = false;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) any = any || mk[q] != 0ull;
             }
-            const size_t row = (size_t)g * a.K + r;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int col = lane + 64 * j;
                 if (col < CIN) {
-                    const float y = a.Yp[row * a.ldyp + col];
-                    float *dst = a.Gp + row * a.ldgp + col;
-                    *dst += acc[j];
-                    const float gm = fmaf(y, cps[j], cpt[j]) > 0.f ? acc[j] : 0.f;
+                    a.Gp[row * a.ldgp + col] = old[j] + acc[j];
+                    const float gm = fmaf(y[j], cps[j], cpt[j]) > 0.f ? acc[j] : 0.f;
                     m1[j] += gm;
-                    m2[j] += gm * ((y - cmu[j]) * cis[j]);
-                }
-            }
-        }
-        // ---- channels: thread (channel, column range)
-        {
-            const float t = s_T[ch];
-            if (t != 0.f) {
-                const float *src = a.Yp + ((size_t)g * a.K + s_arg[ch]) * a.ldyp + part * CPT;
-#pragma unroll
-                for (int i = 0; i < CPT / 4; ++i) {
-                    const float4 y = ld4(src + 4 * i);
-                    const float4 s = *reinterpret_cast<const float4 *>(&s_ps[part * CPT + 4 * i]);
-                    const float4 sh = *reinterpret_cast<const float4 *>(&s_pt[part * CPT + 4 * i]);
-                    accw[i].x = fmaf(t, fmaxf(fmaf(y.x, s.x, sh.x), 0.f), accw[i].x);
-                    accw[i].y = fmaf(t, fmaxf(fmaf(y.y, s.y, sh.y), 0.f), accw[i].y);
-                    accw[i].z = fmaf(t, fmaxf(fmaf(y.z, s.z, sh.z), 0.f), accw[i].z);
-                    accw[i].w = fmaf(t, fmaxf(fmaf(y.w, s.w, sh.w), 0.f), accw[i].w);
+                    m2[j] += gm * ((y[j] - cmu[j]) * cis[j]);
                 }
             }
         }
     }
-    // ---- this workgroup's partials
-    float *dst = a.dws_part + ((size_t)blockIdx.x * COUT + ch) * CIN + part * CPT;
-#pragma unroll
-    for (int i = 0; i < CPT / 4; ++i) *reinterpret_cast<float4 *>(dst + 4 * i) = accw[i];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int col = lane + 64 * j;
@@ -141,6 +151,51 @@ __global__ __launch_bounds__(NTH) void pool_alg_sparse_kernel(const SparseArgs a
         for (int w = 0; w < NW; ++w) v += s_red[w][which][col];
         a.red_slab[((size_t)blockIdx.x * 2 + which) * CIN + col] = v;
     }
+}
+
+// grid (Cout / 4, nsplit), 256 threads: wave = channel, blockIdx.y = split of the groups
+template <int COUT, int CIN>
+__global__ __launch_bounds__(256) void pool_alg_channels_kernel(const SparseArgs a)
+{
+    constexpr int J = (CIN + 63) / 64;
+    constexpr int UNR = 8;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int per = (a.G + a.nsplit - 1) / a.nsplit;
+    const int g0 = blockIdx.y * per, g1 = min(a.G, g0 + per);
+    float cps[J], cpt[J], acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int col = lane + 64 * j, cc = col < CIN ? col : 0;
+        cps[j] = a.ps[cc]; cpt[j] = a.pt[cc]; acc[j] = 0.f;
+    }
+    for (int gc = g0; gc < g1; gc += 64) {                   // the (arg, T) pairs of 64 groups in the lanes
+        const int cnt = min(64, g1 - gc);
+        const size_t at = (size_t)(gc + (lane < cnt ? lane : 0)) * COUT + c;
+        const int al = a.arg[at];
+        const float tl = lane < cnt ? a.T[at] : 0.f;
+        for (int u0 = 0; u0 < cnt; u0 += UNR) {
+            float x[UNR][J], tt[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const bool live = u0 + u < cnt;              // (wave-uniform)
+                const int ar = live ? __builtin_amdgcn_readlane(al, u0 + u) : 0;
+                tt[u] = live ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl), u0 + u)) : 0.f;
+                // unconditional loads (a dead slot re-reads the chunk's first row): a branch around a load makes the compiler
+                // wait for it at the join and the row loads of a batch would go out one by one
+                const float *src = a.Yp + ((size_t)(gc + (live ? u0 + u : 0)) * a.K + ar) * a.ldyp + lane;
+#pragma unroll
+                for (int j = 0; j < J; ++j) x[u][j] = (lane + 64 * j) < CIN ? src[64 * j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[j] = fmaf(tt[u], fmaxf(fmaf(x[u][j], cps[j], cpt[j]), 0.f), acc[j]);
+        }
+    }
+    float *dst = a.dws_part + ((size_t)blockIdx.y * COUT + c) * CIN + lane;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if (lane + 64 * j < CIN) dst[64 * j] = acc[j];
 }
 
 // out[i] = sum over the slabs of part[slab][i], four interleaved chains in a fixed order
@@ -236,7 +291,15 @@ __global__ __launch_bounds__(256) void global_pool_channels_kernel(const int32_t
     for (int j = 0; j < J; ++j) dst[64 * j] += acc[j];
 }
 
-int sparse_grid(int G) { return G < 256 ? G : 256; }
+int sparse_grid(int G) { return G < SPARSE_ROW_GRID ? G : SPARSE_ROW_GRID; }
+
+// splits of the groups in the channel pass: ~2048 workgroups in all, at least 64 groups per split
+int sparse_splits(int G, int Cout)
+{
+    int ns = 2048 / (Cout / 4);
+    if (ns > (G + 63) / 64) ns = (G + 63) / 64;
+    return ns < 1 ? 1 : ns;
+}
 
 bool sparse_shape_ok(int Cout, int Cin)
 {
@@ -251,7 +314,7 @@ int prifit_pool_alg_sparse_supported(int G, int K, int Cout, int Cin) { return (
 int prifit_pool_alg_sparse_slabs(int G) { return G > 0 ? sparse_grid(G) : 0; }
 long long prifit_pool_alg_sparse_workspace(int G, int Cout, int Cin)
 {
-    return (G > 0 && sparse_shape_ok(Cout, Cin)) ? (long long)sparse_grid(G) * Cout * Cin : 0;
+    return (G > 0 && sparse_shape_ok(Cout, Cin)) ? (long long)sparse_splits(G, Cout) * Cout * Cin : 0;
 }
 
 int prifit_pool_alg_sparse_f32(int G, int K, int Cout, int Cin, const int32_t *arg, const float *T, const float *W,
@@ -260,20 +323,26 @@ int prifit_pool_alg_sparse_f32(int G, int K, int Cout, int Cin, const int32_t *a
                                void *stream)
 {
     if (!arg || !T || !W || !Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !Gp || !red_slab || !dWs || !workspace ||
-        !prifit_pool_alg_sparse_supported(G, K, Cout, Cin) || ldyp < Cin || (ldyp & 3) || ldgp < Cin ||
-        (((uintptr_t)Yp | (uintptr_t)workspace) & 15))
+        !prifit_pool_alg_sparse_supported(G, K, Cout, Cin) || ldyp < Cin || ldgp < Cin)
         return PRIFIT_EINVAL;
     SparseArgs a;
     a.G = G; a.K = K; a.arg = arg; a.T = T; a.W = W; a.Yp = Yp; a.ldyp = ldyp; a.ps = p_scale; a.pt = p_shift; a.pmu = p_mean;
     a.pis = p_invstd; a.Gp = Gp; a.ldgp = ldgp; a.red_slab = red_slab; a.dws_part = workspace;
-    const int grid = sparse_grid(G);
+    a.nsplit = sparse_splits(G, Cout);
+    const dim3 rgrid((unsigned)sparse_grid(G)), cgrid((unsigned)(Cout / 4), (unsigned)a.nsplit);
     hipStream_t st = as_stream(stream);
-    if (Cout == 128 && Cin == 96) hipLaunchKernelGGL((pool_alg_sparse_kernel<128, 96, 256>), dim3(grid), dim3(256), 0, st, a);
-    else if (Cout == 128 && Cin == 64) hipLaunchKernelGGL((pool_alg_sparse_kernel<128, 64, 256>), dim3(grid), dim3(256), 0, st, a);
-    else if (Cout == 256 && Cin == 128) hipLaunchKernelGGL((pool_alg_sparse_kernel<256, 128, 512>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((pool_alg_sparse_kernel<64, 32, 256>), dim3(grid), dim3(256), 0, st, a);
+#define SPARSE(CO, CI)                                                                          \
+    do {                                                                                        \
+        hipLaunchKernelGGL((pool_alg_rows_kernel<CO, CI>), rgrid, dim3(64 * PA_NW), 0, st, a);         \
+        hipLaunchKernelGGL((pool_alg_channels_kernel<CO, CI>), cgrid, dim3(256), 0, st, a);     \
+    } while (0)
+    if (Cout == 128 && Cin == 96) SPARSE(128, 96);
+    else if (Cout == 128 && Cin == 64) SPARSE(128, 64);
+    else if (Cout == 256 && Cin == 128) SPARSE(256, 128);
+    else SPARSE(64, 32);
+#undef SPARSE
     const long long n = (long long)Cout * Cin;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, grid, n, dWs);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, a.nsplit, n, dWs);
     return prifit_check_launch();
 }
 

@@ -45,6 +45,13 @@ _FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "auto")
 # (745-1109 us fused, 1254 us as a second launch: DESIGN.md 5.3), so the DEFAULT stays the streaming dA / dW pair over
 # Cout x Cin that reads the pooled layer's pre-activation.  1: the algebraic arm.
 _POOL_ALG = os.environ.get("PRIFIT_POOL_ALG", "0") != "0"
+# "auto": only (Cout, Cin) = (256, 128), SA2 scale 1, the one shape where the passes alone beat the pair they replace (dense 161 us
+# + winners' rows and channels 110 us, after the winners' pass was split into two parallel launches, against 358 us) -- and still
+# +0.18 ms on the c2 step (the small products and launches around the passes): not the default either
+# (profiles/r05_ab_measurements.txt 12).  NOTE for whoever measures this again: in the bench's HEADLINE c3 condition the
+# gradient that reaches the set-abstraction layers is exactly zero (one cluster per shape: the loss does not depend on the
+# embedding), so every value-dependent pass looks free there; c2 or `--embedding clustered` are the conditions to read.
+_POOL_ALG_AUTO = os.environ.get("PRIFIT_POOL_ALG", "0") == "auto"
 # ... with the winners' rows inside the dense pass where that kernel exists (0: dense pass + separate index kernel; A/B, tested)
 _POOL_ALG_FUSED = os.environ.get("PRIFIT_POOL_ALG_FUSED", "1") != "0"
 
@@ -171,6 +178,8 @@ def fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys):
     if not (pooled and _POOL_ALG and _FUSE_RED and training and l > 0 and W is not None and ctx.needs_input_grad[2 + 6 * l]):
         return False
     K = cfg["pool_K"]
+    if _POOL_ALG_AUTO and not (Cout == 256 and Kin == 128):
+        return False
     return bool(K % 64 == 0 and P % K == 0 and Ys[l - 1] is not None and Ys[l - 1].stride(0) % 4 == 0 and
                 Ys[l - 1].data_ptr() % 16 == 0 and dll().prifit_pool_alg_supported(_LL(P), Kin) and
                 dll().prifit_pool_alg_sparse_supported(P // K, K, Cout, Kin))

@@ -267,8 +267,8 @@ def test_pooled_layer_backward_in_algebraic_form_matches_the_products_over_cout(
     gout = _rand((P // K, dims[-1][1]), 33).cuda()
     res = {}
     for alg in (True, "unfused", False):
-        old = nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED
-        nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED = bool(alg), alg is True
+        old = nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED, nn_ops._POOL_ALG_AUTO
+        nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED, nn_ops._POOL_ALG_AUTO = bool(alg), alg is True, False
         try:
             xi = x.clone().requires_grad_(True)
             cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
@@ -276,7 +276,7 @@ def test_pooled_layer_backward_in_algebraic_form_matches_the_products_over_cout(
             grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
             res[alg] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
         finally:
-            nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED = old
+            nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED, nn_ops._POOL_ALG_AUTO = old
     assert torch.equal(res[True][0], res[False][0])
     for arm in (True, "unfused"):      # the winners' rows inside the dense pass (where that kernel exists) / as a second launch
         worst = 0.0

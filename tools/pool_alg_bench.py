@@ -69,7 +69,20 @@ for P, Cout, Cin, pool_K in [(1572864, 128, 96, 128), (786432, 128, 64, 64), (19
             call("prifit_pool_alg_fused_f32", LL(P), pool_K, Cout, Cin, ptr(Yp), LL(Cin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(M), LL(Cin),
                  ptr(v), ptr(arg2), ptr(T2), ptr(W2), ptr(Gp), LL(Cin), ptr(sl), ptr(gram), ptr(asum), ptr(dWs), ptr(wsf), cur_stream())
         t_fused = timeit(fused)
-    print("   with the winners' rows inside the pass: %7.1f us" % t_fused)
+    t_sparse = float("nan")
+    if dll().prifit_pool_alg_sparse_supported(P // pool_K, pool_K, Cout, Cin):
+        G_ = P // pool_K
+        arg3 = torch.randint(0, pool_K, (G_, Cout), device="cuda", generator=g, dtype=torch.int32)
+        T3 = rnd(G_, Cout) * (torch.rand(G_, Cout, device="cuda", generator=g) > 0.4)
+        W3 = rnd(Cout, Cin)
+        dWs3 = torch.empty(Cout, Cin, device="cuda")
+        sl3 = torch.empty(dll().prifit_pool_alg_sparse_slabs(G_), 2, Cin, device="cuda")
+        ws3 = torch.empty(dll().prifit_pool_alg_sparse_workspace(G_, Cout, Cin), device="cuda")
+        def sparse():
+            call("prifit_pool_alg_sparse_f32", G_, pool_K, Cout, Cin, ptr(arg3), ptr(T3), ptr(W3), ptr(Yp), LL(Cin), ptr(s1), ptr(t1),
+                 ptr(mu1), ptr(is1), ptr(Gp), LL(Cin), ptr(sl3), ptr(dWs3), ptr(ws3), cur_stream())
+        t_sparse = timeit(sparse)
+    print("   with the winners' rows inside the pass: %7.1f us;   winners' rows + channels as their own launches: %7.1f us" % (t_fused, t_sparse))
     print("[%8d rows, Cout %3d, Cin %3d] algebraic dense pass %7.1f us (%.0f GB/s of 8 P Cin B, %.1f TFLOP/s of its %.1f GFLOP)   today's pooled pair %7.1f us   errors %.1e %.1e %.1e %.1e"
           % (P, Cout, Cin, t_alg, 8.0 * P * Cin / t_alg / 1e3, 2.0 * P * Cin * Cin * 1.0 * (1 + (Cin // 32 + 1) / (2.0 * (Cin // 32))) / t_alg / 1e6,
              2.0 * P * Cin * Cin * (1 + (Cin // 32 + 1) / (2.0 * (Cin // 32))) / 1e9, t_pair, eg, ew, e1, e2), flush=True)
