@@ -166,7 +166,8 @@ int prifit_gram_sym_f32(const float *A, long long lda, long long strideA, float 
  * pool candidates cand[M / 32][4][N] (max, argmax, min, argmin per 32 rows and column) for
  * prifit_pool_from_candidates.  prifit_gemm_pool_supported(M, N, K): 1 when the shape is taken (M % 32 == 0, N > 96, more
  * than 512 output tiles, 16-byte rows).  a_scale / a_shift both NULL: no prologue on A (the DGCNN global-feature layer,
- * src/dgcnn.py:194-197, whose input is already activated). */
+ * src/dgcnn.py:194-197, whose input is already activated).  Y == NULL: the product is not stored (statistics and candidates
+ * only: 201 MB less written for that layer at B = 24 x 2048). */
 int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, const float *W, long long ldb, float *Y,
                          long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
                          float *cand, void *stream);
@@ -267,12 +268,15 @@ int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, con
  * and smallest stored C and the row of their first occurrence, cand [M/32][4][N]; once the BatchNorm affine (scale,
  * shift) of this layer is final, prifit_pool_from_candidates gives out [G, ldo] = max_k relu(bn(Y)) and arg [G, C] (the
  * winning sample, first maximum) for groups of K rows, K % 32 == 0 -- what prifit_pool_fwd computes from Y itself.
- * rows_per_sample > 0 (a multiple of K): scale / shift are per-sample tables [Bs][C] (GroupNorm), else one row [C]. */
+ * rows_per_sample > 0 (a multiple of K): scale / shift are per-sample tables [Bs][C] (GroupNorm), else one row [C].
+ * ystar (may be NULL) [G, C]: the winner's value of C itself (the pre-activation under the pool) -- all a backward needs of
+ * Y when the layer's gradients come from its input (csrc/pool_alg.hip), so that the product need not store Y at all. */
 int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
                                 float *C, long long ldc, const float *a_scale, const float *a_shift, const float *bias,
                                 float *col_stats, float *cand, void *stream);
 int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
-                                int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, void *stream);
+                                int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, float *ystar,
+                                void *stream);
 
 /* dA of a shared-MLP layer with the BatchNorm-backward reduction of the layer below fused into the epilogue:
  * G [M,N] = dY [M,K] . W [K,N] (PRIFIT_GEMM_NN, streaming shapes), and red_slab [prifit_gemm_stream_slabs(M,K)][2][N]

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void pool_from_candidates_kernel(const float *
                                                                    const float *__restrict__ scale,
                                                                    const float *__restrict__ shift, int G, int K, int C,
                                                                    int rps, float slope, float *__restrict__ out, long long ldo,
-                                                                   int32_t *__restrict__ arg)
+                                                                   int32_t *__restrict__ arg, float *__restrict__ ystar)
 {
     const long long total = (long long)G * C;
     const int nb = K >> 5;
@@ -918,6 +918,7 @@ __global__ __launch_bounds__(256) void pool_from_candidates_kernel(const float *
         }
         out[gidx * ldo + c] = act(fmaf(best, s, t), slope);
         arg[id] = bi;
+        if (ystar) ystar[id] = best;     // the winner's pre-activation: what the backward needs of Y when Y is not stored
     }
 }
 
@@ -1197,13 +1198,14 @@ int prifit_pool_bwd_table(const float *gp, long long ldgp, const float *Y, long 
 }
 
 int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
-                                int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, void *stream)
+                                int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, float *ystar,
+                                void *stream)
 {
     if (!cand || !scale || !shift || !out || !arg || G <= 0 || K < 32 || (K & 31) || C <= 0 || ldo < C || rows_per_sample < 0 ||
         (rows_per_sample % K) != 0)
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_from_candidates_kernel, dim3(ew_grid((long long)G * C)), dim3(256), 0, as_stream(stream), cand,
-                       scale, shift, G, K, C, rows_per_sample, slope, out, ldo, arg);
+                       scale, shift, G, K, C, rows_per_sample, slope, out, ldo, arg, ystar);
     return prifit_check_launch();
 }
 

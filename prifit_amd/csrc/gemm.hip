@@ -758,7 +758,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     la.store(lds); lb.store(lds + SZA);
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)((long long)g.M * g.ldc * 4), 0x00020000);
+    // (C == NULL, the pooled forward whose backward does not read Y: an empty resource -- the bounds check drops every store)
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.C ? (int)((long long)g.M * g.ldc * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(RED ? g.aux : nullptr), 0, RED ? (int)((long long)g.M * g.ldaux * 4) : 0, 0x00020000);
     const int ldc4 = (int)g.ldc * 4, ldy4 = RED ? (int)g.ldaux * 4 : 0;
@@ -1476,7 +1477,7 @@ int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, con
                          long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
                          float *cand, void *stream)
 {
-    if (!A || !W || !Y || ((a_scale == nullptr) != (a_shift == nullptr)) || !cand || !prifit_gemm_pool_supported(M, N, K) ||
+    if (!A || !W || ((a_scale == nullptr) != (a_shift == nullptr)) || !cand || !prifit_gemm_pool_supported(M, N, K) ||
         lda < K || ldb < K || ldc < N)
         return PRIFIT_EINVAL;
     GemmArgs g;

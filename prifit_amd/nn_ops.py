@@ -338,7 +338,7 @@ class SharedMLPFn(torch.autograd.Function):
             arg = torch.empty(G, CL, dtype=torch.int32, device=dev)
             if cand is not None:
                 call("prifit_pool_from_candidates", ptr(cand), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
-                     ptr(out), _LL(CL), ptr(arg), cur_stream())
+                     ptr(out), _LL(CL), ptr(arg), None, cur_stream())
             else:
                 call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
                      ptr(out), _LL(CL), ptr(arg), cur_stream())

@@ -182,16 +182,16 @@ def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None, chsum=N
     return scale, shift, mean, invstd
 
 
-def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None, chsum=None):
+def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None, chsum=None, shape=None, ystar=None):
     """GroupNorm statistics from the 128-row (or `tile`-row) column-statistics slabs of Y [P, C] -> per-sample coefficient
     tables, then LeakyReLU [+ max over the pool_K rows of each group].  Returns (out, scale, shift, mean, invstd, arg).
     offset [Bs, C] (optional): the normalised tensor is Y + offset[sample] (prifit_gn_finalize_offset: the tables come out
     relative to Y, so nothing downstream changes)."""
-    P, Cout = Y.shape
+    P, Cout = shape if Y is None else Y.shape          # Y None: the product was not stored (candidates only; `shape` given)
     G, rps, slope, pool_K, eps = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"], cfg["eps"]
     assert P % rps == 0 and rps % tile == 0 and Cout % G == 0
     Bs = P // rps
-    dev = Y.device
+    dev = slab.device
     scale, shift, mean, invstd = _gn_tables(slab, Bs, rps // tile, Cout, rps, gamma, beta, cfg, offset, chsum)
     arg = None
     if pool_K:
@@ -200,7 +200,7 @@ def _gn_forward(Y, slab, tile, gamma, beta, cfg, offset=None, cand=None, chsum=N
         arg = torch.empty(Gp, Cout, dtype=torch.int32, device=dev)
         if cand is not None:    # (max, argmax, min, argmin) per 32 rows from the product's epilogue: Y is not read again
             call("prifit_pool_from_candidates", ptr(cand), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope), ptr(out),
-                 _LL(Cout), ptr(arg), cur_stream())
+                 _LL(Cout), ptr(arg), ptr(ystar), cur_stream())
         else:
             call("prifit_pool_fwd", ptr(Y), _LL(Cout), ptr(scale), ptr(shift), Gp, pool_K, Cout, rps, _F(slope),
                  ptr(out), _LL(Cout), ptr(arg), cur_stream())
@@ -230,18 +230,20 @@ def _gn_backward(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chsum=Non
 
 def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chsum=None, sums=None):
     """The reduction half of the GroupNorm backward: (gout contiguous, ca, cb, cd [Bs, C], dgamma, dbeta) with
-    dY = ca * act'(.) * g + cb * Y + cd."""
-    P, Cout = Y.shape
+    dY = ca * act'(.) * g + cb * Y + cd.  Y None (the cloud-pooled layer whose product was not stored): sums["ystar"] holds the
+    winners' pre-activations, sums["shape"] = (P, Cout)."""
+    P, Cout = sums["shape"] if Y is None else Y.shape
     G, rps, slope, pool_K = cfg["groups"], cfg["rps"], cfg["slope"], cfg["pool_K"]
     Bs = P // rps
-    dev = Y.device
+    dev = gout.device
     gout = gout.contiguous()
     rows = dll().prifit_reduce_rows_per_slab()
     if pool_K and pool_K == rps:
         # one pooling group per sample (the global max over a cloud, src/dgcnn.py:197): the per-sample partials are the
         # winners' terms themselves, [Bs, C] numbers -- (sum Gm, sum Gm * yhat) with Gm = act'(.) * gout at the winning row
         Gp = P // pool_K
-        yw = torch.gather(Y.view(Gp, pool_K, Cout), 1, arg.long().unsqueeze(1)).squeeze(1)       # [Bs, C]
+        ystar = None if sums is None else sums.get("ystar")
+        yw = ystar if ystar is not None else torch.gather(Y.view(Gp, pool_K, Cout), 1, arg.long().unsqueeze(1)).squeeze(1)   # [Bs, C]
         gm = torch.where(yw * scale + shift > 0, gout, gout * slope)
         slab = torch.stack([gm, gm * ((yw - mean) * invstd)], dim=1).contiguous()                # [Bs, 2, C]
         nslab = Gp
@@ -352,25 +354,33 @@ class ConvGNActFn(torch.autograd.Function):
         Cout = W.shape[0]
         assert cfg["rps"] % 512 == 0
         dev = x.device
-        Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
         tile = dll().prifit_gemm_stats_tile_m(P, Cout)   # rows per statistics slab (divides rps: 64 or 128)
         nslab = (P + tile - 1) // tile
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
-        cand = None
-        if cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and tile == 128 and pool_product_ok(P, Cout, Kin):
-            # the pooled layer on the persistent kernel: its epilogue leaves the per-32-row (max, argmax, min, argmin)
-            # candidates, so neither the pool nor an activation pass reads Y again
-            cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
-            call("prifit_gemm_pool_f32", P, Cout, Kin, ptr(x), _LL(Kin), ptr(W), _LL(Kin), ptr(Y), _LL(Cout), None, None,
-                 ptr(bias), ptr(slab), ptr(cand), cur_stream())
-        else:
-            gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
         # a bias or an offset in front of the normalisation: their gradients are column sums of dY, which the backward's
         # finalize gives from the statistics alone if the forward keeps the column sums of Y (24 x C numbers)
         chsum = None
         if (bias is not None or offset is not None) and _GN_COLSUMS and _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, cfg["groups"]):
             chsum = torch.empty(P // cfg["rps"], Cout, dtype=torch.float64, device=dev)
-        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset, cand, chsum)
+        cand = ystar = None
+        pooled_tiled = bool(cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and tile == 128 and pool_product_ok(P, Cout, Kin))
+        # the layer pooled over the whole cloud, backward in the algebraic form: nothing reads Y but the winners' values, which
+        # the pool leaves in `ystar` -- the product is not stored (201 MB at B = 24 x 2048 x 1024)
+        nostore = bool(pooled_tiled and _GLOBAL_POOL_NOSTORE and cfg["pool_K"] == cfg["rps"] and chsum is not None and
+                       offset is None and _global_pool_alg_ok(P, cfg["rps"], Cout, Kin, x))
+        Y = None if nostore else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+        if pooled_tiled:
+            # the pooled layer on the persistent kernel: its epilogue leaves the per-32-row (max, argmax, min, argmin)
+            # candidates, so neither the pool nor an activation pass reads Y again
+            cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
+            if nostore:
+                ystar = torch.empty(P // cfg["pool_K"], Cout, dtype=torch.float32, device=dev)
+            call("prifit_gemm_pool_f32", P, Cout, Kin, ptr(x), _LL(Kin), ptr(W), _LL(Kin), ptr(Y), _LL(Cout), None, None,
+                 ptr(bias), ptr(slab), ptr(cand), cur_stream())
+        else:
+            gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset, cand, chsum, (P, Cout), ystar)
+        ctx.ystar = ystar
         ctx.cfg = cfg
         ctx.has_bias = bias is not None
         ctx.has_offset = offset is not None
@@ -388,8 +398,10 @@ class ConvGNActFn(torch.autograd.Function):
         Cout = W.shape[0]
         dev = x.device
         sums = {}
-        if (cfg["pool_K"] and cfg["pool_K"] == cfg["rps"] and ctx.chsum is not None and not ctx.has_offset and
-                _global_pool_alg_ok(P, cfg["rps"], Cout, Kin, x)):
+        if ctx.ystar is not None:
+            sums["ystar"], sums["shape"] = ctx.ystar, (P, Cout)
+        if Y is None or (cfg["pool_K"] and cfg["pool_K"] == cfg["rps"] and ctx.chsum is not None and not ctx.has_offset and
+                         _global_pool_alg_ok(P, cfg["rps"], Cout, Kin, x)):
             # the layer pooled over the whole cloud: everything from the statistics, the input and B x Cout winners
             gout, ca, cb, cd, dgamma, dbeta = _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, ctx.chsum, sums)
             dx, dW = _global_pool_alg_bwd(x, W, ctx.bias, ca, cb, cd, sums["gm"], arg, cfg["rps"], ctx.needs_input_grad[0],
@@ -553,6 +565,8 @@ _GLOBAL_POOL_FUSED = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_FUSED", "1
 # ... and its backward in the algebraic form: no [B N, Cout] tensor dY, the two products over it replaced by per-sample
 # [Cin, Cin] products and B x Cout winners' rows (0: pool_bwd_apply + the dense dA / dW products; A/B arm, tested)
 _GLOBAL_POOL_ALG = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_ALG", "1") != "0"
+# ... whose forward then does not store the product at all (0: stores it; A/B arm, tested)
+_GLOBAL_POOL_NOSTORE = __import__("os").environ.get("PRIFIT_GLOBAL_POOL_NOSTORE", "1") != "0"
 
 
 def _w2d(conv, kp=None):

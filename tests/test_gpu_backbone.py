@@ -391,12 +391,17 @@ def test_pool_candidates_match_pool_fwd(nn_ops, P, K, N, Kin):
     s2d, t2d = s2.cuda(), t2.cuda()
     out1, arg1 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")
     out2, arg2 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")
-    call("prifit_pool_from_candidates", ptr(cand), ptr(s2d), ptr(t2d), G, K, N, 0, _F(0.0), ptr(out1), _LL(N), ptr(arg1), cur_stream())
+    ystar = torch.empty(G, N, device="cuda")
+    call("prifit_pool_from_candidates", ptr(cand), ptr(s2d), ptr(t2d), G, K, N, 0, _F(0.0), ptr(out1), _LL(N), ptr(arg1), ptr(ystar), cur_stream())
     call("prifit_pool_fwd", ptr(Y), _LL(N), ptr(s2d), ptr(t2d), G, K, N, 0, _F(0.0), ptr(out2), _LL(N), ptr(arg2), cur_stream())
     assert torch.equal(out1, out2)
     live = out2 > 0
     assert torch.equal(arg1[live], arg2[live])
     assert live.float().mean() > 0.2
+    # ystar = the stored product at the winner (where the scale is not zero: there the first row wins by convention)
+    want = torch.gather(Y.view(G, K, N), 1, arg1.long().unsqueeze(1)).squeeze(1)
+    nz = (s2d != 0).view(1, N).expand(G, N)
+    assert torch.equal(ystar[nz], want[nz])
 
 
 def _run_pair(my, orc_mod, args_gpu, args_cpu, gout, n_out=1, pick=lambda o: o):

@@ -136,13 +136,14 @@ def test_bias_and_offset_gradients_come_from_the_statistics(D, case, monkeypatch
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6 * b.abs().max().item(), msg=lambda m, name=name: name + ": " + m)
 
 
-@pytest.mark.parametrize("Cin,alg", [(64, True), (256, True), (64, False)])
-def test_global_max_pool_fused_into_the_block(D, Cin, alg, monkeypatch):
+@pytest.mark.parametrize("Cin,alg,nostore", [(64, True, True), (256, True, True), (256, True, False), (64, False, True)])
+def test_global_max_pool_fused_into_the_block(D, Cin, alg, nostore, monkeypatch):
     """relu(gn(conv(.))) followed by the max over the whole cloud (src/dgcnn.py:194-197) as one pooled block with K = N
     (candidates from the product's epilogue, gradient routed through the winners) against plain torch.  alg: the backward in
     the algebraic form (default: per-sample [Cin, Cin] products + B x Cout winners' rows, no [B N, Cout] tensor dY) or through
     pool_bwd_apply and the two dense products over dY."""
     monkeypatch.setattr(D, "_GLOBAL_POOL_ALG", alg)
+    monkeypatch.setattr(D, "_GLOBAL_POOL_NOSTORE", nostore)     # (with the algebraic backward: the product is not stored at all)
     B, N, Cout, G = 6, 2048, 1024, 8
     assert D.pool_product_ok(B * N, Cout, Cin)
     x = _t(synth.features(1, B * N, Cin, 25))[0]
