@@ -785,6 +785,16 @@ int prifit_ellipsoid_sdf_matrix_bwd(const float *points, int B, int M, const flo
 int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, int cap, int32_t *n,
                          int32_t *off, void *stream);
 
+/* The segmentation loss F.cross_entropy(pred, target) of models/pointnet2_part_seg_msg.py:137-144 (mean over the rows) and its
+ * gradient, x [P, ld] rows of C <= 64 class scores, target [P] int64 (clamped to [0, C)): loss [1] = mean_r (lse_r - x[r, t_r]);
+ * lse [P] is kept for the backward, dx[r, c] = (exp(x[r, c] - lse_r) - [c == t_r]) g[0] / P.  workspace:
+ * prifit_cross_entropy_workspace() floats.  Per-workgroup partial sums in a fixed row order: the same bits from run to run. */
+int prifit_cross_entropy_workspace(void);
+int prifit_cross_entropy_fwd(const float *x, long long ld, const long long *target, long long P, int C, float *lse, float *workspace,
+                             float *loss, void *stream);
+int prifit_cross_entropy_bwd(const float *x, long long ld, const long long *target, const float *lse, const float *g, long long P,
+                             int C, float *dx, long long ldd, void *stream);
+
 /* The combination step of analytic_chamfer_distance (src/utils.py:417-426) in one launch: per shape
  * (d2_sum[b] / max(total[b], 1) + sdf_sum[b] / M) / 2, averaged over the shapes with at least one valid primitive
  * (valid [B,KM]); 0 when none has.  loss [1]; part [2][B] = the two per-shape halves; coef [2 B + 1] = what the backward

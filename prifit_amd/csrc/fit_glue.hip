@@ -126,6 +126,67 @@ __global__ __launch_bounds__(64) void chamfer_combine_bwd_kernel(const float *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The segmentation loss (models/pointnet2_part_seg_msg.py:137-144: F.cross_entropy(pred, target), mean over the B N points, on
+// rows of C <= 64 class scores): loss = mean_r (lse_r - x[r, target_r]), lse_r = max + log sum exp(x - max).
+// torch's nll_loss_forward / _backward reduce with ONE workgroup (73 + 47 us for 49152 x 50 at B = 24); here a wave per row,
+// per-workgroup partial sums in a fixed row order, a second tiny launch for the mean.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int CE_WGS = 512;
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x, long long ld, const long long *__restrict__ target,
+                                                     long long P, int C, float *__restrict__ lse, float *__restrict__ part)
+{
+    __shared__ float s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < P; r += (long long)gridDim.x * 4) {
+        const float v = lane < C ? x[r * ld + lane] : -INFINITY;
+        const float m = wave_max_f32(v);
+        const float e = lane < C ? __expf(v - m) : 0.f;
+        const float l = m + __logf(wave_sum_f32(e));
+        long long t = target[r];
+        t = t < 0 ? 0 : (t >= C ? C - 1 : t);
+        const float xt = __shfl(v, (int)t, 64);
+        if (lane == 0) lse[r] = l;
+        acc += l - xt;                                   // (the same value in every lane)
+    }
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(64) void ce_final_kernel(const float *__restrict__ part, int n, double count, float *__restrict__ out)
+{
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) a += (double)part[i];
+    a = wave_sum_f64(a);
+    if (threadIdx.x == 0) out[0] = (float)(a / count);
+}
+
+// d loss / d x[r, c] = (softmax(x)[r, c] - [c == target_r]) g / P
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float *__restrict__ x, long long ld, const long long *__restrict__ target,
+                                                     const float *__restrict__ lse, const float *__restrict__ g, long long P, int C,
+                                                     float *__restrict__ dx, long long ldd)
+{
+    const long long total = P * C;
+    const float gs = g[0] / (float)P;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long r = id / C;
+        const int c = (int)(id - r * C);
+        long long t = target[r];
+        t = t < 0 ? 0 : (t >= C ? C - 1 : t);
+        dx[r * ldd + c] = (__expf(x[r * ld + c] - lse[r]) - (c == (int)t ? 1.f : 0.f)) * gs;
+    }
+}
+
 extern "C" {
 
 int prifit_bandwidth_from_kth(const float *kth, int B, int N, float *bw, void *stream)
@@ -172,6 +233,28 @@ int prifit_chamfer_combine_bwd(const float *g, const float *coef, int B, float *
 {
     if (!g || !coef || !g_d2 || !g_sdf || B <= 0) return PRIFIT_EINVAL;
     hipLaunchKernelGGL(chamfer_combine_bwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), g, coef, B, g_d2, g_sdf);
+    return prifit_check_launch();
+}
+
+int prifit_cross_entropy_workspace(void) { return CE_WGS; }
+
+int prifit_cross_entropy_fwd(const float *x, long long ld, const long long *target, long long P, int C, float *lse, float *workspace,
+                             float *loss, void *stream)
+{
+    if (!x || !target || !lse || !workspace || !loss || P <= 0 || C <= 0 || C > 64 || ld < C) return PRIFIT_EINVAL;
+    const int grid = (int)((P + 3) / 4 < CE_WGS ? (P + 3) / 4 : CE_WGS);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ld, target, P, C, lse, workspace);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, grid, (double)P, loss);
+    return prifit_check_launch();
+}
+
+int prifit_cross_entropy_bwd(const float *x, long long ld, const long long *target, const float *lse, const float *g, long long P,
+                             int C, float *dx, long long ldd, void *stream)
+{
+    if (!x || !target || !lse || !g || !dx || P <= 0 || C <= 0 || C > 64 || ld < C || ldd < C) return PRIFIT_EINVAL;
+    long long grid = (P * C + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, ld, target, lse, g, P, C, dx, ldd);
     return prifit_check_launch();
 }
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..nn_ops import LinearFn, SharedMLPFn
+from ..nn_ops import LinearFn, SharedMLPFn, cross_entropy
 from .. import arena as zero_pool
 from .pointnet_util import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
                             _mlp_cfg, _mlp_tensors, batched_bn_counters)
@@ -134,7 +134,7 @@ class get_loss(nn.Module):
     """upstream :137-144: F.cross_entropy on log-probabilities (softmax applied twice: kept)."""
 
     def forward(self, pred, target, trans_feat=None):
-        return F.cross_entropy(pred, target)
+        return cross_entropy(pred, target)       # (F.cross_entropy; on the GPU one pass each way, nn_ops.CrossEntropyFn)
 
 
 class get_selfsup_loss(nn.Module):

@@ -883,6 +883,45 @@ class LinearFn(torch.autograd.Function):
         return dx, dW, db
 
 
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(x, target) (mean over the rows; models/pointnet2_part_seg_msg.py:137-144) for x [P, C <= 64] on the GPU:
+    one pass forward (+ a one-workgroup mean), one pass backward (prifit_cross_entropy_fwd / _bwd).  torch's nll_loss reduces
+    with a single workgroup: 73 + 47 us per step at 49152 x 50."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        target = target.contiguous()
+        P, C = x.shape
+        lse = torch.empty(P, dtype=torch.float32, device=x.device)
+        ws = torch.empty(dll().prifit_cross_entropy_workspace(), dtype=torch.float32, device=x.device)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        call("prifit_cross_entropy_fwd", ptr(x), _LL(x.stride(0)), ptr(target), _LL(P), C, ptr(lse), ptr(ws), ptr(loss), cur_stream())
+        ctx.save_for_backward(x, target, lse)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target, lse = ctx.saved_tensors
+        P, C = x.shape
+        dx = torch.empty(P, C, dtype=torch.float32, device=x.device)
+        g = g.reshape(1).to(torch.float32).contiguous()
+        call("prifit_cross_entropy_bwd", ptr(x), _LL(x.stride(0)), ptr(target), ptr(lse), ptr(g), _LL(P), C, ptr(dx), _LL(C), cur_stream())
+        return dx, None
+
+
+# the segmentation loss on the library's kernels (0: torch's F.cross_entropy; A/B arm)
+_CE_KERNEL = os.environ.get("PRIFIT_CE_KERNEL", "1") != "0"
+
+
+def cross_entropy(x, target):
+    """F.cross_entropy with the default arguments; rows of up to 64 classes on the GPU go through CrossEntropyFn."""
+    if _CE_KERNEL and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] <= 64 and target.dim() == 1 and target.dtype == torch.int64:
+        return CrossEntropyFn.apply(x, target)
+    return torch.nn.functional.cross_entropy(x, target)
+
+
 class GroupGatherFn(torch.autograd.Function):
     """Grouped rows [B*S*K, ld] = [feat[idx], xyz[idx] - centre, 0-pad] (order 0) or
     [xyz[idx] - centre, feat[idx], 0-pad] (order 1); gradient flows to `feat` only (xyz is data)."""

@@ -789,3 +789,26 @@ def test_col_sum_is_deterministic_and_exact_enough(hiplib):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         want = Y.double().sum(0).cpu()
         assert (outs[0].double() - want).abs().max() <= 1e-5 * Y.double().abs().sum(0).max().cpu()
+
+
+@pytest.mark.parametrize("P,C", [(49152, 50), (1000, 16), (4097, 64), (7, 3)])
+def test_cross_entropy_matches_torch(nn_ops, P, C):
+    """nn_ops.cross_entropy (the segmentation loss of models/pointnet2_part_seg_msg.py:137-144 on the GPU, one pass each way)
+    against F.cross_entropy on the same rows in fp64: value and gradient, on log-probabilities as upstream feeds it and on raw
+    scores; the same bits from run to run."""
+    g = torch.Generator().manual_seed(P + C)
+    raw = torch.randn(P, C, generator=g) * 3.0
+    target = torch.randint(0, C, (P,), generator=g)
+    for x in (torch.log_softmax(raw, dim=1), raw):
+        xr = x.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(xr, target)
+        ref.backward()
+        xd = x.cuda().requires_grad_(True)
+        got = nn_ops.cross_entropy(xd, target.cuda())
+        (got * 1.5).backward()
+        assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-7
+        torch.testing.assert_close(xd.grad.cpu().double(), 1.5 * xr.grad, rtol=1e-5, atol=1e-9)
+        xd2 = x.cuda().requires_grad_(True)
+        got2 = nn_ops.cross_entropy(xd2, target.cuda())
+        (got2 * 1.5).backward()
+        assert torch.equal(got, got2) and torch.equal(xd.grad, xd2.grad)
