@@ -27,6 +27,9 @@ __device__ __forceinline__ float act_grad(float z, float g, float slope) { retur
 
 // ---- CSR of the neighbour lists: offs[b][n] .. offs[b][n+1] = positions in lst[b] of the edges (i k + j) with idx[b,i,j] = n;
 // pos[b][e] = the position of edge e in lst[b] ----
+// SPLIT_FILL: lst[pos[e]] = e is 40 960 scattered 4-byte stores per shape -- 64 cache lines per wave instruction, from the ONE
+// CU this workgroup runs on, most of the kernel's 32 us; edge_csr_fill_kernel does them from the whole chip.
+template <bool SPLIT_FILL>
 __global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restrict__ idx, int N, int k,
                                                         int32_t *__restrict__ offs, int32_t *__restrict__ lst,
                                                         int32_t *__restrict__ pos)
@@ -38,7 +41,10 @@ __global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restric
     const int32_t *ix = idx + (size_t)b * E;
     for (int i = tid; i < N; i += 1024) s_bin[i] = 0;
     __syncthreads();
-    constexpr int CU = 8;                       // independent index loads in flight per thread
+#ifndef EC_CSR_CU
+#define EC_CSR_CU 8
+#endif
+    constexpr int CU = EC_CSR_CU;               // independent index loads in flight per thread
     for (int e0 = tid; e0 < E; e0 += 1024 * CU) {
         int n[CU];
 #pragma unroll
@@ -84,10 +90,19 @@ __global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restric
             if (e < E) {
                 const bool ok = n[j] >= 0 && n[j] < N;
                 const int p = ok ? atomicAdd(&s_bin[n[j]], 1) : -1;
-                if (ok) lb[p] = e;
+                if (ok && !SPLIT_FILL) lb[p] = e;
                 pb[e] = p;                                  // where edge e sits in the lists (-1: not in any)
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_csr_fill_kernel(const int32_t *__restrict__ pos, int E, long long total,
+                                                            int32_t *__restrict__ lst)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const int p = pos[id];
+        if (p >= 0) lst[(id / E) * E + p] = (int)(id % E);
     }
 }
 
@@ -328,7 +343,9 @@ int prifit_edge_tables_supported(int N, int k, int C)
 int prifit_edge_csr(const int32_t *idx, int B, int N, int k, int32_t *offs, int32_t *lst, int32_t *pos, void *stream)
 {
     if (!idx || !offs || !lst || !pos || B <= 0 || N <= 0 || N > EC_MAXN || k <= 0 || (long long)N * k > 0x7fffffffLL) return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(edge_csr_kernel, dim3(B), dim3(1024), 0, as_stream(stream), idx, N, k, offs, lst, pos);
+    hipLaunchKernelGGL(edge_csr_kernel<true>, dim3(B), dim3(1024), 0, as_stream(stream), idx, N, k, offs, lst, pos);
+    const long long total = (long long)B * N * k;
+    hipLaunchKernelGGL(edge_csr_fill_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), pos, N * k, total, lst);
     return prifit_check_launch();
 }
 
