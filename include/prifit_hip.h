@@ -491,6 +491,26 @@ int prifit_gather_linear_bwd_bn_supported(int N, int C);
 int prifit_gather_linear_bwd_bn(const float *G, const float *Y, const float *scale, const float *shift, const float *coef_a,
                                 const float *coef_b, const float *coef_d, const int32_t *idx, int B, int N, int S, int K,
                                 int C, float *dU, float *dVc, void *stream);
+/* The same gradients as a GATHER (round 5): no atomics, no LDS staging, and the layer's rows y1 are not read -- all in-edges of
+ * point n carry the same row U[n], so y1[(g, k)] = (U[b, n] - Vc[b, g]) + bias is re-formed from the [S, C] table of the centres
+ * (the subtraction the forward did: the same bits) and only G is read (once per pass).  offs [B, N + 1], lst [B, S K]: the CSR of
+ * the index lists idx [B, S, K] over the N points with the owner of every list position (prifit_list_csr).  The lists are cut
+ * into chunks of 64 entries, one wave each, whatever the in-degrees (ball queries pad with their first index: a few points own
+ * thousands of entries); a point whose list spans chunks is summed from per-chunk partials in chunk order by a second small
+ * pass.  dU [B,N,C] and dVc [B,S,C] are WRITTEN (no zero-init).  workspace: prifit_gather_linear_bwd_csr_workspace doubles.
+ * bias may be NULL.  C <= 128, even. */
+int prifit_gather_linear_bwd_csr_supported(int N, int C);
+long long prifit_gather_linear_bwd_csr_workspace(int B, int S, int K, int C);
+int prifit_gather_linear_bwd_csr(const float *G, const float *U, const float *Vc, const float *bias, const float *scale,
+                                 const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
+                                 const int32_t *idx, const int32_t *offs, const int32_t *lst, const int32_t *owner, int B, int N,
+                                 int S, int K, int C, float *dU, float *dVc, double *workspace, void *stream);
+/* CSR of B sets of index lists: idx [B, E] with values in [0, nbins) (others: in no list) -> offs [B, nbins + 1], lst [B, E]
+ * (the positions e of the entries with idx[e] = n at lst[offs[n] .. offs[n + 1])), pos [B, E] (where entry e sits, -1: nowhere),
+ * owner (may be NULL) [B, E]: the bin of every list position.  prifit_edge_csr is this with E = N k.  nbins <= 8192. */
+int prifit_list_csr(const int32_t *idx, int B, int nbins, int E, int32_t *offs, int32_t *lst, int32_t *pos, int32_t *owner,
+                    void *stream);
+
 
 /* Set-abstraction front end in ONE launch per layer: multi-radius ball query (models/pointnet_util.py:87-107 with
  * :19-40 fused, bit-exact like prifit_ball_query) + grouping (:43-60, :127-133 / :243-249) + the first 1x1 conv of

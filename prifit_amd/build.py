@@ -26,6 +26,7 @@ SOURCES = {
     "gemm_stream.hip": [],
     "gemm_stream_bwd.hip": [],
     "pool_alg.hip": [],
+    "sa_gather_bwd.hip": [],
     "bn.hip": [],
     "meanshift.hip": [],
     "meanshift_fused.hip": [],

@@ -30,14 +30,13 @@ __device__ __forceinline__ float act_grad(float z, float g, float slope) { retur
 // SPLIT_FILL: lst[pos[e]] = e is 40 960 scattered 4-byte stores per shape -- 64 cache lines per wave instruction, from the ONE
 // CU this workgroup runs on, most of the kernel's 32 us; edge_csr_fill_kernel does them from the whole chip.
 template <bool SPLIT_FILL>
-__global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restrict__ idx, int N, int k,
+__global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restrict__ idx, int N, int E,
                                                         int32_t *__restrict__ offs, int32_t *__restrict__ lst,
                                                         int32_t *__restrict__ pos)
 {
     __shared__ int s_bin[EC_MAXN];
     __shared__ int s_wave[16];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int E = N * k;
     const int32_t *ix = idx + (size_t)b * E;
     for (int i = tid; i < N; i += 1024) s_bin[i] = 0;
     __syncthreads();
@@ -97,12 +96,16 @@ __global__ __launch_bounds__(1024) void edge_csr_kernel(const int32_t *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void edge_csr_fill_kernel(const int32_t *__restrict__ pos, int E, long long total,
-                                                            int32_t *__restrict__ lst)
+// owner (may be NULL) [B, E]: the bin of every list position (the point an in-edge list entry belongs to)
+__global__ __launch_bounds__(256) void edge_csr_fill_kernel(const int32_t *__restrict__ pos, const int32_t *__restrict__ idx, int E,
+                                                            long long total, int32_t *__restrict__ lst, int32_t *__restrict__ owner)
 {
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const int p = pos[id];
-        if (p >= 0) lst[(id / E) * E + p] = (int)(id % E);
+        if (p >= 0) {
+            lst[(id / E) * E + p] = (int)(id % E);
+            if (owner) owner[(id / E) * E + p] = idx[id];
+        }
     }
 }
 
@@ -340,12 +343,22 @@ int prifit_edge_tables_supported(int N, int k, int C)
     return (N > 0 && N <= EC_MAXN && N % EC_PTS == 0 && k > 0 && k < 1024 && (C == 64 || C == 128 || C == 256)) ? 1 : 0;
 }
 
+int prifit_list_csr(const int32_t *idx, int B, int nbins, int E, int32_t *offs, int32_t *lst, int32_t *pos, int32_t *owner,
+                    void *stream);
+
 int prifit_edge_csr(const int32_t *idx, int B, int N, int k, int32_t *offs, int32_t *lst, int32_t *pos, void *stream)
 {
     if (!idx || !offs || !lst || !pos || B <= 0 || N <= 0 || N > EC_MAXN || k <= 0 || (long long)N * k > 0x7fffffffLL) return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(edge_csr_kernel<true>, dim3(B), dim3(1024), 0, as_stream(stream), idx, N, k, offs, lst, pos);
-    const long long total = (long long)B * N * k;
-    hipLaunchKernelGGL(edge_csr_fill_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), pos, N * k, total, lst);
+    return prifit_list_csr(idx, B, N, N * k, offs, lst, pos, nullptr, stream);
+}
+
+int prifit_list_csr(const int32_t *idx, int B, int nbins, int E, int32_t *offs, int32_t *lst, int32_t *pos, int32_t *owner,
+                    void *stream)
+{
+    if (!idx || !offs || !lst || !pos || B <= 0 || nbins <= 0 || nbins > EC_MAXN || E <= 0) return PRIFIT_EINVAL;
+    hipLaunchKernelGGL(edge_csr_kernel<true>, dim3(B), dim3(1024), 0, as_stream(stream), idx, nbins, E, offs, lst, pos);
+    const long long total = (long long)B * E;
+    hipLaunchKernelGGL(edge_csr_fill_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), pos, idx, E, total, lst, owner);
     return prifit_check_launch();
 }
 

@@ -521,11 +521,28 @@ class SharedMLPFn(torch.autograd.Function):
                 Bq, Nq, Sq, Kq = info["B"], info["N"], info["S"], info["K"]
                 grads[2] = dgamma
                 grads[3] = dbeta
-                dU = zero_pool.zeros(Bq, Nq, Cout, device=dev)
-                dVc = zero_pool.zeros(Bq, Sq, Cout, device=dev)
-                with profiler.span("gather_linear_bwd", 4.0 * (2.0 * P * Cout + P + (Bq * Nq + Bq * Sq) * Cout)):
-                    call("prifit_gather_linear_bwd_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
-                         ptr(info["idx"]), Bq, Nq, Sq, Kq, Cout, ptr(dU), ptr(dVc), cur_stream())
+                if _GATHER_BWD_CSR and dll().prifit_gather_linear_bwd_csr_supported(Nq, Cout) and G_in.is_contiguous():
+                    # as a gather over the in-edge lists of the points: no atomics, no staging, y1 re-formed from U / Vc (the
+                    # layer's rows are not read); the CSR of the ball-query lists is built here, once per level and scale
+                    Uq, Vq = info["U"].detach().contiguous(), info["Vc"].detach().contiguous()
+                    E = Sq * Kq
+                    offs = torch.empty(Bq, Nq + 1, dtype=torch.int32, device=dev)
+                    lst, pos, own = (torch.empty(Bq, E, dtype=torch.int32, device=dev) for _ in range(3))
+                    wsd = torch.empty(dll().prifit_gather_linear_bwd_csr_workspace(Bq, Sq, Kq, Cout), dtype=torch.float64, device=dev)
+                    dU = torch.empty(Bq, Nq, Cout, dtype=torch.float32, device=dev)
+                    dVc = torch.empty(Bq, Sq, Cout, dtype=torch.float32, device=dev)
+                    # bytes: G twice (once per pass), the lists, the tables
+                    with profiler.span("gather_linear_bwd", 4.0 * (2.0 * P * Cout + 4.0 * P + 2.0 * (Bq * Nq + Bq * Sq) * Cout)):
+                        call("prifit_list_csr", ptr(info["idx"]), Bq, Nq, E, ptr(offs), ptr(lst), ptr(pos), ptr(own), cur_stream())
+                        call("prifit_gather_linear_bwd_csr", ptr(G_in), ptr(Uq), ptr(Vq), ptr(ctx.biases[0]), ptr(scale), ptr(shift),
+                             ptr(ca), ptr(cb), ptr(cd), ptr(info["idx"]), ptr(offs), ptr(lst), ptr(own), Bq, Nq, Sq, Kq, Cout, ptr(dU),
+                             ptr(dVc), ptr(wsd), cur_stream())
+                else:
+                    dU = zero_pool.zeros(Bq, Nq, Cout, device=dev)
+                    dVc = zero_pool.zeros(Bq, Sq, Cout, device=dev)
+                    with profiler.span("gather_linear_bwd", 4.0 * (2.0 * P * Cout + P + (Bq * Nq + Bq * Sq) * Cout)):
+                        call("prifit_gather_linear_bwd_bn", ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd),
+                             ptr(info["idx"]), Bq, Nq, Sq, Kq, Cout, ptr(dU), ptr(dVc), cur_stream())
                 grads[0] = dU
                 if ctx.needs_input_grad[3]:
                     grads[1] = zero_pool.zeros(Cout, device=dev)   # bias in front of a batch-stat BatchNorm
@@ -911,6 +928,8 @@ class CrossEntropyFn(torch.autograd.Function):
         return dx, None
 
 
+# SA first layer by linearity, backward as a gather over the points' in-edge lists (0: the walk-and-stage kernel with atomics; A/B, tested)
+_GATHER_BWD_CSR = os.environ.get("PRIFIT_GATHER_BWD_CSR", "1") != "0"
 # the segmentation loss on the library's kernels (0: torch's F.cross_entropy; A/B arm)
 _CE_KERNEL = os.environ.get("PRIFIT_CE_KERNEL", "1") != "0"
 

@@ -185,7 +185,8 @@ def test_modules_fused_vs_separate_launches(mods, case):
 
 
 def test_gather_mode_fused_first_layer_backward(mods):
-    """Gather mode in training: dU / dVc from prifit_gather_linear_bwd_bn (first BatchNorm + ReLU backward formed on load, scatter
+    """Gather mode in training: dU / dVc from prifit_gather_linear_bwd_csr (a gather over the points' in-edge lists) and from
+    prifit_gather_linear_bwd_bn (first BatchNorm + ReLU backward formed on load, scatter
     staged in LDS) against the bn_relu_bwd_apply pass + prifit_gather_linear_bwd (global atomics).  Same forward launch,
     so every parameter gradient and the input-feature gradient agree to float-atomic rounding; padded groups (surface
     cloud: first-index repeats) and an SSG module (one scale, [rel, feat] order) included."""
@@ -202,20 +203,31 @@ def test_gather_mode_fused_first_layer_backward(mods):
                    torch.zeros(B, dtype=torch.long, device="cuda"))))
     for make, args in cases:
         res = []
-        for fused_bwd in (True, False):
-            old = pu._GATHER_FUSED_BWD
-            pu._GATHER_FUSED_BWD = fused_bwd
+        # arms: the gather over the points' in-edge lists (default, round 5: no atomics, y1 re-formed from U / Vc), the
+        # walk-and-stage kernel (LDS + atomics), and the apply pass + global-atomics scatter they both replace
+        for fused_bwd, csr in ((True, True), (True, False), (False, False)):
+            old = pu._GATHER_FUSED_BWD, nn_ops._GATHER_BWD_CSR
+            pu._GATHER_FUSED_BWD, nn_ops._GATHER_BWD_CSR = fused_bwd, csr
             try:
                 res.append(_run_module(pu, True, make, args, 11, True))
             finally:
-                pu._GATHER_FUSED_BWD = old
-        (out_a, gr_a, gin_a, st_a), (out_b, gr_b, gin_b, st_b) = res
-        assert torch.equal(out_a, out_b)
-        for n in gr_b:
-            _close(gr_a[n], gr_b[n], 2e-5)
-        _close(gin_a, gin_b, 2e-5)
-        for n in st_b:
-            assert torch.equal(st_a[n], st_b[n]), n
+                pu._GATHER_FUSED_BWD, nn_ops._GATHER_BWD_CSR = old
+        out_b, gr_b, gin_b, st_b = res[-1]
+        for out_a, gr_a, gin_a, st_a in res[:-1]:
+            assert torch.equal(out_a, out_b)
+            for n in gr_b:
+                _close(gr_a[n], gr_b[n], 2e-5)
+            _close(gin_a, gin_b, 2e-5)
+            for n in st_b:
+                assert torch.equal(st_a[n], st_b[n]), n
+        # the gather sums in fp64 over lists whose order may differ from run to run: same bits all the same
+        pu_old = nn_ops._GATHER_BWD_CSR
+        nn_ops._GATHER_BWD_CSR = True
+        try:
+            again = _run_module(pu, True, make, args, 11, True)
+        finally:
+            nn_ops._GATHER_BWD_CSR = pu_old
+        assert torch.equal(again[2], res[0][2])
 
 
 @pytest.mark.parametrize("switch,case", [("_SA_LINEARITY", "msg_sa2"), ("_DIRECT_FUSED_BWD", "msg_sa1"), ("_SA_NOROWS", "msg_sa1")])
