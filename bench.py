@@ -2,7 +2,7 @@
 """Headline benchmark of the PRIFIT hot path on MI355X (contract: see the task statement).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--cloud cube|blobs|surface]
-                    [--embedding untrained|clustered] [--no-extra]
+                    [--embedding clustered|untrained|clustered25|retry40] [--no-extra]
 
 One "step" = one training iteration of the hot path over one batch of B=24 synthetic 2048-point
 clouds per GPU: zero_grad, forward, loss, backward, gradient all-reduce (N>1, RCCL), Adam step.
@@ -13,13 +13,15 @@ clouds per GPU: zero_grad, forward, loss, backward, gradient all-reduce (N>1, RC
   c5: DGCNN backbone (k=20) + the same fit path                (configs[4])
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-The headline (`value`) is the condition BASELINE.json words: synthetic clouds, seeded untrained network.  Two things
-about it are NOT like training: the untrained embedding collapses to ONE cluster per shape
-(the reference's regime is up to 25, README.md:62), and synthetic clouds have emptier balls than pc_normalize'd scans.
-So at N = 1 the c3 line also carries `extra`: the same step timed with a clustered embedding (the network's embedding
-plus 8 part prototypes per shape, synth.part_embedding_offset: ~8 clusters per shape), on surface clouds, and on both --
-shapes/s, clusters per shape, speculation fallbacks and the fit-path kernel rows of each.  `--cloud` / `--embedding` make one of them THE
-measured condition (then named in config; never the default).
+The headline (`value`) is measured on synthetic clouds with a seeded network whose embedding carries 8 part prototypes per
+shape (`--embedding clustered`, synth.part_embedding_offset: ~8 clusters per shape, the reference's regime is up to 25,
+README.md:62).  The seeded untrained network ALONE collapses to ONE cluster per shape: membership is identically 1, the loss
+does not depend on the embedding and the gradient into the whole backbone is exactly zero -- that condition is
+kept as `extra.untrained_embedding`, never `value`.  After the timed region the line asserts that the first backbone layer
+received a gradient (config.backbone_grad_ratio = |grad W| / |W| >= 1e-6; the one-cluster condition gives exactly 0).  At N = 1 the c3 line also carries `extra`: the
+same step on surface clouds, at K = 25, with a retry in every step, the untrained condition, and short c2 / c5 runs --
+shapes/s, clusters per shape, speculation fallbacks and the fit-path kernel rows of each.  `--cloud` / `--embedding` make one
+of them THE measured condition (then named in config).
 
 `--gpus N` with N > 1 and no RANK in the environment: this process only LAUNCHES -- it starts N copies of
 itself, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (prifit_amd/launch.py), before anything
@@ -63,6 +65,16 @@ WORKLOADS = {
 # smooth output stretches a part into two modes, 22 of 30 steps retry; in between, isotropic noise dominates)
 EMBEDDING_PARTS = {"clustered25": ((5, 5), 0.02, 0.03), "retry40": ((5, 8), 0.005, 0.01)}
 DEFAULT_CLOUD = {"c2": "cube", "c3": "blobs", "c5": "blobs"}   # uniform cube; blobs where clusters must exist
+# The measured condition of the fit workloads is the CLUSTERED embedding: with the seeded untrained network
+# alone mean-shift finds one cluster per shape, the membership weights are identically 1 and the gradient that reaches the
+# backbone is exactly zero -- a step that multiplies zeros.  8 part prototypes per shape added to the network's own embedding
+# (synth.part_embedding_offset) give K ~ 8 and real gradients through every layer; parity of exactly this step at B = 24:
+# tests/test_gpu_bench_step_parity.py[clustered].  `untrained` stays as an `extra` entry.
+DEFAULT_EMBEDDING = {"c2": "untrained", "c3": "clustered", "c5": "clustered"}
+# |grad W| / |W| of the FIRST backbone layer after the last timed step, asserted outside the timed region.  Measured (round 6):
+# c3 clustered 4e-5 (first steps) .. 5e-4 (after 25 Adam steps), surface clouds 6e-5, c5 7e-5, c2 8e-3, K = 25 4e-6; the one-cluster
+# condition gives EXACTLY 0 on the HIP path and <= 1e-8 (rounding noise) in the oracle -- the bar sits between the two.
+MIN_BACKBONE_GRAD_RATIO = 1e-6
 METRIC = {"c2": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG seg loss only",
           "c3": "shapes/sec (fwd+bwd) B=24x2048 pts, PointNet++-MSG+ellipsoid fit",
           "c5": "shapes/sec (fwd+bwd) B=24x2048 pts, DGCNN+ellipsoid fit"}
@@ -140,10 +152,14 @@ def cpu_baseline(workload, Bs=4, passes=5):
     s = (torch.from_numpy(synth.fps_start(Bs, NPTS, 0)), torch.from_numpy(synth.fps_start(Bs, 512, 100)))
     fit = dict(quantile=0.05, iterations=10, max_num_clusters=25)
     if workload != "c2":
-        cham = torch.from_numpy(synth.cloud("blobs", Bs, 5000, 0))
+        cham_np, lab = synth.blobs_with_labels(Bs, 5000, 0)
+        cham = torch.from_numpy(cham_np)
         sel = np.random.default_rng(1).choice(5000, NPTS, replace=False)
         xyz = cham[:, sel].transpose(1, 2).contiguous()
         cham_t = cham.transpose(1, 2).contiguous()
+        # the condition the GPU line measures (DEFAULT_EMBEDDING: 8 part prototypes per shape added to the embedding)
+        if DEFAULT_EMBEDDING[workload] == "clustered":
+            fit["embedding_offset"] = torch.from_numpy(synth.part_embedding_offset(lab[:, sel], 128, 0))
     if workload == "c5":
         net = orc.OracleDGCNGn(emb_size=128, num_channels=3, nn_nb=20).train()
 
@@ -160,6 +176,8 @@ def cpu_baseline(workload, Bs=4, passes=5):
         if workload == "c3":
             extra = dict(chamfer_points=cham_t, include_convex_loss=True, quantile=0.05, msc_iterations=10,
                          max_num_clusters=25)
+            if "embedding_offset" in fit:
+                extra["fit_inputs"] = dict(embedding_offset=fit["embedding_offset"])
 
         def one():
             net.zero_grad()
@@ -319,6 +337,12 @@ def run_rank(args):
         report = distributed_report(mine, rehearsal=share)
     if rank == 0:
         line = headline(args, ctx, head, cloud)
+        # the measured step must DO the backbone's backward: a condition whose loss does not depend on
+        # the embedding (one cluster per shape) multiplies zeros -- refuse to report it as `value` unless asked for by name
+        if head["grad_ratio"] < MIN_BACKBONE_GRAD_RATIO and not (args.embedding == "untrained" and args.workload != "c2"):
+            raise SystemExit("bench.py: |grad %s| / |W| = %.3e < %.0e after the last timed step: the loss did not reach the "
+                             "backbone (clusters per shape: %s)" % (head["grad_param"], head["grad_ratio"],
+                                                                    MIN_BACKBONE_GRAD_RATIO, line["config"]["clusters_per_shape"]))
         if report is not None:
             line["distributed"] = report
             line["n_gpus"] = report["world_size"]
@@ -328,18 +352,20 @@ def run_rank(args):
             line["experiment"] = SPLIT_NOTE
         if backend != "nccl" and use_dist:
             line["rehearsal"] = "backend=%s%s: NOT a reportable number" % (backend, ", ranks share GPUs" if share else "")
-    # the same step under training-like conditions, beside the headline (single GPU, c3, default condition only)
-    if (world == 1 and args.workload == "c3" and not args.no_extra and args.cloud is None and args.embedding == "untrained"
-            and args.ms_split == "0"):
+    # the same step under other conditions, beside the headline (single GPU, c3, default condition only)
+    if world == 1 and args.workload == "c3" and not args.no_extra and args.default_condition and args.ms_split == "0":
         # (the headline is measured and stays: an exception in a side measurement is recorded in its entry, not raised)
         extra = {}
-        for name, cl, emb in (("clustered_embedding", "blobs", "clustered"), ("surface_cloud", "surface", "untrained"),
-                              ("surface_cloud_clustered_embedding", "surface", "clustered"),
-                              ("clusters_at_the_cap_25_parts", "blobs", "clustered25"),
-                              ("retry_every_step_40_parts_q0.01", "blobs", "retry40")):
+        short = max(10, min(args.steps, 30))
+        for name, cl, emb, wl in (("untrained_embedding", "blobs", "untrained", None),
+                                  ("surface_cloud_clustered_embedding", "surface", "clustered", None),
+                                  ("clusters_at_the_cap_25_parts", "blobs", "clustered25", None),
+                                  ("retry_every_step_40_parts_q0.01", "blobs", "retry40", None),
+                                  ("c2_seg_loss_only", DEFAULT_CLOUD["c2"], DEFAULT_EMBEDDING["c2"], "c2"),
+                                  ("c5_dgcnn_fit", DEFAULT_CLOUD["c5"], DEFAULT_EMBEDDING["c5"], "c5")):
             try:
-                r = measure(args, ctx, cl, emb, max(10, min(args.steps, 30)), 5, full=False)
-                extra[name] = condition_summary(r, cl, emb)
+                r = measure(args, ctx, cl, emb, min(short, 20) if wl else short, 5, full=False, workload=wl)
+                extra[name] = condition_summary(r, cl, emb, wl or args.workload)
             except Exception as e:   # noqa: BLE001
                 extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         # LABELLED EXPERIMENT beside the headline (never the headline): the headline's own condition with the mean-shift
@@ -348,7 +374,7 @@ def run_rank(args):
         for mode in ("fp16x3", "bf16x6"):
             try:
                 r = measure(args, ctx, cloud, args.embedding, max(10, min(args.steps, 30)), 5, full=False, split=mode)
-                c = condition_summary(r, cloud, args.embedding)
+                c = condition_summary(r, cloud, args.embedding, args.workload)
                 rows = family_rows(r["fams_all"], r["fams_all_steps"])
                 exp[mode] = {"dtype": SPLIT_DTYPE % mode, "value": c["value"], "unit": "shapes/s", "ms_per_step": c["ms_per_step"],
                              "vs_fp32_headline": c["value"] / line["value"], "loss": c["loss"],
@@ -360,10 +386,18 @@ def run_rank(args):
         line["extra"] = extra
         # the training-like conditions at the top level of the line (the driver's parsed record keeps top-level keys)
         line["extra_summary"] = {k: {"value": v.get("value"), "unit": "shapes/s", "ms_per_step": v.get("ms_per_step"),
+                                     "workload": v.get("workload"), "launches_per_step": v.get("launches_per_step"),
+                                     "backbone_grad_ratio": v.get("backbone_grad_ratio"),
                                      "clusters_per_shape_mean": (v.get("clusters_per_shape") or {}).get("mean"),
                                      "speculation_fallbacks": v.get("speculation_fallbacks"), "error": v.get("error")}
                                  for k, v in extra.items() if k != "split_mean_shift_products_experiment"}
     if rank == 0:
+        if world == 1 and os.environ.get("PRIFIT_BENCH_COUNT_LAUNCHES", "1") != "0":
+            try:   # after every timed measurement of this process
+                line["launches_per_step"] = count_launches(head["_step"])
+            except Exception as e:   # noqa: BLE001
+                line["launches_per_step"] = None
+                line["launches_per_step_error"] = "%s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_shapes,
@@ -386,12 +420,15 @@ FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_fused_fwd", "ms_split_fwd", "ms
                 "ellipsoid_fit", "sdf", "sample_nn", "sample_nn_bwd")
 
 
-def measure(args, ctx, cloud, embedding, steps, warmup, full, split="0"):
+def measure(args, ctx, cloud, embedding, steps, warmup, full, split="0", workload=None):
     """Build the network and the inputs of one condition, run `warmup` untimed + `steps` timed training steps bracketed by
     barrier + synchronize, and return the raw measurements.  full: the headline's extras (enqueue time, all ranks' MAX).
-    split: the LABELLED EXPERIMENT of csrc/meanshift_split.hip for this measurement ("0" = the fp32 product path)."""
+    split: the LABELLED EXPERIMENT of csrc/meanshift_split.hip for this measurement ("0" = the fp32 product path).
+    workload: another workload than args.workload (the short c2 / c5 side runs of the c3 line)."""
     from prifit_amd import fit_ops
     fit_ops.MS_SPLIT = split
+    if workload is not None and workload != args.workload:
+        args = argparse.Namespace(**dict(vars(args), workload=workload))
     try:
         return _measure(args, ctx, cloud, embedding, steps, warmup, full)
     finally:
@@ -565,6 +602,10 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     bucket.flush()     # the deferred has-gradient check of the last exchange (ddp.FlatGradBucket)
     gc.enable()
     profiler.disable()
+    # OUTSIDE the timed region: did the last timed step send a gradient into the backbone?  (first weight matrix of the
+    # network = the first set-abstraction / edge-convolution layer; after the exchange, so the averaged gradient at N > 1)
+    wname, w0 = next((n, p) for n, p in net.named_parameters() if p.dim() >= 2)
+    grad_ratio = float(w0.grad.norm() / w0.detach().norm()) if w0.grad is not None else 0.0
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -575,7 +616,8 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
                 n, ms, work = cal[k]
                 fams[k] = (n * steps, ms * steps, work * steps)
     res = {"elapsed": el.item(), "elapsed_local": elapsed_local, "allreduce_ms": allreduce_ms, "steps": steps, "warmup": warmup, "fams": fams, "loss": float(loss.item()), "graph": graph_note,
-           "fallbacks": runner.fallbacks - fallbacks0, "ahead_on": ahead_on,
+           "fallbacks": runner.fallbacks - fallbacks0, "ahead_on": ahead_on, "grad_ratio": grad_ratio, "grad_param": wname,
+           "_step": step,
            "clusters": last["count"].tolist() if "count" in last else None}
     if full:
         # host time to ENQUEUE one step, measured outside the timed region from an empty queue (inside it the launch
@@ -601,6 +643,24 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     if os.environ.get("PRIFIT_BENCH_CENSUS"):   # diagnosis, outside the timed region: who launches the small torch kernels
         launch_census(step, os.environ["PRIFIT_BENCH_CENSUS"])
     return res
+
+
+def count_launches(step):
+    """Device kernels + memsets / copies of ONE step (torch.profiler's device activity: the same records rocprofv3 sees).
+    Called after every timed measurement of the process is over."""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    dev_type = getattr(torch.autograd, "DeviceType", None)
+    n = 0
+    for ev in prof.events():
+        if dev_type is not None and getattr(ev, "device_type", None) == dev_type.CUDA:
+            n += 1
+    return n
 
 
 def launch_census(step, path):
@@ -693,8 +753,8 @@ def grouping_roofline(detail):
                                   "rows, U / Vc)"}}
 
 
-def condition_summary(r, cloud, embedding):
-    """One `extra` entry: the step under a training-like condition."""
+def condition_summary(r, cloud, embedding, workload="c3"):
+    """One `extra` entry: the step under another condition / workload."""
     ms = 1e3 * r["elapsed"] / r["steps"]
     ks = r["clusters"] or []
     hist = {}
@@ -702,7 +762,9 @@ def condition_summary(r, cloud, embedding):
         hist[str(int(k))] = hist.get(str(int(k)), 0) + 1
     rows = family_rows(r["fams_all"], r["fams_all_steps"])
     grouping = grouping_roofline(rows)
-    return {"cloud": cloud, "embedding": embedding, "quantile": EMBEDDING_PARTS.get(embedding, (None, None, 0.05))[2],
+    return {"workload": workload, "cloud": cloud, "embedding": embedding if workload != "c2" else None,
+            "quantile": EMBEDDING_PARTS.get(embedding, (None, None, 0.05))[2] if workload != "c2" else None,
+            "backbone_grad_ratio": r.get("grad_ratio"), "launches_per_step": r.get("launches_per_step"),
             "value": B_PER_GPU * r["steps"] / r["elapsed"], "unit": "shapes/s",
             "ms_per_step": ms, "steps": r["steps"], "warmup": r["warmup"], "loss": r["loss"],
             "clusters_per_shape": {"mean": (sum(ks) / len(ks)) if ks else None, "min": min(ks) if ks else None,
@@ -755,6 +817,7 @@ def headline(args, ctx, r, cloud):
                    "global_batch": world * B_PER_GPU, "points": NPTS, "parallelism": "dp%d" % world,
                    "cloud": cloud, "embedding": args.embedding if args.workload != "c2" else None,
                    "clusters_per_shape": (sum(ks) / len(ks)) if ks else None,
+                   "backbone_grad_ratio": r["grad_ratio"], "backbone_grad_param": r["grad_param"],
                    "loss": r["loss"],
                    "launch": r.get("graph") or "eager",
                    "fps": ("side stream, one batch ahead: every step launches one batch's sampling (behind its backbone forward) "
@@ -779,13 +842,17 @@ def main():
     ap.add_argument("--cpu-baseline-shapes", type=int, default=4, help="shapes of the CPU-baseline sample (4: ~15 s)")
     # the measured condition (defaults = the headline: BASELINE.json's synthetic clouds, seeded untrained network)
     ap.add_argument("--cloud", default=None, choices=("cube", "blobs", "surface"))
-    ap.add_argument("--embedding", default="untrained", choices=("untrained", "clustered") + tuple(sorted(EMBEDDING_PARTS)))
+    ap.add_argument("--embedding", default=None, choices=("untrained", "clustered") + tuple(sorted(EMBEDDING_PARTS)),
+                    help="default: clustered for c3 / c5 (~8 clusters per shape: real gradients into the backbone), n/a for c2")
     ap.add_argument("--no-extra", action="store_true", help="skip the training-like conditions reported under `extra`")
     ap.add_argument("--graph", action="store_true", help="replay the backbone forward + backward as HIP graphs (static shapes)")
     ap.add_argument("--ms-split", default="0", choices=("0", "bf16x3", "bf16x6", "fp16x3"),
                     help="LABELLED EXPERIMENT: mean-shift forward products on the 16-bit matrix pipe, error-compensated; the line's "
                          "dtype says so and it is never the reported fp32 number")
     args = ap.parse_args()
+    args.default_condition = args.embedding is None and args.cloud is None
+    if args.embedding is None:
+        args.embedding = DEFAULT_EMBEDDING[args.workload]
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # launcher: nothing in this branch imports torch or loads the HIP library

@@ -844,7 +844,8 @@ def golden_dgcnn_selfsup():
 
 
 def golden_data():
-    """pc_normalize (data_utils/ShapeNetDataLoader.py:17-22): reference vs oracle on a small cloud."""
+    """pc_normalize (data_utils/ShapeNetDataLoader.py:17-22): reference vs oracle on a small cloud; then the reference's dataset
+    classes, its two augmentation functions and its `evaluation` run on a synthetic tree (golden_data_readers / golden_eval)."""
     print("[data]")
     DL = refshim.ref("data_utils.ShapeNetDataLoader")
     pc = (synth.cloud("blobs", 1, 96, 5)[0] * 3.0 + np.array([[0.5, -1.0, 2.0]], dtype=np.float32)).astype(np.float32)
@@ -852,6 +853,145 @@ def golden_data():
     got = orc.pc_normalize_np(pc.copy())
     eq(torch.from_numpy(got), torch.from_numpy(ref), "pc_normalize")
     save("data_normalize", cloud=pc, normalized=ref)
+    golden_data_readers(DL)
+    golden_eval()
+
+
+TREE_SEED, ACD_SEED, NPOINT = 21, 22, 48
+ITEM_SEED = 1000          # np.random.seed(ITEM_SEED + index) in front of every __getitem__ (both sides)
+
+
+def _rel(paths, root):
+    return np.array([os.path.relpath(p, root) for p in paths])
+
+
+def golden_data_readers(DL):
+    """The reference's PartNormalDataset / SelfSupPartNormalDataset / ACDSelfSupDataset (ShapeNetDataLoader.py:24-140, :149-262,
+    :265-412) on the seeded synthetic trees of prifit_amd/synth.py, every `__getitem__` under a replayed `np.random` state,
+    and provider.random_scale_point_cloud / shift_point_cloud (provider.py:278-303) under a seeded state.  The fixture holds
+    the reference's outputs; the trees are re-written from their seeds by the tests."""
+    import random
+    import tempfile
+    provider = refshim.ref("provider")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        root, acd = os.path.join(tmp, "shapenet"), os.path.join(tmp, "acd")
+        synth.write_partseg_tree(root, TREE_SEED)
+        for tag, kw in (("trainval", dict(split="trainval", normal_channel=False)), ("test_n", dict(split="test", normal_channel=True)),
+                        ("train_car_chair", dict(split="train", normal_channel=False, class_choice=["Car", "Chair"]))):
+            ds = DL.PartNormalDataset(root=root, npoints=NPOINT, **kw)
+            out["pn_%s_paths" % tag] = _rel([fn for _, fn in ds.datapath], root)
+            out["pn_%s_cats" % tag] = np.array([c for c, _ in ds.datapath])
+            out["pn_%s_classes" % tag] = np.array(["%s=%d" % kv for kv in sorted(ds.classes.items())])
+            for i in range(len(ds)):
+                np.random.seed(ITEM_SEED + i)
+                pts, cls, seg = ds[i]
+                out["pn_%s_pts_%d" % (tag, i)], out["pn_%s_cls_%d" % (tag, i)], out["pn_%s_seg_%d" % (tag, i)] = pts, cls, seg
+            out["pn_%s_n" % tag] = len(ds)
+        # the few-shot draw (`random.sample`, :77-79) under a seeded `random`
+        random.seed(5)
+        ds = DL.PartNormalDataset(root=root, npoints=NPOINT, split="trainval", k_shot=1)
+        out["pn_kshot_paths"] = _rel([fn for _, fn in ds.datapath], root)
+        # the trainer's "dummy" self-supervision set: everything that is not labeled data (train:190-203)
+        train = DL.PartNormalDataset(root=root, npoints=NPOINT, split="train", k_shot=-1)
+        test = DL.PartNormalDataset(root=root, npoints=NPOINT, split="test")
+        labeled = [f for v in test.meta.values() for f in v] + [f for v in train.meta.values() for f in v]
+        ss = DL.SelfSupPartNormalDataset(root=root, npoints=NPOINT, split="trainval", labeled_fns=labeled)
+        out["ss_paths"] = _rel([fn for _, fn in ss.datapath], root)
+        for i in range(len(ss)):
+            np.random.seed(ITEM_SEED + i)
+            pts, cls, seg = ss[i]
+            out["ss_pts_%d" % i], out["ss_cls_%d" % i], out["ss_seg_%d" % i] = pts, cls, seg
+        out["ss_n"] = len(ss)
+        # ACD self-supervision set with the trainer's overlap removal ('.txt' paths of labeled files against '.npy' tokens)
+        overlap = ["chair_t0", "lamp_t2"]
+        synth.write_acd_tree(acd, ACD_SEED, overlap_tokens=overlap)
+        ad = DL.ACDSelfSupDataset(root=acd, npoints=NPOINT, exclude_fns=labeled, prefetch=False)
+        out["acd_tokens"] = np.array([os.path.splitext(os.path.basename(fn))[0] for _, fn in ad.datapath])
+        out["acd_cats"] = np.array([c for c, _ in ad.datapath])
+        for i in range(len(ad)):
+            tok = out["acd_tokens"][i]
+            np.random.seed(ITEM_SEED + i)
+            pts, cham, cls, seg = ad[i]
+            out["acd_pts_" + tok], out["acd_cham_" + tok], out["acd_seg_" + tok] = pts, np.array(cham), seg
+        out["acd_n"] = len(ad)
+        assert not any(t in overlap for t in out["acd_tokens"]), "overlap removal"
+    # augmentation: one seeded state, scale then shift as train:372-373 calls them
+    batch = synth.cloud("blobs", 5, 40, 9)
+    np.random.seed(77)
+    aug = batch.copy()
+    aug[:, :, 0:3] = provider.random_scale_point_cloud(aug[:, :, 0:3])
+    aug[:, :, 0:3] = provider.shift_point_cloud(aug[:, :, 0:3])
+    out["aug_in"], out["aug_out"] = batch, aug
+    save("data_readers", **out)
+
+
+def eval_args(**over):
+    """The fields of args_parser.py's namespace that testing.evaluation reads (testing.py:55-139)."""
+    import argparse
+    a = dict(gpu=None, cudnn_off=False, eval_split="test", npoint=NPOINT, normal=False, batch_size=5, num_classes=16, num_parts=50,
+             seed=3, pretrained_model=None, model="models.pointnet2_part_seg_msg", category=True, if_cuboid=False, quantile=0.05,
+             msc_iterations=10, max_num_clusters=25, alpha=1.0, beta=1.0, embed=False, reconstruct=False, dgcnn_k=20)
+    a.update(over)
+    return argparse.Namespace(**a)
+
+
+def golden_eval():
+    """The reference's `testing.evaluation(args, epoch, classifier, metrics)` (testing.py:49-249) itself, run in a temporary
+    working directory that holds the synthetic tree at the relative path it reads (:72), with a stub classifier
+    (prifit_oracle.StubSegClassifier: logits = a fixed function of the points) and the resampling draws replayed from one
+    seeded `np.random` state.  Two environment shims, both outside the metric arithmetic: `torch.utils.data.DataLoader` is
+    forced to num_workers=0 (the draws then come from THIS process's np.random in dataset order) and `np.float` (removed from
+    numpy 1.24 on, used at :230) is mapped to `float`."""
+    import contextlib
+    import io
+    import re
+    import tempfile
+    T = refshim.ref("testing")
+    real_loader = torch.utils.data.DataLoader
+
+    def loader0(ds, **kw):
+        kw["num_workers"] = 0
+        return real_loader(ds, **kw)
+
+    had_float = hasattr(np, "float")
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "ShapeSelfSup/dataset/shapenetcore_partanno_segmentation_benchmark_v0_normal")
+        synth.write_partseg_tree(root, TREE_SEED)
+        os.chdir(tmp)
+        torch.utils.data.DataLoader = loader0
+        if not had_float:
+            np.float = float
+        try:
+            net = orc.StubSegClassifier(50, seed=4)
+            metrics = {"best_class_avg_miou": -1.0, "best_acc": 0.0, "best_epoch": 0, "best_instance_avg_miou": 0.0, "best_chamfer_loss": 1e9}
+            np.random.seed(123)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ret = T.evaluation(eval_args(), 6, net, metrics)
+            # a second call that must NOT update the running best (class-average mIoU below the stored best)
+            keep = dict(ret, best_class_avg_miou=2.0)
+            np.random.seed(123)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ret2 = T.evaluation(eval_args(), 9, orc.StubSegClassifier(50, seed=4), dict(keep))
+        finally:
+            os.chdir(cwd)
+            torch.utils.data.DataLoader = real_loader
+            if not had_float:
+                del np.float
+    assert ret is metrics and ret2 == keep
+    cat_iou = dict(re.findall(r"eval mIoU of (\w+)\s+([0-9.]+|nan)", buf.getvalue()))
+    assert len(cat_iou) == 16, buf.getvalue()[-800:]
+    names = sorted(cat_iou)
+    print("  reference evaluation: acc %.6f  class mIoU %.6f  instance mIoU %.6f  loss %.6f  (epoch %d)" % (
+        ret["best_acc"], ret["best_class_avg_miou"], ret["best_instance_avg_miou"], ret["best_chamfer_loss"], ret["best_epoch"]))
+    # the forward keywords the reference passes (testing.py:139): names only
+    kw_names = np.array(sorted(net.calls[0]))
+    save("eval_metrics", accuracy=ret["best_acc"], class_avg_iou=ret["best_class_avg_miou"],
+         instance_avg_iou=ret["best_instance_avg_miou"], chamfer_loss=ret["best_chamfer_loss"], best_epoch=ret["best_epoch"],
+         category_names=np.array(names), category_iou=np.array([float(cat_iou[n]) for n in names]), forward_kwargs=kw_names,
+         n_batches=len(net.calls))
 
 
 if __name__ == "__main__":

@@ -1089,3 +1089,29 @@ def eval_metrics_loops(batches, num_part=50):
     return {'accuracy': total_correct / float(total_seen), 'class_avg_accuracy': class_acc,
             'class_avg_iou': np.mean([v for v in per_cat.values() if not np.isnan(v)]),
             'instance_avg_iou': np.mean(all_ious), 'category_iou': per_cat}
+
+
+class StubSegClassifier(torch.nn.Module):
+    """TEST INFRASTRUCTURE: a segmentation "network" with the call surface testing.py:139 needs --
+    `classifier(points [B,C,N], one_hot_label [B,1,16], **kwargs) -> (seg_pred [B,N,50], _, feat [B,C',N], _, chamfer_loss)`
+    -- whose logits are a fixed function of its inputs, always evaluated on the CPU in float64 (the same bits wherever the
+    caller's tensors live).  Used by oracle/make_golden.py under the REFERENCE's `evaluation` and by the tests under
+    prifit_amd.testing.evaluation: same points in, same logits out, so the metrics must agree."""
+
+    def __init__(self, num_part=50, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.register_buffer("Wp", torch.randn(3, num_part, generator=g, dtype=torch.float64))
+        self.register_buffer("Wc", torch.randn(16, num_part, generator=g, dtype=torch.float64) * 0.5)
+        self.dummy = torch.nn.Parameter(torch.zeros(1))      # (evaluate_loader takes the device from the first parameter)
+        self.calls = []
+
+    def forward(self, points, cls_label, **kwargs):
+        self.calls.append(dict(kwargs))
+        dev = points.device
+        xyz = points.detach().cpu().double().transpose(1, 2)[:, :, :3]                     # [B,N,3]
+        logits = torch.sin(3.0 * xyz) @ self.Wp.cpu() + cls_label.detach().cpu().double().reshape(xyz.shape[0], 1, -1) @ self.Wc.cpu()
+        seg = logits.float().to(dev)
+        feat = torch.zeros(points.shape[0], 4, points.shape[2], device=dev)
+        cham = torch.full((points.shape[0],), 0.25, device=dev) + 0.01 * float(len(self.calls))
+        return seg, None, feat, None, cham

@@ -10,7 +10,9 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprifit_hip.so")
+# PRIFIT_LIB: another build of the same library (A/B measurements of kernel variants, tools/ab_libs.sh) -- the product
+# library in lib/ is never overwritten by a measurement
+LIB_PATH = os.environ.get("PRIFIT_LIB") or os.path.join(_HERE, "lib", "libprifit_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "prifit_hip.h")
 
 _P = ctypes.c_void_p

@@ -4,9 +4,12 @@ batched device ops, plus readers for its two on-disk formats.
     pc_normalize(points)                      data_utils/ShapeNetDataLoader.py:17-22, batched [B,N,3+]
     resample(points, seg, npoints, gen)       :132-135 / :404-407  np.random.choice(len, npoints, replace=True)
     random_scale_shift(points)                provider.py:278-303 (lives in train_step.py, re-exported here)
-    PartNormalDataset / ACDSelfSupDataset     :24-140 / :265-412   same folder layout, split files and
-                                              __getitem__ contract (numpy out), so torch DataLoader code written
-                                              against the reference keeps working
+    PartNormalDataset / SelfSupPartNormalDataset / ACDSelfSupDataset
+                                              :24-140 / :149-262 / :265-412   same constructor arguments, folder layout,
+                                              split files and __getitem__ contract (numpy out, the reference's draws from
+                                              `np.random` / `random`), so the trainer's DataLoader code
+                                              (train_partseg_shapenet.py:170-213) keeps working; pinned against the
+                                              reference's own classes on a synthetic tree (tests/golden/data_readers.npz)
     DeviceBatcher                             takes the RAW clouds of a batch (ragged point counts) and does
                                               normalise + resample on the device in one go
 
@@ -14,7 +17,9 @@ The datasets only parse directories and read files (host work by nature); everyt
 runs on whatever device the tensors live on.
 """
 import json
+import math
 import os
+import random
 
 import numpy as np
 import torch
@@ -103,16 +108,28 @@ def _normalize_np(pc):
     return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
 
 
+def _few_shot(fns, k, rng):
+    """`random.sample(fns, k)` (ShapeNetDataLoader.py:77-79, :208-210): Python's `random` module, as upstream, unless the
+    caller passed a numpy generator."""
+    if rng is None:
+        return random.sample(fns, k)
+    return list(rng.choice(fns, k, replace=False))
+
+
 class PartNormalDataset(torch.utils.data.Dataset):
     """ShapeNet part annotation benchmark, `<synset>/<token>.txt` rows `x y z nx ny nz label`
-    (ShapeNetDataLoader.py:24-140).  raw=True returns the un-normalised, un-resampled arrays for DeviceBatcher."""
+    (ShapeNetDataLoader.py:24-140).  raw=True returns the un-normalised, un-resampled arrays for DeviceBatcher.
+    rng: a numpy Generator for the resampling / few-shot draws (default: the global `np.random` / `random` state, as
+    upstream).  `labeled_fns` (SelfSupPartNormalDataset): files left out by base name."""
 
-    def __init__(self, root, npoints=2500, split='train', class_choice=None, normal_channel=False, k_shot=-1,
-                 raw=False, rng=None):
-        self.npoints, self.root, self.normal_channel, self.raw = npoints, root, normal_channel, raw
+    def __init__(self, root='./data/shapenetcore_partanno_segmentation_benchmark_v0_normal', npoints=2500, split='train',
+                 class_choice=None, normal_channel=False, k_shot=-1, raw=False, rng=None, _labeled_fns=None):
+        self.npoints, self.root, self.normal_channel, self.raw, self.k_shot = npoints, root, normal_channel, raw, k_shot
+        self._rng = rng
         self.rng = rng if rng is not None else np.random
+        self.catfile = os.path.join(root, 'synsetoffset2category.txt')
         self.cat = {}
-        with open(os.path.join(root, 'synsetoffset2category.txt')) as f:
+        with open(self.catfile) as f:
             for line in f:
                 ls = line.strip().split()
                 if len(ls) >= 2:
@@ -127,16 +144,24 @@ class PartNormalDataset(torch.utils.data.Dataset):
 
         train_ids, val_ids, test_ids = (ids('shuffled_%s_file_list.json' % s) for s in ('train', 'val', 'test'))
         wanted = {'trainval': train_ids | val_ids, 'train': train_ids, 'val': val_ids, 'test': test_ids}
+        if _labeled_fns is None:
+            wanted['val2'] = test_ids          # a fixed fraction of the test files (:67-70), PartNormalDataset only
         if split not in wanted:
             raise ValueError('Unknown split: %s' % split)
+        labeled = set(os.path.basename(x) for x in (_labeled_fns or ()))
         self.datapath = []
         self.meta = {}      # {category: [paths]} -- the trainer builds the self-supervised exclude list from it
         for item in self.cat:
             dir_point = os.path.join(root, self.cat[item])
-            fns = [fn for fn in sorted(os.listdir(dir_point)) if fn[0:-4] in wanted[split]]
-            if k_shot > 0 and len(fns) > k_shot:
-                fns = list(self.rng.choice(fns, k_shot, replace=False))   # random few-shot subset (:77-79)
-            self.meta[item] = [os.path.join(dir_point, os.path.splitext(fn)[0] + '.txt') for fn in fns]
+            fns = [fn for fn in sorted(os.listdir(dir_point)) if fn not in labeled and fn[0:-4] in wanted[split]]
+            if split == 'val2':
+                fns = _few_shot(fns, round((len(fns) / 2874) * 1870), self._rng)
+            if _labeled_fns is None:
+                if k_shot > 0 and len(fns) > k_shot:
+                    fns = _few_shot(fns, k_shot, self._rng)     # random few-shot subset (:77-79)
+            elif k_shot > 0:
+                fns = _few_shot(fns, k_shot, self._rng)         # (:208-210: no length guard upstream -- raises when too few)
+            self.meta[item] = [os.path.join(dir_point, os.path.splitext(os.path.basename(fn))[0] + '.txt') for fn in fns]
             self.datapath += [(item, fn) for fn in self.meta[item]]
         self.classes = {k: self.classes_original[k] for k in self.cat}
         self.seg_classes = SEG_CLASSES
@@ -167,14 +192,32 @@ class PartNormalDataset(torch.utils.data.Dataset):
         return len(self.datapath)
 
 
+class SelfSupPartNormalDataset(PartNormalDataset):
+    """The "dummy" self-supervision set of the trainer (train_partseg_shapenet.py:199-203): the ShapeNet part files that are
+    NOT used as labeled data -- `labeled_fns` are left out by base name (ShapeNetDataLoader.py:149-262).  Same items as
+    PartNormalDataset: (points [npoints, C], cls [1], seg [npoints])."""
+
+    def __init__(self, root='./data/shapenetcore_partanno_segmentation_benchmark_v0_normal', npoints=2500, split='train',
+                 class_choice=None, normal_channel=False, k_shot=-1, labeled_fns=None, raw=False, rng=None):
+        if labeled_fns is None:
+            raise TypeError("SelfSupPartNormalDataset: labeled_fns (the labeled datasets' file list) is required")
+        super().__init__(root, npoints, split, class_choice, normal_channel, k_shot, raw=raw, rng=rng, _labeled_fns=list(labeled_fns))
+        self.labeled_files = set(os.path.basename(x) for x in labeled_fns)
+
+
 class ACDSelfSupDataset(torch.utils.data.Dataset):
     """Self-supervised clouds, `<root>/<subfolder>/<token>.npy`, rows `x y z ... label`
     (ShapeNetDataLoader.py:265-412).  Item: (points [npoints,C], chamfer_points [n,C] = the whole normalised
     cloud, cls [1], seg [npoints])."""
 
-    def __init__(self, root, npoints=2500, class_choice=None, normal_channel=False, k_shot=-1, exclude_fns=(),
-                 raw=False, rng=None):
+    def __init__(self, root='/srv/data2/mgadelha/ShapeNetACD/', npoints=2500, class_choice=None, normal_channel=False,
+                 k_shot=-1, exclude_fns=(), splits=None, use_val=False, prefetch=False, raw=False, rng=None):
+        """splits: unused upstream too.  use_val: keep a random 80 % of every sub-folder (:321-323).  prefetch: load, normalise
+        and resample every item once, here (:340-366); items are then the stored arrays.  Sub-folders and files are listed
+        in SORTED order (upstream takes `os.listdir` order, which is the file system's)."""
         self.npoints, self.root, self.normal_channel, self.raw = npoints, root, normal_channel, raw
+        self.k_shot, self.use_val, self.prefetch = k_shot, use_val, prefetch
+        self._rng = rng
         self.rng = rng if rng is not None else np.random
         subfolders = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
         self.classes_original = dict(zip(subfolders, range(len(subfolders))))
@@ -182,17 +225,23 @@ class ACDSelfSupDataset(torch.utils.data.Dataset):
         # overlap removal compares extension-less tokens: the trainer passes the labeled datasets' '.txt' paths
         # (train_partseg_shapenet.py:194-210) against '.npy' files here (ShapeNetDataLoader.py:305-311)
         exclude = set(os.path.splitext(os.path.basename(x))[0] for x in exclude_fns)
+        self.exclude_fns = [os.path.basename(x) for x in exclude_fns]
         self.datapath = []
         self.meta = {}
         for item in self.cat:
             fns = [fn for fn in sorted(os.listdir(os.path.join(root, item)))
                    if fn.endswith('.npy') and os.path.splitext(fn)[0] not in exclude]
-            if k_shot > 0 and len(fns) > k_shot:
-                fns = list(self.rng.choice(fns, k_shot, replace=False))
-            self.meta[item] = [os.path.join(root, item, fn) for fn in fns]
+            num = len(fns)
+            if k_shot > 0 and len(fns) > k_shot:     # (:316-318; upstream's branch stops at an undefined name in its print)
+                fns = _few_shot(fns, k_shot, self._rng)
+            if use_val:
+                fns = _few_shot(fns, math.floor(num * 0.8), self._rng)
+            self.meta[item] = [os.path.join(root, item, os.path.splitext(os.path.basename(fn))[0] + '.npy') for fn in fns]
             self.datapath += [(item, fn) for fn in self.meta[item]]
         self.classes = {k: self.classes_original[k] for k in self.cat}
         self.cache = {}
+        self.cache_size = len(self.datapath)
+        self._items = [self._item(i) for i in range(len(self.datapath))] if (prefetch and not raw) else None
 
     def _load(self, index):
         if index in self.cache:
@@ -205,14 +254,19 @@ class ACDSelfSupDataset(torch.utils.data.Dataset):
         self.cache[index] = (point_set, cls, seg)
         return point_set, cls, seg
 
-    def __getitem__(self, index):
+    def _item(self, index):
         point_set, cls, seg = self._load(index)
-        if self.raw:
-            return point_set, cls, seg
         point_set = point_set.copy()
         point_set[:, 0:3] = _normalize_np(point_set[:, 0:3])
         choice = self.rng.choice(len(seg), self.npoints, replace=True)
         return point_set[choice, :], point_set, cls, seg[choice]
+
+    def __getitem__(self, index):
+        if self.raw:
+            return self._load(index)
+        if self._items is not None:
+            return self._items[index]
+        return self._item(index)
 
     def __len__(self):
         return len(self.datapath)

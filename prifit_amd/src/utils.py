@@ -71,3 +71,31 @@ def analytic_chamfer_distance(ellipsoid_params_batch, source_points, target_poin
     if not per:
         return torch.zeros(1, requires_grad=True, device=dev)
     return torch.stack(per).mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Visualisation names of src/utils.py:51-81 (out of scope as features): the trainer and testing.py import
+# them by name (train_partseg_shapenet.py:6, testing.py:2, fitting.py:3,13), so they resolve here and do the file-less part of
+# their job: no open3d, nothing is drawn.
+# ---------------------------------------------------------------------------------------------------------------------
+def save_point_cloud(filename, data):
+    """src/utils.py:51-52: `np.savetxt(filename, data, delimiter=" ")`."""
+    import numpy as np
+    np.savetxt(filename, data.detach().cpu().numpy() if torch.is_tensor(data) else data, delimiter=" ")
+
+
+def visualize_point_cloud(points, normals=[], colors=[], file="", viz=False):   # noqa: B006 (the reference's signature)
+    """src/utils.py:55-72 builds an open3d point cloud, optionally draws and writes it.  Here: returns the arrays it was
+    given as a dict (nothing is drawn; `viz=True` raises -- there is no display path in this package)."""
+    if viz:
+        raise NotImplementedError("visualize_point_cloud(viz=True): visualisation is out of scope (no open3d on this path)")
+    return {"points": points, "normals": normals, "colors": colors}
+
+
+def visualize_point_cloud_from_labels(points, labels, COLORS=None, normals=None, viz=False):
+    """src/utils.py:75-81: colours the points by label and hands them to visualize_point_cloud."""
+    import numpy as np
+    lab = labels.detach().cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
+    if COLORS is None:
+        COLORS = np.random.rand(500, 3)
+    return visualize_point_cloud(points, colors=COLORS[lab.astype(np.int64)], normals=normals if normals is not None else [], viz=viz)

@@ -164,3 +164,73 @@ def part_embedding_offset(labels, D=128, seed=0, K=8, noise=0.03, scale=30.0):
     clusters are the parts, memberships are soft (noise 0.03), and the gradient still flows through head and backbone.
     labels int64 [B,N] -> float32 [B,N,D]."""
     return (scale * prototype_embedding(np.asarray(labels), D, seed + 2, K=K, noise=noise)).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Synthetic dataset TREES in the reference's two on-disk formats (data_utils/ShapeNetDataLoader.py:24-140, :265-412): the
+# same seeded files for oracle/make_golden.py (which runs the reference's dataset classes and evaluation on them) and for the
+# tests (which run prifit_amd/data.py and prifit_amd/testing.py on them and compare with the stored outputs).
+# ----------------------------------------------------------------------------------------------------------------------
+PARTSEG_CATEGORIES = [("Airplane", "02691156", [0, 1, 2, 3]), ("Bag", "02773838", [4, 5]), ("Cap", "02954340", [6, 7]),
+                      ("Car", "02958343", [8, 9, 10, 11]), ("Chair", "03001627", [12, 13, 14, 15]),
+                      ("Earphone", "03261776", [16, 17, 18]), ("Guitar", "03467517", [19, 20, 21]), ("Knife", "03624134", [22, 23]),
+                      ("Lamp", "03636649", [24, 25, 26, 27]), ("Laptop", "03642806", [28, 29]),
+                      ("Motorbike", "03790512", [30, 31, 32, 33, 34, 35]), ("Mug", "03797390", [36, 37]),
+                      ("Pistol", "03948459", [38, 39, 40]), ("Rocket", "04099429", [41, 42, 43]),
+                      ("Skateboard", "04225987", [44, 45, 46]), ("Table", "04379243", [47, 48, 49])]
+
+
+def write_partseg_tree(root, seed=0):
+    """ShapeNet part-annotation layout under `root`: synsetoffset2category.txt, train_test_split/shuffled_{train,val,test}
+    _file_list.json, <synset>/<token>.txt with rows `x y z nx ny nz label`.  All 16 categories (the reference's class-average
+    mIoU is nan unless every category has a test shape, testing.py:226-234), per category tokens t0 (train), t1 (val), t2 (test)
+    and for every third category t3 (test); 24..63 points per file, labels drawn from the category's parts (the first row's
+    label decides the category at evaluation time, testing.py:142).  Returns {token: array [n, 7] float64 as written}."""
+    import json
+    import os
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "train_test_split"), exist_ok=True)
+    with open(os.path.join(root, "synsetoffset2category.txt"), "w") as f:
+        for name, syn, _ in PARTSEG_CATEGORIES:
+            f.write("%s\t%s\n" % (name, syn))
+    split = {"train": [], "val": [], "test": []}
+    written = {}
+    for ci, (name, syn, parts) in enumerate(PARTSEG_CATEGORIES):
+        os.makedirs(os.path.join(root, syn), exist_ok=True)
+        toks = [("t0", "train"), ("t1", "val"), ("t2", "test")] + ([("t3", "test")] if ci % 3 == 0 else [])
+        for t, s in toks:
+            token = "%s_%s" % (name.lower(), t)
+            n = int(rng.integers(24, 64))
+            xyz = rng.normal(size=(n, 3)) * rng.uniform(0.5, 2.0, size=(1, 3)) + rng.uniform(-1.5, 1.5, size=(1, 3))
+            nrm = rng.normal(size=(n, 3))
+            nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            lab = rng.choice(parts, size=n).astype(np.float64)
+            arr = np.concatenate([xyz, nrm, lab[:, None]], 1)
+            np.savetxt(os.path.join(root, syn, token + ".txt"), arr)
+            written[token] = arr
+            split[s].append("shape_data/%s/%s" % (syn, token))
+    for s, names in split.items():
+        with open(os.path.join(root, "train_test_split", "shuffled_%s_file_list.json" % s), "w") as f:
+            json.dump(names, f)
+    return written
+
+
+def write_acd_tree(root, seed=0, overlap_tokens=()):
+    """Self-supervised layout under `root`: <sub-folder>/<token>.npy with rows `x y z label` (ACD component ids).  Two
+    sub-folders x three files, 40..79 points each, plus one file per `overlap_tokens` entry in the first sub-folder (tokens
+    of labeled shapes: the trainer's overlap removal must drop them, train_partseg_shapenet.py:190-210).
+    Returns {token: array [n, 4] float64}."""
+    import os
+    rng = np.random.default_rng(seed)
+    written = {}
+    for si, sub in enumerate(("acd_a", "acd_b")):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+        toks = ["%s_%d" % (sub, i) for i in range(3)] + (list(overlap_tokens) if si == 0 else [])
+        for token in toks:
+            n = int(rng.integers(40, 80))
+            xyz = rng.normal(size=(n, 3)) * rng.uniform(0.5, 2.0, size=(1, 3)) + rng.uniform(-1.0, 1.0, size=(1, 3))
+            lab = rng.integers(0, 9, size=n).astype(np.float64)
+            arr = np.concatenate([xyz, lab[:, None]], 1)
+            np.save(os.path.join(root, sub, token + ".npy"), arr)
+            written[token] = arr
+    return written

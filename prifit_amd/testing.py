@@ -5,12 +5,16 @@
     ev.update(seg_pred [B,N,50] logits, target [B,N])
     ev.compute() -> {'accuracy', 'class_avg_accuracy', 'class_avg_iou', 'instance_avg_iou', 'category_iou': {...}}
 
-    evaluation(model, loader, ...)                   # the loop of testing.py:110-137 around a model of this package
+    evaluation(args, epoch, classifier, metrics)     # testing.py:49, the reference's signature (train_partseg_shapenet.py:487)
+    evaluate_loader(model, loader, ...)              # the loop of testing.py:110-137 around a model and any iterable of batches
 
 Rules kept from the reference: the category of a shape is that of its first target label (:142); the prediction
 is the arg-max over that category's parts only (:143-144); a part absent from both prediction and target counts
 as IoU 1 (:203-204); a shape's IoU is the mean over its category's parts; class_avg_iou averages the per-category
 means, instance_avg_iou averages all shapes (:226-240)."""
+import importlib
+import os
+
 import numpy as np
 import torch
 
@@ -93,9 +97,55 @@ class SegmentationEvaluator:
                 'category_iou': per_cat}
 
 
+DATA_ROOT = 'ShapeSelfSup/dataset/shapenetcore_partanno_segmentation_benchmark_v0_normal'   # testing.py:72, relative to the cwd
+
+
+def evaluation(args, epoch=0, classifier=None, metrics={}, loader=None):   # noqa: B006 (the reference's signature)
+    """testing.py:49-249 under the reference's signature: `evaluation(args, epoch, classifier, metrics)` as the trainer calls
+    it after every epoch (train_partseg_shapenet.py:487), `evaluation(args)` as `python testing.py` does (:253-255).
+
+    args: the namespace of args_parser.py -- eval_split, npoint, normal, batch_size, num_classes, num_parts, category, seed and,
+    when `classifier` is None, model / pretrained_model (+ dgcnn_k, reconstruct) to build and load one (:96-110).  The test
+    split is read from DATA_ROOT below the current directory (:72-77) unless `loader` is given.  The forward keywords of
+    :139 (quantile, msc_iterations, max_num_clusters, alpha, beta, if_cuboid, embed, seed) are taken from `args` where present.
+    Returns `metrics` -- the running best, updated in place when the class-average mIoU did not fall (:241-247) -- like the
+    reference; the metrics of THIS evaluation are left in `evaluation.last`."""
+    from . import data as D
+    if getattr(args, "gpu", None) is not None:
+        os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu              # :55-56
+    if loader is None:
+        ds = D.PartNormalDataset(root=DATA_ROOT, npoints=args.npoint, split=args.eval_split, normal_channel=args.normal)
+        loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=0)
+        print("The number of test data is: %d" % len(ds))
+    if classifier is None:
+        if getattr(args, "pretrained_model", None) is None:
+            raise ValueError("evaluation(args): no classifier given and args.pretrained_model is not set")
+        MODEL = importlib.import_module(args.model)
+        if 'dgcnn' in args.model:
+            classifier = MODEL.get_model(args.num_parts, normal_channel=args.normal, k=args.dgcnn_k).cuda()
+        else:
+            classifier = MODEL.get_model(args.num_parts, normal_channel=args.normal).cuda()
+        ckpt = torch.load(args.pretrained_model, map_location="cuda")
+        state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt['model_state_dict'].items()}
+        classifier.load_state_dict(state)                        # (upstream wraps in DataParallel first: 'module.' keys)
+    fwd = {k: getattr(args, k) for k in ("quantile", "msc_iterations", "max_num_clusters", "alpha", "beta", "if_cuboid",
+                                          "embed", "seed") if hasattr(args, k)}
+    test_metrics = evaluate_loader(classifier, loader, num_classes=args.num_classes, num_part=args.num_parts,
+                                   category=bool(args.category), metrics=metrics if metrics != {} else None, epoch=epoch, **fwd)
+    evaluation.last = test_metrics
+    if metrics != {}:
+        print('Best test Accuracy: {:6f}, Best Epoch: {},  Best Class avg mIOU: {:6f}, Best Instance avg mIOU: {:6f}, Best Loss: {:6f}'
+              .format(metrics['best_acc'], metrics['best_epoch'], metrics['best_class_avg_miou'],
+                      metrics['best_instance_avg_miou'], metrics['best_chamfer_loss']))
+    print('%sAccuracy: %f  Class avg mIOU: %f   Instance avg mIOU: %f, Loss: %f' % (
+        ('Epoch %d test ' % (epoch + 1)) if metrics != {} else 'Test ', test_metrics['accuracy'], test_metrics['class_avg_iou'],
+        test_metrics['instance_avg_iou'], test_metrics['chamfer_loss']))
+    return metrics
+
+
 @torch.no_grad()
-def evaluation(classifier, loader, num_classes=16, num_part=50, category=True, device=None, metrics=None, epoch=0,
-               **forward_kwargs):
+def evaluate_loader(classifier, loader, num_classes=16, num_part=50, category=True, device=None, metrics=None, epoch=0,
+                    **forward_kwargs):
     """testing.py:110-249 for a model of this package: loader yields (points [B,N,C], label [B,1], target [B,N]).
     Returns the test metrics; if `metrics` (the running best, :241-247) is given it is updated in place."""
     device = device if device is not None else next(classifier.parameters()).device
@@ -107,11 +157,9 @@ def evaluation(classifier, loader, num_classes=16, num_part=50, category=True, d
         points = torch.as_tensor(points).float().to(device).transpose(2, 1).contiguous()
         label = torch.as_tensor(label).long().to(device)
         target = torch.as_tensor(target).long().to(device)
-        if category:
-            category_label = to_categorical(label, num_classes).contiguous()
-        else:
-            category_label = torch.zeros(label.shape[0], 1, num_classes, device=device)
-        out = classifier(points, category_label, include_convex_loss=False, evaluation=True, **forward_kwargs)
+        # (the reference passes the one-hot label whatever args.category says, :139: its `category_label` of :131-134 is
+        # computed and never used; `category` is kept in the signature for the same reason)
+        out = classifier(points, to_categorical(label, num_classes), include_convex_loss=False, evaluation=True, **forward_kwargs)
         seg_pred = out[0]
         if len(out) >= 5 and torch.is_tensor(out[4]):
             chamfer.append(float(out[4].float().mean()))
@@ -120,7 +168,7 @@ def evaluation(classifier, loader, num_classes=16, num_part=50, category=True, d
     test_metrics = ev.compute()
     test_metrics['chamfer_loss'] = float(np.mean(chamfer)) if chamfer else 0.0
     if metrics:
-        if metrics.get('best_class_avg_miou', -1.0) <= test_metrics['class_avg_iou']:
+        if metrics['best_class_avg_miou'] <= test_metrics['class_avg_iou']:
             metrics.update(best_chamfer_loss=test_metrics['chamfer_loss'], best_epoch=epoch + 1,
                            best_acc=test_metrics['accuracy'], best_class_avg_miou=test_metrics['class_avg_iou'],
                            best_instance_avg_miou=test_metrics['instance_avg_iou'])

@@ -1,5 +1,6 @@
 """A/B builds: python tools/build_variant.py NAME [-DFOO=1 ...] -> prifit_amd/lib/variants/NAME.so (own object directory).
-On the GPU box: cp prifit_amd/lib/variants/NAME.so prifit_amd/lib/libprifit_hip.so (tools/ab_libs.sh alternates two of them)."""
+On the GPU box: PRIFIT_LIB=$PWD/prifit_amd/lib/variants/NAME.so python bench.py ... (tools/ab_libs.sh alternates two of them; the
+product library is never overwritten)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

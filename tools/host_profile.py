@@ -13,7 +13,7 @@ import bench   # noqa: E402
 
 
 class A:
-    workload, graph, ms_split = "c3", False, "0"
+    workload, graph, ms_split = os.environ.get("HOSTPROF_WORKLOAD", "c3"), False, "0"
 
 
 ctx = {"world": 1, "rank": 0, "device": torch.device("cuda", 0), "use_dist": False}
@@ -29,7 +29,7 @@ def grab(step, path):
 
 bench.launch_census = grab
 os.environ["PRIFIT_BENCH_CENSUS"] = "x"
-bench.measure(A, ctx, "blobs", "untrained", 5, 5, full=False)
+bench.measure(A, ctx, "blobs", os.environ.get("HOSTPROF_EMBEDDING", "clustered"), 5, 5, full=False)
 step = steps[0]
 for _ in range(3):
     step()
