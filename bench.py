@@ -447,7 +447,12 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     net, M = build_model(device, args.workload)
     bucket = FlatGradBucket(net)
     bucket.broadcast_parameters(0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, fused=True)
+    flat_adam = os.environ.get("PRIFIT_FLAT_ADAM", "1") != "0"
+    if flat_adam:
+        from prifit_amd.optim import FlatAdam     # one launch per step (csrc/optim.hip); 0: torch's fused Adam (A/B)
+        opt = FlatAdam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, fused=True)
     data = make_inputs(args.workload, rank, device, cloud)
     crit = M.get_loss() if M is not None else None
     runner = SpeculativeRunner(net)
@@ -528,7 +533,10 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
             ar_events.append((a, b))
         else:
             bucket.allreduce()
-        opt.step()
+        if flat_adam:
+            opt.step(grads=bucket.grads())
+        else:
+            opt.step()
         return loss
 
     ar_events = None   # a list inside the timed region: the (pack + all-reduce + scale) span of every step, by HIP events
@@ -622,14 +630,21 @@ def _measure(args, ctx, cloud, embedding, steps, warmup, full):
     if full:
         # host time to ENQUEUE one step, measured outside the timed region from an empty queue (inside it the launch
         # thread runs ahead until the queue is full and then advances at the GPU's pace, which says nothing)
-        t_host = []
-        for _ in range(3):
+        # (c3 / c5: the host then BLOCKS until the GPU reaches the clustering verdict of this very step, ~8 ms in -- that wait is
+        # not enqueue work and is taken out: fit_ops.spec_wait_s; reported beside it)
+        from prifit_amd import fit_ops as _fo
+        t_host, t_wait = [], []
+        for _ in range(5):
             torch.cuda.synchronize()
+            w0 = _fo.spec_wait_s
             h0 = time.perf_counter()
             step()
-            t_host.append(time.perf_counter() - h0)
+            dt = time.perf_counter() - h0
+            t_wait.append(_fo.spec_wait_s - w0)
+            t_host.append(dt - t_wait[-1])
         torch.cuda.synchronize()
-        res["t_host"] = sorted(t_host)[1]
+        res["t_host"] = sorted(t_host)[2]
+        res["t_host_wait"] = sorted(t_wait)[2]
     else:
         # every kernel family bracketed on two more (untimed) steps: the fit-path rows of this condition
         profiler.reset()
@@ -825,6 +840,7 @@ def headline(args, ctx, r, cloud):
         "roofline": roof, "roofline_grouping": grouping, "kernels": detail, "roofline_model_violations": over,
         "speculation_fallbacks": r["fallbacks"],
         "host_enqueue_ms_per_step": 1e3 * r["t_host"],
+        "host_verdict_wait_ms_per_step": 1e3 * r.get("t_host_wait", 0.0),
     }
     return line
 

@@ -32,6 +32,36 @@ extern "C" {
 #define PRIFIT_EINVAL (-1)   /* bad argument (shape / alignment / unsupported size) */
 #define PRIFIT_ELAUNCH (-2)  /* hipGetLastError() != hipSuccess after the launch   */
 
+/* BatchNorm tails (round 6).  A kernel that produces the per-column sums of a BatchNorm layer can also FINALIZE them: pass one of
+ * these descriptors (host structs, read at launch) instead of a statistics-slab pointer and the launch leaves the layer's
+ * coefficients in `out` -- the separate prifit_bn_finalize / prifit_bn_bwd_finalize launch (and the slab) disappear.
+ *   acc     [prifit_bn_tail_replicas()][2][C] doubles, ZERO on entry (left zero);  ticket  one int32, ZERO on entry (left zero)
+ * prifit_bn_fwd: train-mode nn.BatchNorm of models/pointnet_util.py:195-197 / :250-252 / :310-313 -- out [4][C] = scale
+ *   (gamma * invstd), shift (beta - mean * scale), mean, invstd; running statistics updated with `momentum` (unbiased variance)
+ *   when the pointers are given; count = rows behind the sums.
+ * prifit_bn_bwd: its autograd -- out [5][C] = dgamma, dbeta and the coefficients (a, b, d) of dY = a Gm + b Y + d.
+ * A NULL descriptor (or acc == NULL) keeps the slab form of the entry point. */
+int prifit_bn_tail_replicas(void);
+
+typedef struct prifit_bn_fwd {
+    double *acc;
+    int32_t *ticket;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    float *out;
+    double count;
+    float eps, momentum;
+} prifit_bn_fwd;
+
+typedef struct prifit_bn_bwd {
+    double *acc;
+    int32_t *ticket;
+    const float *scale, *mean, *invstd;
+    float *out;
+    double count;
+    int training;
+} prifit_bn_bwd;
+
 /* Library identification: returns 10000*major + 100*minor + patch; *arch (may be NULL) receives a
  * static string naming the code object target ("gfx950"). */
 int prifit_version(const char **arch);
@@ -145,7 +175,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     const float *bias, long long bias_batch_stride, float *col_stats, int epilogue,
                     const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
                     long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
-                    void *stream);
+                    const prifit_bn_fwd *bn, void *stream);
 
 /* Chord-distance matrix of a point set with itself (src/mean_shift.py:154 bandwidth statistic, :185 non-maximum
  * suppression): C[z] = 2 - 2 A[z] A[z]^T for unit rows, [n, n] per batch item; n % 128 == 0, K % 32 == 0, 16-byte rows.
@@ -170,7 +200,7 @@ int prifit_gram_sym_f32(const float *A, long long lda, long long strideA, float 
  * only: 201 MB less written for that layer at B = 24 x 2048). */
 int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, const float *W, long long ldb, float *Y,
                          long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
-                         float *cand, void *stream);
+                         float *cand, const prifit_bn_fwd *bn, void *stream);
 int prifit_gemm_pool_supported(int M, int N, int K);
 
 /* Weights-stationary streaming variant for the tall-and-skinny (HBM-bound) layers of the shared MLPs: layout
@@ -180,7 +210,7 @@ int prifit_gemm_pool_supported(int M, int N, int K);
  * [prifit_gemm_stream_slabs(M,K)][2][N] or NULL receives one column (sum, sum of squares) slab per workgroup. */
 int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long long lda, const float *B,
                            long long ldb, float *C, long long ldc, const float *a_scale, const float *a_shift,
-                           const float *bias, float *col_stats, void *stream);
+                           const float *bias, float *col_stats, const prifit_bn_fwd *bn, void *stream);
 int prifit_gemm_stream_supported(int layout, int M, int N, int K);  /* 1 / 0 */
 int prifit_gemm_stream_slabs(int M, int K);                         /* workgroups = statistics slabs */
 
@@ -197,22 +227,7 @@ int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const
 int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
-                                void *stream);
-/* EXPERIMENT (round 5; not on the default path): the row-dense part of a max-pooled last layer's backward in
- * the algebraic form (models/pointnet_util.py:252-256 through autograd).  With dY = T [row == winner] + b Y + d and
- * Y = A W^T + bias, A = relu(bn(Yp)): dA = A M + 1 v^T + (winners' rows), dW = diag(b) W (A^T A) + ... -- two products over
- * Cin x Cin that read only Yp [P, Cin].  Gp [P, Cin] = A M + v; red_slab [slabs][2][Cin] = the (m1, m2) BatchNorm-backward sums
- * of the layer below from Gp; gram [Cin, Cin] = A^T A, asum [Cin] = 1^T A.  Cin in {64, 96, 128}; workspace: _workspace floats.
- * prifit_pool_alg_sparse_f32 (run AFTER the dense pass, same stream): the winners' rows -- Gp[winner row] += sum T_c W[c, :]
- * with their share of the (m1, m2) sums (red_slab [_sparse_slabs][2][Cin], to be handed to prifit_bn_bwd_finalize together
- * with the dense pass's slabs), and dWs [Cout, Cin] = S^T A.  arg / T [G, Cout]: winning row inside each group of K rows and
- * the pooled gradient there (prifit_pool_bwd_table).  (Cout, Cin) in {(128, 96), (128, 64), (256, 128), (64, 32)}. */
-int prifit_pool_alg_supported(long long P, int Cin);
-int prifit_pool_alg_slabs(long long P, int Cin);
-long long prifit_pool_alg_workspace(long long P, int Cin);
-int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
-                              const float *p_mean, const float *p_invstd, const float *M, long long ldm, const float *v, float *Gp,
-                              long long ldgp, float *red_slab, float *gram, float *asum, float *workspace, void *stream);
+                                const prifit_bn_bwd *bn, void *stream);
 /* The winners' terms of a layer max-pooled over the WHOLE cloud (src/dgcnn.py:194-197: x.max(dim=-1) behind conv + GroupNorm +
  * ReLU; one pooling group per sample, K rows, Cout winners), backward in the algebraic form (csrc/pool_alg.hip):
  *   dX[b, arg[b,c], :] += T[b,c] W[c, :]   (rows; channels in ascending order)      dX [Bs K, lddx], NULL: skipped
@@ -228,23 +243,6 @@ int prifit_global_pool_winners_f32(int Bs, int K, int Cout, int Cin, const int32
                                    long long ldw, const float *X, long long ldx, float *dX, long long lddx, float *dW,
                                    long long lddw, void *stream);
 
-/* Both in ONE pass (the default where it exists: Cout == 128, Cin in {64, 96}, K % 64 == 0): the winners' rows are added inside
- * the dense pass by one more wave (S tile in LDS from W in LDS; dWs accumulated in registers) -- Gp, red_slab [_slabs][2][Cin],
- * gram, asum and dWs [Cout, Cin] complete, no second pass over Gp or Yp.  workspace: _fused_workspace floats. */
-int prifit_pool_alg_fused_supported(long long P, int K, int Cout, int Cin);
-long long prifit_pool_alg_fused_workspace(long long P, int Cout, int Cin);
-int prifit_pool_alg_fused_f32(long long P, int K, int Cout, int Cin, const float *Yp, long long ldyp, const float *p_scale,
-                              const float *p_shift, const float *p_mean, const float *p_invstd, const float *M, long long ldm,
-                              const float *v, const int32_t *arg, const float *T, const float *W, float *Gp, long long ldgp,
-                              float *red_slab, float *gram, float *asum, float *dWs, float *workspace, void *stream);
-int prifit_pool_alg_sparse_supported(int G, int K, int Cout, int Cin);
-int prifit_pool_alg_sparse_slabs(int G);
-long long prifit_pool_alg_sparse_workspace(int G, int Cout, int Cin);
-int prifit_pool_alg_sparse_f32(int G, int K, int Cout, int Cin, const int32_t *arg, const float *T, const float *W,
-                               const float *Yp, long long ldyp, const float *p_scale, const float *p_shift, const float *p_mean,
-                               const float *p_invstd, float *Gp, long long ldgp, float *red_slab, float *dWs, float *workspace,
-                               void *stream);
-
 /* Rows that are never stored (round 4).  The first layer of a set-abstraction MLP written by linearity --
  * y1[row] = U[b, idx[row]] - Vc[b, s], U [B,N,64] per point (bias folded in), Vc [B,S,64] per centre, models/pointnet_util.py
  * :243-252 -- has ~10^6 rows of 256 bytes that its three consumers used to read back from HBM (0.6 GB written + 3 reads per
@@ -256,13 +254,13 @@ int prifit_pool_alg_sparse_f32(int G, int K, int Cout, int Cin, const int32_t *a
  * only); rows_per_centre % 64 == 0, M % (n_centres * rows_per_centre) == 0. */
 int prifit_gemm_stream_gather_f32(int M, int N, const int32_t *idx, const float *U, const float *Vc, int n_points, int n_centres,
                                   int rows_per_centre, const float *B, long long ldb, float *C, long long ldc,
-                                  const float *a_scale, const float *a_shift, const float *bias, float *col_stats, void *stream);
+                                  const float *a_scale, const float *a_shift, const float *bias, float *col_stats, const prifit_bn_fwd *bn, void *stream);
 int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, const float *Y, const float *scale,
                                       const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
                                       const float *W, long long ldw, const int32_t *idx, const float *U, const float *Vc,
                                       int n_points, int n_centres, int rows_per_centre, const float *p_scale,
                                       const float *p_shift, const float *p_mean, const float *p_invstd, float *Gp, long long ldgp,
-                                      float *red_slab, float *dW, long long lddw, float *workspace, void *stream);
+                                      float *red_slab, float *dW, long long lddw, float *workspace, const prifit_bn_bwd *bn, void *stream);
 /* Forward of a max-pooled last layer without re-reading it for the pool (models/pointnet_util.py:199,256):
  * prifit_gemm_stream_f32 (NT, prologue required, M % 32 == 0) that also emits, per 32-row block and column, the largest
  * and smallest stored C and the row of their first occurrence, cand [M/32][4][N]; once the BatchNorm affine (scale,
@@ -273,7 +271,7 @@ int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, con
  * Y when the layer's gradients come from its input (csrc/pool_alg.hip), so that the product need not store Y at all. */
 int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
                                 float *C, long long ldc, const float *a_scale, const float *a_shift, const float *bias,
-                                float *col_stats, float *cand, void *stream);
+                                float *col_stats, float *cand, const prifit_bn_fwd *bn, void *stream);
 int prifit_pool_from_candidates(const float *cand, const float *scale, const float *shift, int G, int K, int C,
                                 int rows_per_sample, float slope, float *out, long long ldo, int32_t *arg, float *ystar,
                                 void *stream);
@@ -286,7 +284,7 @@ int prifit_pool_from_candidates(const float *cand, const float *scale, const flo
 int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
                                  float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                  const float *shift, const float *mean, const float *invstd, float *red_slab,
-                                 void *stream);
+                                 const prifit_bn_bwd *bn, void *stream);
 
 /* The max-pooled LAST layer of a per-group MLP (models/pointnet_util.py:199,256), autograd without materialising
  * its dY: with (a, b, d) = prifit_bn_bwd_finalize's coefficients, dY[g,k,c] = T[g,c]*[k == arg[g,c]] + b[c]*Y[g,k,c] + d[c]
@@ -303,7 +301,7 @@ int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long 
                                       float *G, long long ldc, const float *bias_dW, const int32_t *pool_arg,
                                       const float *pool_T, const float *coef_b, int pool_K, const float *Yprev,
                                       long long ldy, const float *scale, const float *shift, const float *mean,
-                                      const float *invstd, float *red_slab, void *stream);
+                                      const float *invstd, float *red_slab, const prifit_bn_bwd *bn, void *stream);
 int prifit_gemm_stream_tn_pool_f32(int Mo, int No, long long P, const float *Y, long long ldy, const float *A,
                                    long long lda, float *out, long long ldo, const float *b_scale,
                                    const float *b_shift, const int32_t *pool_arg, const float *pool_T,
@@ -331,7 +329,7 @@ int prifit_gemm_stream_dgrad_bn_f32(int M, int N, int K, const float *Gin, const
                                     long long ldb, float *G, long long ldc, const float *scale_l, const float *shift_l,
                                     const float *coef_a, const float *coef_b, const float *coef_d, const float *Yprev,
                                     long long ldy, const float *scale, const float *shift, const float *mean,
-                                    const float *invstd, float *red_slab, void *stream);
+                                    const float *invstd, float *red_slab, const prifit_bn_bwd *bn, void *stream);
 int prifit_gemm_stream_tn_f32(int Mo, int No, long long P, const float *G, long long ldg, const float *A,
                               long long lda, float *out, long long ldo, const float *b_scale,
                               const float *b_shift, float *workspace, void *stream);
@@ -530,7 +528,7 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
                                const float *radius2, const int *nsample, const int *width, int mode,
                                const float *feat, int D, int feat_first, int feat_xyz, const float *const *W,
                                const float *const *U, const float *const *Vc, const float *const *bias,
-                               float *const *Y, float *const *slab, int32_t *const *idx, void *stream);
+                               float *const *Y, float *const *slab, int32_t *const *idx, const prifit_bn_fwd *const *bn, void *stream);
 /* Queries per statistics slab of the call above (the workgroup size it will pick for B shapes x S centres). */
 int prifit_sa_group_queries_per_slab(int B, int S);
 /* autograd of mode 0 w.r.t. the weight: partial [nblocks][C][D+3] (upstream column order) with
@@ -568,13 +566,13 @@ int prifit_sa_first_layer_dw_bn_gather(const float *G, const float *U, const flo
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy,
                               const float *scale, const float *shift, const float *mean,
                               const float *invstd, int P, int C, int rows_per_sample, float slope,
-                              float *slab, void *stream);
+                              float *slab, const prifit_bn_bwd *bn, void *stream);
 
 /* The same partials when the gradient gp [G, ldgp] arrives through the group max-pool. */
 int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long long ldy,
                            const int32_t *arg, const float *scale, const float *shift,
                            const float *mean, const float *invstd, int G, int K, int C,
-                           int rows_per_sample, float slope, float *slab, void *stream);
+                           int rows_per_sample, float slope, float *slab, const prifit_bn_bwd *bn, void *stream);
 
 /* m1, m2 -> dgamma, dbeta and the per-channel coefficients of dY = a*(G*mask) + b*Y + d
  * (training != 0: batch-stat BatchNorm backward; training == 0: running-stat affine). */
@@ -669,7 +667,7 @@ int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, c
                                const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
                                const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
                                const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
-                               float *dW, long long lddw, float *workspace, void *stream);
+                               float *dW, long long lddw, float *workspace, const prifit_bn_bwd *bn, void *stream);
 
 /* Row-sparse backward of `iterations` mean-shift updates, for a loss that reads the shifted points through
  * `center = new_X[indices]` only (src/mean_shift.py:44-46; autograd of :61-82).  Row i of an iterate depends on row i of
@@ -901,6 +899,18 @@ int prifit_comm_unique_id(void *out);
 int prifit_comm_init(void **comm, int nranks, int rank, const void *unique_id);
 int prifit_allreduce_flat(float *buf, long long count, void *comm, void *stream);
 int prifit_comm_destroy(void *comm);
+
+/* Adam over the whole parameter set in one launch: train_partseg_shapenet.py:252-259 (torch.optim.Adam(lr, betas=(0.9, 0.999),
+ * eps=1e-08, weight_decay)) and `optimizer.step()` at :398 / :451.  params / exp_avg / exp_avg_sq: three flat fp32 buffers of
+ * `total` floats with one layout -- parameter s at [offsets[s], offsets[s] + lengths[s]), offsets multiples of
+ * prifit_adam_flat_alignment() floats; grads [nparams] DEVICE array of device pointers, NULL = no gradient this step (the
+ * parameter is skipped: no decay, no step count, as torch does); step_in / step_out [nparams] the per-parameter step counts before
+ * / after (two different arrays: the caller alternates them); skip: optional device flag, non-zero = a no-op (discarded step).
+ * Arithmetic of torch/optim/adam.py:_single_tensor_adam (L2 weight decay, lerp first moment, bias corrections in double). */
+int prifit_adam_flat_alignment(void);
+int prifit_adam_flat(float *params, float *exp_avg, float *exp_avg_sq, const float *const *grads, const int32_t *offsets,
+                     const int32_t *lengths, int nparams, long long total, const int32_t *step_in, int32_t *step_out, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, const int32_t *skip, void *stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ SOURCES = {
     "meanshift_split.hip": [],
     "fit.hip": [],
     "fit_glue.hip": [],
+    "optim.hip": [],
     "edge_conv.hip": [],
     "dgcnn.hip": ["-ffp-contract=off"],
     "comm.hip": [],        # host-only: the RCCL export (RCCL itself is resolved with dlopen at run time)

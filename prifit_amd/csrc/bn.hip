@@ -15,9 +15,10 @@ __device__ __forceinline__ void st4g(float *p, float4 v) { *reinterpret_cast<flo
 constexpr int POOL_RED_ROWS = 16;  // groups per workgroup in the pooled-layer reduction (only G = P/K rows: keep the grid wide)
 
 template <int ROWS = RED_ROWS, typename F>
-__device__ __forceinline__ void column_reduce(int P, int C, float *__restrict__ slab, F f)
+__device__ __forceinline__ void column_reduce(int P, int C, float *__restrict__ slab, F f, const BnTail &tail = BnTail{})
 {
     __shared__ float4 s_red[2][256];
+    __shared__ int s_tail;
     const int C4 = C >> 2;
     const int r_begin = blockIdx.x * ROWS, r_end = min(P, r_begin + ROWS);
     for (int cbase = 0; cbase < C4; cbase += 256) {
@@ -37,11 +38,19 @@ __device__ __forceinline__ void column_reduce(int P, int C, float *__restrict__ 
                 t0.x += u0.x; t0.y += u0.y; t0.z += u0.z; t0.w += u0.w;
                 t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
             }
-            st4g(slab + ((size_t)blockIdx.x * 2 + 0) * C + 4 * c4, t0);
-            st4g(slab + ((size_t)blockIdx.x * 2 + 1) * C + 4 * c4, t1);
+            if (tail.acc) {   // the sums finalized by this launch (common.h) instead of one slab per workgroup
+                bn_tail_add(tail, 0, 4 * c4, t0.x); bn_tail_add(tail, 0, 4 * c4 + 1, t0.y);
+                bn_tail_add(tail, 0, 4 * c4 + 2, t0.z); bn_tail_add(tail, 0, 4 * c4 + 3, t0.w);
+                bn_tail_add(tail, 1, 4 * c4, t1.x); bn_tail_add(tail, 1, 4 * c4 + 1, t1.y);
+                bn_tail_add(tail, 1, 4 * c4 + 2, t1.z); bn_tail_add(tail, 1, 4 * c4 + 3, t1.w);
+            } else {
+                st4g(slab + ((size_t)blockIdx.x * 2 + 0) * C + 4 * c4, t0);
+                st4g(slab + ((size_t)blockIdx.x * 2 + 1) * C + 4 * c4, t1);
+            }
         }
         __syncthreads();
     }
+    if (tail.acc) bn_tail_finish(tail, &s_tail);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -71,20 +80,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
     if (threadIdx.x == 0) {
         s = s_s[0] + s_s[1] + s_s[2] + s_s[3];
         q = s_q[0] + s_q[1] + s_q[2] + s_q[3];
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
-        mean_o[c] = (float)mean;
-        invstd_o[c] = invstd;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
+        float o[4];
+        bn_fwd_coefs(s, q, count, gamma[c], beta[c], eps, momentum, running_mean ? running_mean + c : nullptr,
+                     running_var ? running_var + c : nullptr, o, 1);
+        scale[c] = o[0];
+        shift[c] = o[1];
+        mean_o[c] = o[2];
+        invstd_o[c] = o[3];
     }
 }
 
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float *__
                                                                  const float *__restrict__ shift,
                                                                  const float *__restrict__ mean,
                                                                  const float *__restrict__ invstd, int P, int C,
-                                                                 int rps, float slope, float *__restrict__ slab)
+                                                                 int rps, float slope, float *__restrict__ slab, const BnTail tail)
 {
     column_reduce(P, C, slab, [&](int r, int c4, float4 &a0, float4 &a1) {
         const int c = 4 * c4;
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const float *__
         a0.x += gx; a0.y += gy; a0.z += gz; a0.w += gw;
         a1.x += gx * ((y.x - mu.x) * is.x); a1.y += gy * ((y.y - mu.y) * is.y);
         a1.z += gz * ((y.z - mu.z) * is.z); a1.w += gw * ((y.w - mu.w) * is.w);
-    });
+    }, tail);
 }
 
 // Same partials when the gradient arrives through the group max-pool: only the winning sample of
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
                                                               const float *__restrict__ mean,
                                                               const float *__restrict__ invstd, int G, int K,
                                                               int C, int rps, float slope,
-                                                              float *__restrict__ slab)
+                                                              float *__restrict__ slab, const BnTail tail)
 {
     column_reduce<POOL_RED_ROWS>(G, C, slab, [&](int gi, int c4, float4 &a0, float4 &a1) {
         const int c = 4 * c4;
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float *__res
         a0.x += gx; a0.y += gy; a0.z += gz; a0.w += gw;
         a1.x += gx * ((yx - mu.x) * is.x); a1.y += gy * ((yy - mu.y) * is.y);
         a1.z += gz * ((yz - mu.z) * is.z); a1.w += gw * ((yw - mu.w) * is.w);
-    });
+    }, tail);
 }
 
 // m1, m2 -> dgamma = m2, dbeta = m1 and the coefficients of dY = a * Gmasked + b * Y + d:
@@ -693,18 +695,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     if (threadIdx.x == 0) {
         const double m1 = s_s[0] + s_s[1] + s_s[2] + s_s[3];
         const double m2 = s_q[0] + s_q[1] + s_q[2] + s_q[3];
-        dgamma[c] = (float)m2;
-        dbeta[c] = (float)m1;
-        const double a = (double)scale[c];  // gamma * invstd
-        ca[c] = (float)a;
-        if (training) {
-            const double is = (double)invstd[c], mu = (double)mean[c];
-            cb[c] = (float)(-a * is * m2 / count);
-            cd[c] = (float)(a * (-m1 / count + mu * is * m2 / count));
-        } else {
-            cb[c] = 0.f;
-            cd[c] = 0.f;
-        }
+        float o[5];
+        bn_bwd_coefs(m1, m2, count, training, scale[c], mean[c], invstd[c], o, 1);
+        dgamma[c] = o[0];
+        dbeta[c] = o[1];
+        ca[c] = o[2];
+        cb[c] = o[3];
+        cd[c] = o[4];
     }
 }
 
@@ -1097,29 +1094,34 @@ int prifit_gather_linear_bwd_bn(const float *G, const float *Y, const float *sca
     return prifit_check_launch();
 }
 
+int prifit_bn_tail_replicas(void) { return BN_TAIL_REPLICAS; }
+
 int prifit_bn_relu_bwd_reduce(const float *G, long long ldg, const float *Y, long long ldy, const float *scale,
                               const float *shift, const float *mean, const float *invstd, int P, int C,
-                              int rows_per_sample, float slope, float *slab, void *stream)
+                              int rows_per_sample, float slope, float *slab, const prifit_bn_bwd *bn, void *stream)
 {
-    if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || !scale || !shift || !mean || !invstd || !slab || P <= 0 ||
-        rows_per_sample < 0 || (rows_per_sample % RED_ROWS) != 0)
+    const bool tail = bn && bn->acc;
+    if (bad_mat(G, ldg, C) || bad_mat(Y, ldy, C) || !scale || !shift || !mean || !invstd || (!slab && !tail) || P <= 0 ||
+        rows_per_sample < 0 || (rows_per_sample % RED_ROWS) != 0 || bn_bwd_bad(bn) || (tail && rows_per_sample != 0))
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3((P + RED_ROWS - 1) / RED_ROWS), dim3(256), 0,
                        as_stream(stream), G, ldg, Y, ldy, scale, shift, mean, invstd, P, C, rows_per_sample, slope,
-                       slab);
+                       slab, bn_tail_bwd(bn, C));
     return prifit_check_launch();
 }
 
 int prifit_pool_bwd_reduce(const float *gp, long long ldgp, const float *Y, long long ldy, const int32_t *arg,
                            const float *scale, const float *shift, const float *mean, const float *invstd, int G,
-                           int K, int C, int rows_per_sample, float slope, float *slab, void *stream)
+                           int K, int C, int rows_per_sample, float slope, float *slab, const prifit_bn_bwd *bn, void *stream)
 {
-    if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || !arg || !scale || !shift || !mean || !invstd || !slab ||
-        G <= 0 || K <= 0 || rows_per_sample < 0 || (rows_per_sample % (K * POOL_RED_ROWS)) != 0)
+    const bool tail = bn && bn->acc;
+    if (bad_mat(gp, ldgp, C) || bad_mat(Y, ldy, C) || !arg || !scale || !shift || !mean || !invstd || (!slab && !tail) ||
+        G <= 0 || K <= 0 || rows_per_sample < 0 || (rows_per_sample % (K * POOL_RED_ROWS)) != 0 || bn_bwd_bad(bn) ||
+        (tail && rows_per_sample != 0))
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(pool_bwd_reduce_kernel, dim3((G + POOL_RED_ROWS - 1) / POOL_RED_ROWS), dim3(256), 0,
                        as_stream(stream), gp, ldgp, Y, ldy, arg, scale, shift, mean, invstd, G, K, C, rows_per_sample,
-                       slope, slab);
+                       slope, slab, bn_tail_bwd(bn, C));
     return prifit_check_launch();
 }
 

@@ -55,6 +55,7 @@ struct GemmArgs {
     int vecA, vecB;                  // 16-byte loads legal for the operand
     int ntiles;                      // gemm_pers_kernel: output tiles, walked with a grid stride
     float *cand;                     // gemm_pers_kernel<.., PMAX>: [M / 32][4][N] pool candidates
+    BnTail tail;                     // the column sums `stats` would receive, finalized by this launch instead (common.h)
 };
 
 #ifndef GEMM_W8
@@ -656,7 +657,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
             }
         }
     }
-    if (g.stats) {
+    const bool tail = g.tail.acc != nullptr;
+    if (g.stats || tail) {
         __syncthreads();  // LDS tiles are dead: reuse as [WAVES_M][2][BN]
         float *red = lds;
 #pragma unroll
@@ -674,8 +676,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < BM / WM; ++w) s += red[(w * 2 + which) * BN + c];
-            if (n0 + c < g.N) g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
+            if (n0 + c < g.N) {
+                if (tail) bn_tail_add(g.tail, which, n0 + c, s);
+                else g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
+            }
         }
+        if (tail) bn_tail_finish(g.tail, reinterpret_cast<int *>(lds));   // (its first barrier: `red` is read; lds[0] becomes the flag)
     }
 }
 
@@ -867,7 +873,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         PERS_STAMP(3);
-        if (g.stats) {
+        if (g.stats || g.tail.acc) {
             float *red = lds;   // both stages are dead: everybody passed the barrier that ended the k-loop
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
@@ -884,9 +890,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < BM / WM; ++w) s += red[(w * 2 + which) * BN + c];
-                if (n0 + c < g.N) g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
+                if (n0 + c < g.N) {
+                    if (g.tail.acc) bn_tail_add(g.tail, which, n0 + c, s);
+                    else g.stats[((long long)tile_m * 2 + which) * g.N + n0 + c] = s;
+                }
             }
-            if (has_next) __syncthreads();   // `red` is read before the next tile is staged over it
+            if (has_next || g.tail.acc) __syncthreads();   // `red` is read before the next tile is staged over it
         }
         PERS_STAMP(4);
         if (!has_next) break;
@@ -899,6 +908,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         ++st_tile;
 #endif
     }
+    if (g.tail.acc) bn_tail_finish(g.tail, reinterpret_cast<int *>(lds));   // (after the last tile's barrier: lds is free)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1112,7 +1122,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // the split-K kernel's cases: TN, one batch item, no epilogue / statistics / bias / A prologue, 16-byte rows, spans < 2 GiB
 static bool launch_tnsk(const GemmArgs &g, hipStream_t st)
 {
-    if (g.batch != 1 || g.a_scale || g.bias || g.stats || g.epi != EPI_NONE || g.a_rowsum || g.kswitch ||
+    if (g.batch != 1 || g.a_scale || g.bias || g.stats || g.tail.acc || g.epi != EPI_NONE || g.a_rowsum || g.kswitch ||
         !(g.vecA && g.vecB) || (g.M & 3) || (g.N & 3) || (g.splitk > 1 && !g.accumulate) || g.splitk > 65535)
         return false;
     const long long lim = 0x7ff00000LL;
@@ -1339,8 +1349,10 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
                     const float *b_scale, const float *b_shift, const float *bias, long long bias_batch_stride,
                     float *col_stats, int epilogue, const float *epi_batch_scalar, const float *epi_aux, long long ld_aux,
                     long long stride_aux, const float *epi_row_add, float *a_rowsum, int accumulate,
-                    void *stream)
+                    const prifit_bn_fwd *bn, void *stream)
 {
+    const bool has_tail = bn && bn->acc;
+    if (bn_fwd_bad(bn) || (has_tail && (batch != 1 || splitk != 1 || epilogue != EPI_NONE))) return PRIFIT_EINVAL;
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || splitk <= 0 || layout < 0 || layout > 2 ||
         (epilogue != 100 && (epilogue < 0 || epilogue > 3)) || (epilogue >= EPI_MSKERNEL && !epi_batch_scalar) ||
         (epilogue == EPI_MSBWD && !epi_aux) || (splitk > 1 && !accumulate) ||
@@ -1348,6 +1360,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
         (col_stats && (batch != 1 || splitk != 1)) || (epilogue != EPI_NONE && epilogue != 100 && splitk != 1) || (long long)batch * splitk > 65535)
         return PRIFIT_EINVAL;
     GemmArgs g;
+    g.tail = BnTail{};
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.batch = batch; g.splitk = splitk;
@@ -1357,6 +1370,7 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
     g.row_add = epi_row_add; g.a_rowsum = a_rowsum;
     g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr;
     g.dA2 = g.dB2 = 0; g.kswitch = 0;
+    g.tail = bn_tail_fwd(bn, N);
     if (a_rowsum && (layout == LAY_TN || splitk != 1)) return PRIFIT_EINVAL;
     return dispatch(g, layout, stream);
 }
@@ -1373,6 +1387,7 @@ int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const
     // the vector path needs both sources equally aligned
     if ((((uintptr_t)A1 ^ (uintptr_t)A2) | ((uintptr_t)B1 ^ (uintptr_t)B2)) & 15) return PRIFIT_EINVAL;
     GemmArgs g;
+    g.tail = BnTail{};
     g.A = A1; g.B = B1; g.C = C; g.M = M; g.N = N; g.K = K1 + K2;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.batch = batch; g.splitk = splitk;
@@ -1406,12 +1421,13 @@ int prifit_gemm_dual_nn_f32(int M, int N, int K1, int K2, const float *A1, const
 int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
                                 float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                 const float *shift, const float *mean, const float *invstd, float *red_slab,
-                                void *stream)
+                                const prifit_bn_bwd *bn, void *stream)
 {
-    if (!dY || !W || !G || !Yprev || !scale || !shift || !mean || !invstd || !red_slab || M <= 0 || N <= 0 || K <= 0 ||
+    if (!dY || !W || !G || !Yprev || !scale || !shift || !mean || !invstd || (!red_slab && !(bn && bn->acc)) || bn_bwd_bad(bn) || M <= 0 || N <= 0 || K <= 0 ||
         lda < K || ldb < N || ldc < N || ldy < N)
         return PRIFIT_EINVAL;
     GemmArgs g;
+    g.tail = BnTail{};
     g.A = dY; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = g.sB = g.sC = 0;
     g.batch = 1; g.splitk = 1;
@@ -1420,6 +1436,7 @@ int prifit_gemm_dgrad_bnred_f32(int M, int N, int K, const float *dY, long long 
     g.accumulate = 0; g.aux = Yprev; g.ldaux = ldy; g.sAux = 0; g.row_add = nullptr; g.a_rowsum = nullptr;
     g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.dA2 = g.dB2 = 0; g.kswitch = 0;
+    g.tail = bn_tail_bwd(bn, N);
     return dispatch(g, LAY_NN, stream);
 }
 
@@ -1468,6 +1485,7 @@ int prifit_gemm_pool_supported(int M, int N, int K)
 {
     if (M <= 0 || N <= 96 || K <= 0 || (M & 31)) return 0;
     GemmArgs g;
+    g.tail = BnTail{};
     static float dummy[4] __attribute__((aligned(16)));
     pool_gemm_args(g, M, N, K, dummy, K, dummy, K, dummy, N, dummy, dummy, nullptr, nullptr);
     return launch_persistent(g, LAY_NT, nullptr, nullptr, true) ? 1 : 0;
@@ -1475,13 +1493,16 @@ int prifit_gemm_pool_supported(int M, int N, int K)
 
 int prifit_gemm_pool_f32(int M, int N, int K, const float *A, long long lda, const float *W, long long ldb, float *Y,
                          long long ldc, const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
-                         float *cand, void *stream)
+                         float *cand, const prifit_bn_fwd *bn, void *stream)
 {
+    if (bn_fwd_bad(bn)) return PRIFIT_EINVAL;
     if (!A || !W || ((a_scale == nullptr) != (a_shift == nullptr)) || !cand || !prifit_gemm_pool_supported(M, N, K) ||
         lda < K || ldb < K || ldc < N)
         return PRIFIT_EINVAL;
     GemmArgs g;
+    g.tail = BnTail{};
     pool_gemm_args(g, M, N, K, A, lda, W, ldb, Y, ldc, a_scale, a_shift, bias, col_stats);
+    g.tail = bn_tail_fwd(bn, N);
     if (!launch_persistent(g, LAY_NT, as_stream(stream), cand)) return PRIFIT_EINVAL;
     return prifit_check_launch();
 }

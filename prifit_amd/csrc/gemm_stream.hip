@@ -58,6 +58,8 @@ struct StreamArgs {
     const float *bna_s, *bna_t, *bna_a, *bna_b, *bna_d;
     // GATH (forward, K = 64): A is not stored -- its rows are re-formed from (gs.idx, gs.U, gs.Vc), see GatherSrc
     GatherSrc gs;
+    // the column sums (forward statistics, or the RED sums) finalized by this launch instead of written as slabs (common.h)
+    BnTail tail;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     __shared__ __attribute__((aligned(16))) float s_a[2][SBM * LD];
     __shared__ __attribute__((aligned(16))) float s_aff[2][K];   // POOL: [0] = b
     __shared__ float s_red[WM][2][32 * WN];
+    __shared__ int s_tail;
     __shared__ __attribute__((aligned(16))) float s_bna[BNA ? 5 : 1][BNA ? K : 4];   // s, t, a, b, d
 
     // (readfirstlane: wm / wn are wave-uniform and the compiler has to know it, see gemm_stream_tn_kernel)
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
     }
     if (RED) { csum = m1; csq = m2; }
     float *slab_out = RED ? g.red_slab : g.stats;
-    if (slab_out) {
+    const bool tail = g.tail.acc != nullptr;
+    if (slab_out || tail) {
         csum += __shfl_xor(csum, 32, 64);
         csq += __shfl_xor(csq, 32, 64);
         if (lh == 0) { s_red[wm][0][32 * wn + li] = csum; s_red[wm][1][32 * wn + li] = csq; }
@@ -357,11 +361,13 @@ __global__ __launch_bounds__(256, (KG <= 8 ? ((RED || PMAX || POOL) ? 3 : 4) : (
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) s += s_red[w][which][c];
+            if (tail) { bn_tail_add(g.tail, which, c, s); continue; }
             slab_out[((long long)blockIdx.x * 2 + which) * g.N + c] = s;
             // the caller sums g.nslab slabs (prifit_gemm_stream_slabs); this variant may run on fewer workgroups
             for (int extra = blockIdx.x + gridDim.x; extra < g.nslab; extra += gridDim.x)
                 slab_out[((long long)extra * 2 + which) * g.N + c] = 0.f;
         }
+        if (tail) bn_tail_finish(g.tail, &s_tail);
     }
 }
 
@@ -676,18 +682,19 @@ void launch_aff(const StreamArgs &g_, int nslab, hipStream_t st)
     // the plain variant put the register-heavy ones through 1.33 - 1.5 rounds); the statistics slabs beyond it are zeroed
     StreamArgs g = g_;
     g.nslab = nslab;
-    const bool heavy = g.pool_arg || g.red_slab || g.cand || g.bna_G;
+    const bool red = g.red_slab || g.tail.kind == 2;
+    const bool heavy = g.pool_arg || red || g.cand || g.bna_G;
     const int occ = KG <= 8 ? (heavy ? 3 : 4) : (KG <= 12 ? (heavy ? 2 : 3) : 2);
     const int grid = nslab < 256 * occ ? nslab : 256 * occ;
-    if (!BKC && g.bna_G && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
+    if (!BKC && g.bna_G && red) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, st, g);
     else if (!BKC && g.pool_arg) {
         // (K = 96 pooled layers do not exist: a thread's rows of a tile would not share their four channels; launch_k refuses them)
         if constexpr (256 % (2 * KG) == 0) {
-            if (g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
+            if (red) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, true, false>), dim3(grid), dim3(256), 0, st, g);
             else hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, false, true, false>), dim3(grid), dim3(256), 0, st, g);
         }
     }
-    else if (!BKC && g.red_slab) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (!BKC && red) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, false, false, true, false, false>), dim3(grid), dim3(256), 0, st, g);
     else if (BKC && g.gs.idx) {
         if constexpr (KG == 8 && BKC) hipLaunchKernelGGL((gemm_stream_kernel<WN, KG, true, true, false, false, false, false, true>), dim3(grid), dim3(256), 0, st, g);
     }
@@ -808,9 +815,9 @@ static int stream_launch(StreamArgs &g, int layout, void *stream)
 int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long lda, const float *W, long long ldb,
                                  float *G, long long ldc, const float *Yprev, long long ldy, const float *scale,
                                  const float *shift, const float *mean, const float *invstd, float *red_slab,
-                                 void *stream)
+                                 const prifit_bn_bwd *bn, void *stream)
 {
-    if (!dY || !W || !G || !Yprev || !scale || !shift || !mean || !invstd || !red_slab ||
+    if (!dY || !W || !G || !Yprev || !scale || !shift || !mean || !invstd || (!red_slab && !(bn && bn->acc)) || bn_bwd_bad(bn) ||
         !prifit_gemm_stream_supported(1, M, N, K) || lda < K || ldc < N || ldb < N || ldy < N || (lda & 3) ||
         ((uintptr_t)dY & 15))
         return PRIFIT_EINVAL;
@@ -820,6 +827,7 @@ int prifit_gemm_stream_dgrad_f32(int M, int N, int K, const float *dY, long long
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
+    g.tail = bn_tail_bwd(bn, N);
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
     return stream_launch(g, 1, stream);
 }
@@ -828,10 +836,10 @@ int prifit_gemm_stream_dgrad_bn_f32(int M, int N, int K, const float *Gin, const
                                     long long ldb, float *G, long long ldc, const float *scale_l, const float *shift_l,
                                     const float *coef_a, const float *coef_b, const float *coef_d, const float *Yprev,
                                     long long ldy, const float *scale, const float *shift, const float *mean,
-                                    const float *invstd, float *red_slab, void *stream)
+                                    const float *invstd, float *red_slab, const prifit_bn_bwd *bn, void *stream)
 {
     if (!Gin || !Y || !W || !G || !scale_l || !shift_l || !coef_a || !coef_b || !coef_d || !Yprev || !scale || !shift ||
-        !mean || !invstd || !red_slab || !prifit_gemm_stream_supported(1, M, N, K) || lda < K || ldc < N || ldb < N ||
+        !mean || !invstd || (!red_slab && !(bn && bn->acc)) || bn_bwd_bad(bn) || !prifit_gemm_stream_supported(1, M, N, K) || lda < K || ldc < N || ldb < N ||
         ldy < N || (lda & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)Gin & 15))
         return PRIFIT_EINVAL;
     StreamArgs g;
@@ -840,6 +848,7 @@ int prifit_gemm_stream_dgrad_bn_f32(int M, int N, int K, const float *Gin, const
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = nullptr; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
+    g.tail = bn_tail_bwd(bn, N);
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr;
     g.bna_G = Gin; g.bna_s = scale_l; g.bna_t = shift_l; g.bna_a = coef_a; g.bna_b = coef_b; g.bna_d = coef_d;
     return stream_launch(g, 1, stream);
@@ -849,27 +858,30 @@ int prifit_gemm_stream_dgrad_pool_f32(int M, int N, int K, const float *Y, long 
                                       float *G, long long ldc, const float *bias_dW, const int32_t *pool_arg,
                                       const float *pool_T, const float *coef_b, int pool_K, const float *Yprev,
                                       long long ldy, const float *scale, const float *shift, const float *mean,
-                                      const float *invstd, float *red_slab, void *stream)
+                                      const float *invstd, float *red_slab, const prifit_bn_bwd *bn, void *stream)
 {
+    if (bn_bwd_bad(bn)) return PRIFIT_EINVAL;
     if (!Y || !W || !G || !pool_arg || !pool_T || !coef_b || !prifit_gemm_stream_supported(1, M, N, K) || lda < K ||
         ldc < N || ldb < N || (lda & 3) || ((uintptr_t)Y & 15) || pool_K < 64 || (pool_K & 63) || (M % pool_K) ||
         (((uintptr_t)pool_arg | (uintptr_t)pool_T) & 15))
         return PRIFIT_EINVAL;
-    if (red_slab && (!Yprev || !scale || !shift || !mean || !invstd || ldy < N)) return PRIFIT_EINVAL;
+    if ((red_slab || (bn && bn->acc)) && (!Yprev || !scale || !shift || !mean || !invstd || ldy < N)) return PRIFIT_EINVAL;
     StreamArgs g;
     g.gs.idx = nullptr;
     g.A = Y; g.B = W; g.C = G; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = nullptr; g.a_shift = nullptr; g.bias = bias_dW; g.stats = nullptr;
     g.red_Y = Yprev; g.ldry = ldy; g.red_scale = scale; g.red_shift = shift; g.red_mean = mean; g.red_invstd = invstd;
     g.red_slab = red_slab;
+    g.tail = bn_tail_bwd(bn, N);
     g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_b = coef_b; g.pool_K = pool_K; g.cand = nullptr; g.bna_G = nullptr;
     return stream_launch(g, 1, stream);
 }
 
 int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long long lda, const float *B,
                            long long ldb, float *C, long long ldc, const float *a_scale, const float *a_shift,
-                           const float *bias, float *col_stats, void *stream)
+                           const float *bias, float *col_stats, const prifit_bn_fwd *bn, void *stream)
 {
+    if (bn_fwd_bad(bn)) return PRIFIT_EINVAL;
     if (!A || !B || !C || !prifit_gemm_stream_supported(layout, M, N, K) || lda < K || ldc < N ||
         ((a_scale == nullptr) != (a_shift == nullptr)) || (lda & 3) || ((uintptr_t)A & 15) ||
         (layout == 0 && ((ldb & 3) || ((uintptr_t)B & 15) || ldb < K)) || (layout == 1 && ldb < N))
@@ -879,6 +891,7 @@ int prifit_gemm_stream_f32(int layout, int M, int N, int K, const float *A, long
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
+    g.tail = bn_tail_fwd(bn, N);
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
     return stream_launch(g, layout, stream);
 }
@@ -892,9 +905,11 @@ static bool gather_src_ok(const GatherSrc &gs, long long P, int C)
 
 int prifit_gemm_stream_gather_f32(int M, int N, const int32_t *idx, const float *U, const float *Vc, int n_points, int n_centres,
                                   int rows_per_centre, const float *B, long long ldb, float *C, long long ldc,
-                                  const float *a_scale, const float *a_shift, const float *bias, float *col_stats, void *stream)
+                                  const float *a_scale, const float *a_shift, const float *bias, float *col_stats,
+                                  const prifit_bn_fwd *bn, void *stream)
 {
     const int K = 64;
+    if (bn_fwd_bad(bn)) return PRIFIT_EINVAL;
     GatherSrc gs = {idx, U, Vc, n_points, n_centres, rows_per_centre, K, 0u};
     if (!B || !C || !a_scale || !a_shift || !prifit_gemm_stream_supported(0, M, N, K) || ldc < N || (ldb & 3) ||
         ((uintptr_t)B & 15) || ldb < K || !gather_src_ok(gs, M, K))
@@ -905,14 +920,16 @@ int prifit_gemm_stream_gather_f32(int M, int N, const int32_t *idx, const float 
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = nullptr; g.bna_G = nullptr;
+    g.tail = bn_tail_fwd(bn, N);
     g.gs = gs;
     return stream_launch(g, 0, stream);
 }
 
 int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long lda, const float *B, long long ldb,
                                 float *C, long long ldc, const float *a_scale, const float *a_shift, const float *bias,
-                                float *col_stats, float *cand, void *stream)
+                                float *col_stats, float *cand, const prifit_bn_fwd *bn, void *stream)
 {
+    if (bn_fwd_bad(bn)) return PRIFIT_EINVAL;
     if (!A || !B || !C || !cand || !a_scale || !a_shift || !prifit_gemm_stream_supported(0, M, N, K) || lda < K ||
         ldc < N || (lda & 3) || ((uintptr_t)A & 15) || (ldb & 3) || ((uintptr_t)B & 15) || ldb < K || (M & 31))
         return PRIFIT_EINVAL;
@@ -922,6 +939,7 @@ int prifit_gemm_stream_pool_f32(int M, int N, int K, const float *A, long long l
     g.a_scale = a_scale; g.a_shift = a_shift; g.bias = bias; g.stats = col_stats;
     g.red_Y = nullptr; g.ldry = 0; g.red_scale = g.red_shift = g.red_mean = g.red_invstd = nullptr; g.red_slab = nullptr;
     g.pool_arg = nullptr; g.pool_T = nullptr; g.pool_b = nullptr; g.pool_K = 0; g.cand = cand; g.bna_G = nullptr;
+    g.tail = bn_tail_fwd(bn, N);
     return stream_launch(g, 0, stream);
 }
 

@@ -43,6 +43,7 @@ struct BwdArgs {
     float *red_slab;                          // [grid][2][Cin]
     float *dw_part;                           // [grid][Cout][Cin]
     GatherSrc gs;                             // GATH: Yp is not stored, its rows are re-formed from (idx, U, Vc) -- common.h
+    BnTail tail;                              // the (m1, m2) sums finalized by this launch instead of written to red_slab (common.h)
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -76,6 +77,7 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
     __shared__ __attribute__((aligned(16))) float s_dy[2][SBM * LDY];
     __shared__ __attribute__((aligned(16))) float s_p[2][SBM * LDP];
     __shared__ __attribute__((aligned(16))) float s_co[5][COUT];   // s, t, a, b, d
+    __shared__ int s_tail;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
@@ -305,8 +307,13 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
         m1 += __shfl_xor(m1, 32, 64);
         m2 += __shfl_xor(m2, 32, 64);
         if (lh == 0) {
-            g.red_slab[((long long)blockIdx.x * 2 + 0) * CIN + col] = m1;
-            g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
+            if (g.tail.acc) {
+                bn_tail_add(g.tail, 0, col, m1);
+                bn_tail_add(g.tail, 1, col, m2);
+            } else {
+                g.red_slab[((long long)blockIdx.x * 2 + 0) * CIN + col] = m1;
+                g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
+            }
         }
     } else {
         // dW accumulators of this wave's blocks for the life of the workgroup; block id = (cout block) * NA + (cin block)
@@ -383,588 +390,7 @@ __global__ __launch_bounds__((64 * Roles<COUT, CIN>::NW), 1) void gemm_stream_bw
         if constexpr (R::NW > NA + 2) { if (wave == NA + 2) w_role(IC<R::wb0[NA + 2]>{}, IC<R::wcnt[NA + 2]>{}); }
         if constexpr (R::NW > NA + 3) { if (wave == NA + 3) w_role(IC<R::wb0[NA + 3]>{}, IC<R::wcnt[NA + 3]>{}); }
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5 (EXPERIMENT, measured in DESIGN 5.3): the DENSE part of a max-pooled last layer's backward in the algebraic form.
-// With dY = T [row == winner] + b Y + d and Y = A W^T + bias (A = relu(bn(Yp)), the layer's input):
-//     dA = A M + 1 v^T + (winners' rows)        M = W^T diag(b) W  [Cin, Cin],  v = W^T (d + b * bias)
-//     dW = diag(b) W (A^T A) + (d + b * bias) (1^T A) + (winners' rows)
-// so the row-dense work is two products over Cin x Cin -- A M and the Gram matrix A^T A (symmetric: blocks on and above the
-// diagonal) -- that read ONLY Yp; the pooled layer's own pre-activation Y is not needed at all.  This kernel is that pass:
-// the one-pass structure above with the "dY tile" := the activated copy of the Yp tile.  Gp = A M + v, the (m1, m2) sums of the
-// layer below from Gp (yhat re-formed from A where the mask is on: yhat = A e + f), the Gram blocks per workgroup.
-template <int CIN> struct AlgRoles;
-// wave -> list of Gram blocks (row block * NA + column block); A-waves first (one per 32 columns)
-template <> struct AlgRoles<96> { static constexpr int NW = 7; static constexpr int nblk[7] = {0, 0, 0, 3, 1, 1, 1};
-                                  static constexpr int blk[7][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 4, 8}, {1, 0, 0}, {2, 0, 0}, {5, 0, 0}}; };
-template <> struct AlgRoles<64> { static constexpr int NW = 4; static constexpr int nblk[4] = {0, 0, 2, 1};
-                                  static constexpr int blk[4][2] = {{0, 0}, {0, 0}, {0, 3}, {1, 0}}; };
-template <> struct AlgRoles<128> { static constexpr int NW = 8; static constexpr int nblk[8] = {0, 0, 0, 0, 3, 3, 2, 2};
-                                   static constexpr int blk[8][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 5, 10}, {15, 1, 2}, {3, 6, 0}, {7, 11, 0}}; };
-
-struct AlgArgs {
-    long long P;
-    const float *Yp; long long ldyp;          // [P, Cin]
-    const float *ps, *pt, *pmu, *pis;         // the layer below: scale, shift, mean, invstd [Cin]
-    const float *M; long long ldm;            // [Cin, Cin]
-    const float *v;                           // [Cin]
-    float *Gp; long long ldgp;                // [P, Cin]
-    float *red_slab;                          // [grid][2][Cin]
-    float *gram_part;                         // [grid][Cin][Cin] (blocks on and above the diagonal written)
-    float *asum_part;                         // [grid][Cin] column sums of A over the workgroup's rows
-};
-
-template <int CIN>
-__global__ __launch_bounds__((64 * AlgRoles<CIN>::NW), 1) void pool_alg_dense_kernel(const AlgArgs g)
-{
-    using R = AlgRoles<CIN>;
-    constexpr int NA = CIN / 32, NTH = 64 * R::NW;
-    constexpr int LDA = CIN + 4;
-    constexpr int KG = CIN / 8, P4 = CIN / 4, NP4 = SBM * P4, NVP = (NP4 + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) float s_a[2][SBM * LDA];
-    __shared__ __attribute__((aligned(16))) float s_co[2][CIN];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int li = lane & 31, lh = lane >> 5;
-    const bool a_wave = wave < NA;
-    const int wa = a_wave ? wave : 0;
-    for (int t = threadIdx.x; t < CIN; t += NTH) { s_co[0][t] = g.ps[t]; s_co[1][t] = g.pt[t]; }
-    const int tiles = (int)((g.P + SBM - 1) / SBM);
-    float4 stp[NVP];
-    int poff[NVP];
-#pragma unroll
-    for (int p = 0; p < NVP; ++p) {
-        const int id = threadIdx.x + NTH * p;
-        poff[p] = id < NP4 ? ((id / P4) * (int)g.ldyp + 4 * (id % P4)) * 4 : 0x7fffffff;
-    }
-    auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
-        const long long left = g.P - m0;
-        const int rows = left < SBM ? (int)left : SBM;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0, ((rows - 1) * (int)ld + width) * 4, 0x00020000);
-    };
-    auto load_tile = [&](int tile) {
-        const __amdgpu_buffer_rsrc_t rp = tile_rsrc(g.Yp, g.ldyp, tile * SBM, CIN);
-#pragma unroll
-        for (int p = 0; p < NVP; ++p) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, poff[p], 0, 0));
-            stp[p] = make_float4(v.x, v.y, v.z, v.w);
-        }
-    };
-    auto store_tile = [&](int tile, int buf) {
-        const int m0 = tile * SBM;
-        const bool full = (long long)m0 + SBM <= g.P;
-#pragma unroll
-        for (int p = 0; p < NVP; ++p) {
-            const int id = threadIdx.x + NTH * p;
-            if (NVP * NTH != NP4 && id >= NP4) continue;
-            const int row = id / P4, c4 = id - row * P4;
-            const float4 cs = *reinterpret_cast<const float4 *>(&s_co[0][4 * c4]);
-            const float4 ct = *reinterpret_cast<const float4 *>(&s_co[1][4 * c4]);
-            float4 x = stp[p];
-            x.x = fmaxf(fmaf(x.x, cs.x, ct.x), 0.f); x.y = fmaxf(fmaf(x.y, cs.y, ct.y), 0.f);
-            x.z = fmaxf(fmaf(x.z, cs.z, ct.z), 0.f); x.w = fmaxf(fmaf(x.w, cs.w, ct.w), 0.f);
-            if (!full && (long long)m0 + row >= g.P) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(&s_a[buf][row * LDA + 4 * c4]) = x;
-        }
-    };
-    int tile = blockIdx.x;
-    if (tile >= tiles) tile = tiles - 1;
-    load_tile(tile);
-    __syncthreads();
-    store_tile(tile, 0);
-    __syncthreads();
-    if (a_wave) {
-        const int col = 32 * wa + li;
-        float4 bf[KG];
-#pragma unroll
-        for (int q = 0; q < KG; ++q) {
-            const int k0 = 8 * q + 4 * lh;
-            bf[q] = make_float4(g.M[(long long)k0 * g.ldm + col], g.M[(long long)(k0 + 1) * g.ldm + col],
-                                g.M[(long long)(k0 + 2) * g.ldm + col], g.M[(long long)(k0 + 3) * g.ldm + col]);
-        }
-        // yhat of the layer below from its activation where the mask is on: y = (A - t) / s  ->  yhat = A e + f
-        const float rs = g.ps[col], rt = g.pt[col];
-        const float inv_s = rs != 0.f ? 1.0f / rs : 0.f;
-        float r_e = inv_s * g.pis[col], r_f = (-rt * inv_s - g.pmu[col]) * g.pis[col], r_v = g.v[col];
-#pragma unroll
-        for (int q = 0; q < KG; ++q) asm volatile("" : "+v"(bf[q].x), "+v"(bf[q].y), "+v"(bf[q].z), "+v"(bf[q].w));
-        asm volatile("" : "+v"(r_e), "+v"(r_f), "+v"(r_v));
-        float m1 = 0.f, m2 = 0.f, sa = 0.f;
-        const int ldgp4 = (int)g.ldgp * 4;
-        const int c_voff = ((4 * lh) * (int)g.ldgp + col) * 4;
-        for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-            const int cur = it & 1;
-            const int next = tile + gridDim.x;
-            const int ntile = next < tiles ? next : tile;
-            load_tile(ntile);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-            const float *ap = &s_a[cur][li * LDA + 4 * lh];
-#pragma unroll
-            for (int q = 0; q < KG; ++q) {
-                float4 fa[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LDA + 8 * q);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, bf[q].y, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, bf[q].z, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, bf[q].w, acc[a], 0, 0, 0);
-                }
-            }
-            const __amdgpu_buffer_rsrc_t crs = tile_rsrc(g.Gp, g.ldgp, tile * SBM, CIN);
-            const float *yp = &s_a[cur][(4 * lh) * LDA + col];
-            const long long left = g.P - (long long)tile * SBM;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = 32 * a + (r & 3) + 8 * (r >> 2);
-                    const float v = acc[a][r] + r_v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, rl * ldgp4, 0);
-                    const float av = yp[rl * LDA];            // (rows beyond P hold zeros)
-                    const float gm = (av > 0.f && rl + 4 * lh < left) ? v : 0.f;
-                    m1 += gm;
-                    m2 += gm * fmaf(av, r_e, r_f);
-                    sa += av;
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            store_tile(ntile, cur ^ 1);
-            __syncthreads();
-        }
-        m1 += __shfl_xor(m1, 32, 64);
-        m2 += __shfl_xor(m2, 32, 64);
-        sa += __shfl_xor(sa, 32, 64);
-        if (lh == 0) {
-            g.red_slab[((long long)blockIdx.x * 2 + 0) * CIN + col] = m1;
-            g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
-            g.asum_part[(long long)blockIdx.x * CIN + col] = sa;
-        }
-    } else {
-        auto w_role = [&](auto wv) {
-            constexpr int WV = decltype(wv)::value, WCNT = R::nblk[WV];
-            f32x16 accw[WCNT];
-#pragma unroll
-            for (int i = 0; i < WCNT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
-            for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-                const int cur = it & 1;
-                const int next = tile + gridDim.x;
-                const int ntile = next < tiles ? next : tile;
-                load_tile(ntile);
-                __builtin_amdgcn_sched_barrier(0);
-                const float *base = &s_a[cur][lh * LDA + li];
-                constexpr int GS = WCNT >= 3 ? 2 : 4, NG = SBM / 2 / GS;
-                float av[2][GS][WCNT], pv[2][GS][WCNT];
-                auto fetch = [&](int buf, int grp) {
-#pragma unroll
-                    for (int u = 0; u < GS; ++u)
-#pragma unroll
-                        for (int i = 0; i < WCNT; ++i) {
-                            av[buf][u][i] = base[2 * (grp * GS + u) * LDA + 32 * (R::blk[WV][i] / NA)];
-                            pv[buf][u][i] = base[2 * (grp * GS + u) * LDA + 32 * (R::blk[WV][i] % NA)];
-                        }
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int grp = 0; grp < NG; ++grp) {
-                    if (grp + 1 < NG) fetch((grp + 1) & 1, grp + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < GS; ++u)
-#pragma unroll
-                        for (int i = 0; i < WCNT; ++i)
-                            accw[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[grp & 1][u][i], pv[grp & 1][u][i], accw[i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                store_tile(ntile, cur ^ 1);
-                __syncthreads();
-            }
-            float *dst = g.gram_part + (long long)blockIdx.x * CIN * CIN;
-#pragma unroll
-            for (int i = 0; i < WCNT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * (R::blk[WV][i] / NA) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    dst[row * CIN + 32 * (R::blk[WV][i] % NA) + li] = accw[i][r];
-                }
-        };
-        if constexpr (R::NW > NA + 0) { if (wave == NA + 0) w_role(IC<NA + 0>{}); }
-        if constexpr (R::NW > NA + 1) { if (wave == NA + 1) w_role(IC<NA + 1>{}); }
-        if constexpr (R::NW > NA + 2) { if (wave == NA + 2) w_role(IC<NA + 2>{}); }
-        if constexpr (R::NW > NA + 3) { if (wave == NA + 3) w_role(IC<NA + 3>{}); }
-    }
-}
-
-// The same pass with the winners' rows INSIDE it (the default for Cout = 128, Cin in {64, 96}).  The index work is dealt over
-// FOUR helper waves -- the Gram waves that own a single block (they idle two thirds of a tile beside the A-waves' 96 matrix
-// instructions) plus pure helper waves up to four:
-//   * S tile [64, Cin] of the NEXT tile in LDS: helper j owns the rows with (row & 3) == j -- it zeroes them and adds
-//     T_c W[c, :] (W sits in LDS) for every channel whose winning row is one of them: two winners per step, 32 lanes x float4
-//     each; rows have one owner and a wave's LDS accesses execute in order, so the read-modify-writes need no atomics.  The
-//     A-waves add S to their accumulators in the epilogue: Gp and the (m1, m2) sums come out complete.
-//   * dWs[c, :] += T_c A[winning row of c, :] from the activated tile in LDS, accumulated over the workgroup's tiles in
-//     registers: helper j, lane l = channel l + 64 (j & 1), column half j >> 1.
-// (A single S-wave doing all of it was the bottleneck: 1473 us against 542 for the dense pass alone at [1.57 M x 96].)
-// No second pass over Gp or Yp, no atomics, fixed orders.
-#ifndef PALG_PROBE
-#define PALG_PROBE 0      // timing-only diagnosis builds (wrong results): bit 0 no S-tile fill, bit 1 no dWs accumulation
-#endif
-struct AlgFusedArgs {
-    AlgArgs d;
-    const int32_t *arg;                       // [P / K, Cout]
-    const float *T;                           // [P / K, Cout]
-    const float *W;                           // [Cout, Cin]
-    int K;
-    float *dws_part;                          // [grid][Cout][Cin]
-};
-
-template <int CIN> struct FusedWaves { static constexpr int value = AlgRoles<CIN>::NW < CIN / 32 + 4 ? CIN / 32 + 4 : AlgRoles<CIN>::NW + 1; };
-template <> struct FusedWaves<96> { static constexpr int value = 8; };     // A A A | G3 | G1 G1 G1 | H      helpers: waves 4..7
-template <> struct FusedWaves<64> { static constexpr int value = 6; };     // A A | G2 G1 | H H              helpers: waves 2..5
-
-template <int CIN, int COUT>
-__global__ __launch_bounds__((64 * FusedWaves<CIN>::value), 1) void pool_alg_fused_kernel(const AlgFusedArgs ga)
-{
-    using R = AlgRoles<CIN>;
-    const AlgArgs &g = ga.d;
-    constexpr int NA = CIN / 32, NWD = R::NW, NWT = FusedWaves<CIN>::value, NTH = 64 * NWT, H0 = NWT - 4;
-    constexpr int LDA = CIN + 4;
-    constexpr int KG = CIN / 8, P4 = CIN / 4, NP4 = SBM * P4, NVP = (NP4 + NTH - 1) / NTH;
-    constexpr int CPL = COUT / 64;            // channel chunks of 64
-    constexpr int HC = CIN / 2, HC4 = HC / 4; // columns per helper lane in the dWs role
-    static_assert(P4 <= 32 && COUT == 128 && H0 >= NA && HC % 4 == 0, "helper layout");
-    __shared__ __attribute__((aligned(16))) float s_a[2][SBM * LDA];
-    __shared__ __attribute__((aligned(16))) float s_s[2][SBM * LDA];
-    __shared__ __attribute__((aligned(16))) float s_w[COUT * CIN];
-    __shared__ __attribute__((aligned(16))) float s_co[2][CIN];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int li = lane & 31, lh = lane >> 5;
-    const bool a_wave = wave < NA;
-    const int wa = a_wave ? wave : 0;
-    const int hj = wave - H0;                 // helper index (0..3) or negative
-    for (int t = threadIdx.x; t < CIN; t += NTH) { s_co[0][t] = g.ps[t]; s_co[1][t] = g.pt[t]; }
-    for (int t = threadIdx.x; t < COUT * CIN / 4; t += NTH) reinterpret_cast<float4 *>(s_w)[t] = reinterpret_cast<const float4 *>(ga.W)[t];
-    const int tiles = (int)((g.P + SBM - 1) / SBM);
-    float4 stp[NVP];
-    int poff[NVP];
-#pragma unroll
-    for (int p = 0; p < NVP; ++p) {
-        const int id = threadIdx.x + NTH * p;
-        poff[p] = id < NP4 ? ((id / P4) * (int)g.ldyp + 4 * (id % P4)) * 4 : 0x7fffffff;
-    }
-    auto tile_rsrc = [&](const float *base, long long ld, int m0, int width) {
-        const long long left = g.P - m0;
-        const int rows = left < SBM ? (int)left : SBM;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)m0 * ld), 0, ((rows - 1) * (int)ld + width) * 4, 0x00020000);
-    };
-    auto load_tile = [&](int tile) {
-        const __amdgpu_buffer_rsrc_t rp = tile_rsrc(g.Yp, g.ldyp, tile * SBM, CIN);
-#pragma unroll
-        for (int p = 0; p < NVP; ++p) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, poff[p], 0, 0));
-            stp[p] = make_float4(v.x, v.y, v.z, v.w);
-        }
-    };
-    auto store_tile = [&](int tile, int buf) {
-        const int m0 = tile * SBM;
-        const bool full = (long long)m0 + SBM <= g.P;
-#pragma unroll
-        for (int p = 0; p < NVP; ++p) {
-            const int id = threadIdx.x + NTH * p;
-            if (NVP * NTH != NP4 && id >= NP4) continue;
-            const int row = id / P4, c4 = id - row * P4;
-            const float4 cs = *reinterpret_cast<const float4 *>(&s_co[0][4 * c4]);
-            const float4 ct = *reinterpret_cast<const float4 *>(&s_co[1][4 * c4]);
-            float4 x = stp[p];
-            x.x = fmaxf(fmaf(x.x, cs.x, ct.x), 0.f); x.y = fmaxf(fmaf(x.y, cs.y, ct.y), 0.f);
-            x.z = fmaxf(fmaf(x.z, cs.z, ct.z), 0.f); x.w = fmaxf(fmaf(x.w, cs.w, ct.w), 0.f);
-            if (!full && (long long)m0 + row >= g.P) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(&s_a[buf][row * LDA + 4 * c4]) = x;
-        }
-    };
-    // ---- helper-wave pieces: lane l looks at channels l and l + 64 of the tile's pooling group
-    auto load_group = [&](int tile, int (&aa)[CPL], float (&tt)[CPL]) {
-        const size_t go = (size_t)(((long long)tile * SBM) / ga.K) * COUT;
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) { aa[i] = ga.arg[go + lane + 64 * i]; tt[i] = ga.T[go + lane + 64 * i]; }
-    };
-    // rows with (row & 3) == j of the S tile `buf` for tile `tile`: two rows per step (one per half wave, 32 lanes x float4),
-    // each row's sum over the channels that won it formed in registers (ascending channel) and written ONCE -- no
-    // read-modify-write chain, and a row that collects many winners (sparse clouds: every padded slot of a ball is a copy of
-    // its first row, ties go to the first) costs one LDS read per winner
-    auto fill_rows = [&](int tile, int buf, int j, const int (&aa)[CPL], const float (&tt)[CPL]) {
-        float *S = s_s[buf];
-        const int half = lane >> 5, k4 = lane & 31;
-        const int r0 = (int)(((long long)tile * SBM) % ga.K);
-        int rr[CPL];
-#pragma unroll
-        for (int i = 0; i < CPL; ++i) rr[i] = (tt[i] != 0.f && (unsigned)(aa[i] - r0) < (unsigned)SBM) ? aa[i] - r0 : -1;
-        for (int step = 0; step < SBM / 8; ++step) {
-            const int rowA = 8 * step + j, rowB = rowA + 4;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < CPL; ++i) {
-                unsigned long long ma = __ballot(rr[i] == rowA), mb = __ballot(rr[i] == rowB);
-                while (ma | mb) {                                // (wave-uniform)
-                    const int ba = ma ? __builtin_ctzll(ma) : -1, bb = mb ? __builtin_ctzll(mb) : -1;
-                    if (ma) ma &= ma - 1ull;
-                    if (mb) mb &= mb - 1ull;
-                    const float ta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt[i]), ba < 0 ? 0 : ba));
-                    const float tb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tt[i]), bb < 0 ? 0 : bb));
-                    const int bs = half ? bb : ba;
-                    const float tv = bs < 0 ? 0.f : (half ? tb : ta);
-                    if (k4 < P4) {
-                        const float4 w = *reinterpret_cast<const float4 *>(&s_w[(64 * i + (bs < 0 ? 0 : bs)) * CIN + 4 * k4]);
-                        acc.x = fmaf(tv, w.x, acc.x); acc.y = fmaf(tv, w.y, acc.y); acc.z = fmaf(tv, w.z, acc.z); acc.w = fmaf(tv, w.w, acc.w);
-                    }
-                }
-            }
-            if (k4 < P4) *reinterpret_cast<float4 *>(&S[(half ? rowB : rowA) * LDA + 4 * k4]) = acc;
-        }
-    };
-    int tile = blockIdx.x;
-    if (tile >= tiles) tile = tiles - 1;
-    load_tile(tile);
-    __syncthreads();                                             // s_co, s_w visible
-    store_tile(tile, 0);
-    int a_cur[CPL];
-    float t_cur[CPL];
-    if (hj >= 0) {
-        load_group(tile, a_cur, t_cur);
-        fill_rows(tile, 0, hj, a_cur, t_cur);
-    }
-    __syncthreads();
-    if (a_wave) {
-        const int col = 32 * wa + li;
-        float4 bf[KG];
-#pragma unroll
-        for (int q = 0; q < KG; ++q) {
-            const int k0 = 8 * q + 4 * lh;
-            bf[q] = make_float4(g.M[(long long)k0 * g.ldm + col], g.M[(long long)(k0 + 1) * g.ldm + col],
-                                g.M[(long long)(k0 + 2) * g.ldm + col], g.M[(long long)(k0 + 3) * g.ldm + col]);
-        }
-        const float rs = g.ps[col], rt = g.pt[col];
-        const float inv_s = rs != 0.f ? 1.0f / rs : 0.f;
-        float r_e = inv_s * g.pis[col], r_f = (-rt * inv_s - g.pmu[col]) * g.pis[col], r_v = g.v[col];
-#pragma unroll
-        for (int q = 0; q < KG; ++q) asm volatile("" : "+v"(bf[q].x), "+v"(bf[q].y), "+v"(bf[q].z), "+v"(bf[q].w));
-        asm volatile("" : "+v"(r_e), "+v"(r_f), "+v"(r_v));
-        float m1 = 0.f, m2 = 0.f, sa = 0.f;
-        const int ldgp4 = (int)g.ldgp * 4;
-        const int c_voff = ((4 * lh) * (int)g.ldgp + col) * 4;
-        for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-            const int cur = it & 1;
-            const int next = tile + gridDim.x;
-            const int ntile = next < tiles ? next : tile;
-            load_tile(ntile);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-            const float *ap = &s_a[cur][li * LDA + 4 * lh];
-#pragma unroll
-            for (int q = 0; q < KG; ++q) {
-                float4 fa[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) fa[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LDA + 8 * q);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, bf[q].x, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, bf[q].y, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, bf[q].z, acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, bf[q].w, acc[a], 0, 0, 0);
-                }
-            }
-            const __amdgpu_buffer_rsrc_t crs = tile_rsrc(g.Gp, g.ldgp, tile * SBM, CIN);
-            const float *yp = &s_a[cur][(4 * lh) * LDA + col];
-            const float *sp = &s_s[cur][(4 * lh) * LDA + col];
-            const long long left = g.P - (long long)tile * SBM;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = 32 * a + (r & 3) + 8 * (r >> 2);
-                    const float v = (acc[a][r] + r_v) + sp[rl * LDA];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), crs, c_voff, rl * ldgp4, 0);
-                    const float av = yp[rl * LDA];
-                    const float gm = (av > 0.f && rl + 4 * lh < left) ? v : 0.f;
-                    m1 += gm;
-                    m2 += gm * fmaf(av, r_e, r_f);
-                    sa += av;
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            store_tile(ntile, cur ^ 1);
-            __syncthreads();
-        }
-        m1 += __shfl_xor(m1, 32, 64);
-        m2 += __shfl_xor(m2, 32, 64);
-        sa += __shfl_xor(sa, 32, 64);
-        if (lh == 0) {
-            g.red_slab[((long long)blockIdx.x * 2 + 0) * CIN + col] = m1;
-            g.red_slab[((long long)blockIdx.x * 2 + 1) * CIN + col] = m2;
-            g.asum_part[(long long)blockIdx.x * CIN + col] = sa;
-        }
-    } else {
-        // Gram blocks of this wave (none for a pure helper wave) and, for the last four waves, the helper pieces
-        auto w_role = [&](auto wv) {
-            constexpr int WV = decltype(wv)::value;
-            constexpr int WCNT = WV < NWD ? R::nblk[WV < NWD ? WV : 0] : 0, WA = WCNT > 0 ? WCNT : 1;
-            constexpr bool HELP = WV >= H0;
-            f32x16 accw[WA];
-#pragma unroll
-            for (int i = 0; i < WA; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
-            float4 dws[HELP ? HC4 : 1];
-#pragma unroll
-            for (int k = 0; k < (HELP ? HC4 : 1); ++k) dws[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int hch = hj & 1, hcol = (hj >> 1) * HC;       // this helper lane: channel lane + 64 hch, columns hcol ..
-            for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-                const int cur = it & 1;
-                const int next = tile + gridDim.x;
-                const int ntile = next < tiles ? next : tile;
-                load_tile(ntile);
-                int a_nxt[CPL];
-                float t_nxt[CPL];
-                if (HELP) load_group(ntile, a_nxt, t_nxt);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (WCNT > 0) {
-                    const float *base = &s_a[cur][lh * LDA + li];
-                    constexpr int GS = WCNT >= 3 ? 2 : 4, NG = SBM / 2 / GS;
-                    float av[2][GS][WA], pv[2][GS][WA];
-                    auto fetch = [&](int buf, int grp) {
-#pragma unroll
-                        for (int u = 0; u < GS; ++u)
-#pragma unroll
-                            for (int i = 0; i < WCNT; ++i) {
-                                av[buf][u][i] = base[2 * (grp * GS + u) * LDA + 32 * (R::blk[WV < NWD ? WV : 0][i] / NA)];
-                                pv[buf][u][i] = base[2 * (grp * GS + u) * LDA + 32 * (R::blk[WV < NWD ? WV : 0][i] % NA)];
-                            }
-                    };
-                    fetch(0, 0);
-#pragma unroll
-                    for (int grp = 0; grp < NG; ++grp) {
-                        if (grp + 1 < NG) fetch((grp + 1) & 1, grp + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < GS; ++u)
-#pragma unroll
-                            for (int i = 0; i < WCNT; ++i)
-                                accw[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[grp & 1][u][i], pv[grp & 1][u][i], accw[i], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if constexpr (HELP) {
-                    // dWs[c, hcol ..] += T_c A[winning row, hcol ..] where channel c's winner sits in the current tile
-                    const int r0 = (int)(((long long)tile * SBM) % ga.K);
-                    const int ac = hch ? a_cur[CPL - 1] : a_cur[0];
-                    const float tc = hch ? t_cur[CPL - 1] : t_cur[0];
-                    const bool hit = tc != 0.f && (unsigned)(ac - r0) < (unsigned)SBM;
-                    if (__ballot(hit) != 0ull && !(PALG_PROBE & 2)) {                 // (wave-uniform)
-                        const float tv = hit ? tc : 0.f;
-                        const float *src = &s_a[cur][(hit ? ac - r0 : 0) * LDA + hcol];
-#pragma unroll
-                        for (int k = 0; k < HC4; ++k) {
-                            const float4 x = *reinterpret_cast<const float4 *>(src + 4 * k);
-                            dws[k].x = fmaf(tv, x.x, dws[k].x); dws[k].y = fmaf(tv, x.y, dws[k].y);
-                            dws[k].z = fmaf(tv, x.z, dws[k].z); dws[k].w = fmaf(tv, x.w, dws[k].w);
-                        }
-                    }
-                    // this helper's rows of the S tile of the next tile (the A-waves read the current one meanwhile)
-                    if (next < tiles && !(PALG_PROBE & 1)) fill_rows(ntile, cur ^ 1, hj, a_nxt, t_nxt);
-#pragma unroll
-                    for (int i = 0; i < CPL; ++i) { a_cur[i] = a_nxt[i]; t_cur[i] = t_nxt[i]; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                store_tile(ntile, cur ^ 1);
-                __syncthreads();
-            }
-            if constexpr (WCNT > 0) {
-                float *dst = g.gram_part + (long long)blockIdx.x * CIN * CIN;
-#pragma unroll
-                for (int i = 0; i < WCNT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * (R::blk[WV < NWD ? WV : 0][i] / NA) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        dst[row * CIN + 32 * (R::blk[WV < NWD ? WV : 0][i] % NA) + li] = accw[i][r];
-                    }
-            }
-            if constexpr (HELP) {
-                float *dst = ga.dws_part + ((size_t)blockIdx.x * COUT + lane + 64 * hch) * CIN + hcol;
-#pragma unroll
-                for (int k = 0; k < HC4; ++k) *reinterpret_cast<float4 *>(dst + 4 * k) = dws[k];
-            }
-        };
-        if constexpr (NWT > NA + 0) { if (wave == NA + 0) w_role(IC<NA + 0>{}); }
-        if constexpr (NWT > NA + 1) { if (wave == NA + 1) w_role(IC<NA + 1>{}); }
-        if constexpr (NWT > NA + 2) { if (wave == NA + 2) w_role(IC<NA + 2>{}); }
-        if constexpr (NWT > NA + 3) { if (wave == NA + 3) w_role(IC<NA + 3>{}); }
-        if constexpr (NWT > NA + 4) { if (wave == NA + 4) w_role(IC<NA + 4>{}); }
-    }
-}
-
-__global__ __launch_bounds__(256) void pool_alg_slab_sum_kernel(const float *__restrict__ part, int nslab, int n, float *__restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nslab; w += 4) {
-        a0 += part[(size_t)w * n + i]; a1 += part[(size_t)(w + 1) * n + i];
-        a2 += part[(size_t)(w + 2) * n + i]; a3 += part[(size_t)(w + 3) * n + i];
-    }
-    for (; w < nslab; ++w) a0 += part[(size_t)w * n + i];
-    out[i] = (a0 + a1) + (a2 + a3);
-}
-
-// Gram[i][j] = sum over workgroups of their partial blocks (upper triangle of 32 x 32 blocks), mirrored into the lower one.
-// 32 outputs per workgroup, eight threads per output take every eighth slab (four chains each), combined through LDS in a fixed
-// order.  (One thread per output walking all 256 slabs: a serial chain of dependent adds on L2 latency, 51 us per launch.)
-__global__ __launch_bounds__(256) void pool_alg_gram_reduce_kernel(const float *__restrict__ part, const float *__restrict__ apart, int nwg,
-                                                                   int cin, float *__restrict__ Gm, float *__restrict__ asum)
-{
-    __shared__ float s_p[8][32];
-    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int nn = cin * cin;
-    // blocks 0 .. nn / 32 - 1: the Gram entries; the blocks after them: the column sums of A
-    const bool gram = (int)blockIdx.x < nn / 32;
-    const int i = gram ? blockIdx.x * 32 + o : ((int)blockIdx.x - nn / 32) * 32 + o;
-    const int n = gram ? nn : cin;
-    const float *src = gram ? part : apart;
-    bool live = i < n;
-    int r = 0, c = 0;
-    if (gram) { r = i / cin; c = i - r * cin; live = live && (r >> 5) <= (c >> 5); }
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (live) {
-        int w = sl;
-        for (; w + 24 < nwg; w += 32) {
-            a0 += src[(long long)w * n + i]; a1 += src[(long long)(w + 8) * n + i];
-            a2 += src[(long long)(w + 16) * n + i]; a3 += src[(long long)(w + 24) * n + i];
-        }
-        for (; w < nwg; w += 8) a0 += src[(long long)w * n + i];
-    }
-    s_p[sl][o] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sl != 0 || !live) return;
-    float v = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v += s_p[q][o];
-    if (gram) {
-        Gm[i] = v;
-        if ((r >> 5) != (c >> 5)) Gm[c * cin + r] = v;
-    } else {
-        asum[i] = v;
-    }
+    if (g.tail.acc) bn_tail_finish(g.tail, &s_tail);      // every wave of both roles arrives here
 }
 
 // dW[c] = sum over workgroups of their partial slabs, in a fixed order: 64 outputs per workgroup, four threads per output
@@ -1045,9 +471,10 @@ static int stream_bwd_impl(long long P, int Cout, int Cin, const float *G, const
                            const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
                            const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
                            const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
-                           float *dW, long long lddw, float *workspace, const GatherSrc *gs, void *stream)
+                           float *dW, long long lddw, float *workspace, const GatherSrc *gs, const prifit_bn_bwd *bn, void *stream)
 {
     const bool pool = pool_arg != nullptr;
+    if (bn_bwd_bad(bn)) return PRIFIT_EINVAL;
     if (gs) {   // Yp re-formed from (idx, U, Vc): middle layers on a 64-wide first layer only
         if (pool || Cin != 64 || !gs->idx || !gs->U || !gs->Vc || gs->N <= 0 || gs->S <= 0 || gs->Kg <= 0 || (gs->Kg % SBM) ||
             gs->C != Cin || P % ((long long)gs->S * gs->Kg) != 0 || (((uintptr_t)gs->U | (uintptr_t)gs->Vc) & 15) ||
@@ -1056,7 +483,7 @@ static int stream_bwd_impl(long long P, int Cout, int Cin, const float *G, const
         Yp = gs->U;   // (only checked for presence and alignment below)
         ldyp = Cin;
     }
-    if (!Y || !coef_b || !coef_d || !W || !Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !Gp || !red_slab || !dW ||
+    if (!Y || !coef_b || !coef_d || !W || !Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !Gp || (!red_slab && !(bn && bn->acc)) || !dW ||
         !workspace || !prifit_gemm_stream_bwd_supported(P, Cout, Cin, pool ? pool_K : 0) || ldw < Cin || ldyp < Cin || ldgp < Cin ||
         lddw < Cin || (ldyp & 3) || (pool ? (!pool_T) : (!G || !scale || !shift || !coef_a)) ||
         (((uintptr_t)Y | (uintptr_t)G | (uintptr_t)Yp | (uintptr_t)pool_arg | (uintptr_t)pool_T) & 15) ||
@@ -1067,6 +494,7 @@ static int stream_bwd_impl(long long P, int Cout, int Cin, const float *G, const
     g.pool_arg = pool_arg; g.pool_T = pool_T; g.pool_K = pool ? pool_K : 1;
     g.W = W; g.ldw = ldw; g.Yp = Yp; g.ldyp = ldyp; g.ps = p_scale; g.pt = p_shift; g.pmu = p_mean; g.pis = p_invstd;
     g.Gp = Gp; g.ldgp = ldgp; g.red_slab = red_slab; g.dw_part = workspace;
+    g.tail = bn_tail_bwd(bn, Cin);
     g.gs.idx = nullptr;
     if (gs) {
         g.gs = *gs;
@@ -1084,85 +512,15 @@ static int stream_bwd_impl(long long P, int Cout, int Cin, const float *G, const
     return prifit_check_launch();
 }
 
-int prifit_pool_alg_supported(long long P, int Cin) { return (P >= SBM && P <= 0x7fffffffLL * 32 && (Cin == 64 || Cin == 96 || Cin == 128)) ? 1 : 0; }
-
-static int pool_alg_grid(long long P, int Cin)
-{
-    const long long tiles = (P + SBM - 1) / SBM;
-    const long long want = 256LL;     // (one workgroup per CU: 203-256 VGPRs at 7-8 waves)
-    return (int)(tiles < want ? tiles : want);
-}
-
-int prifit_pool_alg_slabs(long long P, int Cin) { return prifit_pool_alg_supported(P, Cin) ? pool_alg_grid(P, Cin) : 0; }
-long long prifit_pool_alg_workspace(long long P, int Cin) { return prifit_pool_alg_supported(P, Cin) ? (long long)pool_alg_grid(P, Cin) * (Cin * Cin + Cin) : 0; }
-
-int prifit_pool_alg_dense_f32(long long P, int Cin, const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
-                              const float *p_mean, const float *p_invstd, const float *M, long long ldm, const float *v, float *Gp,
-                              long long ldgp, float *red_slab, float *gram, float *asum, float *workspace, void *stream)
-{
-    if (!Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !M || !v || !Gp || !red_slab || !gram || !asum || !workspace ||
-        !prifit_pool_alg_supported(P, Cin) || ldyp < Cin || (ldyp & 3) || ldm < Cin || ldgp < Cin || ((uintptr_t)Yp & 15) ||
-        (long long)SBM * ldyp * 4 >= 0x7ff00000LL || (long long)SBM * ldgp * 4 >= 0x7ff00000LL)
-        return PRIFIT_EINVAL;
-    AlgArgs g;
-    g.P = P; g.Yp = Yp; g.ldyp = ldyp; g.ps = p_scale; g.pt = p_shift; g.pmu = p_mean; g.pis = p_invstd; g.M = M; g.ldm = ldm;
-    const int grid = pool_alg_grid(P, Cin);
-    g.v = v; g.Gp = Gp; g.ldgp = ldgp; g.red_slab = red_slab; g.gram_part = workspace;
-    g.asum_part = workspace + (long long)grid * Cin * Cin;
-    hipStream_t st = as_stream(stream);
-    if (Cin == 96) hipLaunchKernelGGL((pool_alg_dense_kernel<96>), dim3(grid), dim3(64 * AlgRoles<96>::NW), 0, st, g);
-    else if (Cin == 64) hipLaunchKernelGGL((pool_alg_dense_kernel<64>), dim3(grid), dim3(64 * AlgRoles<64>::NW), 0, st, g);
-    else hipLaunchKernelGGL((pool_alg_dense_kernel<128>), dim3(grid), dim3(64 * AlgRoles<128>::NW), 0, st, g);
-    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3(Cin * Cin / 32 + (Cin + 31) / 32), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
-                       gram, asum);
-    return prifit_check_launch();
-}
-
-int prifit_pool_alg_fused_supported(long long P, int K, int Cout, int Cin)
-{
-    return (prifit_pool_alg_supported(P, Cin) && K > 0 && K % SBM == 0 && P % K == 0 && Cout == 128 && (Cin == 96 || Cin == 64)) ? 1 : 0;
-}
-
-long long prifit_pool_alg_fused_workspace(long long P, int Cout, int Cin)
-{
-    return prifit_pool_alg_supported(P, Cin) ? (long long)pool_alg_grid(P, Cin) * (Cin * Cin + Cin + Cout * Cin) : 0;
-}
-
-int prifit_pool_alg_fused_f32(long long P, int K, int Cout, int Cin, const float *Yp, long long ldyp, const float *p_scale,
-                              const float *p_shift, const float *p_mean, const float *p_invstd, const float *M, long long ldm,
-                              const float *v, const int32_t *arg, const float *T, const float *W, float *Gp, long long ldgp,
-                              float *red_slab, float *gram, float *asum, float *dWs, float *workspace, void *stream)
-{
-    if (!Yp || !p_scale || !p_shift || !p_mean || !p_invstd || !M || !v || !arg || !T || !W || !Gp || !red_slab || !gram || !asum ||
-        !dWs || !workspace || !prifit_pool_alg_fused_supported(P, K, Cout, Cin) || ldyp < Cin || (ldyp & 3) || ldm < Cin ||
-        ldgp < Cin || (((uintptr_t)Yp | (uintptr_t)W) & 15) || (long long)SBM * ldyp * 4 >= 0x7ff00000LL ||
-        (long long)SBM * ldgp * 4 >= 0x7ff00000LL)
-        return PRIFIT_EINVAL;
-    AlgFusedArgs a;
-    AlgArgs &g = a.d;
-    const int grid = pool_alg_grid(P, Cin);
-    g.P = P; g.Yp = Yp; g.ldyp = ldyp; g.ps = p_scale; g.pt = p_shift; g.pmu = p_mean; g.pis = p_invstd; g.M = M; g.ldm = ldm;
-    g.v = v; g.Gp = Gp; g.ldgp = ldgp; g.red_slab = red_slab; g.gram_part = workspace;
-    g.asum_part = workspace + (long long)grid * Cin * Cin;
-    a.arg = arg; a.T = T; a.W = W; a.K = K; a.dws_part = g.asum_part + (long long)grid * Cin;
-    hipStream_t st = as_stream(stream);
-    if (Cin == 96) hipLaunchKernelGGL((pool_alg_fused_kernel<96, 128>), dim3(grid), dim3(64 * FusedWaves<96>::value), 0, st, a);
-    else hipLaunchKernelGGL((pool_alg_fused_kernel<64, 128>), dim3(grid), dim3(64 * FusedWaves<64>::value), 0, st, a);
-    hipLaunchKernelGGL(pool_alg_gram_reduce_kernel, dim3(Cin * Cin / 32 + (Cin + 31) / 32), dim3(256), 0, st, workspace, g.asum_part, grid, Cin,
-                       gram, asum);
-    hipLaunchKernelGGL(pool_alg_slab_sum_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, st, a.dws_part, grid, Cout * Cin, dWs);
-    return prifit_check_launch();
-}
-
 int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, const float *Y, const float *scale,
                                const float *shift, const float *coef_a, const float *coef_b, const float *coef_d,
                                const int32_t *pool_arg, const float *pool_T, int pool_K, const float *W, long long ldw,
                                const float *Yp, long long ldyp, const float *p_scale, const float *p_shift,
                                const float *p_mean, const float *p_invstd, float *Gp, long long ldgp, float *red_slab,
-                               float *dW, long long lddw, float *workspace, void *stream)
+                               float *dW, long long lddw, float *workspace, const prifit_bn_bwd *bn, void *stream)
 {
     return stream_bwd_impl(P, Cout, Cin, G, Y, scale, shift, coef_a, coef_b, coef_d, pool_arg, pool_T, pool_K, W, ldw, Yp, ldyp,
-                           p_scale, p_shift, p_mean, p_invstd, Gp, ldgp, red_slab, dW, lddw, workspace, nullptr, stream);
+                           p_scale, p_shift, p_mean, p_invstd, Gp, ldgp, red_slab, dW, lddw, workspace, nullptr, bn, stream);
 }
 
 int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, const float *Y, const float *scale,
@@ -1170,11 +528,12 @@ int prifit_gemm_stream_bwd_gather_f32(long long P, int Cout, const float *G, con
                                       const float *W, long long ldw, const int32_t *idx, const float *U, const float *Vc,
                                       int n_points, int n_centres, int rows_per_centre, const float *p_scale,
                                       const float *p_shift, const float *p_mean, const float *p_invstd, float *Gp, long long ldgp,
-                                      float *red_slab, float *dW, long long lddw, float *workspace, void *stream)
+                                      float *red_slab, float *dW, long long lddw, float *workspace, const prifit_bn_bwd *bn,
+                                      void *stream)
 {
     const GatherSrc gs = {idx, U, Vc, n_points, n_centres, rows_per_centre, 64, 0u};
     return stream_bwd_impl(P, Cout, 64, G, Y, scale, shift, coef_a, coef_b, coef_d, nullptr, nullptr, 0, W, ldw, nullptr, 64,
-                           p_scale, p_shift, p_mean, p_invstd, Gp, ldgp, red_slab, dW, lddw, workspace, &gs, stream);
+                           p_scale, p_shift, p_mean, p_invstd, Gp, ldgp, red_slab, dW, lddw, workspace, &gs, bn, stream);
 }
 
 }  // extern "C"

@@ -41,6 +41,7 @@ struct SAGroupArgs {
     const float *bias[4];  // [C] or NULL
     float *Y[4];           // [B*S*K, C]
     float *slab[4];        // [B*ceil(S/NW)][2][C] or NULL
+    BnTail tail[4];        // per radius: the column statistics finalized by this launch instead of written to slab[r] (common.h)
     int32_t *idx[4];       // [B,S,K]
 };
 
@@ -73,7 +74,12 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
     const int nb = (S + NW - 1) / NW;
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int b = (jj / nb) * 8 + xcd, tile = jj % nb;
-    if (b >= a.B) return;  // whole workgroup
+    __shared__ int s_tail;
+    if (b >= a.B) {        // whole workgroup: nothing to do but its tickets
+        for (int r = 0; r < R; ++r)
+            if (a.tail[r].acc) bn_tail_finish(a.tail[r], &s_tail);
+        return;
+    }
     const int slab_id = b * nb + tile;
 
     // (readfirstlane: the wave index, hence the query centre and everything derived from it, is wave-uniform, and the
@@ -272,7 +278,8 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                 for (int k0 = 0; k0 < K; k0 += rpi * SG_UNR) body(k0, std::false_type());
             }
         }
-        if (a.slab[r]) {  // block-uniform
+        const bool tail = a.tail[r].acc != nullptr;
+        if (a.slab[r] || tail) {  // block-uniform
             for (int o = L; o < 64; o <<= 1) {
                 s0.x += __shfl_xor(s0.x, o, 64); s0.y += __shfl_xor(s0.y, o, 64);
                 s0.z += __shfl_xor(s0.z, o, 64); s0.w += __shfl_xor(s0.w, o, 64);
@@ -289,9 +296,11 @@ __global__ __launch_bounds__(NW * 64) void sa_group_kernel(const SAGroupArgs a)
                 float s = 0.f;
 #pragma unroll
                 for (int wv = 0; wv < NW; ++wv) s += s_red[wv][which][c];
-                a.slab[r][((size_t)slab_id * 2 + which) * C + c] = s;
+                if (tail) bn_tail_add(a.tail[r], which, c, s);
+                else a.slab[r][((size_t)slab_id * 2 + which) * C + c] = s;
             }
             __syncthreads();
+            if (tail) bn_tail_finish(a.tail[r], &s_tail);
         }
     }
 }
@@ -505,9 +514,10 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
                                const float *radius2, const int *nsample, const int *width, int mode,
                                const float *feat, int D, int feat_first, int feat_xyz, const float *const *W,
                                const float *const *U, const float *const *Vc, const float *const *bias,
-                               float *const *Y, float *const *slab, int32_t *const *idx, void *stream)
+                               float *const *Y, float *const *slab, int32_t *const *idx, const prifit_bn_fwd *const *bn,
+                               void *stream)
 {
-    if (!xyz || !new_xyz || !radius2 || !nsample || !width || !bias || !Y || !slab || !idx || B <= 0 || N <= 0 ||
+    if (!xyz || !new_xyz || !radius2 || !nsample || !width || !bias || !Y || (!slab && !bn) || !idx || B <= 0 || N <= 0 ||
         N > SG_TILE || S <= 0 || R < 1 || R > 4 || (mode != 0 && mode != 1))
         return PRIFIT_EINVAL;
     if (mode == 0 && (!W || (D != 0 && D != 3 && D != 6) || (D > 0 && !feat) || (feat_xyz && D < 3)))
@@ -527,10 +537,15 @@ int prifit_sa_group_linear_fwd(const float *xyz, const float *new_xyz, int B, in
         a.Vc[r] = (in && mode == 1) ? Vc[r] : nullptr;
         a.bias[r] = in ? bias[r] : nullptr;
         a.Y[r] = in ? Y[r] : nullptr;
-        a.slab[r] = in ? slab[r] : nullptr;
+        a.slab[r] = (in && slab) ? slab[r] : nullptr;
         a.idx[r] = in ? idx[r] : nullptr;
+        a.tail[r] = BnTail{};
         if (!in) continue;
         const int C = width[r];
+        if (bn && bn[r]) {
+            if (bn_fwd_bad(bn[r])) return PRIFIT_EINVAL;
+            a.tail[r] = bn_tail_fwd(bn[r], C);
+        }
         // (gather mode: Y[r] may be NULL -- index lists and statistics only, the rows are re-formed by their consumers)
         if (nsample[r] < 1 || C < 16 || C > SG_CMAX || (C & (C - 1)) || (!Y[r] && mode == 0) || !idx[r] ||
             (mode == 0 ? !W[r] : (!U[r] || !Vc[r])) || ((uintptr_t)Y[r] & 15) ||

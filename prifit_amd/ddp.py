@@ -46,6 +46,7 @@ class FlatGradBucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.seen = [False] * len(self.params)   # has this parameter ever had a gradient ON ANY RANK (see the class docstring)
+        self._grads = None
         if strict_seen and deferred_check:
             raise ValueError("FlatGradBucket: strict_seen=True asks for the synchronous, exact adoption of other ranks' "
                              "gradients; deferred_check=True for the check one exchange late -- choose one")
@@ -67,8 +68,16 @@ class FlatGradBucket:
             self.native = NativeComm.from_process_group(process_group)
 
     def zero(self):
+        self._grads = None
         for p in self.params:
             p.grad = None
+
+    def grads(self):
+        """The gradients as the optimizer will see them, in parameter order (None = skipped), valid after allreduce() until
+        the next zero(): `optimizer.step(grads=bucket.grads())` saves FlatAdam a second pass over ~150 `p.grad` getters."""
+        if self._grads is None:
+            self._grads = [p.grad for p in self.params]
+        return self._grads
 
     def _mark_seen(self):
         for i, p in enumerate(self.params):
@@ -151,13 +160,16 @@ class FlatGradBucket:
         Single process: nothing moves; parameters that got no gradient this step but had one before get their
         (zeroed) bucket slice as gradient."""
         if not self.dist:
-            self._mark_seen()
-            missing = [v for v, p, s in zip(self.views, self.params, self.seen) if s and p.grad is None]
-            if missing:
-                torch._foreach_zero_(missing)
-                for v, p, s in zip(self.views, self.params, self.seen):
-                    if s and p.grad is None:
-                        p.grad = v
+            grads = [p.grad for p in self.params]      # ONE pass over the `.grad` getters (~1 us each, 144 parameters)
+            have = [g is not None for g in grads]
+            if have != self.seen:                      # (steady state: equal lists, nothing else to do)
+                self.seen = [s or h for s, h in zip(self.seen, have)]
+                missing = [i for i, (s, h) in enumerate(zip(self.seen, have)) if s and not h]
+                if missing:
+                    torch._foreach_zero_([self.views[i] for i in missing])
+                    for i in missing:
+                        self.params[i].grad = grads[i] = self.views[i]
+            self._grads = grads
             return
         local = self.pack(adopt=False)
         if self.native is not None:
@@ -165,6 +177,7 @@ class FlatGradBucket:
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self._adopt(local)
+        self._grads = None
         self.flat[:self.nflat].mul_(1.0 / self.world)
 
     def broadcast_parameters(self, src=0):

@@ -9,6 +9,8 @@ src/ellipsoid_utils.py:19-27).  Reference sites are cited per function (paths re
 import contextlib
 import ctypes
 
+import time
+
 import torch
 
 from . import profiler
@@ -570,15 +572,21 @@ class ChamferCombineFn(torch.autograd.Function):
 # checks `spec.ok()` once everything is enqueued and, if the assumption was wrong, discards the step and re-runs
 # it outside the context (train_step.SpeculativeRunner does exactly that) - results are the reference's either way.
 # ------------------------------------------------------------------------------------------------
+spec_wait_s = 0.0    # host seconds spent blocked in _Speculation.ok() since import (bench.py: enqueue time without the wait)
+
+
 class _Speculation:
     def __init__(self):
         self.checks = []
 
     def ok(self):
+        global spec_wait_s
         good = True
+        t0 = time.perf_counter()
         for ev, flag in self.checks:
             ev.synchronize()
             good = good and int(flag[0]) == 0
+        spec_wait_s += time.perf_counter() - t0
         self.checks.clear()
         return good
 

@@ -247,7 +247,7 @@ def nn_ops_point_tables(first_convs, feats, xyz, new_xyz, feat_first):
     return Us, Vcs
 
 
-def _fused_first_layers_norows(first_convs, norows, feats, xyz, new_xyz, radii, nsamples, kp, feat_first):
+def _fused_first_layers_norows(first_convs, norows, feats, xyz, new_xyz, radii, nsamples, kp, feat_first, first_bns=None):
     """Direct-mode level in training with some scales' rows unstored: ONE launch in the by-linearity form for all scales
     (y = U_j - Vc_g, U = [feat | xyz] W1^T + b per point, Vc = c W1x^T per centre: the index lists and the BatchNorm
     statistics of every scale, rows only where `norows` is False).  The first conv's weight gradient stays the direct
@@ -259,7 +259,7 @@ def _fused_first_layers_norows(first_convs, norows, feats, xyz, new_xyz, radii, 
         Us, Vcs = nn_ops_point_tables(first_convs, feats, xyz, new_xyz, feat_first)
         Ys, slabs, idxs = _sa_group_launch(1, xyz, new_xyz, None, True, list(radii), list(nsamples),
                                            [u.shape[-1] for u in Us], None, Us, Vcs, [None] * len(first_convs),
-                                           rows=[not nr for nr in norows])
+                                           rows=[not nr for nr in norows], bn=_bn_args(first_bns))
     out = []
     for i in range(len(first_convs)):
         info = {"idx": idxs[i], "xyz": xyz, "new_xyz": new_xyz, "feat": feats, "feat_first": feat_first, "K": nsamples[i], "D": D}
@@ -269,8 +269,17 @@ def _fused_first_layers_norows(first_convs, norows, feats, xyz, new_xyz, radii, 
     return out
 
 
+def _bn_args(first_bns):
+    """(gamma, beta, running_mean, running_var, eps, momentum) of every scale's first BatchNorm: the front end's launch
+    finalizes the statistics itself (nn_ops._sa_group_launch(bn=...))."""
+    if first_bns is None:
+        return None
+    return [(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, 0.1 if bn.momentum is None else bn.momentum)
+            for bn in first_bns]
+
+
 def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii, nsamples, kp, feat_first,
-                        fused_gather_bwd=False):
+                        fused_gather_bwd=False, first_bns=None):
     """-> per radius (Y1 [B*S*K, C1], column-statistics slab, info): `info` is None, or -- direct mode in training --
     the dict SharedMLPFn needs to take over the first conv's weight gradient (cfg["preact_direct"]): Y1 is then plain
     data for autograd and the BatchNorm backward of that layer is fused into the weight-gradient kernel."""
@@ -281,7 +290,7 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
             bs = [None if c.bias is None else c.bias.contiguous() for c in first_convs]
             fx = feats is not None and D == 3 and feats.data_ptr() == xyz.data_ptr()
             Ys, slabs, idxs = _sa_group_launch(0, xyz, new_xyz, feats, feat_first, list(radii), list(nsamples),
-                                               [w.shape[0] for w in Ws], Ws, None, None, bs, feat_xyz=fx)
+                                               [w.shape[0] for w in Ws], Ws, None, None, bs, feat_xyz=fx, bn=_bn_args(first_bns))
         return [(Ys[i], slabs[i], {"idx": idxs[i], "xyz": xyz, "new_xyz": new_xyz, "feat": feats, "feat_first": feat_first,
                                    "K": nsamples[i], "D": D}) for i in range(len(first_convs))]
     if mode == "gather" and training and fused_gather_bwd:
@@ -296,7 +305,7 @@ def _fused_first_layers(mode, first_convs, training, feats, xyz, new_xyz, radii,
             Vcs = [v.detach().contiguous() for _, v in ops_]
             bs = [None if c.bias is None else c.bias.detach().contiguous() for c in first_convs]
             Ys, slabs, idxs = _sa_group_launch(1, xyz, new_xyz, None, True, list(radii), list(nsamples),
-                                               [u.shape[-1] for u in Us], None, Us, Vcs, bs)
+                                               [u.shape[-1] for u in Us], None, Us, Vcs, bs, bn=_bn_args(first_bns))
         return [(Ys[i], slabs[i], {"gather": True, "idx": idxs[i], "U": ops_[i][0], "Vc": ops_[i][1], "B": B, "N": N, "S": S,
                                    "K": nsamples[i]}) for i in range(len(first_convs))]
     if mode == "direct":
@@ -437,7 +446,8 @@ class PointNetSetAbstraction(nn.Module):
             if mode is not None:
                 (y1, slab, info), = _fused_first_layers(mode, [self.mlp_convs[0]], self.training, feats, xyz, new_xyz,
                                                         [self.radius], [K], kp, feat_first=False,
-                                                        fused_gather_bwd=_gather_bwd_ok(mode, [self.mlp_convs], N))
+                                                        fused_gather_bwd=_gather_bwd_ok(mode, [self.mlp_convs], N),
+                                                        first_bns=[self.mlp_bns[0]] if self.training else None)
                 cfg = _preact_cfg(_mlp_cfg(self.mlp_bns, K, self.training), slab, info)
                 out = SharedMLPFn.apply(y1, cfg, *_mlp_tensors_preact(self.mlp_convs, self.mlp_bns, info))
                 return new_xyz, out.reshape(B, S, -1)
@@ -494,11 +504,12 @@ class PointNetSetAbstractionMsg(nn.Module):
             norows = _norows_scales(mode, self.conv_blocks, self.training, B, S, self.nsample_list)
             if any(norows):
                 ys = _fused_first_layers_norows(firsts, norows, feats, xyz, new_xyz, self.radius_list, self.nsample_list, kp,
-                                                feat_first=True)
+                                                feat_first=True, first_bns=[b[0] for b in self.bn_blocks])
             else:
                 ys = _fused_first_layers(mode, firsts, self.training, feats, xyz, new_xyz, self.radius_list,
                                          self.nsample_list, kp, feat_first=True,
-                                         fused_gather_bwd=_gather_bwd_ok(mode, self.conv_blocks, N))
+                                         fused_gather_bwd=_gather_bwd_ok(mode, self.conv_blocks, N),
+                                         first_bns=[b[0] for b in self.bn_blocks] if self.training else None)
             for i, K in enumerate(self.nsample_list):
                 cfg = _preact_cfg(_mlp_cfg(self.bn_blocks[i], K, self.training), ys[i][1], ys[i][2])
                 pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i],

@@ -27,6 +27,67 @@ def _rows_per_slab():
     return dll().prifit_reduce_rows_per_slab()
 
 
+# BatchNorm tails (round 6, include/prifit_hip.h: prifit_bn_fwd / prifit_bn_bwd): the launch that produces a
+# layer's column sums also finalizes them -- fp64 atomics into 32 replicas of a [2][C] accumulator, the workgroup that draws the
+# last ticket writes the coefficients -- instead of writing a slab per workgroup for a separate prifit_bn_finalize /
+# prifit_bn_bwd_finalize launch.  MEASURED AND NOT THE DEFAULT (profiles/r06_bn_tail.txt, same box, alternating runs): 50
+# launches less per c3 step (317 -> 267), host enqueue -0.15 ms, the two finalize families' 0.33 ms of GPU time gone -- and
+# +0.8 ms in the producers: c3 15.10 -> 15.59 ms per step.  Atomics of many workgroups on one address are performed one after
+# the other at ~0.3 us each (memory-side, past the per-XCD L2s), so every producer pays (workgroups / 32) x 0.3 us plus the
+# ticket's and the last workgroup's load round trips: +5-9 us for the persistent kernels (break-even against a ~6 us finalize
+# launch), +10-30 us for the products with thousands of tiles and the reduce passes.  Same coefficients bit for bit (tested).
+# 1: tails on (fewer launches: a host-bound multi-rank job may prefer them).
+_BN_TAIL = os.environ.get("PRIFIT_BN_TAIL", "0") != "0"
+
+
+class _BnFwdDesc(ctypes.Structure):
+    _fields_ = [("acc", ctypes.c_void_p), ("ticket", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("out", ctypes.c_void_p),
+                ("count", ctypes.c_double), ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+
+
+class _BnBwdDesc(ctypes.Structure):
+    _fields_ = [("acc", ctypes.c_void_p), ("ticket", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("mean", ctypes.c_void_p),
+                ("invstd", ctypes.c_void_p), ("out", ctypes.c_void_p), ("count", ctypes.c_double), ("training", ctypes.c_int)]
+
+
+_REPLICAS = None
+
+
+def _tail_replicas():
+    global _REPLICAS
+    if _REPLICAS is None:
+        _REPLICAS = dll().prifit_bn_tail_replicas()
+    return _REPLICAS
+
+
+def bn_fwd_tail(C, count, gamma, beta, rmean, rvar, eps, momentum, dev):
+    """-> (descriptor for the producing launch, coef [4, C] = scale, shift, mean, invstd once that launch has run)."""
+    R = _tail_replicas()
+    st = zero_pool.zeros(4 * C * R + 4, device=dev)        # [R][2][C] doubles + the ticket, zero on entry
+    coef = torch.empty(4, C, dtype=torch.float32, device=dev)
+    p = st.data_ptr()
+    d = _BnFwdDesc(p, p + 16 * C * R, gamma.data_ptr(), beta.data_ptr(), None if rmean is None else rmean.data_ptr(),
+                   None if rvar is None else rvar.data_ptr(), coef.data_ptr(), float(count), float(eps), float(momentum))
+    d._keep = (st, coef, gamma, beta, rmean, rvar)
+    return d, coef
+
+
+def bn_bwd_tail(C, count, scale, mean, invstd, training, dev):
+    """-> (descriptor, coef [5, C] = dgamma, dbeta, a, b, d of dY = a Gm + b Y + d once the producing launch has run)."""
+    R = _tail_replicas()
+    st = zero_pool.zeros(4 * C * R + 4, device=dev)
+    coef = torch.empty(5, C, dtype=torch.float32, device=dev)
+    p = st.data_ptr()
+    d = _BnBwdDesc(p, p + 16 * C * R, scale.data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), float(count), int(training))
+    d._keep = (st, coef, scale, mean, invstd)
+    return d, coef
+
+
+def _ref(d):
+    return None if d is None else ctypes.byref(d)
+
+
 _STREAM = os.environ.get("PRIFIT_GEMM_STREAM", "1") != "0"   # 0: every product takes the tiled kernel (A/B runs)
 _FUSE_RED = os.environ.get("PRIFIT_FUSE_BN_REDUCE", "1") != "0"  # 0: separate bn_relu_bwd_reduce launches (A/B runs)
 _FUSE_POOL_FWD = os.environ.get("PRIFIT_FUSE_POOL_FWD", "1") != "0"  # 0: pool_fwd re-reads the last layer's Y (A/B runs)
@@ -37,24 +98,9 @@ _FUSE_POOL = os.environ.get("PRIFIT_FUSE_POOL_BWD", "1") != "0"  # 0: pool_bwd_a
 # where it measured faster -- the unpooled middle layers (_FUSE_BWD_AUTO below; round 3 had only the 96 -> 64 one);
 # "1": every supported shape (slower on the others: the kernel's dW role is latency-bound); "0": never.
 _FUSE_BWD = os.environ.get("PRIFIT_FUSE_DA_DW", "auto")
-# Max-pooled last layer, backward in the algebraic form (round 5 EXPERIMENT; csrc/pool_alg.hip, prifit_pool_alg_dense_f32): with
-# dY = T [row == winner] + b Y + d and Y = A W^T + bias the row-dense work is A M (M = W^T diag(b) W) and the Gram matrix
-# A^T A -- products over Cin x Cin that read only the layer's INPUT -- plus index work on the winners' rows.  Parity with the
-# default arm at 1.5e-6 (tests/test_gpu_backbone.py), and the dense pass alone is 30-55 % faster than the pair it replaces
-# (575 against 843 us at [1.57 M x 128 x 96]); but the winners' rows cost more than that saves, inside the pass or behind it
-# (745-1109 us fused, 1254 us as a second launch: DESIGN.md 5.3), so the DEFAULT stays the streaming dA / dW pair over
-# Cout x Cin that reads the pooled layer's pre-activation.  1: the algebraic arm.
-_POOL_ALG = os.environ.get("PRIFIT_POOL_ALG", "0") != "0"
-# "auto": only (Cout, Cin) = (256, 128), SA2 scale 1, the one shape where the passes alone beat the pair they replace (dense 161 us
-# + winners' rows and channels 110 us, after the winners' pass was split into two parallel launches, against 358 us) -- and still
-# +0.18 ms on the c2 step (the small products and launches around the passes): not the default either
-# (profiles/r05_ab_measurements.txt 12).  NOTE for whoever measures this again: in the bench's HEADLINE c3 condition the
-# gradient that reaches the set-abstraction layers is exactly zero (one cluster per shape: the loss does not depend on the
-# embedding), so every value-dependent pass looks free there; c2 or `--embedding clustered` are the conditions to read.
-_POOL_ALG_AUTO = os.environ.get("PRIFIT_POOL_ALG", "0") == "auto"
-# ... with the winners' rows inside the dense pass where that kernel exists (0: dense pass + separate index kernel; A/B, tested)
-_POOL_ALG_FUSED = os.environ.get("PRIFIT_POOL_ALG_FUSED", "1") != "0"
-
+# (round 5 carried an opt-in algebraic form of the max-pooled set-abstraction layers' backward here, PRIFIT_POOL_ALG: parity-green,
+# its dense pass 30-55 % faster than the dA / dW pair, slower on the step because of the winners' index work; removed in round 6,
+# the measurements are in DESIGN.md Appendix A.  The layer pooled over the WHOLE cloud keeps that form: src/dgcnn.py.)
 
 # (round 4, tools/fam_table.py on one box: one-pass kernel against the separate dA + dW pair)
 #   [1.57 M x 96 x 64] 546 / 712 us, [786 K x 64 x 64] 171 / 282, [197 K x 128 x 128] 152 / 176, [49 K x 128 x 128] 54 / 72;
@@ -95,9 +141,10 @@ def gemm_stats_slabs(M, N, K):
 
 def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, splitk=1, a_affine=None,
          b_affine=None, bias=None, bias_stride=0, stats=None, epi=EPI_NONE, epi_scalar=None, aux=None, ld_aux=0, s_aux=0,
-         row_add=None, a_rowsum=None, accumulate=None, tiled_stats=False):
+         row_add=None, a_rowsum=None, accumulate=None, tiled_stats=False, bn=None):
     """tiled_stats=True: the caller reads `stats` as one slab per 128 rows of C (per-sample statistics, src/dgcnn.py);
-    otherwise the slab count is gemm_stats_slabs(M, N, K)."""
+    otherwise the slab count is gemm_stats_slabs(M, N, K).  bn: a bn_fwd_tail descriptor -- the launch finalizes the column
+    statistics itself (stats may then be None)."""
     if accumulate is None:
         accumulate = splitk > 1
     if (not (tiled_stats and stats is not None) and _stream_ok(layout, M, N, K, batch, splitk, epi, b_affine, a_rowsum, accumulate, aux, row_add) and lda % 4 == 0 and
@@ -106,7 +153,7 @@ def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, spl
         with profiler.span(profiler.tag("gemm_stream_%s" % ("nt", "nn")[layout], M, N, K), 4.0 * (M * K + M * N + N * K)):
             call("prifit_gemm_stream_f32", layout, M, N, K, ptr(A), _LL(lda), ptr(B), _LL(ldb), ptr(C), _LL(ldc),
                  ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None, ptr(bias), ptr(stats),
-                 cur_stream())
+                 _ref(bn), cur_stream())
         return
     # span name = the kernel instantiation (layout, BN tile) so that it lines up with rocprofv3's per-kernel rows
     with profiler.span(profiler.tag("gemm_%s_bn%d" % (("nt", "nn", "tn")[layout], 32 if N <= 32 else (64 if N <= 64 else (96 if N <= 96 else 128))),
@@ -116,7 +163,7 @@ def gemm(layout, M, N, K, A, lda, B, ldb, C, ldc, batch=1, sA=0, sB=0, sC=0, spl
              ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
              ptr(b_affine[0]) if b_affine else None, ptr(b_affine[1]) if b_affine else None,
              ptr(bias), _LL(bias_stride), ptr(stats), epi, ptr(epi_scalar), ptr(aux), _LL(ld_aux), _LL(s_aux), ptr(row_add),
-             ptr(a_rowsum), int(accumulate), cur_stream())
+             ptr(a_rowsum), int(accumulate), _ref(bn), cur_stream())
 
 
 # split-K of the tiled dW products: one round of resident workgroups (512: two 8-wave workgroups per CU) measured best
@@ -155,10 +202,10 @@ def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
     return dW
 
 
-def _fused_bwd(P, Cout, Kin, G, Y, scale, shift, ca, cb, cd, arg, Ttab, pool_K, W, Yp, aff_p, stats_p, dW, dev):
-    """Gp, (m1, m2) slab of the layer below and dW of one layer in one pass (prifit_gemm_stream_bwd_f32)."""
-    ns = dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin)
-    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+def _fused_bwd(P, Cout, Kin, G, Y, scale, shift, ca, cb, cd, arg, Ttab, pool_K, W, Yp, aff_p, stats_p, dW, dev, red):
+    """Gp, the (m1, m2) sums of the layer below and dW of one layer in one pass (prifit_gemm_stream_bwd_f32).
+    red(Cp, ns_fn) -> (slab or None, BatchNorm-tail descriptor or None, fused_red): SharedMLPFn.backward's red_target."""
+    rslab, tail_p, fused = red(Kin, lambda: dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin))
     ws = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
     Gp = torch.empty(P, Kin, dtype=torch.float32, device=dev)
     (sc1, sh1), (mu1, is1) = aff_p, stats_p
@@ -169,60 +216,8 @@ def _fused_bwd(P, Cout, Kin, G, Y, scale, shift, ca, cb, cd, arg, Ttab, pool_K, 
         call("prifit_gemm_stream_bwd_f32", _LL(P), Cout, Kin, ptr(None if pooled else G), ptr(Y), ptr(None if pooled else scale),
              ptr(None if pooled else shift), ptr(None if pooled else ca), ptr(cb), ptr(cd), ptr(arg), ptr(Ttab), int(pool_K or 0),
              ptr(W), _LL(Kin), ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(rslab),
-             ptr(dW), _LL(Kin), ptr(ws), cur_stream())
-    return Gp, rslab, ns
-
-
-def fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys):
-    """The algebraic backward of a max-pooled last layer (_POOL_ALG) takes this layer."""
-    if not (pooled and _POOL_ALG and _FUSE_RED and training and l > 0 and W is not None and ctx.needs_input_grad[2 + 6 * l]):
-        return False
-    K = cfg["pool_K"]
-    if _POOL_ALG_AUTO and not (Cout == 256 and Kin == 128):
-        return False
-    return bool(K % 64 == 0 and P % K == 0 and Ys[l - 1] is not None and Ys[l - 1].stride(0) % 4 == 0 and
-                Ys[l - 1].data_ptr() % 16 == 0 and dll().prifit_pool_alg_supported(_LL(P), Kin) and
-                dll().prifit_pool_alg_sparse_supported(P // K, K, Cout, Kin))
-
-
-def _pool_alg_bwd(P, G, K, Cout, Kin, W, bias, cb, cd, arg, Ttab, Yp, aff_p, stats_p, dW, dev):
-    """Gp [P, Kin], the (m1, m2) slabs of the layer below and dW (written into `dW`) of a max-pooled last layer from its INPUT
-    alone: dense pass (A M + v, Gram matrix, column sums of A) + the winners' rows (csrc/pool_alg.hip)."""
-    (sc1, sh1), (mu1, is1) = aff_p, stats_p
-    e = cd if bias is None else torch.addcmul(cd, cb, bias)             # d + b * bias  [Cout]
-    Wb = W * cb.unsqueeze(1)
-    M = torch.mm(W.t(), Wb)                                             # W^T diag(b) W  [Kin, Kin]
-    v = torch.mv(W.t(), e)
-    nd = dll().prifit_pool_alg_slabs(_LL(P), Kin)
-    Gp = torch.empty(P, Kin, dtype=torch.float32, device=dev)
-    gram = torch.empty(Kin, Kin, dtype=torch.float32, device=dev)
-    asum = torch.empty(Kin, dtype=torch.float32, device=dev)
-    dWs = torch.empty(Cout, Kin, dtype=torch.float32, device=dev)
-    if _POOL_ALG_FUSED and dll().prifit_pool_alg_fused_supported(_LL(P), K, Cout, Kin):
-        rslab = torch.empty(nd, 2, Kin, dtype=torch.float32, device=dev)
-        ws = torch.empty(dll().prifit_pool_alg_fused_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
-        # one pass: Yp read once, Gp written once (the two products over Cin x Cin ride on it)
-        with profiler.span(profiler.tag("pool_alg_fused", P, Cout, Kin), 8.0 * P * Kin):
-            call("prifit_pool_alg_fused_f32", _LL(P), K, Cout, Kin, ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1),
-                 ptr(is1), ptr(M), _LL(Kin), ptr(v), ptr(arg), ptr(Ttab), ptr(W), ptr(Gp), _LL(Kin), ptr(rslab), ptr(gram),
-                 ptr(asum), ptr(dWs), ptr(ws), cur_stream())
-        torch.addmm(dWs, Wb, gram, out=dW)
-        dW.addr_(e, asum)
-        return Gp, rslab, nd
-    nsp = dll().prifit_pool_alg_sparse_slabs(G)
-    rslab = torch.empty(nd + nsp, 2, Kin, dtype=torch.float32, device=dev)
-    ws = torch.empty(dll().prifit_pool_alg_workspace(_LL(P), Kin), dtype=torch.float32, device=dev)
-    with profiler.span(profiler.tag("pool_alg_dense", P, Kin, Kin), 8.0 * P * Kin):
-        call("prifit_pool_alg_dense_f32", _LL(P), Kin, ptr(Yp), _LL(Yp.stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(M),
-             _LL(Kin), ptr(v), ptr(Gp), _LL(Kin), ptr(rslab), ptr(gram), ptr(asum), ptr(ws), cur_stream())
-    ws2 = torch.empty(dll().prifit_pool_alg_sparse_workspace(G, Cout, Kin), dtype=torch.float32, device=dev)
-    with profiler.span(profiler.tag("pool_alg_sparse", P, Cout, Kin), 4.0 * G * Cout * (3.0 * Kin + 2)):
-        call("prifit_pool_alg_sparse_f32", G, K, Cout, Kin, ptr(arg), ptr(Ttab), ptr(W), ptr(Yp), _LL(Yp.stride(0)), ptr(sc1),
-             ptr(sh1), ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(rslab[nd:]), ptr(dWs), ptr(ws2), cur_stream())
-    # dW = S^T A + diag(b) W (A^T A) + (d + b * bias) (1^T A)
-    torch.addmm(dWs, Wb, gram, out=dW)
-    dW.addr_(e, asum)
-    return Gp, rslab, nd + nsp
+             ptr(dW), _LL(Kin), ptr(ws), _ref(tail_p), cur_stream())
+    return Gp, fused
 
 
 class SharedMLPFn(torch.autograd.Function):
@@ -267,16 +262,30 @@ class SharedMLPFn(torch.autograd.Function):
                 Cout, Kin = W.shape
                 assert Kin == (nr["U"].shape[-1] if (l == 1 and nr is not None) else prev.shape[1]), (Kin, l)
                 Y = torch.empty(P, Cout, dtype=torch.float32, device=dev)
-            scale = torch.empty(Cout, dtype=torch.float32, device=dev)
-            shift = torch.empty_like(scale)
-            mean = torch.empty_like(scale)
-            invstd = torch.empty_like(scale)
+            # the layer's coefficients [4, C] = scale, shift, mean, invstd.  Training: written by the launch that produces the
+            # column sums (BatchNorm tail, bn_fwd_tail) or, in the slab form (PRIFIT_BN_TAIL=0), by prifit_bn_finalize
+            tail = coef = None
+            if training and _BN_TAIL and not (preact and cfg["preact_slab"].dim() == 2):
+                tail, coef = bn_fwd_tail(Cout, P, gamma, beta, rmean, rvar, cfg["eps"], cfg["momentum"][l], dev)
+            elif training and preact and cfg["preact_slab"].dim() == 2:
+                coef = cfg["preact_slab"]        # [4, C]: finalized by the front end's own launch (_sa_group_launch(bn=...))
+            elif training:
+                coef = torch.empty(4, Cout, dtype=torch.float32, device=dev)
+            if coef is not None:
+                scale, shift, mean, invstd = coef.unbind(0)
+
+            def finalize(slab, nslab):
+                call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
+                     _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
+                     ptr(mean), ptr(invstd), cur_stream())
+
             if preact:
                 if training:
                     slab = cfg["preact_slab"]
-                    call("prifit_bn_finalize", ptr(slab), slab.shape[0], Cout, _D(float(P)), ptr(gamma), ptr(beta),
-                         _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
-                         ptr(mean), ptr(invstd), cur_stream())
+                    if slab.dim() == 3:
+                        if tail is not None:   # a slab from a front end that did not finalize (functional API paths)
+                            tail = None
+                        finalize(slab, slab.shape[0])
                 else:
                     invstd = torch.rsqrt(rvar + cfg["eps"])
                     mean = rmean.clone()
@@ -285,19 +294,20 @@ class SharedMLPFn(torch.autograd.Function):
             elif training and l == 1 and nr is not None:
                 # layer 2 on rows that were never stored: the streaming product gathers them from U (prifit_gemm_stream_gather_f32)
                 nslab = dll().prifit_gemm_stream_slabs(P, Kin)
-                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                slab = None if tail is not None else torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 with profiler.span(profiler.tag("gemm_stream_nt", P, Cout, Kin, "gather"), 4.0 * (P * Cout + P + Cout * Kin)):
                     call("prifit_gemm_stream_gather_f32", P, Cout, ptr(nr["idx"]), ptr(nr["U"]), ptr(nr["Vc"]), nr["N"], nr["S"],
                          nr["K"], ptr(W), _LL(Kin), ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab),
-                         cur_stream())
-                call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
-                     _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
-                     ptr(mean), ptr(invstd), cur_stream())
+                         _ref(tail), cur_stream())
+                if tail is None:
+                    finalize(slab, nslab)
             elif training:
                 aligned = prev.stride(0) % 4 == 0 and prev.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
-                tile_m = dll().prifit_gemm_stats_tile_m(P, Cout)
-                nslab = gemm_stats_slabs(P, Cout, Kin) if aligned else (P + tile_m - 1) // tile_m
-                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                slab = nslab = None
+                if tail is None:
+                    tile_m = dll().prifit_gemm_stats_tile_m(P, Cout)
+                    nslab = gemm_stats_slabs(P, Cout, Kin) if aligned else (P + tile_m - 1) // tile_m
+                    slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 if (l == L - 1 and cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and _FUSE_POOL_FWD and aligned and
                         prev_aff is not None and _stream_ok(NT, P, Cout, Kin)):
                     # max-pooled last layer on the streaming kernel: (max, argmax, min, argmin) per 32 rows and column come
@@ -305,19 +315,18 @@ class SharedMLPFn(torch.autograd.Function):
                     cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
                     with profiler.span(profiler.tag("gemm_stream_nt", P, Cout, Kin, 1), 4.0 * (P * Kin + P * Cout + Cout * Kin)):
                         call("prifit_gemm_stream_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin),
-                             ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), cur_stream())
+                             ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), _ref(tail), cur_stream())
                 elif (l == L - 1 and cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and _FUSE_POOL_FWD and aligned and
                         prev_aff is not None and not _stream_ok(NT, P, Cout, Kin) and dll().prifit_gemm_pool_supported(P, Cout, Kin)):
                     # the same on the tiled (persistent) kernel: SA2's 256-wide last layers
                     cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
                     with profiler.span(profiler.tag("gemm_nt_bn128", P, Cout, Kin, "pool"), 2.0 * P * Cout * Kin):
                         call("prifit_gemm_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin), ptr(Y),
-                             _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), cur_stream())
+                             _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), _ref(tail), cur_stream())
                 else:
-                    gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab)
-                call("prifit_bn_finalize", ptr(slab), nslab, Cout, _D(float(P)), ptr(gamma), ptr(beta),
-                     _F(cfg["eps"]), _F(cfg["momentum"][l]), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift),
-                     ptr(mean), ptr(invstd), cur_stream())
+                    gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b, stats=slab, bn=tail)
+                if tail is None:
+                    finalize(slab, nslab)
             else:
                 gemm(NT, P, Cout, Kin, prev, prev.stride(0), W, Kin, Y, Cout, a_affine=prev_aff, bias=b)
                 invstd = torch.rsqrt(rvar + cfg["eps"])
@@ -392,10 +401,19 @@ class SharedMLPFn(torch.autograd.Function):
             Cout, Kin = W.shape if W is not None else ((nr["U"].shape[-1] if Y is None else Y.shape[1]), 0)
             scale, shift = affines[l]
             mean, invstd = stats_saved[l]
-            dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
-            dbeta = torch.empty_like(dgamma)
-            ca, cb, cd = torch.empty_like(dgamma), torch.empty_like(dgamma), torch.empty_like(dgamma)
             pooled = (l == L - 1) and cfg["pool_K"]
+            # the layer's backward coefficients [5, C] = dgamma, dbeta, a, b, d (dY = a Gm + b Y + d): finalized by the launch that
+            # produced the (m1, m2) sums -- the dA product of the layer above, or the reduce pass below -- (BatchNorm tail), or by
+            # prifit_bn_bwd_finalize from slabs (PRIFIT_BN_TAIL=0)
+            tail = None
+            final = fused_red is not None and isinstance(fused_red[0], str)
+            if final:
+                coef = fused_red[1]
+            elif _BN_TAIL and fused_red is None:
+                tail, coef = bn_bwd_tail(Cout, P, scale, mean, invstd, training, dev)
+            else:
+                coef = torch.empty(5, Cout, dtype=torch.float32, device=dev)
+            dgamma, dbeta, ca, cb, cd = coef.unbind(0)
             # the pooled last layer: dY = T*[k == arg] + b*Y + d is formed inside the streaming dA / dW kernels from Y
             # itself (no pool_bwd_apply pass writing dY, no reads of it) when both consumers are streaming shapes
             fuse_pool = bool(pooled and _FUSE_POOL and training and l > 0 and W is not None and cfg["pool_K"] % 64 == 0 and Cout != 96 and
@@ -408,45 +426,43 @@ class SharedMLPFn(torch.autograd.Function):
             fuse_bn = bool(_FUSE_BN_APPLY and _FUSE_RED and not pooled and not direct0 and training and l > 0 and W is not None and
                            ctx.needs_input_grad[2 + 6 * l] and G_in.stride(0) == Cout and G_in.data_ptr() % 16 == 0 and
                            _stream_ok(NN, P, Kin, Cout) and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
-            dY = None if (fuse_pool or direct0 or gather0 or fuse_bn or fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys)) \
-                else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            dY = None if (fuse_pool or direct0 or gather0 or fuse_bn) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
+            slab = nslab = None
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
-                prs = dll().prifit_pool_reduce_groups_per_slab()
-                nslab = (G + prs - 1) // prs
-                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                if tail is None:
+                    prs = dll().prifit_pool_reduce_groups_per_slab()
+                    nslab = (G + prs - 1) // prs
+                    slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
-                     ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, 0, _F(0.0), ptr(slab), cur_stream())
+                     ptr(scale), ptr(shift), ptr(mean), ptr(invstd), G, K, Cout, 0, _F(0.0), ptr(slab), _ref(tail), cur_stream())
+            elif final:
+                pass
             elif fused_red is not None:
                 slab, nslab = fused_red   # emitted by the dA product of the layer above (prifit_gemm_stream_dgrad_f32)
             else:
-                nslab = (P + rps - 1) // rps
-                slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
+                if tail is None:
+                    nslab = (P + rps - 1) // rps
+                    slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_bn_relu_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(scale),
-                     ptr(shift), ptr(mean), ptr(invstd), P, Cout, 0, _F(0.0), ptr(slab), cur_stream())
+                     ptr(shift), ptr(mean), ptr(invstd), P, Cout, 0, _F(0.0), ptr(slab), _ref(tail), cur_stream())
             fused_red = None
-            call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
-                 ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
-            alg_pool = bool(fuse_pool_alg_ok(pooled, training, l, W, cfg, ctx, P, Cout, Kin, Ys))
-            if alg_pool:
-                K = cfg["pool_K"]
-                G = P // K
-                Ttab = torch.empty(G, Cout, dtype=torch.float32, device=dev)
-                call("prifit_pool_bwd_table", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
-                     ptr(shift), ptr(ca), G, K, Cout, _F(0.0), ptr(Ttab), cur_stream())
-                wo, wn, bo, bn_ = wslots[l]
-                dW = arena[wo:wo + wn].view(Cout, Kin)
-                G_prev, rslab, ns = _pool_alg_bwd(P, G, K, Cout, Kin, W, ctx.biases[l], cb, cd, arg, Ttab, Ys[l - 1], affines[l - 1],
-                                                  stats_saved[l - 1], dW, dev)
-                grads[6 * l] = dW
-                if ctx.needs_input_grad[2 + 6 * l + 1]:
-                    grads[6 * l + 1] = arena[bo:bo + bn_]
-                grads[6 * l + 2] = dgamma
-                grads[6 * l + 3] = dbeta
-                fused_red = (rslab, ns)
-                G_in = G_prev
-                continue
+            if slab is not None:
+                call("prifit_bn_bwd_finalize", ptr(slab), nslab, Cout, _D(float(P)), int(training), ptr(scale),
+                     ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ca), ptr(cb), ptr(cd), cur_stream())
+
+            def red_target(Cp, ns_fn):
+                """Where a dA product of this layer leaves the (m1, m2) sums of the layer below (Cp channels): -> (slab or None,
+                descriptor or None, the `fused_red` value of the next iteration)."""
+                if _BN_TAIL:
+                    (sc_p, _), (mu_p, is_p) = affines[l - 1], stats_saved[l - 1]
+                    d, cf = bn_bwd_tail(Cp, P, sc_p, mu_p, is_p, training, dev)
+                    return None, d, ("coef", cf)
+                ns = ns_fn()
+                rs = torch.empty(ns, 2, Cp, dtype=torch.float32, device=dev)
+                return rs, None, (rs, ns)
+
             if fuse_pool:
                 Ttab = torch.empty(G, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_table", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
@@ -454,14 +470,13 @@ class SharedMLPFn(torch.autograd.Function):
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
                 if _fuse_bwd_on(Cout, Kin, True) and _FUSE_RED and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, K) and Ys[l - 1].stride(0) % 4 == 0:
-                    G_prev, rslab, ns = _fused_bwd(P, Cout, Kin, None, Y, None, None, None, cb, cd, arg, Ttab, K, W, Ys[l - 1],
-                                                   affines[l - 1], stats_saved[l - 1], dW, dev)
+                    G_prev, fused_red = _fused_bwd(P, Cout, Kin, None, Y, None, None, None, cb, cd, arg, Ttab, K, W, Ys[l - 1],
+                                                   affines[l - 1], stats_saved[l - 1], dW, dev, red_target)
                     grads[6 * l] = dW
                     if ctx.needs_input_grad[2 + 6 * l + 1]:
                         grads[6 * l + 1] = arena[bo:bo + bn_]
                     grads[6 * l + 2] = dgamma
                     grads[6 * l + 3] = dbeta
-                    fused_red = (rslab, ns)
                     G_in = G_prev
                     continue
                 ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
@@ -477,16 +492,15 @@ class SharedMLPFn(torch.autograd.Function):
                 grads[6 * l + 3] = dbeta
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
                 bias_dw = torch.mv(W.t(), cd)   # the constant d^T W of every row of dY . W
-                rslab, ns = None, 0
+                rslab = tail_p = fused_next = None
                 if _FUSE_RED:
-                    ns = dll().prifit_gemm_stream_slabs(P, Cout)
-                    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                    rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_slabs(P, Cout))
                 (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, 1), 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
                     call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
                          _LL(Kin), ptr(bias_dw), ptr(arg), ptr(Ttab), ptr(cb), K, ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)),
-                         ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), cur_stream())
-                fused_red = (rslab, ns) if rslab is not None else None
+                         ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), _ref(tail_p), cur_stream())
+                fused_red = fused_next
                 G_in = G_prev
                 continue
             if direct0:
@@ -555,8 +569,7 @@ class SharedMLPFn(torch.autograd.Function):
                 assert fuse_bn, "norows: the streaming backward of layer 2 is required (pointnet_util._norows_scales)"
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
-                ns = dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin)
-                rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin))
                 ws = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
                 (sc1, sh1), (mu1, is1) = affines[0], stats_saved[0]
@@ -564,27 +577,26 @@ class SharedMLPFn(torch.autograd.Function):
                     call("prifit_gemm_stream_bwd_gather_f32", _LL(P), Cout, ptr(G_in), ptr(Y), ptr(scale), ptr(shift), ptr(ca),
                          ptr(cb), ptr(cd), ptr(W), _LL(Kin), ptr(nr["idx"]), ptr(nr["U"]), ptr(nr["Vc"]), nr["N"], nr["S"], nr["K"],
                          ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(G_prev), _LL(Kin), ptr(rslab), ptr(dW), _LL(Kin), ptr(ws),
-                         cur_stream())
+                         _ref(tail_p), cur_stream())
                 grads[6 * l] = dW
                 if ctx.needs_input_grad[2 + 6 * l + 1]:
                     grads[6 * l + 1] = arena[bo:bo + bn_]   # bias in front of a batch-stat BatchNorm: zero gradient
                 grads[6 * l + 2] = dgamma
                 grads[6 * l + 3] = dbeta
-                fused_red = (rslab, ns)
+                fused_red = fused_next
                 G_in = G_prev
                 continue
             if fuse_bn:
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
                 if _fuse_bwd_on(Cout, Kin, False) and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, 0) and Ys[l - 1].stride(0) % 4 == 0:
-                    G_prev, rslab, ns = _fused_bwd(P, Cout, Kin, G_in, Y, scale, shift, ca, cb, cd, None, None, 0, W, Ys[l - 1],
-                                                   affines[l - 1], stats_saved[l - 1], dW, dev)
+                    G_prev, fused_red = _fused_bwd(P, Cout, Kin, G_in, Y, scale, shift, ca, cb, cd, None, None, 0, W, Ys[l - 1],
+                                                   affines[l - 1], stats_saved[l - 1], dW, dev, red_target)
                     grads[6 * l] = dW
                     if ctx.needs_input_grad[2 + 6 * l + 1]:
                         grads[6 * l + 1] = arena[bo:bo + bn_]   # bias in front of a batch-stat BatchNorm: zero gradient
                     grads[6 * l + 2] = dgamma
                     grads[6 * l + 3] = dbeta
-                    fused_red = (rslab, ns)
                     G_in = G_prev
                     continue
                 ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
@@ -599,14 +611,13 @@ class SharedMLPFn(torch.autograd.Function):
                 grads[6 * l + 2] = dgamma
                 grads[6 * l + 3] = dbeta
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
-                ns = dll().prifit_gemm_stream_slabs(P, Cout)
-                rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_slabs(P, Cout))
                 (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, "bn"), 4.0 * (2 * P * Cout + 2 * P * Kin + Kin * Cout)):
                     call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G_in), ptr(Y), _LL(Cout), ptr(W), _LL(Kin),
                          ptr(G_prev), _LL(Kin), ptr(scale), ptr(shift), ptr(ca), ptr(cb), ptr(cd), ptr(Ys[l - 1]),
-                         _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), cur_stream())
-                fused_red = (rslab, ns)
+                         _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1), ptr(rslab), _ref(tail_p), cur_stream())
+                fused_red = fused_next
                 G_in = G_prev
                 continue
             if pooled:
@@ -635,26 +646,23 @@ class SharedMLPFn(torch.autograd.Function):
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
                 if l > 0 and _FUSE_RED and _stream_ok(NN, P, Kin, Cout):
                     # streaming dA product with the BatchNorm-backward column sums of layer l-1 in its epilogue
-                    ns = dll().prifit_gemm_stream_slabs(P, Cout)
-                    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                    rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_slabs(P, Cout))
                     (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                     with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, 0), 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
                         call("prifit_gemm_stream_dgrad_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
                              _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
-                             ptr(rslab), cur_stream())
-                    fused_red = (rslab, ns)
+                             ptr(rslab), _ref(tail_p), cur_stream())
+                    fused_red = fused_next
                 elif l > 0 and _FUSE_RED:
                     # tiled kernel, same epilogue
-                    t = dll().prifit_gemm_stats_tile_m(P, Kin)
-                    ns = (P + t - 1) // t
-                    rslab = torch.empty(ns, 2, Kin, dtype=torch.float32, device=dev)
+                    rslab, tail_p, fused_next = red_target(Kin, lambda: (P + dll().prifit_gemm_stats_tile_m(P, Kin) - 1) // dll().prifit_gemm_stats_tile_m(P, Kin))
                     (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                     with profiler.span(profiler.tag("gemm_nn_bn%d" % (32 if Kin <= 32 else (64 if Kin <= 64 else (96 if Kin <= 96 else 128))),
                                                     P, Kin, Cout, "red"), 2.0 * P * Kin * Cout):
                         call("prifit_gemm_dgrad_bnred_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
                              _LL(Kin), ptr(Ys[l - 1]), _LL(Ys[l - 1].stride(0)), ptr(sc1), ptr(sh1), ptr(mu1), ptr(is1),
-                             ptr(rslab), cur_stream())
-                    fused_red = (rslab, ns)
+                             ptr(rslab), _ref(tail_p), cur_stream())
+                    fused_red = fused_next
                 else:
                     gemm(NN, P, Kin, Cout, dY, Cout, W, Kin, G_prev, Kin)
                 G_in = G_prev
@@ -715,10 +723,13 @@ def sa_group_supported(N, nsamples, widths):
 
 
 def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widths, Ws, Us, Vcs, biases,
-                     feat_xyz=False, rows=None):
+                     feat_xyz=False, rows=None, bn=None):
     """One launch: ball query for every radius + the first-layer pre-activations Y_r [B*S*K_r, C_r], their
     BatchNorm column-statistics slabs and the int32 index lists.  rows (gather mode): per radius False = do not store
-    Y_r (None is returned for it): index lists and statistics only."""
+    Y_r (None is returned for it): index lists and statistics only.
+    bn: per radius (gamma, beta, running_mean, running_var, eps, momentum) of the BatchNorm behind the first conv -- the launch
+    then FINALIZES the statistics (BatchNorm tail) and the second return value holds, per radius, the coefficients [4, C_r] =
+    scale, shift, mean, invstd instead of a slab [nslab, 2, C_r]."""
     import numpy as np
 
     B, N, _ = xyz.shape
@@ -731,7 +742,13 @@ def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widt
     assert mode == 1 or all(rows)
     Ys = [torch.empty(B * S * k, c, dtype=torch.float32, device=dev) if keep else None
           for k, c, keep in zip(nsamples, widths, rows)]
-    slabs = [torch.empty(nslab, 2, c, dtype=torch.float32, device=dev) for c in widths]
+    tails = None
+    if bn is not None and _BN_TAIL:
+        tails = [bn_fwd_tail(c, B * S * k, g_, b_, rm, rv, eps, mom, dev) for c, k, (g_, b_, rm, rv, eps, mom) in zip(widths, nsamples, bn)]
+        slabs = [cf for _, cf in tails]
+        bn_arr = (ctypes.POINTER(_BnFwdDesc) * R)(*[ctypes.pointer(d) for d, _ in tails])
+    else:
+        slabs = [torch.empty(nslab, 2, c, dtype=torch.float32, device=dev) for c in widths]
     idxs = [torch.empty(B, S, k, dtype=torch.int32, device=dev) for k in nsamples]
     r2 = (ctypes.c_float * R)(*[float(np.float32(r ** 2)) for r in radii])  # fp32(radius^2), like ops.ball_query_multi
     ns = (ctypes.c_int * R)(*[int(k) for k in nsamples])
@@ -745,8 +762,8 @@ def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widt
     with profiler.span("sa_group_linear", work):
         call("prifit_sa_group_linear_fwd", ptr(xyz), ptr(new_xyz), B, N, S, R, r2, ns, wd, mode, ptr(feat), D,
              int(feat_first), int(feat_xyz), _ptr_array(Ws) if Ws else None, _ptr_array(Us) if Us else None,
-             _ptr_array(Vcs) if Vcs else None, _ptr_array(biases), _ptr_array(Ys), _ptr_array(slabs), _ptr_array(idxs),
-             cur_stream())
+             _ptr_array(Vcs) if Vcs else None, _ptr_array(biases), _ptr_array(Ys), None if tails else _ptr_array(slabs), _ptr_array(idxs),
+             bn_arr if tails else None, cur_stream())
     return Ys, slabs, idxs
 
 

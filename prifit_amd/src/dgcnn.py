@@ -255,12 +255,12 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chs
         nslab = (Gp + rows - 1) // rows
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         call("prifit_pool_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
-             ptr(shift), ptr(mean), ptr(invstd), Gp, pool_K, Cout, rps, _F(slope), ptr(slab), cur_stream())
+             ptr(shift), ptr(mean), ptr(invstd), Gp, pool_K, Cout, rps, _F(slope), ptr(slab), None, cur_stream())
     else:
         nslab = (P + rows - 1) // rows
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         call("prifit_bn_relu_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(scale), ptr(shift),
-             ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), cur_stream())
+             ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), None, cur_stream())
     m = float(cfg.get("count_rows", rps) * (Cout // G))     # count_rows: Y is a per-group table of a tensor with more rows
     ca = scale.contiguous()
     if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
@@ -376,7 +376,7 @@ class ConvGNActFn(torch.autograd.Function):
             if nostore:
                 ystar = torch.empty(P // cfg["pool_K"], Cout, dtype=torch.float32, device=dev)
             call("prifit_gemm_pool_f32", P, Cout, Kin, ptr(x), _LL(Kin), ptr(W), _LL(Kin), ptr(Y), _LL(Cout), None, None,
-                 ptr(bias), ptr(slab), ptr(cand), cur_stream())
+                 ptr(bias), ptr(slab), ptr(cand), None, cur_stream())
         else:
             gemm(NT, P, Cout, Kin, x, Kin, W, Kin, Y, Cout, bias=bias, stats=slab, tiled_stats=True)
         out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, tile, gamma, beta, cfg, offset, cand, chsum, (P, Cout), ystar)

@@ -144,9 +144,15 @@ class Trainer:
         self.model = model
         self.num_part = num_part
         self.lr0, self.lr_decay, self.step_size, self.lmbda = learning_rate, lr_decay, step_size, lmbda
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, betas=(0.9, 0.999), eps=1e-08,
-                                          weight_decay=decay_rate,
-                                          fused=bool(fused_adam and next(model.parameters()).is_cuda))
+        # one launch per step over a flat parameter buffer on the GPU (prifit_amd/optim.py; PRIFIT_FLAT_ADAM=0 / fused_adam=False:
+        # torch's optimizer, the A/B arm); host tensors (the gloo tests of the exchange logic) take torch's
+        on_gpu = next(model.parameters()).is_cuda
+        if on_gpu and fused_adam and os.environ.get("PRIFIT_FLAT_ADAM", "1") != "0":
+            from .optim import FlatAdam
+            self.optimizer = FlatAdam(model.parameters(), lr=learning_rate, betas=(0.9, 0.999), eps=1e-08, weight_decay=decay_rate)
+        else:
+            self.optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, betas=(0.9, 0.999), eps=1e-08,
+                                              weight_decay=decay_rate, fused=bool(fused_adam and on_gpu))
         # strict_seen: ranks may disagree on which parameters get a gradient (see ddp.FlatGradBucket._adopt)
         self.bucket = FlatGradBucket(model, strict_seen=strict_seen)
         self._next = None          # the batch prepared by prefetch_selfsup
@@ -173,7 +179,10 @@ class Trainer:
         if loss is not None:
             loss.backward()
         self.bucket.allreduce()
-        self.optimizer.step()
+        if hasattr(self.optimizer, "exp_avg"):           # FlatAdam: hand over the gradient list the exchange just read
+            self.optimizer.step(grads=self.bucket.grads())
+        else:
+            self.optimizer.step()
 
     # ------------------------------------------------------------------ supervised step (upstream :372-399)
     def supervised_step(self, points, target, category_label=None, augment=True, fps_start=None):

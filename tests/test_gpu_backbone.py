@@ -247,48 +247,6 @@ def test_shared_mlp_fused_da_dw_matches_separate_kernels(nn_ops, P, K, dims):
         assert (a - b).norm() <= 2e-5 * b.norm() + 1e-7, ((a - b).norm().item(), b.norm().item())
 
 
-@pytest.mark.parametrize("P,K,dims", [(98304, 128, ((64, 64), (64, 96), (96, 128))),       # SA1 scale 3's widths
-                                      (65536, 64, ((64, 64), (64, 64), (64, 128))),        # SA1 scale 2
-                                      (32768, 64, ((128, 128), (128, 128), (128, 256))),   # SA2 scale 1: tiled kernels in the other arm
-                                      (65600 // 64 * 64, 64, ((32, 64), (64, 128)))])      # two layers, ragged tile count
-def test_pooled_layer_backward_in_algebraic_form_matches_the_products_over_cout(nn_ops, P, K, dims):
-    """SharedMLPFn with the max-pooled last layer's backward in the algebraic form (default: A M and the Gram matrix A^T A over
-    Cin x Cin from the layer's INPUT, the winners' rows as index work; csrc/pool_alg.hip) against the arm that multiplies over
-    Cout x Cin and reads the pooled layer's pre-activation: same forward bit for bit, every gradient to fp32 rounding --
-    with conv biases that are NOT zero (they enter v = W^T (d + b * bias) and the weight gradient)."""
-    x = _rand((P, dims[0][0]), 31).cuda()
-    g = torch.Generator().manual_seed(32)
-    tens = []
-    for cin, cout in dims:
-        tens += [(torch.randn(cout, cin, generator=g) * (2.0 / cin ** 0.5)).cuda().requires_grad_(True),
-                 (torch.randn(cout, generator=g) * 0.3).cuda().requires_grad_(True),
-                 (torch.rand(cout, generator=g) + 0.5).cuda().requires_grad_(True), (torch.randn(cout, generator=g) * 0.1).cuda().requires_grad_(True),
-                 torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")]
-    gout = _rand((P // K, dims[-1][1]), 33).cuda()
-    res = {}
-    for alg in (True, "unfused", False):
-        old = nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED, nn_ops._POOL_ALG_AUTO
-        nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED, nn_ops._POOL_ALG_AUTO = bool(alg), alg is True, False
-        try:
-            xi = x.clone().requires_grad_(True)
-            cfg = {"pool_K": K, "training": True, "eps": 1e-5, "momentum": [0.1] * len(dims)}
-            out = nn_ops.SharedMLPFn.apply(xi, cfg, *[t.clone() if not t.requires_grad else t for t in tens])
-            grads = torch.autograd.grad(out, [xi] + [t for t in tens if t.requires_grad], gout, allow_unused=True)
-            res[alg] = [out.detach()] + [None if gg is None else gg.detach().clone() for gg in grads]
-        finally:
-            nn_ops._POOL_ALG, nn_ops._POOL_ALG_FUSED, nn_ops._POOL_ALG_AUTO = old
-    assert torch.equal(res[True][0], res[False][0])
-    for arm in (True, "unfused"):      # the winners' rows inside the dense pass (where that kernel exists) / as a second launch
-        worst = 0.0
-        for a, b in zip(res[arm][1:], res[False][1:]):
-            if b is None:
-                assert a is None
-                continue
-            worst = max(worst, ((a - b).norm() / (b.norm() + 1e-30)).item())
-            assert (a - b).norm() <= 5e-5 * b.norm() + 1e-6, (arm, (a - b).norm().item(), b.norm().item())
-        print("algebraic pooled backward (%s) vs products over Cout: worst relative deviation %.2e" % (arm, worst))
-
-
 @pytest.mark.parametrize("P,Cout,Kin", [(40008, 96, 64), (65536, 64, 64), (33000, 128, 128), (50000, 128, 96)])
 def test_bn_apply_on_load_matches_apply_pass(nn_ops, P, Cout, Kin):
     """prifit_gemm_stream_tn_bn_f32 / prifit_gemm_stream_dgrad_bn_f32 (a middle layer's dY formed from G and Y inside the
@@ -315,9 +273,9 @@ def test_bn_apply_on_load_matches_apply_pass(nn_ops, P, Cout, Kin):
     Gp_ref, Gp = torch.empty(P, Kin, device="cuda"), torch.full((P, Kin), float("nan"), device="cuda")
     sl_ref, sl = torch.empty(ns, 2, Kin, device="cuda"), torch.full((ns, 2, Kin), float("nan"), device="cuda")
     call("prifit_gemm_stream_dgrad_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp_ref), _LL(Kin), ptr(A), _LL(Kin),
-         ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), cur_stream())
+         ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), None, cur_stream())
     call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G), ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp), _LL(Kin), ptr(s), ptr(t),
-         ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), cur_stream())
+         ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), None, cur_stream())
     assert torch.equal(Gp, Gp_ref)
     torch.testing.assert_close(sl.double().sum(0), sl_ref.double().sum(0), rtol=1e-6, atol=1e-3)
 
@@ -348,7 +306,7 @@ def test_fused_da_dw_kernel_matches_separate_streaming_kernels(nn_ops, P, Cout, 
         call("prifit_gemm_stream_tn_pool_f32", Cout, Kin, _LL(P), ptr(Y), _LL(Cout), ptr(A), _LL(Kin), ptr(dW_ref), _LL(Kin), ptr(s1),
              ptr(t1), ptr(arg), ptr(T), ptr(cb), ptr(cd), pool_K, ptr(ws), cur_stream())
         call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp_ref), _LL(Kin), ptr(bias_dw),
-             ptr(arg), ptr(T), ptr(cb), pool_K, ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), cur_stream())
+             ptr(arg), ptr(T), ptr(cb), pool_K, ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), None, cur_stream())
         G = None
     else:
         G = _rand((P, Cout), 61).cuda()
@@ -356,7 +314,7 @@ def test_fused_da_dw_kernel_matches_separate_streaming_kernels(nn_ops, P, Cout, 
         call("prifit_gemm_stream_tn_bn_f32", Cout, Kin, _LL(P), ptr(G), ptr(Y), _LL(Cout), ptr(A), _LL(Kin), ptr(dW_ref), _LL(Kin), ptr(s1),
              ptr(t1), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), ptr(ws), cur_stream())
         call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G), ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(Gp_ref), _LL(Kin), ptr(s), ptr(t),
-             ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), cur_stream())
+             ptr(ca), ptr(cb), ptr(cd), ptr(A), _LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl_ref), None, cur_stream())
     ns = dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin)
     Gp = torch.full((P, Kin), float("nan"), device="cuda")
     sl = torch.full((ns, 2, Kin), float("nan"), device="cuda")
@@ -364,7 +322,7 @@ def test_fused_da_dw_kernel_matches_separate_streaming_kernels(nn_ops, P, Cout, 
     ws2 = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), device="cuda")
     call("prifit_gemm_stream_bwd_f32", _LL(P), Cout, Kin, ptr(G), ptr(Y), ptr(None if pool_K else s), ptr(None if pool_K else t),
          ptr(None if pool_K else ca), ptr(cb), ptr(cd), ptr(arg), ptr(T), pool_K, ptr(W), _LL(Kin), ptr(A), _LL(Kin), ptr(s1), ptr(t1),
-         ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(sl), ptr(dW), _LL(Kin), ptr(ws2), cur_stream())
+         ptr(mu1), ptr(is1), ptr(Gp), _LL(Kin), ptr(sl), ptr(dW), _LL(Kin), ptr(ws2), None, cur_stream())
     assert torch.isfinite(Gp).all() and torch.isfinite(dW).all() and torch.isfinite(sl).all()
     assert (Gp - Gp_ref).abs().max() <= 2e-5 * Gp_ref.abs().max()
     assert (dW - dW_ref).norm() <= 2e-6 * dW_ref.norm()
@@ -386,7 +344,7 @@ def test_pool_candidates_match_pool_fwd(nn_ops, P, K, N, Kin):
     cand = torch.empty(P // 32, 4, N, device="cuda")
     slab = torch.empty(nn_ops.gemm_stats_slabs(P, N, Kin), 2, N, device="cuda")
     call("prifit_gemm_stream_pool_f32", P, N, Kin, ptr(Ad), _LL(Kin), ptr(Wd), _LL(Kin), ptr(Y), _LL(N), ptr(sc.cuda()),
-         ptr(sh.cuda()), ptr(bias.cuda()), ptr(slab), ptr(cand), cur_stream())
+         ptr(sh.cuda()), ptr(bias.cuda()), ptr(slab), ptr(cand), None, cur_stream())
     G = P // K
     s2d, t2d = s2.cuda(), t2.cuda()
     out1, arg1 = torch.empty(G, N, device="cuda"), torch.empty(G, N, dtype=torch.int32, device="cuda")

@@ -97,6 +97,7 @@ def test_labelled_experiment_line_says_what_it_is(hiplib):
     """`bench.py --ms-split MODE` (the 16-bit-planes experiment of the mean-shift forward): the line carries the label in
     `dtype` and `experiment`, the split kernel is the dominant family, no `extra`; without the flag `dtype` is plain f32."""
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    base["PRIFIT_BENCH_EVENTS"] = "all"     # every kernel family in `kernels` (by default only the dominant one and the grouping launches)
     bench = os.path.join(ROOT, "bench.py")
     args = ["--steps", "2", "--warmup", "2", "--workload", "c3", "--no-cpu-baseline", "--no-extra"]
     exp = _line([sys.executable, bench] + args + ["--ms-split", "fp16x3"], base)

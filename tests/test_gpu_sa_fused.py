@@ -261,3 +261,63 @@ def test_ab_arms_of_the_front_end(mods, switch, case):
         _close(gr_a[n], gr_b[n], 1e-2)      # (BatchNorm sums in another order: a few ReLU / pool winners flip, see above)
     if gin_b is not None:
         _close(gin_a, gin_b, 1e-2)
+
+
+@pytest.mark.parametrize("case", ["msg_sa1", "msg_sa2", "ssg", "sa3_all", "fp"])
+def test_batchnorm_tails_give_the_coefficients_of_the_finalize_launches(mods, case):
+    """PRIFIT_BN_TAIL=1 (the kernels that produce a BatchNorm layer's column sums also finalize them: fp64 atomics into 32 replica
+    accumulators, the workgroup with the last ticket writes scale / shift / mean / invstd resp. dgamma / dbeta / a / b / d;
+    csrc/common.h) against the slab + prifit_bn_finalize / prifit_bn_bwd_finalize launches: the fp64 sums of fp32 partials are
+    exact, the coefficient arithmetic is one shared function with contraction off -- so the forward output, the running
+    statistics and (the backward sums being exact up to a last-bit event) the gradients agree bit for bit or to 1e-6.  Every
+    producer: the set-abstraction front end (direct and gather mode), streaming / persistent / tiled products forward, the
+    dA products' and reduce passes' backward sums."""
+    ops, nn_ops, pu = mods
+    B = 3
+    if case == "msg_sa1":
+        xyz = _t(synth.cloud("surface", B, 2048, 1)).cuda()
+        make = lambda: pu.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], 3, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        args, fg = (xyz, xyz, torch.zeros(B, dtype=torch.long, device="cuda")), False
+    elif case == "msg_sa2":
+        xyz = _t(synth.cloud("surface", B, 512, 2)).cuda()
+        make = lambda: pu.PointNetSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 320, [[128, 128, 256], [128, 196, 256]])
+        args, fg = (xyz, torch.randn(B, 512, 320, device="cuda"), torch.zeros(B, dtype=torch.long, device="cuda")), True
+    elif case == "ssg":
+        xyz = _t(synth.cloud("cube", B, 1024, 3)).cuda()
+        make = lambda: pu.PointNetSetAbstraction(256, 0.2, 32, 6 + 3, [64, 64, 128], False)
+        args, fg = (xyz, torch.cat([xyz, torch.randn(B, 1024, 3, device="cuda")], -1), torch.zeros(B, dtype=torch.long, device="cuda")), False
+    elif case == "sa3_all":
+        xyz = _t(synth.cloud("cube", B, 128, 4)).cuda()
+        make = lambda: pu.PointNetSetAbstraction(None, None, None, 512 + 3, [256, 512, 1024], True)
+        args, fg = (xyz, torch.randn(B, 128, 512, device="cuda"), None), True
+    else:
+        make = lambda: pu.PointNetFeaturePropagation(150, [128, 128])
+    res = []
+    for tail in (True, False):
+        old = nn_ops._BN_TAIL
+        nn_ops._BN_TAIL = tail
+        try:
+            if case == "fp":
+                torch.manual_seed(5)
+                m = make().cuda().train()
+                x1 = _t(synth.cloud("cube", B, 2048, 6)).cuda()
+                x2 = x1[:, :512].contiguous()
+                p1 = torch.randn(B, 2048, 22, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+                p2 = torch.randn(B, 512, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)).requires_grad_(True)
+                out = m.forward_cl(x1, x2, p1, p2)
+                g = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).cuda()
+                (out * g).sum().backward()
+                res.append((out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()}, p2.grad.clone(),
+                            {n: b.clone() for n, b in m.named_buffers()}))
+            else:
+                res.append(_run_module(pu, True, make, args, 11, fg))
+        finally:
+            nn_ops._BN_TAIL = old
+    (out_a, gr_a, gin_a, st_a), (out_b, gr_b, gin_b, st_b) = res
+    assert torch.equal(out_a, out_b)
+    for n in st_b:
+        assert torch.equal(st_a[n], st_b[n]), n
+    for n in gr_b:
+        _close(gr_a[n], gr_b[n], 1e-6)
+    if gin_b is not None:
+        _close(gin_a, gin_b, 1e-6)

@@ -318,3 +318,78 @@ def test_alternating_trainer_steps_train(hiplib):
     # conv2 first gets a gradient in step 1 (supervised), extra_conv_emb in step 2 (self-supervised): afterwards every
     # parameter steps every time
     assert steps <= {2 * iters, 2 * iters - 1}, steps
+
+
+def test_flat_adam_matches_torch_adam(hiplib):
+    """prifit_adam_flat (one launch over the flat parameter buffer, prifit_amd/optim.py) against torch.optim.Adam (the
+    single-tensor CPU path, in fp32 and in fp64) on the same gradients: ragged tensor sizes (a length that is not a multiple of
+    four, a scalar), a parameter that gets its first gradient at step 3 and one that never does (skipped: no decay, no step
+    count), a learning-rate change in between, a step discarded through the device `skip` flag, and the checkpoint format in both
+    directions (train_partseg_shapenet.py:252-259, :398, :467-475)."""
+    from prifit_amd.optim import FlatAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    shapes = [(64, 9), (50,), (1,), (128, 64, 1, 1), (7, 3), (33,), (256, 131)]
+    mk = lambda dt, d: [torch.nn.Parameter(torch.randn(*s, dtype=dt, device=d)) for s in shapes]
+    torch.manual_seed(3)
+    ref32 = mk(torch.float32, "cpu")
+    ref64 = [torch.nn.Parameter(p.detach().double()) for p in ref32]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref32]
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    o32, o64 = torch.optim.Adam(ref32, **kw), torch.optim.Adam(ref64, **kw)
+    opt = FlatAdam(mine, **kw)
+    assert all(p.data_ptr() % 512 == 0 for p in mine)           # every tensor keeps an allocator-like alignment
+    late, never = 4, 5
+    skip = torch.zeros(1, dtype=torch.int32, device=dev)
+    for step in range(8):
+        if step == 5:
+            for o in (o32, o64):
+                o.param_groups[0]["lr"] = 2.5e-4
+            opt.param_groups[0]["lr"] = 2.5e-4
+        gs = [torch.randn(*s) * (0.1 + i) for i, s in enumerate(shapes)]
+        for i in range(len(shapes)):
+            has = i != never and (i != late or step >= 3)
+            ref32[i].grad = gs[i].clone() if has else None
+            ref64[i].grad = gs[i].double() if has else None
+            # odd steps: a gradient that is a misaligned view (scalar loads in the kernel); even steps: its own tensor
+            if has and step % 2 == 1 and gs[i].numel() > 1:
+                buf = torch.zeros(gs[i].numel() + 1, device=dev)
+                buf[1:].copy_(gs[i].reshape(-1))
+                mine[i].grad = buf[1:].view(shapes[i])
+            else:
+                mine[i].grad = gs[i].to(dev) if has else None
+        if step == 6:       # a discarded step: nothing may change, the counters included
+            before = [p.detach().clone() for p in mine]
+            skip.fill_(1)
+            opt.step(skip=skip)
+            skip.zero_()
+            assert all(torch.equal(a, b) for a, b in zip(before, mine))
+        o32.step()
+        o64.step()
+        opt.step()
+    torch.cuda.synchronize()
+    for i, (a, b, c) in enumerate(zip(mine, ref32, ref64)):
+        noise = float((b.detach().double() - c.detach()).abs().max())
+        err = float((a.detach().cpu().double() - c.detach()).abs().max())
+        assert err <= 4 * noise + 1e-7, (i, err, noise)
+    assert torch.equal(mine[never].detach().cpu(), ref32[never].detach())          # untouched
+    sd = opt.state_dict()
+    steps = {i: int(s["step"]) for i, s in sd["state"].items()}
+    assert never not in steps and steps[late] == 5 and steps[0] == 8, steps
+    assert opt.uploads <= 9
+    # torch -> flat and flat -> torch through the checkpoint format
+    fresh = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt2 = FlatAdam(fresh, **kw)
+    opt2.load_state_dict(o32.state_dict())
+    t2 = torch.optim.Adam([torch.nn.Parameter(p.detach().clone().cpu()) for p in mine], **kw)
+    t2.load_state_dict(sd)
+    g = [torch.randn(*s) for s in shapes]
+    for i in range(len(shapes)):
+        fresh[i].grad = g[i].to(dev) if i != never else None
+        t2.param_groups[0]["params"][i].grad = g[i].clone() if i != never else None
+        ref32[i].grad = g[i].clone() if i != never else None
+    opt2.step(); t2.step(); o32.step()
+    for i in range(len(shapes)):
+        assert torch.allclose(fresh[i].detach().cpu(), ref32[i].detach(), rtol=0, atol=2e-6), i
+        assert torch.allclose(t2.param_groups[0]["params"][i].detach(), ref32[i].detach(), rtol=0, atol=2e-6), i
+    assert opt2.param_groups[0]["lr"] == 2.5e-4

@@ -52,7 +52,7 @@ def run_red(M, N, K):
     for i in range(4):
         if i == 3: ev[0].record()
         call("prifit_gemm_dgrad_bnred_f32", M, N, K, ptr(dY), _LL(K), ptr(W), _LL(N), ptr(G), _LL(N), ptr(Y), _LL(N),
-             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), ptr(slab), cur_stream())
+             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), ptr(slab), None, cur_stream())
     ev[1].record(); torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 512)()
     assert dll().prifit_debug_pers_stamps(buf, 512) == 0

@@ -34,16 +34,16 @@ for P, Cout, Kin, pool_K in CASES:
         bias_dw = torch.mv(W.t(), cd); G = None
         def sep():
             call("prifit_gemm_stream_tn_pool_f32", Cout, Kin, LL(P), ptr(Y), LL(Cout), ptr(A), LL(Kin), ptr(dW), LL(Kin), ptr(s1), ptr(t1), ptr(arg), ptr(T), ptr(cb), ptr(cd), pool_K, ptr(ws), cur_stream())
-            call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), LL(Cout), ptr(W), LL(Kin), ptr(Gp), LL(Kin), ptr(bias_dw), ptr(arg), ptr(T), ptr(cb), pool_K, ptr(A), LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), cur_stream())
+            call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), LL(Cout), ptr(W), LL(Kin), ptr(Gp), LL(Kin), ptr(bias_dw), ptr(arg), ptr(T), ptr(cb), pool_K, ptr(A), LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), None, cur_stream())
     else:
         G = rnd(P, Cout); arg = T = None
         def sep():
             call("prifit_gemm_stream_tn_bn_f32", Cout, Kin, LL(P), ptr(G), ptr(Y), LL(Cout), ptr(A), LL(Kin), ptr(dW), LL(Kin), ptr(s1), ptr(t1), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), ptr(ws), cur_stream())
-            call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G), ptr(Y), LL(Cout), ptr(W), LL(Kin), ptr(Gp), LL(Kin), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), ptr(A), LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), cur_stream())
+            call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G), ptr(Y), LL(Cout), ptr(W), LL(Kin), ptr(Gp), LL(Kin), ptr(s), ptr(t), ptr(ca), ptr(cb), ptr(cd), ptr(A), LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(sl), None, cur_stream())
     sl2 = torch.empty(dll().prifit_gemm_stream_bwd_slabs(LL(P), Cout, Kin), 2, Kin, device="cuda")
     ws2 = torch.empty(dll().prifit_gemm_stream_bwd_workspace(LL(P), Cout, Kin), device="cuda")
     def fused():
-        call("prifit_gemm_stream_bwd_f32", LL(P), Cout, Kin, ptr(G), ptr(Y), ptr(None if pool_K else s), ptr(None if pool_K else t), ptr(None if pool_K else ca), ptr(cb), ptr(cd), ptr(arg), ptr(T), pool_K, ptr(W), LL(Kin), ptr(A), LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(Gp), LL(Kin), ptr(sl2), ptr(dW), LL(Kin), ptr(ws2), cur_stream())
+        call("prifit_gemm_stream_bwd_f32", LL(P), Cout, Kin, ptr(G), ptr(Y), ptr(None if pool_K else s), ptr(None if pool_K else t), ptr(None if pool_K else ca), ptr(cb), ptr(cd), ptr(arg), ptr(T), pool_K, ptr(W), LL(Kin), ptr(A), LL(Kin), ptr(s1), ptr(t1), ptr(mu1), ptr(is1), ptr(Gp), LL(Kin), ptr(sl2), ptr(dW), LL(Kin), ptr(ws2), None, cur_stream())
     dW.zero_(); sep(); torch.cuda.synchronize(); ref = (Gp.clone(), dW.clone())
     dW.zero_(); Gp.zero_(); fused(); torch.cuda.synchronize()
     eg = ((Gp - ref[0]).norm() / ref[0].norm()).item(); ew = ((dW - ref[1]).norm() / ref[1].norm()).item()
