@@ -1031,6 +1031,9 @@ if __name__ == "__main__":
     if "center_grad" in which:
         import make_golden_fit
         make_golden_fit.run_center_grad(save, eq, close)
+    if "many_clusters" in which:
+        import make_golden_fit
+        make_golden_fit.run_many_clusters(save, eq, close)
     if "prune" in which:
         import make_golden_fit
         make_golden_fit.run_prune(save, eq, close)

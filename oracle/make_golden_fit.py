@@ -519,3 +519,62 @@ def run(save, eq, close):
         assert np.allclose(np.sort(r.numpy()), np.sort(abc_k[k]), rtol=2e-2), (r, abc_k[k])
     save("fit_kat", points=pk, W=wk, abc=np.array(abc_k), centres=np.array(ctr_k), R=R,
          r_ref=torch.stack([p[0] for p in prm[0]]), c_ref=torch.stack([p[2] for p in prm[0]]))
+
+
+def many_cluster_inputs(B=2, N=2048, D=128, seed=61, K=40, M=5000):
+    """A cloud of K = 40 tight blobs with K embedding prototypes: more clusters per shape than the loss path's 32 slots."""
+    cham, lab = synth.blobs_with_labels(B, M, seed, K=K, sigma=0.05)
+    sel = np.random.default_rng(seed + 1).choice(M, N, replace=False)
+    emb = synth.prototype_embedding(lab[:, sel], D, seed + 2, K=K, noise=0.03)   # (0.02: memberships saturate, |dX| ~ 1e-6)
+    return torch.from_numpy(cham[:, sel]), torch.from_numpy(cham), torch.from_numpy(emb)
+
+
+def run_many_clusters(save, eq, close):
+    """`--max_num_clusters 49` (args_parser.py:48; the reference's own gaurd_mean_shift accepts 49 clusters,
+    src/mean_shift.py:212-226) on shapes with 40 modes: clustering, fit and the whole convex loss with its gradient from the
+    reference (same harness conventions as run(): one noise matrix, canonical SVD signs, the Fibonacci sampler), the oracle
+    checked against it.  VERDICT r5 item 8: cluster capacity above 32."""
+    print("[fit, 40 clusters per shape, max_num_clusters = 49]")
+    EF = refshim.ref("src.ellipsoid_fitting")
+    EU = refshim.ref("src.ellipsoid_utils")
+    CL = refshim.ref("convex_loss")
+    SE = refshim.ref("src.sample_ellipsoid")
+    B, N, D, seed, q, iters, cap = 2, 2048, 128, 61, 0.01, 10, 49
+    pts, cham, emb = many_cluster_inputs(B, N, D, seed)
+    R = torch.from_numpy(synth.uniform01((3, 3), seed))
+
+    def ref_customsvd_canonical(M):
+        U, S, V = refshim.ref("src.fitting_utils").customsvd(M)
+        s = orc.canonical_signs(V).view(1, 3)
+        return U * s, S, V * s
+
+    def ref_sample(self, a, b_, c, center, transformation, n=500):
+        U, V = orc.fibonacci_uv(int(n))
+        p = self.uniform_sample_points_on_ellipsoid(U, V, a, b_, c)
+        return p @ transformation.T + center, None
+
+    Ws_r, labs_r = EU.clustering(emb, num_samples=N, quantile=q, iterations=iters, max_num_clusters=cap)
+    Ks = [w.shape[1] for w in Ws_r]
+    print("  reference: clusters per shape", Ks)
+    assert min(Ks) >= 33 and max(Ks) <= cap, Ks
+    Ws_o, labs_o, _ = orc.clustering(emb, q, iters, cap)
+    for b in range(B):
+        assert same_partition(labs_r[b], labs_o[b]), "label partition differs"
+    Xr = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    with patched(torch, "rand", lambda *a, **k: R.clone()), patched(EF, "customsvd", ref_customsvd_canonical), \
+            patched(SE.SampleEllipsoid, "sample", ref_sample):
+        tot_r, ch_r, prm_r, lab_r = CL.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xr, quantile=q,
+                                                   iterations=iters, max_num_clusters=cap)
+    tot_r.sum().backward()
+    Xo = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    tot_o, ch_o, prm_o, lab_o = orc.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), Xo, quantile=q, iterations=iters,
+                                                max_num_clusters=cap, rand_table=[[R] * 64] * B, canonical=True)
+    tot_o.sum().backward()
+    close(tot_o, tot_r, "convex_loss total (40 clusters)", rtol=1e-5)
+    close(Xo.grad, Xr.grad, "convex_loss dX (40 clusters)", rtol=2e-3, atol=1e-3 * Xr.grad.abs().max().item())
+    order = [canonical_order(lab_r[b], Ks[b]) for b in range(B)]
+    save("fit_many_clusters", seed=seed, R=R, quantile=q, max_num_clusters=cap, total=tot_r.detach(), chamfer=ch_r.detach(),
+         K=np.array([len(p) for p in prm_r]), labels=torch.stack(lab_r).to(torch.int16), dX_norm=Xr.grad.norm(),
+         dX_head=Xr.grad[:, :, :32].contiguous(),
+         r=torch.stack([torch.stack([prm_r[b][int(k)][0] for k in order[b]] + [torch.zeros(3)] * (cap - Ks[b])) for b in range(B)]).detach(),
+         c=torch.stack([torch.stack([prm_r[b][int(k)][2] for k in order[b]] + [torch.zeros(3)] * (cap - Ks[b])) for b in range(B)]).detach())

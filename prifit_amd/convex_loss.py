@@ -338,7 +338,7 @@ def convex_loss(points, chamfer_points, X, batch_id=0, epoch=-1, seed=0, N=500, 
         entropy_loss = entropy(emb[:, entropy_indices.to(emb.device)])
     cl = fit_ops.cluster(emb, quantile, iterations, max_num_clusters, center_ids=center_ids)   # clustering(): :68
     if rand_table is None:
-        rand_table = torch.rand(pts.shape[0], fit_ops.KM, 3, 3, device=pts.device)
+        rand_table = torch.rand(pts.shape[0], cl["W"].shape[2], 3, 3, device=pts.device)
     r, V, c, valid = fit_ops.EllipsoidFitFn.apply(pts, cl["W"], cl["count"], rand_table.to(pts.device), canonical)  # :70
     if evaluation is False:
         tgt = chamfer_points.permute(0, 2, 1).contiguous()

@@ -33,9 +33,10 @@ constexpr int KT = 64;        // keys per workgroup
 #define MSR_RC 4
 #endif
 constexpr int RC = MSR_RC;    // rows per chunk of the score phase (LDS: 50 KB per workgroup, three per CU: the 768 of B = 24 in one round)
-constexpr int RMAX = 32;
+constexpr int RCAP = 64;      // live rows per shape: kernels are instantiated for RMAX = 32 (the loss path: <= 25 clusters, KM = 32 slots)
+                              // and RMAX = 64 (max_num_clusters up to 64: the reference's own guard uses 49, src/mean_shift.py:212-226)
 constexpr int CH = 8;         // rows per ticket: the slabs of a shape are summed per chunk of 8 rows, by whichever workgroup finishes it last
-constexpr int NCH = RMAX / CH;
+constexpr int NCH_CAP = RCAP / CH;
 constexpr float LOG2E = 1.44269504088896341f;
 #ifndef MSR_PROBE
 #define MSR_PROBE 0           // timing probes only (wrong results): 1 no ticket / tail, 2 also no partial dZ, 3 the key tile load alone
@@ -49,7 +50,7 @@ struct RowsArgs {
     // rows_iter, iteration t: where its partials go, the shape tickets (the prepared rows [B][R][D] x 2, [B][R] and the tables
     // [B][R][N] x 2 it writes are kernel parameters of their own)
     float *part;                                        // [B][ntile][R][D]
-    int *counter;                                       // [B][NCH]
+    int *counter;                                       // [B][NCH_CAP]
     // what prep_rows reads and writes: the saved tensors of the iteration it prepares (all NULL: iterate 0 is reached)
     const float *pZin, *pZout, *pO, *prsum, *pnrm;
     float *p_zrow, *p_gO, *p_grs;
@@ -165,12 +166,12 @@ template <int D>
 __global__ __launch_bounds__(256) void ms_rows_first_kernel(RowsArgs a)
 {
     const int b = blockIdx.x;
-    if (threadIdx.x < NCH) a.counter[b * NCH + threadIdx.x] = 0;
+    if (threadIdx.x < NCH_CAP) a.counter[b * NCH_CAP + threadIdx.x] = 0;
     prep_rows<D>(a, b, 0, live_rows(a, b), a.g_rows);
 }
 
 // grid (ntile, B), 256 threads: one iteration
-template <int D>
+template <int D, int RMAX>
 __global__ __launch_bounds__(256) void ms_rows_iter_kernel(RowsArgs a, const float *__restrict__ zrow, const float *__restrict__ gO,
                                                            const float *__restrict__ grs, float *__restrict__ coef_gs,
                                                            float *__restrict__ coef_k)
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void ms_rows_iter_kernel(RowsArgs a, const flo
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            int *ticket = a.counter + b * NCH + q;
+            int *ticket = a.counter + b * NCH_CAP + q;
             const int last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.ntile - 1;
             if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
             s_last = last;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void ms_rows_iter_kernel(RowsArgs a, const flo
 }
 
 // grid (ntile, B), 256 threads: dX_j += sum_t sum_r gS^t_rj z^t_r + K^t_rj gO^t_r, + g0_r where key j is kept point r
-template <int D>
+template <int D, int RMAX>
 __global__ __launch_bounds__(256) void ms_rows_apply_kernel(RowsArgs a)
 {
     constexpr int ND4 = D / 4;
@@ -391,12 +392,12 @@ RowsLayout rows_layout(int B, int N, int D, int R, int T)
     l.g0 = at; at += l.rows_stride;
     l.part = at; at += (size_t)B * ntile * R * D;
     l.coef = at; at += 2 * Tn * l.coef_stride;           // gS tables [T], then K tables [T]
-    l.counter = at; at += ((size_t)B * NCH + pad) & ~pad;
+    l.counter = at; at += ((size_t)B * NCH_CAP + pad) & ~pad;
     l.total = at;
     return l;
 }
 
-template <int D>
+template <int D, int RMAX>
 int rows_bwd(const float *X, const float *bw, int B, int N, int T, const float *const *Zin, const float *const *Zout,
              const float *const *O, const float *const *rsum, const float *const *nrm, const long long *ids,
              const int *nrows, int R, const float *g_rows, float *ws, float *dX, hipStream_t st)
@@ -427,11 +428,11 @@ int rows_bwd(const float *X, const float *bw, int B, int N, int T, const float *
     hipLaunchKernelGGL(ms_rows_first_kernel<D>, dim3(B), dim3(256), 0, st, a);
     for (int t = T - 1; t >= 0; --t) {
         prepares(t - 1);
-        hipLaunchKernelGGL(ms_rows_iter_kernel<D>, dim3(a.ntile, B), dim3(256), 0, st, a, zrows + (size_t)t * l.rows_stride,
+        hipLaunchKernelGGL((ms_rows_iter_kernel<D, RMAX>), dim3(a.ntile, B), dim3(256), 0, st, a, zrows + (size_t)t * l.rows_stride,
                            gorows + (size_t)t * l.rows_stride, grs + (size_t)t * l.grs_stride, cgs + (size_t)t * l.coef_stride,
                            ck + (size_t)t * l.coef_stride);
     }
-    hipLaunchKernelGGL(ms_rows_apply_kernel<D>, dim3(a.ntile, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((ms_rows_apply_kernel<D, RMAX>), dim3(a.ntile, B), dim3(256), 0, st, a);
     return prifit_check_launch();
 }
 
@@ -441,7 +442,7 @@ extern "C" {
 
 int prifit_meanshift_rows_supported(int N, int D, int R)
 {
-    return (N > 0 && R >= 1 && R <= RMAX && (D == 32 || D == 64 || D == 128)) ? 1 : 0;
+    return (N > 0 && R >= 1 && R <= RCAP && (D == 32 || D == 64 || D == 128)) ? 1 : 0;
 }
 
 long long prifit_meanshift_rows_bwd_workspace(int B, int N, int D, int R, int T)
@@ -459,11 +460,15 @@ int prifit_meanshift_rows_bwd(const float *X, const float *bw, int B, int N, int
         !prifit_meanshift_rows_supported(N, D, R) || (((uintptr_t)X | (uintptr_t)dX | (uintptr_t)workspace) & 15))
         return PRIFIT_EINVAL;
     hipStream_t st = as_stream(stream);
+#define ROWS_CASE(DD)                                                                                                  \
+    return R <= 32 ? rows_bwd<DD, 32>(X, bw, B, N, T, Zin, Zout, O, rowsum, nrm, ids, nrows, R, g_rows, workspace, dX, st) \
+                   : rows_bwd<DD, 64>(X, bw, B, N, T, Zin, Zout, O, rowsum, nrm, ids, nrows, R, g_rows, workspace, dX, st)
     switch (D) {
-    case 128: return rows_bwd<128>(X, bw, B, N, T, Zin, Zout, O, rowsum, nrm, ids, nrows, R, g_rows, workspace, dX, st);
-    case 64: return rows_bwd<64>(X, bw, B, N, T, Zin, Zout, O, rowsum, nrm, ids, nrows, R, g_rows, workspace, dX, st);
-    default: return rows_bwd<32>(X, bw, B, N, T, Zin, Zout, O, rowsum, nrm, ids, nrows, R, g_rows, workspace, dX, st);
+    case 128: ROWS_CASE(128);
+    case 64: ROWS_CASE(64);
+    default: ROWS_CASE(32);
     }
+#undef ROWS_CASE
 }
 
 }  // extern "C"

@@ -19,9 +19,27 @@ from ._lib import call, cur_stream, dll, ptr
 from .nn_ops import EPI_CHORD, EPI_MSBWD, EPI_MSKERNEL, NN, NT, TN, gemm
 
 _LL = ctypes.c_longlong
-KM = 32          # cluster slots per shape (>= max_num_clusters = 25, src/ellipsoid_utils.py:6)
+KM = 32          # cluster slots per shape on the loss path (>= max_num_clusters = 25, src/ellipsoid_utils.py:6); slots_for()
+KM_MAX = 64      # ... and up to 64 when the caller raises --max_num_clusters (args_parser.py:48; the reference's own
+                 # gaurd_mean_shift accepts 49, src/mean_shift.py:212-226): every kernel takes the slot count at run time
 NMS_CAP = 64     # centre ids kept by nms before the cluster-count check
-SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106)
+SAMPLE_CAP = 13312  # >= 10000 + KM * 100 surface samples per shape (src/ellipsoid_utils.py:105-106); sample_cap(K)
+
+
+def slots_for(max_num_clusters):
+    """Cluster slots per shape for a cluster-count limit: 32 (the loss path's 25) or 64."""
+    m = int(max_num_clusters)
+    if m <= KM:
+        return KM
+    if m <= KM_MAX:
+        return KM_MAX
+    raise ValueError("max_num_clusters = %d: at most %d clusters per shape are supported (cluster slots, nms keeps %d centres)"
+                     % (m, KM_MAX, NMS_CAP))
+
+
+def sample_cap(K):
+    """Surface-sample slots per shape for K cluster slots: 10000 + 100 K (src/ellipsoid_utils.py:105-106), in blocks of 256."""
+    return SAMPLE_CAP if K <= KM else (10000 + 100 * K + 255) // 256 * 256
 # mean-shift backward engine: "hybrid" (default) | "gemm" | "fused", see MeanShiftFn.backward
 BWD_MODE = __import__("os").environ.get("PRIFIT_MS_BWD", "hybrid")
 # 1: dX from the stream-fed flash-style kernel (prifit_meanshift_dx_streams: no split-K atomics, so dX is bit-reproducible
@@ -509,15 +527,16 @@ class SampleNNLossFn(torch.autograd.Function):
         off = torch.empty(Bt, K + 1, dtype=torch.int32, device=dev)
         # cuboid: src/ellipsoid_utils.py:162-214 + src/sample_ellipsoid.py:65-96 on the build's box-surface table
         ctx.pre = "prifit_cuboid_sample" if cuboid else "prifit_sample"
-        call(ctx.pre + "_budget", ptr(r), ptr(valid), Bt, K, SAMPLE_CAP, ptr(n), ptr(off), cur_stream())
-        nn_idx = torch.empty(Bt, SAMPLE_CAP, dtype=torch.int32, device=dev)
+        cap = ctx.cap = sample_cap(K)
+        call(ctx.pre + "_budget", ptr(r), ptr(valid), Bt, K, cap, ptr(n), ptr(off), cur_stream())
+        nn_idx = torch.empty(Bt, cap, dtype=torch.int32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
-        ws = torch.empty(dll().prifit_sample_nn_workspace_floats(Bt, SAMPLE_CAP), dtype=torch.float32, device=dev)
+        ws = torch.empty(dll().prifit_sample_nn_workspace_floats(Bt, cap), dtype=torch.float32, device=dev)
         # VALU-bound exact search: every surface sample (budget ~10^4 per shape, src/ellipsoid_utils.py:105) against every
         # target, 8 flop per pair (3 sub, 3 fma-equivalents, compare + select)
         with profiler.span("sample_nn", 8.0 * Bt * 10000.0 * M):
             call(ctx.pre + "_nn_fwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M,
-                 SAMPLE_CAP, ptr(nn_idx), ptr(s), ptr(ws), cur_stream())
+                 cap, ptr(nn_idx), ptr(s), ptr(ws), cur_stream())
         total = off[:, K].clone()
         ctx.save_for_backward(r, V, c, n, off, targets, nn_idx)
         ctx.mark_non_differentiable(total)
@@ -531,7 +550,7 @@ class SampleNNLossFn(torch.autograd.Function):
         g_r, g_V, g_c = zero_pool.zeros_like(r), zero_pool.zeros_like(V), zero_pool.zeros_like(c)
         # HBM: per sample its (U, V) entry, its nearest target (gathered) and index; parameters from LDS
         with profiler.span("sample_nn_bwd", Bt * 10000.0 * (8.0 + 12.0 + 4.0)):
-            call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, SAMPLE_CAP,
+            call(ctx.pre + "_nn_bwd", ptr(r), ptr(V), ptr(c), ptr(n), ptr(off), Bt, K, ptr(targets), M, ctx.cap,
                  ptr(nn_idx), ptr(gs.contiguous()), ptr(g_r), ptr(g_V), ptr(g_c), cur_stream())
         return g_r, g_V, g_c, None, None, None
 
@@ -614,11 +633,11 @@ def speculative():
         _spec = prev
 
 
-def _shift(X, bw, iterations):
+def _shift(X, bw, iterations, km=KM):
     """The shifted points for nms + what the centre gather needs afterwards: (Z detached, handle).  Row-sparse engine:
     handle = the trajectory (no autograd graph yet); dense engine: handle = the differentiable Z of MeanShiftFn."""
     Bt, N, D = X.shape
-    if ROWS_BWD and rows_supported(N, D, KM):
+    if ROWS_BWD and rows_supported(N, D, km):
         with torch.no_grad():
             Z, traj = mean_shift_trajectory(X.detach().contiguous(), bw, iterations, keep_kernel=False)
         return Z, traj
@@ -635,20 +654,21 @@ def _centres(X, bw, handle, ids, count):
 
 def _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples=None, bandwidth_rows=None):
     Bt, N, D = X.shape
+    km = slots_for(max_num_clusters)
     with torch.no_grad():
         bw = compute_bandwidth(X, quantile, num_samples, bandwidth_rows)
-    Z, handle = _shift(X, bw, iterations)
+    Z, handle = _shift(X, bw, iterations, km)
     with torch.no_grad():
         ids, count, labels, used = nms(Z, bw)
         bad = torch.empty(1, dtype=torch.int32, device=X.device)
-        call("prifit_cluster_verdict", ptr(count), ptr(used), Bt, NMS_CAP, int(max_num_clusters), KM, None, ptr(bad),
+        call("prifit_cluster_verdict", ptr(count), ptr(used), Bt, NMS_CAP, int(max_num_clusters), km, None, ptr(bad),
              cur_stream())
         flag = _pinned_flag()
         flag.copy_(bad, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         _spec.checks.append((ev, flag))
-    return {"bw": bw, "ids": ids[:, :KM].long(), "count": count, "labels": labels.long(),
+    return {"bw": bw, "ids": ids[:, :km].long(), "count": count, "labels": labels.long(),
             "quantile": [quantile] * Bt, "Z": Z, "_handle": handle}
 
 
@@ -661,17 +681,18 @@ def _pin_representatives(res, center_ids):
     reference's (ascending id) order.  The partition must be the one nms found (checked, on the host)."""
     Z = res["Z"].detach()
     Bt, N, D = Z.shape
+    km = res["ids"].shape[1]
     ids = torch.as_tensor(center_ids).to(Z.device).long()
-    if ids.shape[1] < KM:
-        ids = torch.cat([ids, ids.new_full((Bt, KM - ids.shape[1]), -1)], 1)
-    ids = ids[:, :KM]
+    if ids.shape[1] < km:
+        ids = torch.cat([ids, ids.new_full((Bt, km - ids.shape[1]), -1)], 1)
+    ids = ids[:, :km]
     k = (ids >= 0).sum(1)
     if not torch.equal(k.cpu(), res["count"].long().cpu()):
         raise RuntimeError("center_ids: %s representatives for %s clusters" % (k.tolist(), res["count"].tolist()))
     ids = ids.clamp(min=0)
     cen = torch.gather(Z, 1, ids.unsqueeze(-1).expand(-1, -1, D))
     dots = torch.bmm(cen, Z.transpose(1, 2))                                    # labels = argmax_k centres_k . x (ms:199-201)
-    dots.masked_fill_(torch.arange(KM, device=Z.device).view(1, KM, 1) >= k.view(Bt, 1, 1), float("-inf"))
+    dots.masked_fill_(torch.arange(km, device=Z.device).view(1, km, 1) >= k.view(Bt, 1, 1), float("-inf"))
     labels = dots.argmax(dim=1)
     for b in range(Bt):
         pairs = torch.unique(torch.stack([res["labels"][b], labels[b]], 1), dim=0)
@@ -693,7 +714,8 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
         res["centres"] = _centres(X, res["bw"], res.pop("_handle"), res["ids"], res["count"])
         res["W"] = MembershipFn.apply(res["centres"], X, res["bw"], res["count"])
         return res
-    res = {"bw": torch.empty(Bt, device=dev), "ids": torch.zeros(Bt, KM, dtype=torch.int64, device=dev),
+    km = slots_for(max_num_clusters)
+    res = {"bw": torch.empty(Bt, device=dev), "ids": torch.zeros(Bt, km, dtype=torch.int64, device=dev),
            "count": torch.zeros(Bt, dtype=torch.int32, device=dev),
            "labels": torch.zeros(Bt, N, dtype=torch.int64, device=dev), "quantile": [quantile] * Bt}
     pending = torch.arange(Bt, device=dev)
@@ -706,24 +728,24 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
             if rows_p is not None and pending.numel() != Bt:
                 rows_p = rows_p.to(dev).index_select(0, pending)
             bw = compute_bandwidth(Xp, q, num_samples, rows_p)
-        Z, handle = _shift(Xp, bw, iterations)
+        Z, handle = _shift(Xp, bw, iterations, km)
         with torch.no_grad():
             ids, count, labels, used = nms(Z, bw)
             nb = count.shape[0]
             both = torch.empty(2, nb, dtype=torch.int32, device=dev)
             both[0].copy_(count)
             scratch = torch.empty(1, dtype=torch.int32, device=dev)
-            call("prifit_cluster_verdict", ptr(count), ptr(used), nb, NMS_CAP, int(max_num_clusters), KM, ptr(both[1]),
+            call("prifit_cluster_verdict", ptr(count), ptr(used), nb, NMS_CAP, int(max_num_clusters), km, ptr(both[1]),
                  ptr(scratch), cur_stream())
             host = both.cpu()  # the one host sync of the round (guard_mean_shift's check)
         ok = host[1] <= max_num_clusters
-        if bool((ok & (host[0] > KM)).any()):
-            raise RuntimeError("more than %d kept centres with <= %d distinct labels: unsupported corner" % (KM, max_num_clusters))
+        if bool((ok & (host[0] > km)).any()):
+            raise RuntimeError("more than %d kept centres with <= %d distinct labels: unsupported corner" % (km, max_num_clusters))
         okd = ok.to(dev)
         sel = pending[okd]
         if sel.numel():
             res["bw"][sel] = bw[okd]
-            res["ids"][sel] = ids[okd][:, :KM].long()
+            res["ids"][sel] = ids[okd][:, :km].long()
             res["count"][sel] = count[okd]
             res["labels"][sel] = labels[okd].long()
             rounds.append((pending, okd, Xp, bw, Z, handle))
@@ -744,7 +766,7 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
         _, _, Xp, bw, _, handle = rounds[0]
         centres = _centres(Xp, bw, handle, res["ids"], res["count"])
     else:
-        centres = torch.zeros(Bt, KM, D, device=dev)
+        centres = torch.zeros(Bt, km, D, device=dev)
         for shapes, okd, Xp, bw, _, handle in rounds:
             live = torch.where(okd, res["count"].index_select(0, shapes), torch.zeros_like(res["count"].index_select(0, shapes)))
             cen = _centres(Xp, bw, handle, res["ids"].index_select(0, shapes), live)

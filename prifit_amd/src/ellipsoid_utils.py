@@ -75,7 +75,7 @@ def sample_from_pred_params(ellipse_params_batch, N=500, batch_id=0, seed=0, vis
     B, K = valid.shape
     n = torch.empty(B, K, dtype=torch.int32, device=dev)
     off = torch.empty(B, K + 1, dtype=torch.int32, device=dev)
-    call("prifit_sample_budget", ptr(r.detach().contiguous()), ptr(valid), B, K, fit_ops.SAMPLE_CAP, ptr(n), ptr(off),
+    call("prifit_sample_budget", ptr(r.detach().contiguous()), ptr(valid), B, K, fit_ops.sample_cap(K), ptr(n), ptr(off),
          cur_stream())
     n = n.cpu()
     out = []
@@ -97,7 +97,7 @@ def sample_from_pred_params_cuboid(ellipse_params_batch, N=500, batch_id=0, seed
     B, K = valid.shape
     n = torch.empty(B, K, dtype=torch.int32, device=dev)
     off = torch.empty(B, K + 1, dtype=torch.int32, device=dev)
-    call("prifit_cuboid_sample_budget", ptr(r.detach().contiguous()), ptr(valid), B, K, fit_ops.SAMPLE_CAP, ptr(n), ptr(off),
+    call("prifit_cuboid_sample_budget", ptr(r.detach().contiguous()), ptr(valid), B, K, fit_ops.sample_cap(K), ptr(n), ptr(off),
          cur_stream())
     n = n.cpu()
     out = []

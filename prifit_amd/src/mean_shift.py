@@ -42,7 +42,7 @@ class MeanShift:
                 _, indices, labels = self.nms(new_X.detach(), new_X.detach(), b=bw)
             return new_X[indices], bw, labels
         N, D = X.shape
-        rows = fit_ops.ROWS_BWD and fit_ops.rows_supported(N, D, fit_ops.KM)
+        rows = fit_ops.ROWS_BWD and fit_ops.rows_supported(N, D, fit_ops.KM_MAX)
         if rows:   # the gradient enters through `new_X[indices]` (:46) alone: trajectory now, row-sparse backward later
             with torch.no_grad():
                 Z, traj = fit_ops.mean_shift_trajectory(Xb.detach(), bwb, iterations, keep_kernel=False)
@@ -55,7 +55,7 @@ class MeanShift:
         if K > fit_ops.NMS_CAP:
             raise RuntimeError("more than %d clusters" % fit_ops.NMS_CAP)
         ids = ids[:, :K].long()
-        if rows and K <= fit_ops.KM:
+        if rows and K <= fit_ops.KM_MAX:
             return fit_ops.MeanShiftRowsFn.apply(Xb, bwb, ids, None, traj)[0], bw, labels[0].long()
         if rows:   # more kept centres than row slots: the dense engine
             Zg = fit_ops.MeanShiftFn.apply(Xb, bwb, iterations)
@@ -119,7 +119,7 @@ class MeanShift:
     def membership(self, centers, X, bandwidth):
         """upstream :230-247 -> [K, N]."""
         K = centers.shape[0]
-        cpad = torch.zeros(1, fit_ops.KM, X.shape[1], device=X.device)
+        cpad = torch.zeros(1, fit_ops.slots_for(K), X.shape[1], device=X.device)
         cpad[0, :K] = centers
         W = fit_ops.MembershipFn.apply(cpad, X.unsqueeze(0).contiguous(),
                                        torch.as_tensor(bandwidth, dtype=torch.float32, device=X.device).reshape(1),

@@ -40,12 +40,11 @@ def pack_params(ellipsoid_params_batch, device):
     if isinstance(ellipsoid_params_batch, EllipseParams):
         p = ellipsoid_params_batch
         return p.r, p.V, p.c, p.valid
-    B, KM = len(ellipsoid_params_batch), fit_ops.KM
+    B = len(ellipsoid_params_batch)
+    KM = fit_ops.slots_for(max([len(prm) for prm in ellipsoid_params_batch] + [1]))
     rows_r, rows_V, rows_c = [], [], []
     valid = torch.zeros(B, KM, dtype=torch.int32, device=device)
     for b, prm in enumerate(ellipsoid_params_batch):
-        if len(prm) > KM:
-            raise RuntimeError("more than %d primitives in a shape" % KM)
         valid[b, :len(prm)] = 1
         pad = KM - len(prm)
         rows_r.append(torch.stack([p[0] for p in prm] + [torch.ones(3, device=device)] * pad))

@@ -292,6 +292,42 @@ def test_convex_loss_end_to_end(F, golden, split, monkeypatch):
     torch.testing.assert_close(X.grad[:, :, :32].cpu(), ref, rtol=1e-2, atol=1e-3 * ref.abs().max().item())
 
 
+def test_convex_loss_with_forty_clusters_per_shape(F, golden):
+    """Cluster capacity above the loss path's 32 slots: `max_num_clusters = 49` -- the reference's own
+    gaurd_mean_shift accepts 49, src/mean_shift.py:212-226 -- on shapes with 40 modes takes 64 slots per shape (fit_ops.slots_for):
+    row-sparse mean-shift backward with 40 live rows, membership / fit / SDF / sampling kernels at K = 64.  Clusters, partition,
+    loss at 1e-4 and the embedding gradient against the REFERENCE (fit_many_clusters.npz); 25 clusters still take 32 slots."""
+    from tests_helpers import many_cluster_inputs
+    from prifit_amd.convex_loss import convex_loss
+    g = golden("fit_many_clusters")
+    assert F.slots_for(25) == 32 and F.slots_for(32) == 32 and F.slots_for(33) == 64 and F.slots_for(49) == 64
+    with pytest.raises(ValueError):
+        F.slots_for(65)
+    pts, cham, emb = many_cluster_inputs(seed=int(g["seed"]))
+    X = emb.permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    total, l, params, labels, info = convex_loss(pts.permute(0, 2, 1).cuda(), cham.permute(0, 2, 1).cuda(), X,
+                                                 quantile=float(g["quantile"]), iterations=10, max_num_clusters=int(g["max_num_clusters"]),
+                                                 rand_table=_t(g["R"]).cuda(), canonical=True, return_info=True)
+    total.sum().backward()
+    assert [len(p) for p in params] == list(g["K"]) and min(g["K"]) >= 33
+    for b in range(2):
+        assert same_partition(labels[b].cpu(), _t(g["labels"])[b].long())
+    torch.testing.assert_close(total.detach().cpu(), _t(g["total"]), rtol=1e-4, atol=1e-7)
+    ref = _t(g["dX_head"])
+    assert abs(X.grad.norm().item() - float(g["dX_norm"])) < 2e-2 * float(g["dX_norm"])
+    torch.testing.assert_close(X.grad[:, :, :32].cpu(), ref, rtol=2e-2, atol=2e-3 * ref.abs().max().item())
+    # the fitted ellipsoids themselves, in partition-canonical order (ascending smallest member index)
+    for b in range(2):
+        K = int(g["K"][b])
+        lab = labels[b].cpu()
+        first = [int(torch.nonzero(lab == k).min()) for k in range(K)]
+        order = np.argsort(np.array(first), kind="stable")
+        r = torch.stack([params[b][int(k)][0] for k in order]).detach().cpu()
+        c = torch.stack([params[b][int(k)][2] for k in order]).detach().cpu()
+        torch.testing.assert_close(c, _t(g["c"])[b, :K], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(r, _t(g["r"])[b, :K], rtol=1e-3, atol=1e-4)
+
+
 def test_cluster_retry_and_degenerate(F):
     """quantile-doubling retry (src/ellipsoid_utils.py:19-27) and a shape whose fit is ill-conditioned."""
     B, N, D = 2, 1024, 32

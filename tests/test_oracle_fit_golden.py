@@ -229,3 +229,23 @@ def test_sample_axis_golden(golden):
     g = golden("fit_intersections")
     got = orc.sample_axis(_t(g["r_0"][1]), _t(g["V_0"][1]), _t(g["c_0"][1]))
     torch.testing.assert_close(got, _t(g["axis_samples"]), rtol=1e-6, atol=1e-7)
+
+
+def test_many_clusters_golden(golden):
+    """--max_num_clusters 49 (args_parser.py:48; src/mean_shift.py:212-226) on shapes with 40 modes: the oracle's clustering,
+    fit, loss and its gradient against the reference's (fit_many_clusters.npz)."""
+    from tests_helpers import many_cluster_inputs
+    g = golden("fit_many_clusters")
+    pts, cham, emb = many_cluster_inputs(seed=int(g["seed"]))
+    R = _t(g["R"])
+    X = emb.permute(0, 2, 1).clone().requires_grad_(True)
+    total, ch, params, labels = orc.convex_loss(pts.permute(0, 2, 1), cham.permute(0, 2, 1), X, quantile=float(g["quantile"]),
+                                                iterations=10, max_num_clusters=int(g["max_num_clusters"]),
+                                                rand_table=[[R] * 64] * 2, canonical=True)
+    total.sum().backward()
+    assert [len(p) for p in params] == list(g["K"]) and min(g["K"]) >= 33
+    for b in range(2):
+        assert same_partition(labels[b], _t(g["labels"])[b].long())
+    torch.testing.assert_close(total.detach(), _t(g["total"]), rtol=1e-5, atol=1e-8)
+    ref = _t(g["dX_head"])
+    torch.testing.assert_close(X.grad[:, :, :32], ref, rtol=2e-3, atol=1e-3 * ref.abs().max().item())

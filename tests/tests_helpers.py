@@ -31,3 +31,11 @@ def check_intersection_grads(g, name, P, rtol=1e-4):
             want = _t(g[f"{name}_d{tag}_{b}"])
             got = torch.stack([torch.zeros_like(p[i]) if p[i].grad is None else p[i].grad for p in P[b]]).cpu()
             torch.testing.assert_close(got, want, rtol=rtol, atol=2e-6 * max(1.0, want.abs().max().item()))
+
+
+def many_cluster_inputs(B=2, N=2048, D=128, seed=61, K=40, M=5000):
+    """oracle/make_golden_fit.py:many_cluster_inputs -- a cloud of 40 tight blobs with 40 embedding prototypes."""
+    cham, lab = synth.blobs_with_labels(B, M, seed, K=K, sigma=0.05)
+    sel = np.random.default_rng(seed + 1).choice(M, N, replace=False)
+    emb = synth.prototype_embedding(lab[:, sel], D, seed + 2, K=K, noise=0.03)
+    return torch.from_numpy(cham[:, sel]), torch.from_numpy(cham), torch.from_numpy(emb)
