@@ -804,14 +804,17 @@ int prifit_sample_budget(const float *r, const int32_t *valid, int B, int KM, in
                          int32_t *off, void *stream);
 
 /* The segmentation loss F.cross_entropy(pred, target) of models/pointnet2_part_seg_msg.py:137-144 (mean over the rows) and its
- * gradient, x [P, ld] rows of C <= 64 class scores, target [P] int64 (clamped to [0, C)): loss [1] = mean_r (lse_r - x[r, t_r]);
- * lse [P] is kept for the backward, dx[r, c] = (exp(x[r, c] - lse_r) - [c == t_r]) g[0] / P.  workspace:
- * prifit_cross_entropy_workspace() floats.  Per-workgroup partial sums in a fixed row order: the same bits from run to run. */
+ * gradient, x [P, ld] rows of C <= 64 class scores, target [P] int64 with torch's default semantics: rows whose label is -100
+ * (ignore_index) contribute nothing and are left out of the mean's denominator; any other label outside [0, C) is an error --
+ * torch stops with a device-side assert, here the loss and that row's gradient become NaN (loud, no host read-back).
+ * loss [2] = (mean over the kept rows of lse_r - x[r, t_r], number of kept rows); lse [P] is kept for the backward,
+ * dx[r, c] = (exp(x[r, c] - lse_r) - [c == t_r]) g[0] / kept (kept = loss + 1).  workspace: prifit_cross_entropy_workspace()
+ * floats.  Per-workgroup partial sums in a fixed row order: the same bits from run to run. */
 int prifit_cross_entropy_workspace(void);
 int prifit_cross_entropy_fwd(const float *x, long long ld, const long long *target, long long P, int C, float *lse, float *workspace,
                              float *loss, void *stream);
-int prifit_cross_entropy_bwd(const float *x, long long ld, const long long *target, const float *lse, const float *g, long long P,
-                             int C, float *dx, long long ldd, void *stream);
+int prifit_cross_entropy_bwd(const float *x, long long ld, const long long *target, const float *lse, const float *g,
+                             const float *kept, long long P, int C, float *dx, long long ldd, void *stream);
 
 /* The combination step of analytic_chamfer_distance (src/utils.py:417-426) in one launch: per shape
  * (d2_sum[b] / max(total[b], 1) + sdf_sum[b] / M) / 2, averaged over the shapes with at least one valid primitive

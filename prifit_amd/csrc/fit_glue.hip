@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64) void chamfer_combine_bwd_kernel(const float *__
 // per-workgroup partial sums in a fixed row order, a second tiny launch for the mean.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int CE_WGS = 512;
+constexpr long long CE_IGNORE = -100;    // F.cross_entropy's default ignore_index
 
 __device__ __forceinline__ float wave_max_f32(float v)
 {
@@ -144,46 +145,58 @@ __device__ __forceinline__ float wave_max_f32(float v)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float *__restrict__ x, long long ld, const long long *__restrict__ target,
                                                      long long P, int C, float *__restrict__ lse, float *__restrict__ part)
 {
-    __shared__ float s_w[4];
+    __shared__ float s_w[4], s_n[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float acc = 0.f;
+    float acc = 0.f, kept = 0.f;
     for (long long r = (long long)blockIdx.x * 4 + wave; r < P; r += (long long)gridDim.x * 4) {
         const float v = lane < C ? x[r * ld + lane] : -INFINITY;
         const float m = wave_max_f32(v);
         const float e = lane < C ? __expf(v - m) : 0.f;
         const float l = m + __logf(wave_sum_f32(e));
-        long long t = target[r];
-        t = t < 0 ? 0 : (t >= C ? C - 1 : t);
-        const float xt = __shfl(v, (int)t, 64);
+        const long long t = target[r];
         if (lane == 0) lse[r] = l;
+        if (t == CE_IGNORE) continue;                    // ignore_index = -100: no term, not counted (wave-uniform)
+        // any other label outside [0, C) is an error: torch stops the process with a device-side assert, here the loss (and,
+        // in the backward, the row's gradient) turns into NaN -- loud, and without a host read-back
+        const float xt = (t < 0 || t >= C) ? __builtin_nanf("") : __shfl(v, (int)t, 64);
         acc += l - xt;                                   // (the same value in every lane)
+        kept += 1.f;
     }
-    if (lane == 0) s_w[wave] = acc;
+    if (lane == 0) { s_w[wave] = acc; s_n[wave] = kept; }
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        part[CE_WGS + blockIdx.x] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+    }
 }
 
-__global__ __launch_bounds__(64) void ce_final_kernel(const float *__restrict__ part, int n, double count, float *__restrict__ out)
+// out[0] = mean over the KEPT rows (0 / 0 = NaN when every row is ignored, as torch), out[1] = the number of kept rows
+__global__ __launch_bounds__(64) void ce_final_kernel(const float *__restrict__ part, int n, float *__restrict__ out)
 {
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 64) a += (double)part[i];
+    double a = 0.0, k = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) { a += (double)part[i]; k += (double)part[CE_WGS + i]; }
     a = wave_sum_f64(a);
-    if (threadIdx.x == 0) out[0] = (float)(a / count);
+    k = wave_sum_f64(k);
+    if (threadIdx.x == 0) { out[0] = (float)(a / k); out[1] = (float)k; }
 }
 
-// d loss / d x[r, c] = (softmax(x)[r, c] - [c == target_r]) g / P
+// d loss / d x[r, c] = (softmax(x)[r, c] - [c == target_r]) g / kept; ignored rows get zeros, rows with an invalid label NaN
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float *__restrict__ x, long long ld, const long long *__restrict__ target,
-                                                     const float *__restrict__ lse, const float *__restrict__ g, long long P, int C,
-                                                     float *__restrict__ dx, long long ldd)
+                                                     const float *__restrict__ lse, const float *__restrict__ g,
+                                                     const float *__restrict__ kept, long long P, int C, float *__restrict__ dx,
+                                                     long long ldd)
 {
     const long long total = P * C;
-    const float gs = g[0] / (float)P;
+    const float gs = g[0] / kept[0];
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const long long r = id / C;
         const int c = (int)(id - r * C);
-        long long t = target[r];
-        t = t < 0 ? 0 : (t >= C ? C - 1 : t);
-        dx[r * ldd + c] = (__expf(x[r * ld + c] - lse[r]) - (c == (int)t ? 1.f : 0.f)) * gs;
+        const long long t = target[r];
+        float v;
+        if (t == CE_IGNORE) v = 0.f;
+        else if (t < 0 || t >= C) v = __builtin_nanf("");
+        else v = (__expf(x[r * ld + c] - lse[r]) - (c == (int)t ? 1.f : 0.f)) * gs;
+        dx[r * ldd + c] = v;
     }
 }
 
@@ -236,7 +249,7 @@ int prifit_chamfer_combine_bwd(const float *g, const float *coef, int B, float *
     return prifit_check_launch();
 }
 
-int prifit_cross_entropy_workspace(void) { return CE_WGS; }
+int prifit_cross_entropy_workspace(void) { return 2 * CE_WGS; }
 
 int prifit_cross_entropy_fwd(const float *x, long long ld, const long long *target, long long P, int C, float *lse, float *workspace,
                              float *loss, void *stream)
@@ -244,17 +257,17 @@ int prifit_cross_entropy_fwd(const float *x, long long ld, const long long *targ
     if (!x || !target || !lse || !workspace || !loss || P <= 0 || C <= 0 || C > 64 || ld < C) return PRIFIT_EINVAL;
     const int grid = (int)((P + 3) / 4 < CE_WGS ? (P + 3) / 4 : CE_WGS);
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, ld, target, P, C, lse, workspace);
-    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, grid, (double)P, loss);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, grid, loss);
     return prifit_check_launch();
 }
 
-int prifit_cross_entropy_bwd(const float *x, long long ld, const long long *target, const float *lse, const float *g, long long P,
-                             int C, float *dx, long long ldd, void *stream)
+int prifit_cross_entropy_bwd(const float *x, long long ld, const long long *target, const float *lse, const float *g,
+                             const float *kept, long long P, int C, float *dx, long long ldd, void *stream)
 {
-    if (!x || !target || !lse || !g || !dx || P <= 0 || C <= 0 || C > 64 || ld < C || ldd < C) return PRIFIT_EINVAL;
+    if (!x || !target || !lse || !g || !kept || !dx || P <= 0 || C <= 0 || C > 64 || ld < C || ldd < C) return PRIFIT_EINVAL;
     long long grid = (P * C + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, ld, target, lse, g, P, C, dx, ldd);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, ld, target, lse, g, kept, P, C, dx, ldd);
     return prifit_check_launch();
 }
 

@@ -770,3 +770,34 @@ def test_cross_entropy_matches_torch(nn_ops, P, C):
         got2 = nn_ops.cross_entropy(xd2, target.cuda())
         (got2 * 1.5).backward()
         assert torch.equal(got, got2) and torch.equal(xd.grad, xd2.grad)
+
+
+def test_cross_entropy_ignore_index_and_invalid_labels(nn_ops):
+    """torch's default label semantics in nn_ops.cross_entropy: rows labelled -100 (ignore_index) contribute nothing
+    and are left out of the mean's denominator -- value and gradient against F.cross_entropy in fp64 --; any other label outside
+    [0, C) is an error: torch stops with a device-side assert, here the loss and that row's gradient are NaN."""
+    P, C = 5000, 50
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(P, C, generator=g) * 2.0
+    target = torch.randint(0, C, (P,), generator=g)
+    target[torch.randperm(P, generator=g)[:700]] = -100
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, target)
+    ref.backward()
+    xd = x.cuda().requires_grad_(True)
+    got = nn_ops.cross_entropy(xd, target.cuda())
+    got.backward()
+    assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-10)
+    assert float(xd.grad[target.cuda() == -100].abs().max()) == 0.0
+    all_ignored = nn_ops.cross_entropy(x.cuda(), torch.full((P,), -100, dtype=torch.long, device="cuda"))
+    assert torch.isnan(all_ignored)                                   # 0 / 0, as torch
+    for bad in (C, -1, 10 ** 6):
+        t2 = target.clone()
+        t2[17] = bad
+        xd = x.cuda().requires_grad_(True)
+        loss = nn_ops.cross_entropy(xd, t2.cuda())
+        loss.backward()
+        assert torch.isnan(loss) and bool(torch.isnan(xd.grad[17]).all())
+        ok = torch.ones(P, dtype=torch.bool); ok[17] = False
+        assert bool(torch.isfinite(xd.grad[ok.cuda()]).all())
