@@ -120,8 +120,16 @@ def apply_rank_affinity(local_rank, local_world, set_torch=True):
             pass
     threads = max(1, len(cores)) if local_world > 1 else None
     if threads is not None:
+        # a value the user (or launch.rank_env) set explicitly wins; the cap never RAISES a pool above it
         for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
-            os.environ[var] = str(threads)
+            try:
+                preset = int(os.environ[var])
+            except (KeyError, ValueError):
+                preset = None
+            if preset is not None and preset > 0:
+                threads = min(threads, preset) if var == "OMP_NUM_THREADS" else threads
+            else:
+                os.environ[var] = str(threads)
         if set_torch:
             import torch
             torch.set_num_threads(threads)
@@ -131,8 +139,19 @@ def apply_rank_affinity(local_rank, local_world, set_torch=True):
 
 
 def apply_from_env(set_torch=True):
-    """apply_rank_affinity for the rank the rendezvous environment describes (LOCAL_RANK / LOCAL_WORLD_SIZE, falling back
-    to RANK / WORLD_SIZE); a single process is left alone."""
-    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    """apply_rank_affinity for the rank the rendezvous environment describes.  The LOCAL size of the job decides how the
+    host's cores are divided: LOCAL_RANK / LOCAL_WORLD_SIZE (torch.distributed.run and launch.rank_env set both).  Without
+    LOCAL_WORLD_SIZE the global RANK / WORLD_SIZE are used only when the job is known to sit on one node (no LOCAL_RANK, or
+    LOCAL_RANK == RANK); a multi-node rank without its local size is left alone rather than given 1 / WORLD_SIZE of this
+    host's cores.  A single process is left alone.  NOTE: pinning reaches threads created AFTER the call -- call it before
+    importing torch (bench.py does; Trainer calls it late and then only caps the pools)."""
+    if "LOCAL_WORLD_SIZE" in os.environ:
+        world = int(os.environ["LOCAL_WORLD_SIZE"])
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+    else:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if local != rank:        # several nodes and no local size: do not guess
+            world, local = 1, 0
     return apply_rank_affinity(local, world, set_torch=set_torch)

@@ -601,12 +601,15 @@ def test_bandwidth_with_more_samples_than_rows(hiplib, golden):
 
 
 @pytest.mark.parametrize("N,D,T,nrows", [(2048, 128, 10, (8, 1, 32)), (300, 128, 3, (5, 0, 2)), (1500, 32, 5, (3, 32, 7)),
-                                         (256, 64, 2, (32, 32, 32)), (2048, 128, 0, (4, 4, 4))])
+                                         (256, 64, 2, (32, 32, 32)), (2048, 128, 0, (4, 4, 4)),
+                                         (2048, 128, 10, (25, 40, 64)), (700, 64, 4, (64, 33, 0))])
 def test_mean_shift_row_sparse_backward_equals_dense(F, N, D, T, nrows):
     """MeanShiftRowsFn (the loss reads new_X[ids] only: backward on those rows alone) against the dense engine --
     MeanShiftFn + gather, whose other rows multiply exact zeros: same centres bit for bit, same dX to fp32 rounding.
-    Ragged N, all three widths, per-shape live counts incl. 0 and the full 32 slots, zero iterations."""
-    B, R = 3, F.KM
+    Ragged N, all three widths, per-shape live counts incl. 0 and the full 32 slots, zero iterations; round 6: 64 slots per
+    shape (max_num_clusters above 32: the kernels' RMAX = 64 instantiation), 25 / 40 / 64 live rows.  Every case runs twice:
+    the last-ticket hand-over between workgroups must give the same bits from run to run."""
+    B, R = 3, (F.KM if max(nrows) <= F.KM else F.KM_MAX)
     gen = torch.Generator().manual_seed(N + D + T)
     # clustered rows so that kernel values span the clamp: prototypes + noise
     proto = torch.nn.functional.normalize(torch.randn(6, D, generator=gen), dim=1)

@@ -17,6 +17,10 @@ ECHO = ("import os,sys; print(' '.join(os.environ[k] for k in "
 
 
 def _spawn(n, code, **kw):
+    # the even split of the host's cores is what these tests assert: a *_VISIBLE_DEVICES variable in the children's environment
+    # makes hostcfg.rank_cpu_set skip the GPU -> NUMA-node lookup (on a two-socket 8-GPU host ranks 0-3 would otherwise share node
+    # 0's cores; that branch has its own test on a faked sysfs tree).  These children never touch a GPU.
+    kw.setdefault("env", dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0,1,2,3,4,5,6,7")))
     with tempfile.TemporaryDirectory() as d:
         outs = [open(os.path.join(d, "r%d.txt" % r), "w+") for r in range(n)]
         rc = launch.spawn_ranks(n, [sys.executable, "-c", code], stdout=outs, **kw)
