@@ -35,6 +35,39 @@ def _declared(header_path=HEADER_PATH):
     return {name: ret for ret, name in re.findall(r"^\s*(int|long long)\s+(prifit_\w+)\s*\(", text, flags=re.M)}
 
 
+def _ctype_of(param):
+    """ctypes type of one C parameter declaration of the public header: every pointer (device pointers, host arrays of pointers,
+    descriptor structs, the stream) travels as void *; scalars by their C type."""
+    p = param.strip()
+    if p in ("void", ""):
+        return None
+    if "*" in p or "[" in p:
+        return ctypes.c_void_p
+    if re.search(r"\blong\s+long\b", p):
+        return ctypes.c_ulonglong if "unsigned" in p else ctypes.c_longlong
+    if re.search(r"\bdouble\b", p):
+        return ctypes.c_double
+    if re.search(r"\bfloat\b", p):
+        return ctypes.c_float
+    if re.search(r"\b(int|int32_t|unsigned|uint32_t)\b", p):
+        return ctypes.c_uint if "unsigned" in p or "uint32_t" in p else ctypes.c_int
+    raise RuntimeError("prifit_hip.h: cannot map parameter %r to a ctypes type" % param)
+
+
+def _signatures(header_path=HEADER_PATH):
+    """{entry point: [ctypes types of its parameters]} parsed from the declarations of the public header.  With argtypes set,
+    Python ints (tensor.data_ptr(), 64-bit sizes) and floats are converted by ctypes itself: no per-argument wrapper objects on
+    the launch path, and a 64-bit value can never be truncated to a C int."""
+    with open(header_path) as f:
+        text = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"^\s*(?:int|long long)\s+(prifit_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.M | re.S):
+        params = [x for x in (q.strip() for q in m.group(2).replace("\n", " ").split(",")) if x]
+        types = [_ctype_of(q) for q in params]
+        sigs[m.group(1)] = [t for t in types if t is not None]
+    return sigs
+
+
 def dll():
     global _dll
     if _dll is None:
@@ -43,16 +76,34 @@ def dll():
                 "libprifit_hip.so is not built (%s). Run `python -m prifit_amd.build` "
                 "(needs hipcc); there is no CPU fallback." % LIB_PATH)
         _dll = ctypes.CDLL(LIB_PATH)
+        sigs = _signatures()
         for name, ret in _declared().items():
             fn = getattr(_dll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = ctypes.c_int if ret == "int" else ctypes.c_longlong
+            if name not in sigs:
+                raise RuntimeError("prifit_hip.h: no parameter list parsed for %s" % name)
+            fn.argtypes = sigs[name]
     return _dll
 
 
 def ptr(t):
+    """Device address of a tensor for a pointer parameter (None = NULL); a plain int: argtypes does the conversion."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+_query_cache = {}
+
+
+def query(name, *args):
+    """A pure function of integer arguments exported by the library (prifit_*_supported / _slabs / _workspace / _tile_m ...),
+    memoised: the launch path asks the same ~30 questions about the same shapes every step."""
+    key = (name,) + args
+    v = _query_cache.get(key)
+    if v is None:
+        v = _query_cache[key] = getattr(dll(), name)(*args)
+    return v
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -71,8 +122,8 @@ def cur_stream(device=None):
         else:
             d = torch.device(device)
             idx = _get_device() if d.index is None else d.index
-        return ctypes.c_void_p(_raw_stream(idx))
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def call(name, *args):

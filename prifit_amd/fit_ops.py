@@ -15,7 +15,7 @@ import torch
 
 from . import profiler
 from . import arena as zero_pool
-from ._lib import call, cur_stream, dll, ptr
+from ._lib import call, cur_stream, dll, ptr, query
 from .nn_ops import EPI_CHORD, EPI_MSBWD, EPI_MSKERNEL, NN, NT, TN, gemm
 
 _LL = ctypes.c_longlong
@@ -69,7 +69,7 @@ def split_mode(N, D, keep_kernel=False):
     if MS_SPLIT in ("0", "", None, False) or keep_kernel:
         return 0
     mode = _SPLIT_MODES[MS_SPLIT]
-    return mode if dll().prifit_meanshift_split_supported(N, D, mode) else 0
+    return mode if query("prifit_meanshift_split_supported", N, D, mode) else 0
 
 
 def _bgemm(layout, M, N, K, A, lda, B_, ldb, C, ldc, batch, sA, sB, sC, **kw):
@@ -181,7 +181,7 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
     scratch = None
     split = split_mode(N, D, keep_kernel) if fused else 0
     if split:   # the dictionary is the same in every iteration (:65): cut once
-        cut = torch.empty(dll().prifit_meanshift_split_workspace(Bt, N, D, split), dtype=torch.uint8, device=dev)
+        cut = torch.empty(query("prifit_meanshift_split_workspace", Bt, N, D, split), dtype=torch.uint8, device=dev)
         call("prifit_meanshift_split_prep", ptr(X), Bt, N, D, split, ptr(cut), cur_stream())
     for _ in range(iterations):
         Kmat = None
@@ -214,7 +214,7 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
 
 
 def rows_supported(N, D, R):
-    return bool(dll().prifit_meanshift_rows_supported(N, D, R))
+    return bool(query("prifit_meanshift_rows_supported", N, D, R))
 
 
 class MeanShiftRowsFn(torch.autograd.Function):
@@ -253,7 +253,7 @@ class MeanShiftRowsFn(torch.autograd.Function):
         g = g.contiguous()
         gX = zero_pool.zeros(Bt, N, D, device=X.device)
         T = len(traj)
-        ws = torch.empty(dll().prifit_meanshift_rows_bwd_workspace(Bt, N, D, R, T), dtype=torch.float32, device=X.device)
+        ws = torch.empty(query("prifit_meanshift_rows_bwd_workspace", Bt, N, D, R, T), dtype=torch.float32, device=X.device)
         arr = lambda k: (ctypes.c_void_p * max(T, 1))(*[it[k].data_ptr() for it in traj])
         # HBM-bound: per iteration the dictionary is read once (4 B per element); dX read-modified-written once in all (8 B)
         with profiler.span("ms_rows_bwd", 4.0 * Bt * N * D * (T + 2)):
@@ -412,7 +412,7 @@ class MembershipFn(torch.autograd.Function):
         _bgemm(NT, N, K, D, X, D, centres, D, dots, K, Bt, N * D, K * D, N * K)
         gmax = torch.empty(Bt, dtype=torch.float32, device=dev)    # global max over the live (point, cluster) pairs, detached (:242)
         if K % 4 == 0:
-            ws = torch.empty(dll().prifit_membership_gmax_workspace(Bt), dtype=torch.float32, device=dev)
+            ws = torch.empty(query("prifit_membership_gmax_workspace", Bt), dtype=torch.float32, device=dev)
             call("prifit_membership_gmax", ptr(dots), ptr(bw), ptr(count), Bt, N, K, ptr(gmax), ptr(ws), cur_stream())
         else:   # (a slot count that is not a multiple of 4: never on the loss path, KM = 32)
             live = torch.arange(K, device=dev).view(1, 1, K) < count.view(Bt, 1, 1)
@@ -531,7 +531,7 @@ class SampleNNLossFn(torch.autograd.Function):
         call(ctx.pre + "_budget", ptr(r), ptr(valid), Bt, K, cap, ptr(n), ptr(off), cur_stream())
         nn_idx = torch.empty(Bt, cap, dtype=torch.int32, device=dev)
         s = torch.empty(Bt, dtype=torch.float32, device=dev)
-        ws = torch.empty(dll().prifit_sample_nn_workspace_floats(Bt, cap), dtype=torch.float32, device=dev)
+        ws = torch.empty(query("prifit_sample_nn_workspace_floats", Bt, cap), dtype=torch.float32, device=dev)
         # VALU-bound exact search: every surface sample (budget ~10^4 per shape, src/ellipsoid_utils.py:105) against every
         # target, 8 flop per pair (3 sub, 3 fma-equivalents, compare + select)
         with profiler.span("sample_nn", 8.0 * Bt * 10000.0 * M):

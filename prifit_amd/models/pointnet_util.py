@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .. import arena as zero_pool
-from .._lib import call, cur_stream, ptr
+from .._lib import call, cur_stream, ptr, query
 from ..nn_ops import (GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
                       ThreeInterpolateFn, _sa_group_launch, sa_group_supported)
 
@@ -223,7 +223,7 @@ def _norows_scales(mode, conv_blocks, training, B, S, nsamples):
         ok = (len(convs) >= 3 and C1 == 64 and K % 64 == 0 and P < (1 << 24) and convs[1].weight.shape[1] == 64)
         if ok:
             C2 = convs[1].weight.shape[0]
-            ok = bool(dll().prifit_gemm_stream_supported(0, P, C2, 64)) and bool(dll().prifit_gemm_stream_bwd_supported(P, C2, 64, 0))
+            ok = bool(query("prifit_gemm_stream_supported", 0, P, C2, 64)) and bool(query("prifit_gemm_stream_bwd_supported", P, C2, 64, 0))
         out.append(ok)
     return out
 
@@ -354,7 +354,7 @@ _GATHER_FUSED_BWD = os.environ.get("PRIFIT_SA_GATHER_FUSED_BWD", "1") != "0"
 def _gather_bwd_ok(mode, convs_per_scale, N):
     from .._lib import dll
     return (mode == "gather" and _GATHER_FUSED_BWD and all(len(c) >= 2 for c in convs_per_scale) and
-            all(dll().prifit_gather_linear_bwd_bn_supported(N, c[0].weight.shape[0]) for c in convs_per_scale))
+            all(query("prifit_gather_linear_bwd_bn_supported", N, c[0].weight.shape[0]) for c in convs_per_scale))
 
 
 _pending_counters = None   # list while a model forward batches the BatchNorm step counters, else None

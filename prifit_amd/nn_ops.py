@@ -14,7 +14,7 @@ import torch
 
 from . import profiler
 from . import arena as zero_pool
-from ._lib import call, cur_stream, dll, ptr
+from ._lib import call, cur_stream, dll, ptr, query
 
 NT, NN, TN = 0, 1, 2
 EPI_NONE, EPI_CHORD, EPI_MSKERNEL, EPI_MSBWD = 0, 1, 2, 3
@@ -24,7 +24,7 @@ _D = ctypes.c_double
 
 
 def _rows_per_slab():
-    return dll().prifit_reduce_rows_per_slab()
+    return query("prifit_reduce_rows_per_slab")
 
 
 # BatchNorm tails (round 6, include/prifit_hip.h: prifit_bn_fwd / prifit_bn_bwd): the launch that produces a
@@ -57,7 +57,7 @@ _REPLICAS = None
 def _tail_replicas():
     global _REPLICAS
     if _REPLICAS is None:
-        _REPLICAS = dll().prifit_bn_tail_replicas()
+        _REPLICAS = query("prifit_bn_tail_replicas")
     return _REPLICAS
 
 
@@ -120,7 +120,7 @@ def _stream_ok(layout, M, N, K, batch=1, splitk=1, epi=EPI_NONE, b_affine=None, 
     kernel (csrc/gemm_stream.hip); everything else the tiled kernel (csrc/gemm.hip)."""
     return (_STREAM and batch == 1 and splitk == 1 and epi == EPI_NONE and b_affine is None and a_rowsum is None and
             not accumulate and aux is None and row_add is None and
-            bool(dll().prifit_gemm_stream_supported(layout, M, N, K)))
+            bool(query("prifit_gemm_stream_supported", layout, M, N, K)))
 
 
 def slab_sum(part):
@@ -134,8 +134,8 @@ def slab_sum(part):
 def gemm_stats_slabs(M, N, K):
     """Number of column-statistics slabs a forward (NT) product of this shape writes."""
     if _stream_ok(NT, M, N, K):
-        return dll().prifit_gemm_stream_slabs(M, K)
-    t = dll().prifit_gemm_stats_tile_m(M, N)
+        return query("prifit_gemm_stream_slabs", M, K)
+    t = query("prifit_gemm_stats_tile_m", M, N)
     return (M + t - 1) // t
 
 
@@ -181,10 +181,10 @@ def _splitk_for(P, tiles):
 def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
     """dW [Cout, Kin] = dY[P, Cout]^T . A[P, Kin] (A optionally normalised on load).  `out`: a zero-filled
     [Cout, Kin] destination (several layers share one zeroed arena: one fill instead of one per layer)."""
-    if _STREAM and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)):
+    if _STREAM and query("prifit_gemm_stream_tn_supported", Cout, Kin, P):
         # tall reduction, small output: the LDS-free streaming kernel (csrc/gemm_stream.hip), HBM-bound
         dW = out if out is not None else zero_pool.zeros(Cout, Kin, device=dY.device)
-        ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dY.device)
+        ws = torch.empty(query("prifit_gemm_stream_tn_workspace", Cout, Kin, P), dtype=torch.float32, device=dY.device)
         with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P), 4.0 * P * (Cout + Kin)):
             call("prifit_gemm_stream_tn_f32", Cout, Kin, _LL(P), ptr(dY), _LL(dY.stride(0)), ptr(Ain), _LL(Ain.stride(0)),
                  ptr(dW), _LL(Kin), ptr(a_affine[0]) if a_affine else None, ptr(a_affine[1]) if a_affine else None,
@@ -205,8 +205,8 @@ def _weight_grad(dY, P, Cout, Ain, Kin, a_affine, out=None):
 def _fused_bwd(P, Cout, Kin, G, Y, scale, shift, ca, cb, cd, arg, Ttab, pool_K, W, Yp, aff_p, stats_p, dW, dev, red):
     """Gp, the (m1, m2) sums of the layer below and dW of one layer in one pass (prifit_gemm_stream_bwd_f32).
     red(Cp, ns_fn) -> (slab or None, BatchNorm-tail descriptor or None, fused_red): SharedMLPFn.backward's red_target."""
-    rslab, tail_p, fused = red(Kin, lambda: dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin))
-    ws = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
+    rslab, tail_p, fused = red(Kin, lambda: query("prifit_gemm_stream_bwd_slabs", P, Cout, Kin))
+    ws = torch.empty(query("prifit_gemm_stream_bwd_workspace", P, Cout, Kin), dtype=torch.float32, device=dev)
     Gp = torch.empty(P, Kin, dtype=torch.float32, device=dev)
     (sc1, sh1), (mu1, is1) = aff_p, stats_p
     pooled = arg is not None
@@ -293,7 +293,7 @@ class SharedMLPFn(torch.autograd.Function):
                     shift = beta - mean * scale
             elif training and l == 1 and nr is not None:
                 # layer 2 on rows that were never stored: the streaming product gathers them from U (prifit_gemm_stream_gather_f32)
-                nslab = dll().prifit_gemm_stream_slabs(P, Kin)
+                nslab = query("prifit_gemm_stream_slabs", P, Kin)
                 slab = None if tail is not None else torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 with profiler.span(profiler.tag("gemm_stream_nt", P, Cout, Kin, "gather"), 4.0 * (P * Cout + P + Cout * Kin)):
                     call("prifit_gemm_stream_gather_f32", P, Cout, ptr(nr["idx"]), ptr(nr["U"]), ptr(nr["Vc"]), nr["N"], nr["S"],
@@ -305,7 +305,7 @@ class SharedMLPFn(torch.autograd.Function):
                 aligned = prev.stride(0) % 4 == 0 and prev.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0
                 slab = nslab = None
                 if tail is None:
-                    tile_m = dll().prifit_gemm_stats_tile_m(P, Cout)
+                    tile_m = query("prifit_gemm_stats_tile_m", P, Cout)
                     nslab = gemm_stats_slabs(P, Cout, Kin) if aligned else (P + tile_m - 1) // tile_m
                     slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 if (l == L - 1 and cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and _FUSE_POOL_FWD and aligned and
@@ -317,7 +317,7 @@ class SharedMLPFn(torch.autograd.Function):
                         call("prifit_gemm_stream_pool_f32", P, Cout, Kin, ptr(prev), _LL(prev.stride(0)), ptr(W), _LL(Kin),
                              ptr(Y), _LL(Cout), ptr(prev_aff[0]), ptr(prev_aff[1]), ptr(b), ptr(slab), ptr(cand), _ref(tail), cur_stream())
                 elif (l == L - 1 and cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and _FUSE_POOL_FWD and aligned and
-                        prev_aff is not None and not _stream_ok(NT, P, Cout, Kin) and dll().prifit_gemm_pool_supported(P, Cout, Kin)):
+                        prev_aff is not None and not _stream_ok(NT, P, Cout, Kin) and query("prifit_gemm_pool_supported", P, Cout, Kin)):
                     # the same on the tiled (persistent) kernel: SA2's 256-wide last layers
                     cand = torch.empty(P // 32, 4, Cout, dtype=torch.float32, device=dev)
                     with profiler.span(profiler.tag("gemm_nt_bn128", P, Cout, Kin, "pool"), 2.0 * P * Cout * Kin):
@@ -418,21 +418,21 @@ class SharedMLPFn(torch.autograd.Function):
             # itself (no pool_bwd_apply pass writing dY, no reads of it) when both consumers are streaming shapes
             fuse_pool = bool(pooled and _FUSE_POOL and training and l > 0 and W is not None and cfg["pool_K"] % 64 == 0 and Cout != 96 and
                              ctx.needs_input_grad[2 + 6 * l] and _stream_ok(NN, P, Kin, Cout) and
-                             dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
+                             query("prifit_gemm_stream_tn_supported", Cout, Kin, P))
             direct0 = l == 0 and ctx.preact_direct is not None
             gather0 = l == 0 and ctx.preact_gather is not None
             # a middle layer on streaming shapes: dY = a*(relu mask)*G + b*Y + d is formed inside its two consumers (the dW and
             # the dA kernel read G and Y instead of dY: no bn_relu_bwd_apply pass writing dY, one read of it less)
             fuse_bn = bool(_FUSE_BN_APPLY and _FUSE_RED and not pooled and not direct0 and training and l > 0 and W is not None and
                            ctx.needs_input_grad[2 + 6 * l] and G_in.stride(0) == Cout and G_in.data_ptr() % 16 == 0 and
-                           _stream_ok(NN, P, Kin, Cout) and dll().prifit_gemm_stream_tn_supported(Cout, Kin, _LL(P)))
+                           _stream_ok(NN, P, Kin, Cout) and query("prifit_gemm_stream_tn_supported", Cout, Kin, P))
             dY = None if (fuse_pool or direct0 or gather0 or fuse_bn) else torch.empty(P, Cout, dtype=torch.float32, device=dev)
             slab = nslab = None
             if pooled:
                 K = cfg["pool_K"]
                 G = P // K
                 if tail is None:
-                    prs = dll().prifit_pool_reduce_groups_per_slab()
+                    prs = query("prifit_pool_reduce_groups_per_slab")
                     nslab = (G + prs - 1) // prs
                     slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
                 call("prifit_pool_bwd_reduce", ptr(G_in), _LL(G_in.stride(0)), ptr(Y), _LL(Cout), ptr(arg),
@@ -469,7 +469,7 @@ class SharedMLPFn(torch.autograd.Function):
                      ptr(shift), ptr(ca), G, K, Cout, _F(0.0), ptr(Ttab), cur_stream())
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
-                if _fuse_bwd_on(Cout, Kin, True) and _FUSE_RED and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, K) and Ys[l - 1].stride(0) % 4 == 0:
+                if _fuse_bwd_on(Cout, Kin, True) and _FUSE_RED and query("prifit_gemm_stream_bwd_supported", P, Cout, Kin, K) and Ys[l - 1].stride(0) % 4 == 0:
                     G_prev, fused_red = _fused_bwd(P, Cout, Kin, None, Y, None, None, None, cb, cd, arg, Ttab, K, W, Ys[l - 1],
                                                    affines[l - 1], stats_saved[l - 1], dW, dev, red_target)
                     grads[6 * l] = dW
@@ -479,7 +479,7 @@ class SharedMLPFn(torch.autograd.Function):
                     grads[6 * l + 3] = dbeta
                     G_in = G_prev
                     continue
-                ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
+                ws = torch.empty(query("prifit_gemm_stream_tn_workspace", Cout, Kin, P), dtype=torch.float32, device=dev)
                 a_aff = affines[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P, 1), 4.0 * P * (Cout + Kin)):
                     call("prifit_gemm_stream_tn_pool_f32", Cout, Kin, _LL(P), ptr(Y), _LL(Cout), ptr(Ys[l - 1]),
@@ -494,7 +494,7 @@ class SharedMLPFn(torch.autograd.Function):
                 bias_dw = torch.mv(W.t(), cd)   # the constant d^T W of every row of dY . W
                 rslab = tail_p = fused_next = None
                 if _FUSE_RED:
-                    rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_slabs(P, Cout))
+                    rslab, tail_p, fused_next = red_target(Kin, lambda: query("prifit_gemm_stream_slabs", P, Cout))
                 (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, 1), 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
                     call("prifit_gemm_stream_dgrad_pool_f32", P, Kin, Cout, ptr(Y), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
@@ -535,14 +535,14 @@ class SharedMLPFn(torch.autograd.Function):
                 Bq, Nq, Sq, Kq = info["B"], info["N"], info["S"], info["K"]
                 grads[2] = dgamma
                 grads[3] = dbeta
-                if _GATHER_BWD_CSR and dll().prifit_gather_linear_bwd_csr_supported(Nq, Cout) and G_in.is_contiguous():
+                if _GATHER_BWD_CSR and query("prifit_gather_linear_bwd_csr_supported", Nq, Cout) and G_in.is_contiguous():
                     # as a gather over the in-edge lists of the points: no atomics, no staging, y1 re-formed from U / Vc (the
                     # layer's rows are not read); the CSR of the ball-query lists is built here, once per level and scale
                     Uq, Vq = info["U"].detach().contiguous(), info["Vc"].detach().contiguous()
                     E = Sq * Kq
                     offs = torch.empty(Bq, Nq + 1, dtype=torch.int32, device=dev)
                     lst, pos, own = (torch.empty(Bq, E, dtype=torch.int32, device=dev) for _ in range(3))
-                    wsd = torch.empty(dll().prifit_gather_linear_bwd_csr_workspace(Bq, Sq, Kq, Cout), dtype=torch.float64, device=dev)
+                    wsd = torch.empty(query("prifit_gather_linear_bwd_csr_workspace", Bq, Sq, Kq, Cout), dtype=torch.float64, device=dev)
                     dU = torch.empty(Bq, Nq, Cout, dtype=torch.float32, device=dev)
                     dVc = torch.empty(Bq, Sq, Cout, dtype=torch.float32, device=dev)
                     # bytes: G twice (once per pass), the lists, the tables
@@ -569,8 +569,8 @@ class SharedMLPFn(torch.autograd.Function):
                 assert fuse_bn, "norows: the streaming backward of layer 2 is required (pointnet_util._norows_scales)"
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
-                rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_bwd_slabs(_LL(P), Cout, Kin))
-                ws = torch.empty(dll().prifit_gemm_stream_bwd_workspace(_LL(P), Cout, Kin), dtype=torch.float32, device=dev)
+                rslab, tail_p, fused_next = red_target(Kin, lambda: query("prifit_gemm_stream_bwd_slabs", P, Cout, Kin))
+                ws = torch.empty(query("prifit_gemm_stream_bwd_workspace", P, Cout, Kin), dtype=torch.float32, device=dev)
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
                 (sc1, sh1), (mu1, is1) = affines[0], stats_saved[0]
                 with profiler.span(profiler.tag("gemm_stream_bwd", P, Cout, Kin, "gather"), 4.0 * P * (2 * Cout + Kin)):
@@ -589,7 +589,7 @@ class SharedMLPFn(torch.autograd.Function):
             if fuse_bn:
                 wo, wn, bo, bn_ = wslots[l]
                 dW = arena[wo:wo + wn].view(Cout, Kin)
-                if _fuse_bwd_on(Cout, Kin, False) and dll().prifit_gemm_stream_bwd_supported(_LL(P), Cout, Kin, 0) and Ys[l - 1].stride(0) % 4 == 0:
+                if _fuse_bwd_on(Cout, Kin, False) and query("prifit_gemm_stream_bwd_supported", P, Cout, Kin, 0) and Ys[l - 1].stride(0) % 4 == 0:
                     G_prev, fused_red = _fused_bwd(P, Cout, Kin, G_in, Y, scale, shift, ca, cb, cd, None, None, 0, W, Ys[l - 1],
                                                    affines[l - 1], stats_saved[l - 1], dW, dev, red_target)
                     grads[6 * l] = dW
@@ -599,7 +599,7 @@ class SharedMLPFn(torch.autograd.Function):
                     grads[6 * l + 3] = dbeta
                     G_in = G_prev
                     continue
-                ws = torch.empty(dll().prifit_gemm_stream_tn_workspace(Cout, Kin, _LL(P)), dtype=torch.float32, device=dev)
+                ws = torch.empty(query("prifit_gemm_stream_tn_workspace", Cout, Kin, P), dtype=torch.float32, device=dev)
                 a_aff = affines[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_tn", Cout, Kin, P, "bn"), 4.0 * P * (2 * Cout + Kin)):
                     call("prifit_gemm_stream_tn_bn_f32", Cout, Kin, _LL(P), ptr(G_in), ptr(Y), _LL(Cout), ptr(Ys[l - 1]),
@@ -611,7 +611,7 @@ class SharedMLPFn(torch.autograd.Function):
                 grads[6 * l + 2] = dgamma
                 grads[6 * l + 3] = dbeta
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
-                rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_slabs(P, Cout))
+                rslab, tail_p, fused_next = red_target(Kin, lambda: query("prifit_gemm_stream_slabs", P, Cout))
                 (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                 with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, "bn"), 4.0 * (2 * P * Cout + 2 * P * Kin + Kin * Cout)):
                     call("prifit_gemm_stream_dgrad_bn_f32", P, Kin, Cout, ptr(G_in), ptr(Y), _LL(Cout), ptr(W), _LL(Kin),
@@ -646,7 +646,7 @@ class SharedMLPFn(torch.autograd.Function):
                 G_prev = torch.empty(P, Kin, dtype=torch.float32, device=dev)
                 if l > 0 and _FUSE_RED and _stream_ok(NN, P, Kin, Cout):
                     # streaming dA product with the BatchNorm-backward column sums of layer l-1 in its epilogue
-                    rslab, tail_p, fused_next = red_target(Kin, lambda: dll().prifit_gemm_stream_slabs(P, Cout))
+                    rslab, tail_p, fused_next = red_target(Kin, lambda: query("prifit_gemm_stream_slabs", P, Cout))
                     (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                     with profiler.span(profiler.tag("gemm_stream_nn", P, Kin, Cout, 0), 4.0 * (P * Cout + 2 * P * Kin + Kin * Cout)):
                         call("prifit_gemm_stream_dgrad_f32", P, Kin, Cout, ptr(dY), _LL(Cout), ptr(W), _LL(Kin), ptr(G_prev),
@@ -655,7 +655,7 @@ class SharedMLPFn(torch.autograd.Function):
                     fused_red = fused_next
                 elif l > 0 and _FUSE_RED:
                     # tiled kernel, same epilogue
-                    rslab, tail_p, fused_next = red_target(Kin, lambda: (P + dll().prifit_gemm_stats_tile_m(P, Kin) - 1) // dll().prifit_gemm_stats_tile_m(P, Kin))
+                    rslab, tail_p, fused_next = red_target(Kin, lambda: (P + query("prifit_gemm_stats_tile_m", P, Kin) - 1) // query("prifit_gemm_stats_tile_m", P, Kin))
                     (sc1, sh1), (mu1, is1) = affines[l - 1], stats_saved[l - 1]
                     with profiler.span(profiler.tag("gemm_nn_bn%d" % (32 if Kin <= 32 else (64 if Kin <= 64 else (96 if Kin <= 96 else 128))),
                                                     P, Kin, Cout, "red"), 2.0 * P * Kin * Cout):
@@ -736,7 +736,7 @@ def _sa_group_launch(mode, xyz, new_xyz, feat, feat_first, radii, nsamples, widt
     S = new_xyz.shape[1]
     R = len(radii)
     dev = xyz.device
-    q = dll().prifit_sa_group_queries_per_slab(B, S)
+    q = query("prifit_sa_group_queries_per_slab", B, S)
     nslab = B * ((S + q - 1) // q)
     rows = [True] * R if rows is None else list(rows)
     assert mode == 1 or all(rows)
@@ -910,7 +910,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             if Cout % 4 == 0 and gy.data_ptr() % 16 == 0:
                 db = torch.empty(Cout, dtype=torch.float32, device=x.device)
-                ws = torch.empty(dll().prifit_col_sum_workspace(P, Cout), dtype=torch.float32, device=x.device)
+                ws = torch.empty(query("prifit_col_sum_workspace", P, Cout), dtype=torch.float32, device=x.device)
                 call("prifit_col_sum", ptr(gy), _LL(Cout), P, Cout, ptr(db), ptr(ws), cur_stream())
             else:
                 db = gy.sum(dim=0)
@@ -931,7 +931,7 @@ class CrossEntropyFn(torch.autograd.Function):
         target = target.contiguous()
         P, C = x.shape
         lse = torch.empty(P, dtype=torch.float32, device=x.device)
-        ws = torch.empty(dll().prifit_cross_entropy_workspace(), dtype=torch.float32, device=x.device)
+        ws = torch.empty(query("prifit_cross_entropy_workspace"), dtype=torch.float32, device=x.device)
         loss = torch.empty(2, dtype=torch.float32, device=x.device)     # (mean over the kept rows, number of kept rows)
         call("prifit_cross_entropy_fwd", ptr(x), _LL(x.stride(0)), ptr(target), _LL(P), C, ptr(lse), ptr(ws), ptr(loss), cur_stream())
         ctx.save_for_backward(x, target, lse, loss)

@@ -19,7 +19,7 @@ import ctypes
 
 import torch
 
-from ._lib import call, cur_stream, dll, ptr
+from ._lib import call, cur_stream, dll, ptr, query
 
 
 class FlatAdam:
@@ -30,7 +30,7 @@ class FlatAdam:
         dev = self.params[0].device
         if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in self.params):
             raise RuntimeError("FlatAdam needs fp32 parameters on one GPU (HIP backend only, no CPU path)")
-        align = dll().prifit_adam_flat_alignment()
+        align = query("prifit_adam_flat_alignment")
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)

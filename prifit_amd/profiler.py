@@ -32,17 +32,42 @@ def reset():
     _records.clear()
 
 
-@contextlib.contextmanager
+class _Null:
+    """The disabled span: one shared object, nothing allocated per launch (a generator-based context manager costs ~2 us, and a
+    training step opens ~100 spans)."""
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _Null()
+
+
+class _Span:
+    __slots__ = ("name", "work", "a", "b")
+
+    def __init__(self, name, work):
+        self.name, self.work = name, float(work)
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        _records.setdefault(self.name, []).append((self.a, self.b, self.work))
+        return False
+
+
 def span(name, work=0.0):
-    if name not in _enabled and "*" not in _enabled:
-        yield
-        return
-    a = torch.cuda.Event(enable_timing=True)
-    b = torch.cuda.Event(enable_timing=True)
-    a.record()
-    yield
-    b.record()
-    _records.setdefault(name, []).append((a, b, float(work)))
+    if not _enabled or (name not in _enabled and "*" not in _enabled):
+        return _NULL
+    return _Span(name, work)
 
 
 def collect():

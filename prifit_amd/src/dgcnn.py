@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from .. import arena as zero_pool
 from .. import nn_ops
 from .. import profiler
-from .._lib import call, cur_stream, dll, ptr
+from .._lib import call, cur_stream, dll, ptr, query
 from ..nn_ops import NN, NT, TN, LinearFn, gemm
 
 _LL = ctypes.c_longlong
@@ -46,7 +46,7 @@ def _knn_cl(x, k):
     """x [B,N,C] channels-last -> idx int32 [B,N,k]."""
     x = x.contiguous()
     B, N, C = x.shape
-    if C == 3 and _KNN3_FUSED and dll().prifit_knn3_supported(N, k):
+    if C == 3 and _KNN3_FUSED and query("prifit_knn3_supported", N, k):
         idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
         # a VALU row: per pair one multiply, two fmas and the three operations of the value (8 flop), then the selection
         with profiler.span("knn3_topk", 8.0 * B * N * N):
@@ -158,12 +158,12 @@ def _gn_tables(slab, Bs, sps, Cout, rows, gamma, beta, cfg, offset=None, chsum=N
     dev = slab.device
     m = float(rows * (Cout // G))
     if offset is not None:
-        assert dll().prifit_gn_finalize_supported(Cout, G) and offset.shape == (Bs, Cout)
+        assert query("prifit_gn_finalize_supported", Cout, G) and offset.shape == (Bs, Cout)
         scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
         call("prifit_gn_finalize_offset", ptr(slab), Bs, sps, Cout, G, _D(m), ptr(gamma.contiguous()),
              ptr(beta.contiguous()), _D(float(eps)), ptr(offset.contiguous()), _D(float(rows)), ptr(scale), ptr(shift), ptr(mean),
              ptr(invstd), ptr(chsum), cur_stream())
-    elif _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+    elif _GN_KERNELS and query("prifit_gn_finalize_supported", Cout, G):
         # per-sample group statistics -> [Bs, C] tables in one launch (the torch form below: ~15 single-workgroup launches)
         scale, shift, mean, invstd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(4))
         call("prifit_gn_finalize", ptr(slab), Bs, sps, Cout, G, _D(m), ptr(gamma.contiguous()),
@@ -237,7 +237,7 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chs
     Bs = P // rps
     dev = gout.device
     gout = gout.contiguous()
-    rows = dll().prifit_reduce_rows_per_slab()
+    rows = query("prifit_reduce_rows_per_slab")
     if pool_K and pool_K == rps:
         # one pooling group per sample (the global max over a cloud, src/dgcnn.py:197): the per-sample partials are the
         # winners' terms themselves, [Bs, C] numbers -- (sum Gm, sum Gm * yhat) with Gm = act'(.) * gout at the winning row
@@ -251,7 +251,7 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chs
             sums["gm"] = gm
     elif pool_K:
         Gp = P // pool_K
-        rows = dll().prifit_pool_reduce_groups_per_slab()
+        rows = query("prifit_pool_reduce_groups_per_slab")
         nslab = (Gp + rows - 1) // rows
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         call("prifit_pool_bwd_reduce", ptr(gout), _LL(gout.stride(0)), ptr(Y), _LL(Cout), ptr(arg), ptr(scale),
@@ -263,7 +263,7 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chs
              ptr(mean), ptr(invstd), P, Cout, rps, _F(slope), ptr(slab), None, cur_stream())
     m = float(cfg.get("count_rows", rps) * (Cout // G))     # count_rows: Y is a per-group table of a tensor with more rows
     ca = scale.contiguous()
-    if _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, G):
+    if _GN_KERNELS and query("prifit_gn_finalize_supported", Cout, G):
         cb, cd = (torch.empty(Bs, Cout, dtype=torch.float32, device=dev) for _ in range(2))
         S = torch.empty(Bs, 2, Cout, dtype=torch.float64, device=dev)
         dsum = db = None
@@ -292,11 +292,11 @@ def _gn_backward_coefs(gout, Y, gamma, scale, shift, mean, invstd, arg, cfg, chs
 
 def pool_product_ok(P, Cout, Kin):
     """prifit_gemm_pool_f32 takes this product (more output tiles than resident workgroups, 16-byte rows)."""
-    return Kin % 4 == 0 and bool(dll().prifit_gemm_pool_supported(P, Cout, Kin))
+    return Kin % 4 == 0 and bool(query("prifit_gemm_pool_supported", P, Cout, Kin))
 
 
 def _global_pool_alg_ok(P, rps, Cout, Kin, x):
-    return bool(_GLOBAL_POOL_ALG and dll().prifit_global_pool_winners_supported(Cout, Kin) and rps % 512 == 0 and
+    return bool(_GLOBAL_POOL_ALG and query("prifit_global_pool_winners_supported", Cout, Kin) and rps % 512 == 0 and
                 x.data_ptr() % 16 == 0)
 
 
@@ -327,7 +327,7 @@ def _global_pool_alg_bwd(x, W, bias, ca, cb, cd, gm, arg, rps, need_dx, need_dW)
         G = zero_pool.zeros(Bs, Kin, Kin, device=dev)
         gemm(TN, Kin, Kin, rps, x, Kin, x, Kin, G, Kin, batch=Bs, sA=rps * Kin, sB=rps * Kin, sC=Kin * Kin, splitk=4)  # x_b^T x_b
         s = torch.empty(Bs, Kin, dtype=torch.float32, device=dev)                  # 1^T x_b
-        ws = torch.empty(dll().prifit_col_sum_workspace(P, Kin), dtype=torch.float32, device=dev)
+        ws = torch.empty(query("prifit_col_sum_workspace", P, Kin), dtype=torch.float32, device=dev)
         call("prifit_col_sum_samples", ptr(x), _LL(Kin), P, Kin, rps, ptr(s), ptr(ws), cur_stream())
         dW = zero_pool.zeros(Cout, Kin, device=dev)
         gemm(NN, Cout, Kin, Bs * Kin, Acat, Bs * Kin, G, Kin, dW, Kin, splitk=32)   # sum_b A_b G_b as ONE product, K = Bs Kin
@@ -354,13 +354,13 @@ class ConvGNActFn(torch.autograd.Function):
         Cout = W.shape[0]
         assert cfg["rps"] % 512 == 0
         dev = x.device
-        tile = dll().prifit_gemm_stats_tile_m(P, Cout)   # rows per statistics slab (divides rps: 64 or 128)
+        tile = query("prifit_gemm_stats_tile_m", P, Cout)   # rows per statistics slab (divides rps: 64 or 128)
         nslab = (P + tile - 1) // tile
         slab = torch.empty(nslab, 2, Cout, dtype=torch.float32, device=dev)
         # a bias or an offset in front of the normalisation: their gradients are column sums of dY, which the backward's
         # finalize gives from the statistics alone if the forward keeps the column sums of Y (24 x C numbers)
         chsum = None
-        if (bias is not None or offset is not None) and _GN_COLSUMS and _GN_KERNELS and dll().prifit_gn_finalize_supported(Cout, cfg["groups"]):
+        if (bias is not None or offset is not None) and _GN_COLSUMS and _GN_KERNELS and query("prifit_gn_finalize_supported", Cout, cfg["groups"]):
             chsum = torch.empty(P // cfg["rps"], Cout, dtype=torch.float64, device=dev)
         cand = ystar = None
         pooled_tiled = bool(cfg["pool_K"] and cfg["pool_K"] % 32 == 0 and tile == 128 and pool_product_ok(P, Cout, Kin))
@@ -431,7 +431,7 @@ class GNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Y, slab, gamma, beta, cfg):
-        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, dll().prifit_reduce_rows_per_slab(), gamma, beta, cfg)
+        out, scale, shift, mean, invstd, arg = _gn_forward(Y, slab, query("prifit_reduce_rows_per_slab"), gamma, beta, cfg)
         ctx.cfg = cfg
         ctx.save_for_backward(gamma, Y, scale, shift, mean, invstd, *([arg] if arg is not None else []))
         return out
@@ -458,7 +458,7 @@ class EdgeConvLinFn(torch.autograd.Function):
         P = B * N * k
         dev = U.device
         Y = torch.empty(P, C, dtype=torch.float32, device=dev)
-        rows = dll().prifit_reduce_rows_per_slab()
+        rows = query("prifit_reduce_rows_per_slab")
         slab = torch.empty((P + rows - 1) // rows, 2, C, dtype=torch.float32, device=dev)
         # HBM: U and Vc once, the index lists, the C-wide edge pre-activations written once
         with profiler.span("edge_gather_linear", 4.0 * (2.0 * B * N * C + P + P * C)):
@@ -501,7 +501,7 @@ class EdgeConvTabFn(torch.autograd.Function):
         Vc = U[:, :, C:] if stacked else Vc.contiguous()         # a view: rows of stride ld
         k = idx.shape[2]
         dev = U.device
-        pts = dll().prifit_edge_points_per_slab()
+        pts = query("prifit_edge_points_per_slab")
         ymax, ymin, ysum, ystar, vct, out = (torch.empty(B * N, C, dtype=torch.float32, device=dev) for _ in range(6))
         karg = torch.empty(B * N, C, dtype=torch.int32, device=dev)
         slab = torch.empty(B * (N // pts), 2, C, dtype=torch.float32, device=dev)
@@ -532,7 +532,7 @@ class EdgeConvTabFn(torch.autograd.Function):
             ld = C
         # bytes: the CSR lists and positions, U / centre terms / five tables / gout once, dU and dVc written (rows k-fold from L2)
         with profiler.span("edge_bwd_tables", 4.0 * (3.0 * B * N * k + 10.0 * B * N * C)):
-            ws = torch.empty(dll().prifit_edge_bwd_workspace(B, N, k, C) // 8, dtype=torch.int64, device=U.device)
+            ws = torch.empty(query("prifit_edge_bwd_workspace", B, N, k, C) // 8, dtype=torch.int64, device=U.device)
             call("prifit_edge_bwd", ptr(gout), _LL(gout.stride(0)), ptr(ystar), ptr(ysum), ptr(karg), ptr(scale), ptr(shift),
                  ptr(ca), ptr(cb), ptr(cd), ptr(U), _LL(U.shape[2]), ptr(vct), int(ctx.stacked), ptr(idx), ptr(offs), ptr(lst),
                  ptr(pos), B, N, k, C, _F(ctx.cfg["slope"]), ptr(dU), ptr(dVc), _LL(ld), ptr(ws), cur_stream())
@@ -604,11 +604,11 @@ class DGCNNEncoderGn(nn.Module):
         cfg = {"groups": gn.num_groups, "rps": N * k, "slope": 0.2, "pool_K": k, "eps": gn.eps}
         B = feats.shape[0]
         Cout = conv.weight.shape[0]
-        if _EDGE_LINEARITY and conv.bias is None and (N * k) % dll().prifit_reduce_rows_per_slab() == 0 and Cout % 4 == 0:
+        if _EDGE_LINEARITY and conv.bias is None and (N * k) % query("prifit_reduce_rows_per_slab") == 0 and Cout % 4 == 0:
             X = feats.reshape(B * N, C)
             pad = _pad4(C) - C                          # 16-byte rows for the product kernels (the 3 input coordinates)
             # (the backward's reduction runs over the [B N, Cout] table of winners in 128-row slabs: whole slabs per sample)
-            if csr is not None and dll().prifit_edge_tables_supported(N, k, Cout) and N % dll().prifit_reduce_rows_per_slab() == 0:
+            if csr is not None and query("prifit_edge_tables_supported", N, k, Cout) and N % query("prifit_reduce_rows_per_slab") == 0:
                 # ONE product X [Wa; Wb]^T = [U | Vb] per point (y = U_j - U_i + Vb_i) and one [B N, 2 Cout] gradient back;
                 # [Wa; Wb] is a permuted copy of the weight (one launch each way, no slices to re-assemble in the backward)
                 Wst = conv.weight.reshape(Cout, 2, C).permute(1, 0, 2).reshape(2 * Cout, C)
@@ -691,7 +691,7 @@ class DGCNGn(nn.Module):
     def forward(self, points):
         B, _, N = points.shape
         x4, feats = self.encoder.forward_cl(points.transpose(1, 2).contiguous())
-        if _EDGE_LINEARITY and dll().prifit_gn_finalize_supported(self.conv1.weight.shape[0], self.bn1.num_groups):
+        if _EDGE_LINEARITY and query("prifit_gn_finalize_supported", self.conv1.weight.shape[0], self.bn1.num_groups):
             # upstream :253-257 repeats the global feature x4 [B,1024] over the N points and concatenates it with the 256
             # point features in front of conv1 (1280 -> 512).  The x4 part of that product is the same for every point of a
             # sample: ONE row per sample (24 x 1024 x 512) instead of N (49152 x 1024 x 512, 4/5 of the layer's flops, and the

@@ -145,9 +145,9 @@ def test_cur_stream_is_the_current_stream(hiplib):
     """_lib.cur_stream (the raw accessor) names the same hipStream_t as torch.cuda.current_stream(), on the default stream,
     inside a stream context, and for an explicit device."""
     from prifit_amd._lib import cur_stream
-    assert cur_stream().value == (torch.cuda.current_stream().cuda_stream or None)
+    assert (cur_stream() or 0) == torch.cuda.current_stream().cuda_stream        # (a plain int: argtypes converts it to void *)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        assert cur_stream().value == side.cuda_stream and cur_stream(torch.device("cuda", 0)).value == side.cuda_stream
-        assert cur_stream("cuda").value == side.cuda_stream and cur_stream(0).value == side.cuda_stream
-    assert cur_stream().value == (torch.cuda.current_stream().cuda_stream or None)
+        assert cur_stream() == side.cuda_stream and cur_stream(torch.device("cuda", 0)) == side.cuda_stream
+        assert cur_stream("cuda") == side.cuda_stream and cur_stream(0) == side.cuda_stream
+    assert (cur_stream() or 0) == torch.cuda.current_stream().cuda_stream
