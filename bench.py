@@ -206,7 +206,7 @@ def _traffic_per_launch(dom):
     """HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 cannot run inside this
     process): profiles/r0X_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE, see the file's "source"."""
     # (the PMC tool names kernels, the spans name call sites)
-    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false", "ms_fused_bwd": "ms_fused_kernel<1, true, true",
+    alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false, 4, 2, false", "ms_first_fwd": "ms_fused_kernel<0, true, false, 4, 2, true", "ms_fused_bwd": "ms_fused_kernel<1, true, true",
              "gemm_dual_nn": "gemm_dual_sk_kernel"}
     for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
@@ -416,7 +416,7 @@ SPLIT_NOTE = ("the S = Z X^T and O = K X products of the ten mean-shift updates 
               "fp32.  Passes test_convex_loss_end_to_end, test_selfsup_step_matches_reference_golden and the mean-shift golden "
               "at UNCHANGED tolerances (bf16x6, fp16x3); error of ten updates against fp64 next to the fp32 kernel's: "
               "profiles/r03_split_products.json.  Never the headline: `value` of this line is the fp32 path.")
-FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_fused_fwd", "ms_split_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
+FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_first_fwd", "ms_fused_fwd", "ms_split_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
                 "ellipsoid_fit", "sdf", "sample_nn", "sample_nn_bwd")
 
 
@@ -732,7 +732,7 @@ def family_rows(fams, steps):
         elif base in ("sample_nn", "knn3_topk"):    # pairwise searches on the fp32 vector ALU (its peak = the fp32 MFMA peak on gfx950)
             per.update(bound="valu", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=work / steps, flops_per_launch=work / max(n, 1))
-        elif (base.startswith("gemm") and not base.startswith("gemm_stream")) or base.startswith(("ms_fused", "chord_sym")):
+        elif (base.startswith("gemm") and not base.startswith("gemm_stream")) or base.startswith(("ms_fused", "ms_first", "chord_sym")):
             per.update(bound="mfma", achieved=work / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        flops_per_step=work / steps, flops_per_launch=work / max(n, 1))
         else:

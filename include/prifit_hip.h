@@ -626,6 +626,13 @@ int prifit_meanshift_update_bwd(const float *g, const float *out, const float *n
 int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, int B, int N, int D,
                                float *KT, long long ld_kt, long long stride_kt, float *Znext, float *O,
                                float *rowsum, float *nrm, void *stream);
+/* The FIRST update of a trajectory (Z_0 = X, src/mean_shift.py:60): its score matrix X X^T is symmetric and already in HBM as the
+ * chord matrix 2 - 2 X X^T the bandwidth step wrote (src/mean_shift.py:154-158; prifit_chord_sym_f32) -- the S product, half
+ * of the update's matrix work, becomes a read of chord [B][N][ld_c] (s = 1 - chord / 2).  Outputs as prifit_meanshift_fused_fwd
+ * without K^T.  N % 64 == 0, D == 128 (prifit_meanshift_fused_first_supported). */
+int prifit_meanshift_fused_first_supported(int N, int D);
+int prifit_meanshift_fused_first_fwd(const float *X, const float *chord, long long ld_c, long long stride_c, const float *bw, int B,
+                                     int N, int D, float *Znext, float *O, float *rowsum, float *nrm, void *stream);
 /* dZ = gS X with gS = (gO X^T + g_rowsum 1^T) * K / b^2 (clamp-masked), same fused data flow;
  * gST (may be NULL) receives gS^T in the layout of KT (for the dX GEMM).
  * balanced != 0: the caller hands in a ZERO-INITIALISED dZ and allows the stream-K schedule (a grid of exactly the

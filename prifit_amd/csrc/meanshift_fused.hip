@@ -141,7 +141,15 @@ struct KeyTile {
 // NQG (2 or 1 query groups of 32): NW = 4, NQG = 1 is the "narrow" form -- 32 queries, the four waves take four key
 // sub-tiles of a 128-key step, no query tile in LDS (MODE 0 keeps the query fragments in registers; the epilogue reads Z
 // from global): 68 KB of LDS, so TWO independent workgroups per CU like the standard form.
-template <int MODE, bool FAST, bool SK = false, int NW = 4, int NQG = 2>
+// SLOAD (MODE 0, standard form, FAST): the FIRST update of a trajectory.  Z_0 = X (src/mean_shift.py:60), so its score matrix
+// S = X X^T is symmetric and already in HBM: the bandwidth step has just written the chord matrix C = 2 - 2 X X^T
+// (src/mean_shift.py:154-158), s = 1 - C / 2.  The S product -- half of the update's matrix work -- is replaced by four 16-byte
+// loads per lane and step of C[query][key .. key + 3] (GST carries C; C is symmetric, and read along the QUERY's row a
+// workgroup streams 64 contiguous 8 KB rows: read as C[key][query], 256-byte pieces of 2048 different rows, the same bytes took
+// 303 instead of 293 us per launch against 394 for the standard kernel), requested one step ahead, behind the transform and ahead of the 64 MFMAs of O += P X; the
+// query fragments are not needed at all.  fl(1 - fl(2 - 2 d) / 2)
+// differs from the S product's own d by at most one rounding of (1 - d): the same order as the product's accumulation error.
+template <int MODE, bool FAST, bool SK = false, int NW = 4, int NQG = 2, bool SLOAD = false>
 __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     const float *__restrict__ Q, long long q_stride, const float *__restrict__ X, const float *__restrict__ bw,
     int N, const float *__restrict__ row_add,   // q_stride: batch stride of Q; row_add (MODE 1): g_rowsum [B,N]
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
 {
     static_assert((NW == 4 && NQG == 2) || (!SK && ((NW == 8 && NQG == 2) || (NW == 4 && NQG == 1 && MODE == 0))),
                   "standard, wide or (forward only) narrow form");
+    static_assert(!SLOAD || (MODE == 0 && FAST && !SK && NW == 4 && NQG == 2), "SLOAD: the standard forward form on whole tiles");
     constexpr int QB = 32 * NQG;         // queries per workgroup (shadows the standard form's constant)
     constexpr int NKH = NW / NQG;        // key sub-tiles per step
     constexpr int KB = 32 * NKH;         // keys per step
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     const bool q_ok = gq < N;
     const float radd = (MODE == 1 && q_ok) ? row_add[(size_t)b * N + gq] : 0.f;
     float *KTb = KT ? KT + (size_t)b * sk : nullptr;
-    float *GSb = (MODE == 1 && GST) ? GST + (size_t)b * sk : nullptr;
+    float *GSb = ((MODE == 1 || SLOAD) && GST) ? GST + (size_t)b * sk : nullptr;   // (SLOAD: the chord matrix, read only)
     // the N x N streams: element (key, query) at key * ldk + query; this lane's constant part = its query column and
     // the first key row of its accumulator registers, the scalar part = the step's key block and the register's row
     const long long nn_bytes = ((long long)(N - 1) * ldk + N) * 4;
@@ -256,8 +265,8 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     for (int r = 0; r < 16; ++r) row_off[r] = __builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * ldk4);
     auto st_soff = [&](int kbase_bytes, int r) { return FAST ? kbase_bytes + row_off[r] : 0; };
     // MODE 0: the query fragments (B operand of the S product) stay in registers for the whole kernel
-    float4 qf[MODE == 0 ? D / 8 : 1];
-    if (MODE == 0) {
+    float4 qf[(MODE == 0 && !SLOAD) ? D / 8 : 1];
+    if (MODE == 0 && !SLOAD) {
         const int q_voff = q_ok ? (gq * D + lh * 4) * 4 : OOB;
 #pragma unroll
         for (int g = 0; g < D / 8; ++g) {
@@ -269,6 +278,15 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
     float pprev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
+    // SLOAD: the chord values under this wave's sub-tile of the NEXT step: accumulator registers 4 j .. 4 j + 3 of lane (query li,
+    // half lh) are the keys k0 + 32 kh + 8 j + 4 lh + (0..3) -- one float4 of the query's row of C
+    f32x4 cnext[SLOAD ? 4 : 1];
+    const int c_voff = (SLOAD && q_ok) ? (int)(((long long)gq * ldk + kh * 32 + 4 * lh) * 4) : OOB;
+    if (SLOAD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            cnext[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs_rs, c_voff, (kbeg + 8 * j) * 4, 0));
+    }
     int it = 0;
     for (int k0 = kbeg; k0 < kend; k0 += KB, ++it) {
         float *sx = s_x;                 // this step's key tile
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         // previous step's K^T values -- are issued one per group of four S MFMAs below instead of in a block here: their
         // issue (~40 cycles each, in-kernel stamps: 970-1290 cycles per step with the matrix pipe idle) then runs beside
         // the matrix instructions.
-        constexpr bool SPREAD = MODE == 0 && NW == 4 && NQG == 2;
+        constexpr bool SPREAD = MODE == 0 && NW == 4 && NQG == 2 && !SLOAD;
         const bool st_prev = SPREAD && KTb && k0 > kbeg, ld_next = SPREAD && k0 + KB < kend;
         const int pb_bytes_s = __builtin_amdgcn_readfirstlane((k0 - KB) * ldk4);
         if (!SPREAD && (MODE == 0 ? KTb : GSb) && k0 > kbeg) {   // the previous step's stream values (K^T / gS^T)
@@ -313,10 +331,11 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
         const float *qb = s_q + qrow * LDSW + lh * 4;
         f32x16 sacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) sacc[r] = SLOAD ? fmaf(-0.5f, cnext[SLOAD ? r >> 2 : 0][r & 3], 1.0f) : 0.f;   // SLOAD: s = 1 - chord / 2
+        constexpr int PFD = 1;                // groups requested ahead (ring of PFD + 1 fragments); 2 measured the same
+        if constexpr (!SLOAD) {
         // the fragments of k group g + 1 are requested before the four MFMAs of group g (left to itself the compiler reads
         // each group right in front of its MFMAs and waits out the LDS latency with lgkmcnt(0), sixteen times per step)
-        constexpr int PFD = 1;                // groups requested ahead (ring of PFD + 1 fragments); 2 measured the same
         float4 a2[PFD + 1], b2[PFD + 1];
 #pragma unroll
         for (int g = 0; g < PFD; ++g) {
@@ -344,6 +363,7 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        }   // !SLOAD
         // (MODE 1: nothing of the transform -- e.g. the compares on the just-requested K values -- may move above the S MFMAs)
         if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
 #ifdef MSF_STAMPS
@@ -376,6 +396,12 @@ __global__ __launch_bounds__(NW * 64, 2) void ms_fused_kernel(
 #ifdef MSF_STAMPS
         asm volatile("" ::"v"(sacc[15]));
 #endif
+        if (SLOAD && k0 + KB < kend) {   // the next step's chord values: their latency runs under the 64 MFMAs below
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                cnext[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs_rs, c_voff, (k0 + KB + 8 * j) * 4, 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         MSF_STAMP(6);
         // ---- O_q += P . X_sub : A = P from the accumulator registers (k = key), B = X_sub[key][d]
         // Output column of accumulator block d, lane li: 4 li + d (NOT 32 d + li): the four B operands of a key row are then
@@ -805,6 +831,20 @@ int prifit_meanshift_fused_fwd(const float *Z, const float *X, const float *bw, 
         hipLaunchKernelGGL((ms_fused_kernel<0, false>), dim3((N + QB - 1) / QB, B), dim3(256), 0, as_stream(stream), Z,
                            (long long)N * D, X, bw, N, (const float *)nullptr, KT, ld_kt, stride_kt, (float *)nullptr, Z,
                            Znext, O, rowsum, nrm, B, 0, xcd_map());
+    return prifit_check_launch();
+}
+
+int prifit_meanshift_fused_first_supported(int N, int D_) { return (N > 0 && N % QB == 0 && D_ == D) ? 1 : 0; }
+
+int prifit_meanshift_fused_first_fwd(const float *X, const float *chord, long long ld_c, long long stride_c, const float *bw, int B,
+                                     int N, int D_, float *Znext, float *O, float *rowsum, float *nrm, void *stream)
+{
+    if (!X || !chord || !bw || !Znext || !rowsum || !nrm || B <= 0 || B > 65535 || !prifit_meanshift_fused_first_supported(N, D_) ||
+        ld_c < N || stride_c < (long long)(N - 1) * ld_c + N)
+        return PRIFIT_EINVAL;
+    hipLaunchKernelGGL((ms_fused_kernel<0, true, false, 4, 2, true>), dim3(N / QB, B), dim3(256), 0, as_stream(stream), X,
+                       (long long)N * D, X, bw, N, (const float *)nullptr, (float *)nullptr, ld_c, stride_c,
+                       const_cast<float *>(chord), X, Znext, O, rowsum, nrm, B, 0, xcd_map());
     return prifit_check_launch();
 }
 

@@ -111,16 +111,25 @@ def chord_matrix(A, B_, owner_key=None):
     return out
 
 
-def compute_bandwidth(X, quantile, num_samples=None, rows=None):
+# The first mean-shift update of a trajectory reads the chord matrix the bandwidth step has just written instead of forming
+# S = X X^T again (csrc/meanshift_fused.hip, SLOAD: Z_0 = X, one of the 20 N x N x D products of ten updates gone).  0: every
+# update takes the standard kernel (A/B arm, tested against this one).
+MS_FIRST_CHORD = __import__("os").environ.get("PRIFIT_MS_FIRST_CHORD", "1") != "0"
+
+
+def compute_bandwidth(X, quantile, num_samples=None, rows=None, keep_chord=None):
     """src/mean_shift.py:138-160, batched: X [B,N,D] (unit rows) -> bw [B].
 
     num_samples < N (upstream :148-151: a random row subset, the default of `clustering(X)`, num_samples=1000): the
     statistic is taken over `rows` [B, num_samples] (int64 row indices; hidden randomness made an explicit input like
     the other ones) or, when omitted, over a fresh random subset per shape, as upstream.  num_samples > N: upstream's
     slice keeps all N rows and K = int(quantile * num_samples) (:155) all the same -- and so here (topk raises when
-    K exceeds the row length; so does this)."""
+    K exceeds the row length; so does this).
+    keep_chord: a list; when the statistic is taken over ALL rows, the chord matrix [B,N,N] = 2 - 2 X X^T is appended to it
+    (mean_shift_trajectory(chord=...) reads it in the first update)."""
     Bt, N, D = X.shape
     ns = N if num_samples is None else int(num_samples)
+    full = ns >= N
     if ns < N:
         if rows is None:
             rows = torch.stack([torch.randperm(N, device=X.device)[:ns] for _ in range(Bt)])
@@ -130,6 +139,8 @@ def compute_bandwidth(X, quantile, num_samples=None, rows=None):
         X = torch.gather(X, 1, rows.unsqueeze(-1).expand(-1, -1, D)).contiguous()
         N = ns
     dist = chord_matrix(X, X)
+    if keep_chord is not None and full:
+        keep_chord.append(dist)
     k = int(quantile * ns)
     if k < 1:
         raise ValueError("quantile * num_samples < 1: torch.topk(k=0) upstream")
@@ -165,11 +176,13 @@ class Normalize2Fn(torch.autograd.Function):
         return gx
 
 
-def mean_shift_trajectory(X, bw, iterations, keep_kernel):
+def mean_shift_trajectory(X, bw, iterations, keep_kernel, chord=None):
     """`iterations` updates of src/mean_shift.py:61-82 (gaussian kernel, delta = 1) for all shapes at once, no autograd.
     X [B,N,D] unit rows (contiguous), bw [B].  Returns (Z_final, per iteration [Z_in, K or None, O, rowsum, Z_out, nrm]);
     keep_kernel=False: the N x N kernel matrix is not kept (D = 128: never written -- prifit_meanshift_fused_fwd with
-    KT = NULL; other widths: one scratch matrix for the GEMM chain)."""
+    KT = NULL; other widths: one scratch matrix for the GEMM chain).
+    chord: the chord matrix 2 - 2 X X^T [B,N,N] of THIS X when the caller has it (compute_bandwidth(keep_chord=...)): the
+    first update then reads it instead of forming X X^T again (prifit_meanshift_fused_first_fwd; D = 128, N % 64 == 0)."""
     global split_launches
     Bt, N, D = X.shape
     dev = X.device
@@ -199,6 +212,12 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel):
                 call("prifit_meanshift_split_fwd", ptr(Z), ptr(cut), ptr(bw), Bt, N, D, split, ptr(O), ptr(rsum), cur_stream())
             call("prifit_meanshift_update_fwd", ptr(O), ptr(rsum), ptr(Z), D, _LL(Bt * N), ptr(Zn), ptr(nrm),
                  cur_stream())
+        elif (fused and chord is not None and not saved and not keep_kernel and MS_FIRST_CHORD and
+              query("prifit_meanshift_fused_first_supported", N, D)):
+            # Z_0 = X: S = X X^T = 1 - chord / 2 is in HBM already; ONE matrix product (O = K X) + a read of the chord matrix
+            with profiler.span("ms_first_fwd", 2.0 * Bt * N * N * D):
+                call("prifit_meanshift_fused_first_fwd", ptr(X), ptr(chord), _LL(N), _LL(N * N), ptr(bw), Bt, N, D, ptr(Zn), ptr(O),
+                     ptr(rsum), ptr(nrm), cur_stream())
         elif fused:
             with profiler.span("ms_fused_fwd", 4.0 * Bt * N * N * D):
                 call("prifit_meanshift_fused_fwd", ptr(Z), ptr(X), ptr(bw), Bt, N, D, ptr(Kmat), _LL(N),
@@ -633,13 +652,14 @@ def speculative():
         _spec = prev
 
 
-def _shift(X, bw, iterations, km=KM):
+def _shift(X, bw, iterations, km=KM, chord=None):
     """The shifted points for nms + what the centre gather needs afterwards: (Z detached, handle).  Row-sparse engine:
     handle = the trajectory (no autograd graph yet); dense engine: handle = the differentiable Z of MeanShiftFn."""
     Bt, N, D = X.shape
     if ROWS_BWD and rows_supported(N, D, km):
         with torch.no_grad():
-            Z, traj = mean_shift_trajectory(X.detach().contiguous(), bw, iterations, keep_kernel=False)
+            Xc = X.detach().contiguous()
+            Z, traj = mean_shift_trajectory(Xc, bw, iterations, keep_kernel=False, chord=chord)
         return Z, traj
     Z = MeanShiftFn.apply(X, bw, iterations)
     return Z.detach(), Z
@@ -655,9 +675,11 @@ def _centres(X, bw, handle, ids, count):
 def _cluster_speculative(X, quantile, iterations, max_num_clusters, num_samples=None, bandwidth_rows=None):
     Bt, N, D = X.shape
     km = slots_for(max_num_clusters)
+    keep = []
     with torch.no_grad():
-        bw = compute_bandwidth(X, quantile, num_samples, bandwidth_rows)
-    Z, handle = _shift(X, bw, iterations, km)
+        bw = compute_bandwidth(X, quantile, num_samples, bandwidth_rows, keep_chord=keep)
+    Z, handle = _shift(X, bw, iterations, km, chord=keep[0] if keep else None)
+    del keep
     with torch.no_grad():
         ids, count, labels, used = nms(Z, bw)
         bad = torch.empty(1, dtype=torch.int32, device=X.device)
@@ -727,8 +749,10 @@ def cluster(X, quantile, iterations, max_num_clusters, center_ids=None, num_samp
             rows_p = bandwidth_rows
             if rows_p is not None and pending.numel() != Bt:
                 rows_p = rows_p.to(dev).index_select(0, pending)
-            bw = compute_bandwidth(Xp, q, num_samples, rows_p)
-        Z, handle = _shift(Xp, bw, iterations, km)
+            keep = []
+            bw = compute_bandwidth(Xp, q, num_samples, rows_p, keep_chord=keep)
+        Z, handle = _shift(Xp, bw, iterations, km, chord=keep[0] if keep else None)
+        del keep
         with torch.no_grad():
             ids, count, labels, used = nms(Z, bw)
             nb = count.shape[0]

@@ -647,7 +647,10 @@ def test_mean_shift_row_sparse_backward_equals_dense(F, N, D, T, nrows):
 
 
 def test_cluster_gradient_same_with_both_mean_shift_engines(F, monkeypatch):
-    """cluster() -> centres / membership -> a scalar: d/dX with the row-sparse engine (default) and with the dense one."""
+    """cluster() -> centres / membership -> a scalar: d/dX with the row-sparse engine (default) and with the dense one.
+    (Both on the standard forward kernel: the row-sparse engine's first update otherwise reads the chord matrix, whose s differs
+    from the product's by one rounding -- test_first_update_from_the_chord_matrix -- and the forward is compared bit for bit.)"""
+    monkeypatch.setattr(F, "MS_FIRST_CHORD", False)
     _, _, emb = fit_inputs(2, 2048, 128, 7)
     Gc = torch.randn(2, F.KM, 128, generator=torch.Generator().manual_seed(1)).cuda()
     Gw = torch.randn(2, 2048, F.KM, generator=torch.Generator().manual_seed(2)).cuda()
@@ -786,3 +789,32 @@ def test_split_products_one_update_all_mappings(F, B, N):
         assert ((rs.double() - r64).abs() / r64).max().item() < tol
     assert dll().prifit_meanshift_split_supported(300, 128, 2) == 0 and dll().prifit_meanshift_split_supported(256, 64, 2) == 0
     assert dll().prifit_meanshift_split_supported(256, 128, 7) == 0
+
+
+def test_first_update_from_the_chord_matrix(F):
+    """The first mean-shift update of a trajectory reads S = X X^T from the chord matrix the bandwidth step wrote
+    (prifit_meanshift_fused_first_fwd, PRIFIT_MS_FIRST_CHORD) instead of forming it again: every saved tensor of that update
+    (O, row sums, norms, the new points) and the end point of ten updates against the standard kernel.  Measured bar: the two
+    forms of s differ by one rounding of (1 - d), i.e. ~6e-8 absolute in s and up to 6e-8 / b^2 relative in a kernel value."""
+    B, N, D = 3, 2048, 128
+    gen = torch.Generator().manual_seed(5)
+    proto = torch.nn.functional.normalize(torch.randn(8, D, generator=gen), dim=1)
+    X = torch.nn.functional.normalize(proto[torch.randint(0, 8, (B, N), generator=gen)] + 0.05 * torch.randn(B, N, D, generator=gen), dim=2).cuda()
+    keep = []
+    bw = F.compute_bandwidth(X, 0.05, keep_chord=keep)
+    assert len(keep) == 1 and keep[0].shape == (B, N, N)
+    assert F.compute_bandwidth(X, 0.05, num_samples=512, rows=torch.arange(512).repeat(B, 1), keep_chord=keep) is not None and len(keep) == 1
+    Za, sa = F.mean_shift_trajectory(X, bw, 10, keep_kernel=False, chord=keep[0])
+    Zb, sb = F.mean_shift_trajectory(X, bw, 10, keep_kernel=False)
+    for name, i, tol in (("O", 2, 2e-5), ("rowsum", 3, 2e-5), ("Z1", 4, 2e-6), ("nrm", 5, 2e-5)):
+        a, b = sa[0][i], sb[0][i]
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), (name, float((a - b).abs().max()), float(b.abs().max()))
+    assert float((Za - Zb).abs().max()) <= 5e-6
+    # the dense engine (K^T kept) and the switch take the standard kernel
+    old = F.MS_FIRST_CHORD
+    F.MS_FIRST_CHORD = False
+    try:
+        Zc, _ = F.mean_shift_trajectory(X, bw, 10, keep_kernel=False, chord=keep[0])
+    finally:
+        F.MS_FIRST_CHORD = old
+    assert torch.equal(Zc, Zb)
