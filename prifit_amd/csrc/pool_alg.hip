@@ -14,19 +14,32 @@
 #include "common.h"
 
 namespace {
-// out[i] = sum over the slabs of part[slab][i], four interleaved chains in a fixed order
+// out[i] = sum over the slabs of part[slab][i] in a fixed order.  Few outputs, many slabs (the first-layer weight gradient of a
+// set-abstraction scale: 64 x 6 outputs from up to 1024 slabs): 32 outputs per workgroup, eight threads per output take every
+// eighth slab in four interleaved chains, combined through LDS in thread order -- one thread per output walking all slabs was a
+// serial chain of dependent adds on L2 latency in two workgroups (51 us per launch, three launches per step).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ part, int nslab, long long n, float *__restrict__ out)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float s_p[8][32];
+    const int o = threadIdx.x & 31, l = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + o;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nslab; w += 4) {
-        a0 += part[(size_t)w * n + i]; a1 += part[(size_t)(w + 1) * n + i];
-        a2 += part[(size_t)(w + 2) * n + i]; a3 += part[(size_t)(w + 3) * n + i];
+    if (i < n) {
+        int w = l;
+        for (; w + 24 < nslab; w += 32) {
+            a0 += part[(size_t)w * n + i]; a1 += part[(size_t)(w + 8) * n + i];
+            a2 += part[(size_t)(w + 16) * n + i]; a3 += part[(size_t)(w + 24) * n + i];
+        }
+        for (; w < nslab; w += 8) a0 += part[(size_t)w * n + i];
     }
-    for (; w < nslab; ++w) a0 += part[(size_t)w * n + i];
-    out[i] = (a0 + a1) + (a2 + a3);
+    s_p[l][o] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (l == 0 && i < n) {
+        float t = s_p[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += s_p[k][o];
+        out[i] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -142,7 +155,7 @@ int prifit_global_pool_winners_f32(int Bs, int K, int Cout, int Cin, const int32
 int prifit_slab_sum(const float *part, int nslab, long long n, float *out, void *stream)
 {
     if (!part || !out || nslab <= 0 || n <= 0) return PRIFIT_EINVAL;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), part, nslab, n, out);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, as_stream(stream), part, nslab, n, out);
     return prifit_check_launch();
 }
 
