@@ -208,7 +208,7 @@ def _traffic_per_launch(dom):
     # (the PMC tool names kernels, the spans name call sites)
     alias = {"ms_fused_fwd": "ms_fused_kernel<0, true, false, 4, 2, false", "ms_first_fwd": "ms_fused_kernel<0, true, false, 4, 2, true", "ms_fused_bwd": "ms_fused_kernel<1, true, true",
              "gemm_dual_nn": "gemm_dual_sk_kernel"}
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 fams_pmc = json.load(fh)["families"]

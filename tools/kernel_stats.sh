@@ -12,9 +12,9 @@ python3 - $out/${w}_kernel_stats.csv "$pat" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 pat = sys.argv[2]
-# 3 warm-up + 40 timed + 3 of the event pass; for c3 / c5 bench.py sends its first warm-up step through the speculative
-# runner's fall-back once (forward + backward twice): one step-equivalent more
-steps = 46.0 if "c2_kernel_stats" in sys.argv[1] else 47.0
+# 3 warm-up + 40 timed + 5 of the host-time pass + 2 of the launch count (round 6); for c3 / c5 bench.py sends its first warm-up
+# step through the speculative runner's fall-back once (forward + backward twice): one step-equivalent more
+steps = 50.0 if "c2_kernel_stats" in sys.argv[1] else 51.0
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 print("kernel time %.3f ms/step, %.1f launches/step" % (tot / steps / 1e6, sum(int(r["Calls"]) for r in rows) / steps))
 sel = [r for r in rows if pat and any(p in r["Name"] for p in pat.split(","))] if pat else rows[:30]

@@ -17,7 +17,7 @@ for w in c2 c5; do
   python3 bench.py --workload $w > $out/${w}_bench.json 2> $out/${w}_bench.err
 done
 for w in c3 c2 c5; do
-  say "rocprofv3 kernel stats $w (46 steps)"
+  say "rocprofv3 kernel stats $w"
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$w -o $w -- python3 $root/bench.py --workload $w --no-cpu-baseline --no-extra --steps 40 --warmup 3 > $out/prof_$w.log 2>&1 )
   cp $out/prof_$w/*kernel_stats.csv $out/${w}_kernel_stats.csv 2>/dev/null || cp $out/prof_$w/*/*kernel_stats.csv $out/${w}_kernel_stats.csv
   rm -rf $out/prof_$w
@@ -34,6 +34,15 @@ cp gpurun_out/pmc_${tag}_c5/traffic.json $out/pmc_traffic_c5.json; rm -rf gpurun
 say "PMC MFMA busy c3"
 bash tools/prof_mfma.sh ${tag}_c3 --no-extra > $out/pmc_mfma.log 2>&1
 cp gpurun_out/mfma_${tag}_c3/mfma.json $out/pmc_mfma.json; rm -rf gpurun_out/mfma_${tag}_c3
+say "SQ / TCC counter passes c3 (tools/prof_sq_bench.sh + two more passes) -> per-kernel summaries"
+bash tools/prof_sq_bench.sh ${tag} --no-extra > $out/sq_summary.txt 2>&1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $root/gpurun_out/sq_${tag}/p3 -o p3 -- python3 $root/bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 > $root/gpurun_out/sq_${tag}/p3.log 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $root/gpurun_out/sq_${tag}/p4 -o p4 -- python3 $root/bench.py --no-cpu-baseline --no-extra --steps 2 --warmup 1 > $root/gpurun_out/sq_${tag}/p4.log 2>&1 )
+python3 tools/pmc_kernels.py gpurun_out/sq_${tag} $out/sq_stream.json "gemm_stream_kernel,gemm_stream_bwd_kernel,gemm_stream_tn_kernel" > $out/sq_stream.txt 2>&1
+python3 tools/pmc_kernels.py gpurun_out/sq_${tag} $out/sq_all.json "gemm,ms_fused,sa_group,pool_bwd,bn_relu,chord,kth,sample_nn" > /dev/null 2>&1
+rm -rf gpurun_out/sq_${tag}
+say "host time by phase (tools/host_split.py)"
+for w in c3 c5 c2; do python3 tools/host_split.py $w 2>/dev/null | grep -v amdgpu.ids >> $out/host_split.txt; done
 say "launch census c3 / c5"
 PRIFIT_BENCH_CENSUS=$out/c3_launch_census.txt python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extra > /dev/null 2>&1
 PRIFIT_BENCH_CENSUS=$out/c5_launch_census.txt python3 bench.py --workload c5 --steps 5 --warmup 3 --no-cpu-baseline --no-extra > /dev/null 2>&1
