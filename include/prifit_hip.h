@@ -684,10 +684,16 @@ int prifit_gemm_stream_bwd_f32(long long P, int Cout, int Cin, const float *G, c
  * not keep K^T (call prifit_meanshift_fused_fwd with KT = NULL).
  * X [B,N,D], bw [B]; Zin / Zout / O / rowsum / nrm: HOST arrays of T device pointers, the tensors iteration t consumed
  * (Zin[t] [B,N,D]) and produced (Zout[t] [B,N,D], O[t] [B,N,D], rowsum[t] [B,N], nrm[t] [B,N]; Zin[t+1] == Zout[t]);
- * ids [B,R] int64 row indices (clamped to [0,N)), nrows [B] live slots per shape (NULL: all R), R <= 32;
+ * ids [B,R] int64 row indices (clamped to [0,N)), nrows [B] live slots per shape (NULL: all R), R <= 64;
  * g_rows [B,R,D] = dL/d(Zout[T-1][b, ids[b,r]]); dX [B,N,D] is ACCUMULATED into (both uses of the dictionary and the
- * Z_0 = X.clone() of :60) -- read-modified-written ONCE, by the last of the T + 2 launches: the iterations leave their K and
- * gS values in tables [T][B][R][N] inside the workspace.  workspace: prifit_meanshift_rows_bwd_workspace(B, N, D, R, T)
+ * Z_0 = X.clone() of :60) -- read-modified-written ONCE, by the last launch: the iterations leave their K and gS values in
+ * tables [T][B][R][N] inside the workspace.  mode 2: TWO launches -- one workgroup per (shape, live row) runs all T iterations
+ * of its row (the rows are independent of each other in the backward as in the forward; nothing crosses workgroups), then the
+ * dX pass; the choice for few live rows per shape (<= ~16 at B = 24).  mode 1: THREE launches -- the T key-tiled iterations are
+ * one launch that works through a queue of (iteration, shape, key tile) items, an item waiting only for items claimed before
+ * it (no co-residency assumption).  mode 0: one key-tiled launch per iteration (T + 2 launches).  Modes 0 and 1 give the same
+ * bits, mode 2 the same values to fp32 rounding (another summation order over the keys); T <= 16 for modes 1 and 2 (above:
+ * as mode 0).  workspace: prifit_meanshift_rows_bwd_workspace(B, N, D, R, T)
  * floats, 16-byte aligned.  D in {32, 64, 128} (prifit_meanshift_rows_supported).  Deterministic (fixed summation orders;
  * two live slots that name one point are added in slot order). */
 int prifit_meanshift_rows_supported(int N, int D, int R);
@@ -695,7 +701,7 @@ long long prifit_meanshift_rows_bwd_workspace(int B, int N, int D, int R, int T)
 int prifit_meanshift_rows_bwd(const float *X, const float *bw, int B, int N, int D, int T, const float *const *Zin,
                               const float *const *Zout, const float *const *O, const float *const *rowsum,
                               const float *const *nrm, const long long *ids, const int *nrows, int R,
-                              const float *g_rows, float *workspace, float *dX, void *stream);
+                              const float *g_rows, float *workspace, float *dX, int mode, void *stream);
 
 /* LABELLED EXPERIMENT (default off; never the reported precision): the two matrix products of a mean-shift update,
  * S = Z X^T (src/mean_shift.py:65) and O = K X (:73), on the 16-bit matrix pipe with error-compensated operands -- every

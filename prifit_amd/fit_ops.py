@@ -8,6 +8,7 @@ src/ellipsoid_utils.py:19-27).  Reference sites are cited per function (paths re
 """
 import contextlib
 import ctypes
+import os
 
 import time
 
@@ -232,6 +233,18 @@ def mean_shift_trajectory(X, bw, iterations, keep_kernel, chord=None):
     return Z, saved
 
 
+# How the row-sparse backward runs its T iterations (csrc/meanshift_rows.hip, prifit_meanshift_rows_bwd `mode`):
+#   2  one workgroup per live row runs all T iterations of that row (nothing crosses workgroups): 2 launches;
+#   1  key-tiled iterations as ONE launch over a work queue: 3 launches;  0  one launch per iteration: T + 2 launches.
+# "auto": 2 up to 32 cluster slots per shape (the loss path: ~8 live rows per shape, 148 us against 198 / 221 at B = 24), 1 above
+# (many live rows: the key-tiled forms read the dictionary once for all rows).  profiles/r06_ms_rows.txt.
+MS_ROWS_MODE = os.environ.get("PRIFIT_MS_ROWS_MODE", "auto")
+
+
+def rows_mode(R):
+    return (2 if R <= 32 else 1) if MS_ROWS_MODE == "auto" else int(MS_ROWS_MODE)
+
+
 def rows_supported(N, D, R):
     return bool(query("prifit_meanshift_rows_supported", N, D, R))
 
@@ -277,7 +290,7 @@ class MeanShiftRowsFn(torch.autograd.Function):
         # HBM-bound: per iteration the dictionary is read once (4 B per element); dX read-modified-written once in all (8 B)
         with profiler.span("ms_rows_bwd", 4.0 * Bt * N * D * (T + 2)):
             call("prifit_meanshift_rows_bwd", ptr(X), ptr(bw), Bt, N, D, T, arr(0), arr(4), arr(2), arr(3), arr(5), ptr(ids),
-                 ptr(nrows), R, ptr(g), ptr(ws), ptr(gX), cur_stream())
+                 ptr(nrows), R, ptr(g), ptr(ws), ptr(gX), rows_mode(R), cur_stream())
         return gX, None, None, None, None
 
 

@@ -644,6 +644,28 @@ def test_mean_shift_row_sparse_backward_equals_dense(F, N, D, T, nrows):
         _, traj2 = F.mean_shift_trajectory(X2.detach(), bw.cuda(), T, keep_kernel=False)
     (F.MeanShiftRowsFn.apply(X2, bw.cuda(), ids.cuda(), nr.cuda(), traj2) * G.cuda()).sum().backward()
     assert torch.equal(X2.grad, Xr.grad)
+    # round 6: up to 32 slots the default (mode 2) gives every live row a workgroup of its own that runs all T iterations (no
+    # hand-over between workgroups at all); mode 1 (the default above 32 slots) runs the key-tiled iterations as one launch
+    # over a work queue; mode 0 = one launch per iteration.  Modes 0 and 1 compute the same things in the same order: same
+    # bits.  Mode 2 sums over the keys in another order: fp32 rounding.
+    assert F.MS_ROWS_MODE == "auto" and F.rows_mode(32) == 2 and F.rows_mode(64) == 1
+    got = {}
+    for mode in (0, 1, 2):
+        Xm = X.cuda().requires_grad_(True)
+        F.MS_ROWS_MODE = str(mode)
+        try:
+            (F.MeanShiftRowsFn.apply(Xm, bw.cuda(), ids.cuda(), nr.cuda(), traj2_copy(F, Xm, bw, T)) * G.cuda()).sum().backward()
+        finally:
+            F.MS_ROWS_MODE = "auto"
+        got[mode] = Xm.grad
+    assert torch.equal(got[0], got[1])
+    assert torch.equal(got[F.rows_mode(R)], Xr.grad)
+    torch.testing.assert_close(got[2], got[0], rtol=1e-4, atol=2e-6 * ref.abs().max().item())
+
+
+def traj2_copy(F, X, bw, T):
+    with torch.no_grad():
+        return F.mean_shift_trajectory(X.detach(), bw.cuda(), T, keep_kernel=False)[1]
 
 
 def test_cluster_gradient_same_with_both_mean_shift_engines(F, monkeypatch):
