@@ -416,7 +416,7 @@ SPLIT_NOTE = ("the S = Z X^T and O = K X products of the ten mean-shift updates 
               "fp32.  Passes test_convex_loss_end_to_end, test_selfsup_step_matches_reference_golden and the mean-shift golden "
               "at UNCHANGED tolerances (bf16x6, fp16x3); error of ten updates against fp64 next to the fp32 kernel's: "
               "profiles/r03_split_products.json.  Never the headline: `value` of this line is the fp32 path.")
-FIT_FAMILIES = ("chord_sym", "kth_smallest", "ms_first_fwd", "ms_fused_fwd", "ms_split_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
+FIT_FAMILIES = ("chord_sym", "chord_sym_mask", "kth_smallest", "ms_first_fwd", "ms_fused_fwd", "ms_split_fwd", "ms_rows_bwd", "ms_fused_bwd", "gemm_dual_nn", "nms", "membership",
                 "ellipsoid_fit", "sdf", "sample_nn", "sample_nn_bwd")
 
 

@@ -186,6 +186,12 @@ int prifit_gemm_f32(int layout, int M, int N, int K, const float *A, long long l
  * (src/mean_shift.py:168-170) without a second read of the matrix; hand it to prifit_nms. */
 int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC,
                          int n, int K, int batch, unsigned long long *owner_key, void *stream);
+/* The same product for nms alone (src/mean_shift.py:185-190): with the owner pass fused in (owner_key, REQUIRED by
+ * prifit_nms_mask) all nms reads of the matrix is `dist[u][j] < b` -- one bit.  The matrix is not written: mask [batch, n, n / 32]
+ * uint32, bit (col % 32) of word col / 32 of row `row` = (2 - 2 a_row . a_col < thr[z]) -- the comparison prifit_nms makes, on the
+ * same float.  thr [batch] (the bandwidths). */
+int prifit_chord_sym_mask(const float *A, long long lda, long long strideA, const float *thr, uint32_t *mask, int n, int K, int batch,
+                          unsigned long long *owner_key, void *stream);
 /* The plain product C[z] = A[z] A[z]^T on the same kernel (the `inner` of src/dgcnn.py:13 for a neighbour graph over features,
  * K = 64): the same bits as prifit_gemm_f32(NT, A, A), 136 of 256 tiles computed at n = 2048. */
 int prifit_gram_sym_f32(const float *A, long long lda, long long strideA, float *C, long long ldc, long long strideC, int n, int K,
@@ -729,6 +735,10 @@ int prifit_meanshift_split_fwd(const float *Z, const void *workspace, const floa
 int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N, int D, int cap,
                const unsigned long long *owner_key, int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids,
                int32_t *count, int32_t *labels, int32_t *used, void *stream);
+/* prifit_nms on the mask and keys prifit_chord_sym_mask left (N % 128 == 0; counts 16-byte aligned): same outputs, bit for bit. */
+int prifit_nms_mask(const uint32_t *mask, const float *Z, int B, int N, int D, int cap, const unsigned long long *owner_key,
+                    int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count, int32_t *labels, int32_t *used,
+                    void *stream);
 
 /* The same with centres that are not the points, src/mean_shift.py:162-202 as written: nms(centers, X, b) with
  * centers [B,N,D] and X [B,N,D] two tables of the same row count (upstream's `cluster_nbrs[uniques] * num_mem_cluster`

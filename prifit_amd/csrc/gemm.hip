@@ -920,12 +920,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifndef CHORD_XCD
 #define CHORD_XCD 1     // (A/B builds: -DCHORD_XCD=0 is round 4's (tile, shape) launch order)
 #endif
-// GRAM: the plain product A A^T instead (the pairwise matrix of src/dgcnn.py:13 for the second neighbour graph, K = 64).
-template <bool GRAM>
+// MODE 1 (GRAM): the plain product A A^T instead (the pairwise matrix of src/dgcnn.py:13 for the second neighbour graph, K = 64).
+// MODE 2 (MASK): what nms reads of the matrix once its owner pass is fused in (okey) is ONE BIT per element -- `dist[u][j] < b`
+// in the neighbour pick, src/mean_shift.py:185-190 -- so the matrix is not written at all: mask[z][row][col / 32] bit col % 32
+// = (2 - 2 a_row . a_col < thr[z]), 12.6 MB instead of 403 MB at 24 x 2048 x 2048; the same comparison of the same float.
+template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void chord_sym_kernel(
     const float *__restrict__ A, long long lda, long long sA, float *__restrict__ C, long long ldc, long long sC, int n, int K,
-    int batch, unsigned long long *__restrict__ okey)
+    int batch, unsigned long long *__restrict__ okey, const float *__restrict__ thr, unsigned *__restrict__ mask)
 {
+    constexpr bool GRAM = MODE == 1, MASK = MODE == 2;
     constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NTH = 512, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int SZ = BM * (BK + PAD);
     constexpr int TLD = BM + 4;   // transposed staging: [column of the tile][row], 16-byte aligned rows
@@ -946,7 +950,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tile_n = tile_m + t;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const float *Az = A + (long long)zb * sA;
-    float *Cz = C + (long long)zb * sC;
+    float *Cz = MASK ? nullptr : C + (long long)zb * sC;
+    const int MW = n / 32;                                       // mask words per row
+    unsigned *Mz = MASK ? mask + (long long)zb * n * MW : nullptr;
+    const float th = MASK ? thr[zb] : 0.f;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -1007,7 +1014,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int r = 0; r < 16; ++r) {
             const int row = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float v = GRAM ? acc[b][r] : 2.0f - 2.0f * acc[b][r];   // src/mean_shift.py:154 / :168
-            Cz[(long long)(m0 + row) * ldc + n0 + col] = v;
+            if (MASK) {
+                // the 64 lanes hold two rows x 32 columns of this register: one ballot = one mask word of each
+                const unsigned long long m = __ballot(v < th);
+                if (li == 0) Mz[(long long)(m0 + row) * MW + (n0 + wn0 + 32 * b) / 32] = lh ? (unsigned)(m >> 32) : (unsigned)m;
+            } else {
+                Cz[(long long)(m0 + row) * ldc + n0 + col] = v;
+            }
             if (mirror) lds[col * TLD + row] = v;
             if (v < cmin) { cmin = v; cidx = row; }     // rows ascend with r inside a lane: strict keeps the first
         }
@@ -1020,6 +1033,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if (mirror) {
         __syncthreads();
+        if (MASK) {
+            // thread (row of the transposed tile, word): 32 staged values -> one mask word  (BN * BM / 32 = NTH words)
+            static_assert(BN * (BM / 32) == NTH, "one word per thread");
+            const int trow = threadIdx.x / (BM / 32), w = threadIdx.x - trow * (BM / 32);
+            unsigned bits = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(lds + trow * TLD + 32 * w + 4 * q);
+                bits |= (unsigned)(v.x < th) << (4 * q) | (unsigned)(v.y < th) << (4 * q + 1) | (unsigned)(v.z < th) << (4 * q + 2) |
+                        (unsigned)(v.w < th) << (4 * q + 3);
+            }
+            Mz[(long long)(n0 + trow) * MW + m0 / 32 + w] = bits;
+        } else
         for (int i = threadIdx.x; i < BN * (BM / 4); i += NTH) {
             const int trow = i / (BM / 4), c4 = i - trow * (BM / 4);
             *reinterpret_cast<float4 *>(Cz + (long long)(n0 + trow) * ldc + m0 + 4 * c4) =
@@ -1448,8 +1474,20 @@ int prifit_chord_sym_f32(const float *A, long long lda, long long strideA, float
         (long long)n * lda * 4 >= 0x7ff00000LL)
         return PRIFIT_EINVAL;
     const int T = n / 128;
-    hipLaunchKernelGGL(chord_sym_kernel<false>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
-                       strideA, C, ldc, strideC, n, K, batch, owner_key);
+    hipLaunchKernelGGL(chord_sym_kernel<0>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
+                       strideA, C, ldc, strideC, n, K, batch, owner_key, (const float *)nullptr, (unsigned *)nullptr);
+    return prifit_check_launch();
+}
+
+int prifit_chord_sym_mask(const float *A, long long lda, long long strideA, const float *thr, uint32_t *mask, int n, int K, int batch,
+                          unsigned long long *owner_key, void *stream)
+{
+    if (!A || !thr || !mask || n <= 0 || (n % 128) || K <= 0 || (K % BK) || batch <= 0 || batch > 65535 || lda < K || (lda & 3) ||
+        (strideA & 3) || ((uintptr_t)A & 15) || (long long)n * lda * 4 >= 0x7ff00000LL)
+        return PRIFIT_EINVAL;
+    const int T = n / 128;
+    hipLaunchKernelGGL(chord_sym_kernel<2>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
+                       strideA, (float *)nullptr, 0LL, 0LL, n, K, batch, owner_key, thr, mask);
     return prifit_check_launch();
 }
 
@@ -1461,8 +1499,8 @@ int prifit_gram_sym_f32(const float *A, long long lda, long long strideA, float 
         (long long)n * lda * 4 >= 0x7ff00000LL)
         return PRIFIT_EINVAL;
     const int T = n / 128;
-    hipLaunchKernelGGL(chord_sym_kernel<true>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
-                       strideA, C, ldc, strideC, n, K, batch, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(chord_sym_kernel<1>, dim3((unsigned)(T * (T + 1) / 2 * batch)), dim3(512), 0, as_stream(stream), A, lda,
+                       strideA, C, ldc, strideC, n, K, batch, (unsigned long long *)nullptr, (const float *)nullptr, (unsigned *)nullptr);
     return prifit_check_launch();
 }
 

@@ -306,6 +306,45 @@ __global__ __launch_bounds__(256) void nms_pick_kernel(const float *__restrict__
     if (lane == 0) flags[b * N + bi] = 1;
 }
 
+// The same pick on the bit mask prifit_chord_sym_mask wrote (bit j of row u = dist[u][j] < b): one wave per centre, a lane per
+// mask word -- the 32 counts under a word are read whole, columns ascend inside a lane and across the lanes' words.
+__global__ __launch_bounds__(256) void nms_pick_mask_kernel(const uint32_t *__restrict__ mask, const int32_t *__restrict__ counts,
+                                                            int N, long long rows, int32_t *__restrict__ flags)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long b = row / N;
+    if (counts[row] == 0) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int MW = N / 32;
+    const uint32_t *mr = mask + row * MW;
+    const int32_t *cn = counts + b * N;
+    int best = 0, bi = 0x7fffffff;
+    for (int w = lane; w < MW; w += 64) {
+        const uint32_t bits = mr[w];
+        if (bits == 0) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int4 n4 = *reinterpret_cast<const int4 *>(cn + 32 * w + 4 * q);
+            const int nv[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = (bits >> (4 * q + e)) & 1u ? nv[e] : 0;
+                const int c = 32 * w + 4 * q + e;
+                if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    // (no neighbour with a count: the float form's `v == best && c < bi` ends on column 0)
+    if (lane == 0) flags[b * N + (best == 0 ? 0 : bi)] = 1;
+}
+
 // Ordered compaction of the flagged centre ids (torch.unique sorts ascending): ids[b][0..count) and count[b].
 __global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t *__restrict__ flags, int N, int cap,
                                                           int32_t *__restrict__ ids, int32_t *__restrict__ count)
@@ -590,6 +629,24 @@ int prifit_nms(const float *dist, const float *Z, const float *bw, int B, int N,
     else
         hipLaunchKernelGGL(nms_owner_kernel, grid, block, 0, st, dist, N, rows, owner, counts);
     hipLaunchKernelGGL(nms_pick_kernel, grid, block, 0, st, dist, counts, bw, N, rows, flags);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(B), block, 0, st, flags, N, cap, ids, count);
+    hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, Z, Z, N, D, ids, count, cap, rows, labels, used);
+    return prifit_check_launch();
+}
+
+int prifit_nms_mask(const uint32_t *mask, const float *Z, int B, int N, int D, int cap, const unsigned long long *owner_key,
+                    int32_t *owner, int32_t *counts, int32_t *flags, int32_t *ids, int32_t *count, int32_t *labels, int32_t *used,
+                    void *stream)
+{
+    if (!mask || !Z || !owner_key || !owner || !counts || !flags || !ids || !count || !labels || !used || B <= 0 || N <= 0 || (N % 128) ||
+        D <= 0 || D > 256 || cap <= 0 || ((uintptr_t)counts & 15))
+        return PRIFIT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    const long long rows = (long long)B * N;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (nms_zero(counts, flags, used, rows, (size_t)B * cap, st) != PRIFIT_OK) return PRIFIT_ELAUNCH;
+    hipLaunchKernelGGL(nms_owner_from_keys_kernel, dim3((unsigned)((rows + 255) / 256)), block, 0, st, owner_key, N, rows, owner, counts);
+    hipLaunchKernelGGL(nms_pick_mask_kernel, grid, block, 0, st, mask, counts, N, rows, flags);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(B), block, 0, st, flags, N, cap, ids, count);
     hipLaunchKernelGGL(nms_labels_kernel, grid, block, 0, st, Z, Z, N, D, ids, count, cap, rows, labels, used);
     return prifit_check_launch();

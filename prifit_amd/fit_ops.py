@@ -388,14 +388,17 @@ class MeanShiftFn(torch.autograd.Function):
         return gX, None, None
 
 
+# nms reads ONE BIT per element of its chord matrix once the owner pass is fused into the kernel that forms it: the matrix is
+# then never written (csrc/gemm.hip chord_sym_kernel MODE 2: 12.6 MB of mask instead of 403 MB at B = 24, N = 2048).  0: the
+# float matrix (A/B arm, tested equal).
+NMS_MASK = os.environ.get("PRIFIT_NMS_MASK", "1") != "0"
+
+
 def nms(Z, bw):
     """src/mean_shift.py:162-202 as called at :44 (centers = X = shifted points), batched.
     Returns ids [B,NMS_CAP] (ascending kept centre ids), count [B], labels [B,N], used [B,NMS_CAP]."""
     Bt, N, D = Z.shape
     dev = Z.device
-    keys = [] if FUSE_NMS_OWNER else None
-    dist = chord_matrix(Z, Z, keys)
-    okey = keys[0] if keys else None
     i32 = dict(dtype=torch.int32, device=dev)
     owner = torch.empty(Bt, N, **i32)
     # (counts | flags | used in ONE allocation: prifit_nms zeroes them with one memset when they are adjacent)
@@ -405,6 +408,19 @@ def nms(Z, bw):
     ids = torch.empty(Bt, NMS_CAP, **i32)
     count = torch.empty(Bt, **i32)
     labels = torch.empty(Bt, N, **i32)
+    if (NMS_MASK and FUSE_NMS_OWNER and CHORD_SYM and N % 128 == 0 and D % 32 == 0 and Z.is_contiguous() and Z.data_ptr() % 16 == 0):
+        okey = torch.full((Bt, N), -1, dtype=torch.int64, device=dev)             # all bits set: the atomic-min identity
+        mask = torch.empty(Bt, N, N // 32, **i32)
+        nt = N // 128
+        with profiler.span(profiler.tag("chord_sym_mask", N, D, Bt), 2.0 * Bt * (nt * (nt + 1) // 2) * 128 * 128 * D):
+            call("prifit_chord_sym_mask", ptr(Z), _LL(D), _LL(N * D), ptr(bw), ptr(mask), N, D, Bt, ptr(okey), cur_stream())
+        with profiler.span("nms", Bt * N * N / 8.0):
+            call("prifit_nms_mask", ptr(mask), ptr(Z), Bt, N, D, NMS_CAP, ptr(okey), ptr(owner), ptr(counts), ptr(flags), ptr(ids),
+                 ptr(count), ptr(labels), ptr(used), cur_stream())
+        return ids, count, labels, used
+    keys = [] if FUSE_NMS_OWNER else None
+    dist = chord_matrix(Z, Z, keys)
+    okey = keys[0] if keys else None
     # the chord matrix is read once (neighbour pick) when the owner pass ran in the chord kernel's epilogue, else twice
     with profiler.span("nms", (4.0 if okey is not None else 8.0) * Bt * N * N):
         call("prifit_nms", ptr(dist), ptr(Z), ptr(bw), Bt, N, D, NMS_CAP, ptr(okey), ptr(owner), ptr(counts), ptr(flags), ptr(ids),

@@ -577,11 +577,17 @@ def test_nms_owner_pass_fused_into_the_chord_kernel(F, monkeypatch):
         Zc = Z.cuda().contiguous()
         bw = torch.full((Z.shape[0],), 0.3, device="cuda")
         res = []
-        for fused in (True, False):
-            monkeypatch.setattr(F, "FUSE_NMS_OWNER", fused)
-            res.append(F.nms(Zc, bw))
-        for a, b in zip(*res):
-            assert torch.equal(a, b)
+        # round 6: with the owner pass fused in, nms reads one bit per element -- the default forms a bit mask (dist < b) in the
+        # chord kernel and never writes the matrix (NMS_MASK); per-shape bandwidths, one so small that no neighbour qualifies
+        for bws in (bw, torch.tensor([0.3, 1e-9, 0.7][:Z.shape[0]], device="cuda")):
+            res = []
+            for fused, mask in ((True, True), (True, False), (False, False)):
+                monkeypatch.setattr(F, "FUSE_NMS_OWNER", fused)
+                monkeypatch.setattr(F, "NMS_MASK", mask)
+                res.append(F.nms(Zc, bws))
+            for other in res[1:]:
+                for a, b in zip(res[0], other):
+                    assert torch.equal(a, b)
 
 
 def test_bandwidth_with_more_samples_than_rows(hiplib, golden):

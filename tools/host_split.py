@@ -60,3 +60,20 @@ for k, v in T.items():
     m = st.median(v) * 1e3; tot += m if k != "wait" else 0
     print("%s %-5s median %.3f ms  min %.3f  max %.3f" % (w, k, m, min(v) * 1e3, max(v) * 1e3))
 print("%s host enqueue without the verdict wait: %.3f ms per step" % (w, tot))
+if "--profile" in sys.argv:
+    # where the Python time of a step goes: cProfile over 10 steps from an empty queue (the profiler's own overhead inflates
+    # everything ~1.5-2x; the ORDER is what this is for)
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    for i in range(10):
+        torch.cuda.synchronize()
+        pr.enable()
+        step()
+        pr.disable()
+    torch.cuda.synchronize()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).strip_dirs().sort_stats("tottime").print_stats(45)
+    print(s.getvalue())
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).strip_dirs().sort_stats("cumulative").print_stats(60)
+    print(s.getvalue())
