@@ -126,6 +126,13 @@ int prifit_pack_cols(const float *w, int rows, int src_cols, const int32_t *map,
  * (inv_off [src_cols + 1], inv_idx) of the map's inverse. */
 int prifit_unpack_cols(const float *g, int rows, int dst_cols, const int32_t *inv_off, const int32_t *inv_idx, int src_cols,
                        float *gw, void *stream);
+/* The same for up to prifit_pack_cols_max_jobs() matrices in ONE launch per direction (every first-layer weight of a network
+ * at the top of its forward, their gradients at the end of its backward): HOST arrays of njobs entries each. */
+int prifit_pack_cols_max_jobs(void);
+int prifit_pack_cols_multi(int njobs, const float *const *w, const int32_t *rows, const int32_t *src_cols, const int32_t *const *map,
+                           const int32_t *dst_cols, float *const *out, void *stream);
+int prifit_unpack_cols_multi(int njobs, const float *const *g, const int32_t *rows, const int32_t *dst_cols, const int32_t *const *inv_off,
+                             const int32_t *const *inv_idx, const int32_t *src_cols, float *const *gw, void *stream);
 
 /* out[(b,n), col0 + c] = sum_j weight[b,n,j] * points2[b, idx[b,n,j], c]
  * (models/pointnet_util.py:298).  points2 [B,S,C], out rows have stride ld_out. */

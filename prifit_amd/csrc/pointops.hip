@@ -1,6 +1,8 @@
 // PointNet++ index / grouping kernels for gfx950 (wave64).  Compiled with -ffp-contract=off; every
 // distance uses explicit __f*_rn intrinsics so that the rounding sequence equals the reference's
 // PyTorch-CPU arithmetic (see oracle/prifit_oracle.c for the scalar statement of the same recipes).
+#include <algorithm>
+
 #include "common.h"
 #include "distance.h"
 
@@ -440,6 +442,44 @@ __global__ __launch_bounds__(256) void unpack_cols_kernel(const float *__restric
     }
 }
 
+// Every packed weight of a network in ONE launch per direction (blockIdx.y = the job); the jobs travel by value.
+constexpr int PACK_JOBS = 16;
+struct PackJobs {
+    const float *src[PACK_JOBS];
+    float *dst[PACK_JOBS];
+    const int32_t *map[PACK_JOBS];       // pack: map; unpack: inv_off
+    const int32_t *idx[PACK_JOBS];       // unpack: inv_idx
+    int rows[PACK_JOBS], scols[PACK_JOBS], dcols[PACK_JOBS];
+};
+
+__global__ __launch_bounds__(256) void pack_cols_multi_kernel(PackJobs jb)
+{
+    const int j = blockIdx.y;
+    const float *__restrict__ w = jb.src[j];
+    float *__restrict__ out = jb.dst[j];
+    const int32_t *__restrict__ map = jb.map[j];
+    const int scols = jb.scols[j], dcols = jb.dcols[j], total = jb.rows[j] * dcols;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int r = id / dcols, c = map[id - r * dcols];
+        out[id] = c >= 0 ? w[(size_t)r * scols + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_cols_multi_kernel(PackJobs jb)
+{
+    const int j = blockIdx.y;
+    const float *__restrict__ g = jb.src[j];
+    float *__restrict__ gw = jb.dst[j];
+    const int32_t *__restrict__ inv_off = jb.map[j], *__restrict__ inv_idx = jb.idx[j];
+    const int scols = jb.scols[j], dcols = jb.dcols[j], total = jb.rows[j] * scols;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int r = id / scols, c = id - r * scols;
+        float acc = 0.f;
+        for (int e = inv_off[c]; e < inv_off[c + 1]; ++e) acc += g[(size_t)r * dcols + inv_idx[e]];
+        gw[id] = acc;
+    }
+}
+
 extern "C" {
 
 int prifit_version(const char **arch)
@@ -592,6 +632,42 @@ int prifit_unpack_cols(const float *g, int rows, int dst_cols, const int32_t *in
         return PRIFIT_EINVAL;
     hipLaunchKernelGGL(unpack_cols_kernel, dim3(grid_for((long long)rows * src_cols, 256, 256 * 8)), dim3(256), 0,
                        as_stream(stream), g, rows, dst_cols, inv_off, inv_idx, src_cols, gw);
+    return prifit_check_launch();
+}
+
+int prifit_pack_cols_max_jobs(void) { return PACK_JOBS; }
+
+int prifit_pack_cols_multi(int njobs, const float *const *w, const int32_t *rows, const int32_t *src_cols, const int32_t *const *map,
+                           const int32_t *dst_cols, float *const *out, void *stream)
+{
+    if (njobs <= 0 || njobs > PACK_JOBS || !w || !rows || !src_cols || !map || !dst_cols || !out) return PRIFIT_EINVAL;
+    PackJobs jb = {};
+    long long most = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (!w[j] || !map[j] || !out[j] || rows[j] <= 0 || src_cols[j] <= 0 || dst_cols[j] <= 0 || (long long)rows[j] * dst_cols[j] > 0x7fffffffLL)
+            return PRIFIT_EINVAL;
+        jb.src[j] = w[j]; jb.dst[j] = out[j]; jb.map[j] = map[j]; jb.rows[j] = rows[j]; jb.scols[j] = src_cols[j]; jb.dcols[j] = dst_cols[j];
+        most = std::max(most, (long long)rows[j] * dst_cols[j]);
+    }
+    hipLaunchKernelGGL(pack_cols_multi_kernel, dim3(grid_for(most, 256, 256 * 8), njobs), dim3(256), 0, as_stream(stream), jb);
+    return prifit_check_launch();
+}
+
+int prifit_unpack_cols_multi(int njobs, const float *const *g, const int32_t *rows, const int32_t *dst_cols, const int32_t *const *inv_off,
+                             const int32_t *const *inv_idx, const int32_t *src_cols, float *const *gw, void *stream)
+{
+    if (njobs <= 0 || njobs > PACK_JOBS || !g || !rows || !dst_cols || !inv_off || !inv_idx || !src_cols || !gw) return PRIFIT_EINVAL;
+    PackJobs jb = {};
+    long long most = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (!g[j] || !inv_off[j] || !inv_idx[j] || !gw[j] || rows[j] <= 0 || src_cols[j] <= 0 || dst_cols[j] <= 0 ||
+            (long long)rows[j] * src_cols[j] > 0x7fffffffLL)
+            return PRIFIT_EINVAL;
+        jb.src[j] = g[j]; jb.dst[j] = gw[j]; jb.map[j] = inv_off[j]; jb.idx[j] = inv_idx[j]; jb.rows[j] = rows[j];
+        jb.scols[j] = src_cols[j]; jb.dcols[j] = dst_cols[j];
+        most = std::max(most, (long long)rows[j] * src_cols[j]);
+    }
+    hipLaunchKernelGGL(unpack_cols_multi_kernel, dim3(grid_for(most, 256, 256 * 8), njobs), dim3(256), 0, as_stream(stream), jb);
     return prifit_check_launch();
 }
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from ..nn_ops import LinearFn, SharedMLPFn, cross_entropy
 from .. import arena as zero_pool
-from .pointnet_util import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
+from .pointnet_util import (pack_plan, PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg,
                             _mlp_cfg, _mlp_tensors, batched_bn_counters)
 
 
@@ -68,6 +68,10 @@ class get_model(nn.Module):
         pts = xyz.permute(0, 2, 1).contiguous()           # l0_points (= xyz, also without normals: :69-75)
         l0_xyz = pts[:, :, :3].contiguous() if self.normal_channel else pts
         s1, s2 = fps_start if fps_start is not None else (None, None)
+        with pack_plan(self):    # the column-packed first-layer weights of every module: one launch (and one in the backward)
+            return self._embed_layers(B, N, pts, l0_xyz, cls_label, s1, s2)
+
+    def _embed_layers(self, B, N, pts, l0_xyz, cls_label, s1, s2):
         l1_xyz, l1_points = self.sa1.forward_cl(l0_xyz, pts, s1)
         l2_xyz, l2_points = self.sa2.forward_cl(l1_xyz, l1_points, s2)
         l3_xyz, l3_points = self.sa3.forward_cl(l2_xyz, l2_points)

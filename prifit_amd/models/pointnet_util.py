@@ -10,7 +10,9 @@ Differences that are deliberate and documented (SURVEY.md section 8a'):
   * internally activations are channels-last and input channels are zero-padded to multiples of 4
     (weights are re-packed on the fly; gradients flow back to the upstream-shaped parameters).
 """
+import contextlib
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -104,10 +106,102 @@ class PackColsFn(torch.autograd.Function):
         return gw, None
 
 
+class PackAllFn(torch.autograd.Function):
+    """PackColsFn for every packed weight of a network at once: ONE launch forward (prifit_pack_cols_multi), one backward.
+    apply(specs, *ws) -> tuple of packed matrices; specs[i] = the column map of ws[i]."""
+
+    @staticmethod
+    def forward(ctx, specs, *ws):
+        import ctypes
+        from ..nn_ops import _ptr_array
+        ws = [w.contiguous() for w in ws]
+        idx = [_col_index(cols, w.shape[1], w.device) for cols, w in zip(specs, ws)]
+        outs = [torch.empty(w.shape[0], len(cols), dtype=torch.float32, device=w.device) for cols, w in zip(specs, ws)]
+        n = len(ws)
+        ints = lambda v: (ctypes.c_int32 * n)(*v)
+        call("prifit_pack_cols_multi", n, _ptr_array(ws), ints([w.shape[0] for w in ws]), ints([w.shape[1] for w in ws]),
+             _ptr_array([i[0] for i in idx]), ints([len(c) for c in specs]), _ptr_array(outs), cur_stream())
+        ctx.idx, ctx.shapes = idx, [tuple(w.shape) for w in ws]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        from ..nn_ops import _ptr_array
+        live = [i for i, g in enumerate(gs) if g is not None]
+        gws = [None] * len(gs)
+        if live:
+            g = [gs[i].contiguous() for i in live]
+            out = [torch.empty(ctx.shapes[i], dtype=torch.float32, device=g[0].device) for i in live]
+            n = len(live)
+            ints = lambda v: (ctypes.c_int32 * n)(*v)
+            call("prifit_unpack_cols_multi", n, _ptr_array(g), ints([t.shape[0] for t in g]), ints([t.shape[1] for t in g]),
+                 _ptr_array([ctx.idx[i][1] for i in live]), _ptr_array([ctx.idx[i][2] for i in live]),
+                 ints([ctx.shapes[i][1] for i in live]), _ptr_array(out), cur_stream())
+            for i, o in zip(live, out):
+                gws[i] = o
+        return (None, *gws)
+
+
+class PackPlan:
+    """The packed weights a network asks for during a forward, remembered (first forward) and then produced together at the
+    top of every later forward (`with pack_plan(net):`): 8 + 8 launches of a training step become 1 + 1.  A site that is not in
+    the plan -- the first forward, a weight that appeared later -- takes the single launch and joins."""
+
+    def __init__(self):
+        self.sites, self.keys, self.results = [], set(), None
+
+    def begin(self):
+        self.results = {}
+        if self.sites and _PACK_ALL:
+            outs = PackAllFn.apply(tuple(c for _, c in self.sites), *[p.reshape(p.shape[0], -1) for p, _ in self.sites])
+            self.results = {(id(p), c): o for (p, c), o in zip(self.sites, outs)}
+
+    def lookup(self, w, cols):
+        base = w._base if w._base is not None else w
+        key = (id(base), cols)
+        hit = self.results.get(key)
+        if hit is not None:
+            return hit
+        if key not in self.keys and isinstance(base, nn.Parameter) and len(self.sites) < _pack_max_jobs():
+            self.sites.append((base, cols))
+            self.keys.add(key)
+        return None
+
+
+_PACK_ALL = os.environ.get("PRIFIT_PACK_ALL", "1") != "0"    # 0: one launch per packed weight (A/B)
+_plans = weakref.WeakKeyDictionary()
+_active_plan = None
+
+
+def _pack_max_jobs():
+    return query("prifit_pack_cols_max_jobs")
+
+
+@contextlib.contextmanager
+def pack_plan(net):
+    """Inside: `_pack_cols` serves the weights of `net` from one launch (see PackPlan)."""
+    global _active_plan
+    plan = _plans.get(net)
+    if plan is None:
+        plan = _plans[net] = PackPlan()
+    outer, _active_plan = _active_plan, plan
+    plan.begin()
+    try:
+        yield plan
+    finally:
+        plan.results = None
+        _active_plan = outer
+
+
 def _pack_cols(w, cols):
     cols = tuple(cols)
     if cols == tuple(range(w.shape[1])):
         return w
+    if _active_plan is not None and w.is_cuda:
+        hit = _active_plan.lookup(w, cols)
+        if hit is not None:
+            return hit
     return PackColsFn.apply(w, cols)
 
 

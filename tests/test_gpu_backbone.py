@@ -404,6 +404,44 @@ def test_pack_cols_forward_and_backward(hiplib):
     assert torch.equal(wd.grad[:, 7].cpu(), torch.zeros(37))
 
 
+def test_packed_weights_in_one_launch_give_the_same_step(hiplib, monkeypatch):
+    """Round 6: the column-packed first-layer weights of the MSG network come from ONE launch at the top of the forward
+    (PackAllFn; their gradients from one at the end of the backward) from the second forward on -- the first one discovers
+    the sites.  Copies and fixed-order sums: the same loss bit for bit, the same gradients (to the rounding noise of the atomics in the
+    weight-gradient reductions behind them), and the plan holds all the sites the forward asks for."""
+    from prifit_amd.models import pointnet2_part_seg_msg as M
+    from prifit_amd.models import pointnet_util as PU
+    B, N = 2, 1024
+    xyz = _t(synth.cloud("surface", B, N, 5)).transpose(1, 2).contiguous().cuda()
+    cls = torch.zeros(B, 1, 16, device="cuda")
+    cls[:, 0, 2] = 1.0
+    target = _t(synth.labels(B, N, 50, 5)).cuda()
+    s1, s2 = _t(synth.fps_start(B, N, 5)).cuda(), _t(synth.fps_start(B, 512, 6)).cuda()
+    res = []
+    for all_at_once in (True, False):
+        monkeypatch.setattr(PU, "_PACK_ALL", all_at_once)
+        torch.manual_seed(3)
+        net = M.get_model(50)
+        synth.xavier_like_trainer(net)
+        net.cuda().train()
+        net.drop1.eval()
+        for step in range(2):                         # step 0 discovers the sites, step 1 runs from the plan
+            for p in net.parameters():
+                p.grad = None
+            seg = net(xyz, cls, fps_start=(s1, s2))[0]
+            loss = M.get_loss()(seg.contiguous().view(-1, 50), target.view(-1), None)
+            loss.backward()
+        plan = PU._plans[net]
+        assert len(plan.sites) >= 6 and plan.results is None
+        packed = {k for k, p in net.named_parameters() if any(p is q for q, _ in plan.sites)}
+        res.append((loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, packed))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and res[0][2] == res[1][2] and len(res[0][2]) >= 6
+    for k in res[0][1]:
+        # (the weight gradients come from split-K / slab reductions with atomics: equal to rounding, run to run, with either form)
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=1e-4, atol=1e-7, msg=k)
+
+
 def test_sa_msg_module(hiplib, golden):
     from prifit_amd.models import pointnet_util as pu
     g = golden("module_sa_msg")
