@@ -143,6 +143,12 @@ int prifit_three_interpolate(const float *points2, const int32_t *idx, const flo
 int prifit_three_interpolate_bwd(const float *gout, int ld_gout, int col0, const int32_t *idx,
                                  const float *weight, int B, int N, int S, int C, float *dpoints2,
                                  void *stream);
+/* The input rows of a feature-propagation MLP in one launch (models/pointnet_util.py:287-306): out [B N, kp] =
+ * [interpolated (D2) | points1 (D1) | zeros], interpolated as prifit_three_interpolate; idx == NULL: S == 1, every point takes
+ * points2[b, 0] (:287-288).  points1 [B,N,D1] (NULL when D1 == 0).  Backward: prifit_three_interpolate_bwd on the first D2
+ * columns (ld = kp); the points1 columns are their own gradient. */
+int prifit_fp_rows(const float *points2, const int32_t *idx, const float *weight, const float *points1, int B, int N, int S, int D2,
+                   int D1, int kp, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* dense contraction on the matrix cores (fp32 in / fp32 accumulate MFMA, exact f32)            */

@@ -388,6 +388,36 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(
     }
 }
 
+// The whole input row of a feature-propagation MLP in one pass (models/pointnet_util.py:296-306): [interpolated | points1 | 0-pad]
+// (the build's internal order; upstream concatenates [points1, interpolated]) -- the interpolation, the concatenation and the
+// padding were a kernel + a cat (+ an expand copy when S == 1).  idx == NULL: S == 1, every point takes points2[b, 0] (:287-288).
+__global__ __launch_bounds__(256) void fp_rows_kernel(const float *__restrict__ points2, const int32_t *__restrict__ idx,
+                                                      const float *__restrict__ w, const float *__restrict__ points1, int N, int S,
+                                                      int D2, int D1, int kp, long long total, float *__restrict__ out)
+{
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const long long row = id / kp;  // b*N + n
+        const int c = (int)(id - row * kp);
+        float v = 0.f;
+        if (c < D2) {
+            const float *P = points2 + (size_t)(row / N) * S * D2;
+            if (idx) {
+                const int32_t *ii = idx + row * 3;
+                const float *ww = w + row * 3;
+                // (p0*w0 + p1*w1) + p2*w2, the order of torch.sum over the 3-slot axis (pointnet_util.py:298)
+                v = P[(size_t)ii[0] * D2 + c] * ww[0];
+                v += P[(size_t)ii[1] * D2 + c] * ww[1];
+                v += P[(size_t)ii[2] * D2 + c] * ww[2];
+            } else {
+                v = P[c];
+            }
+        } else if (c < D2 + D1) {
+            v = points1[row * D1 + (c - D2)];
+        }
+        out[id] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void three_interpolate_bwd_kernel(
     const float *__restrict__ gout, int ld, int col0, const int32_t *__restrict__ idx,
     const float *__restrict__ w, int N, int S, int C, long long total, float *__restrict__ dp2)
@@ -601,6 +631,18 @@ int prifit_three_interpolate(const float *points2, const int32_t *idx, const flo
     const long long total = (long long)B * N * C;
     hipLaunchKernelGGL(three_interpolate_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0,
                        as_stream(stream), points2, idx, weight, N, S, C, ld_out, col0, total, out);
+    return prifit_check_launch();
+}
+
+int prifit_fp_rows(const float *points2, const int32_t *idx, const float *weight, const float *points1, int B, int N, int S, int D2,
+                   int D1, int kp, float *out, void *stream)
+{
+    if (!points2 || !out || B <= 0 || N <= 0 || S <= 0 || D2 <= 0 || D1 < 0 || kp < D2 + D1 || (D1 > 0 && !points1) ||
+        (idx ? !weight : S != 1))
+        return PRIFIT_EINVAL;
+    const long long total = (long long)B * N * kp;
+    hipLaunchKernelGGL(fp_rows_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, as_stream(stream), points2, idx, weight,
+                       points1, N, S, D2, D1, kp, total, out);
     return prifit_check_launch();
 }
 

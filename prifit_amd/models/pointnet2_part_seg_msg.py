@@ -98,8 +98,7 @@ class get_model(nn.Module):
             # the NEXT batch's farthest-point sampling here, so that its 640 serial rounds on 24 CUs run beside the
             # matrix-bound mean-shift kernels of this step instead of at the head of the next one
             self.after_backbone()
-        total_loss = torch.zeros(1, device=xyz.device)
-        chamfer_loss = torch.zeros(1, device=xyz.device)
+        total_loss = chamfer_loss = None                    # zeros(1) each unless the convex loss sets them (:96-97)
         extra = ()
         feat_embed = None
         if embed and not include_convex_loss:
@@ -125,6 +124,8 @@ class get_model(nn.Module):
             extra = (labels, params, feat_embed)
         elif embed:
             extra = (None, None, feat_embed.reshape(B, N, 128).permute(0, 2, 1))
+        if total_loss is None:
+            total_loss, chamfer_loss = torch.zeros(1, device=xyz.device), torch.zeros(1, device=xyz.device)
         x = self.drop1(feat)
         logits = LinearFn.apply(x, self.conv2.weight.reshape(self.conv2.weight.shape[0], 128), self.conv2.bias)
         seg = F.log_softmax(logits, dim=1).reshape(B, N, -1)

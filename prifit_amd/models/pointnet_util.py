@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from .. import ops
 from .. import arena as zero_pool
 from .._lib import call, cur_stream, ptr, query
-from ..nn_ops import (GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
+from ..nn_ops import (FpRowsFn, GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
                       ThreeInterpolateFn, _sa_group_launch, sa_group_supported)
 
 
@@ -649,19 +649,23 @@ class PointNetFeaturePropagation(nn.Module):
         S = xyz2.shape[1]
         D2 = points2.shape[-1]
         D1 = 0 if points1 is None else points1.shape[-1]
-        if S == 1:
-            interp = points2.expand(B, N, D2).reshape(B * N, D2)
-        else:
-            idx, w = ops.three_nn(xyz1, xyz2)
-            interp = ThreeInterpolateFn.apply(points2, idx, w)
         kp = _pad4(D1 + D2)
         # internal row layout [interpolated, points1, pad]; upstream concatenates [points1, interpolated] (:306)
-        parts = [interp]
-        if points1 is not None:
-            parts.append(points1.reshape(B * N, D1))
-        if kp > D1 + D2:
-            parts.append(_z(interp, B * N, kp - D1 - D2))
-        rows = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
+        if S > 1 or points1 is not None:
+            idx, w = ops.three_nn(xyz1, xyz2) if S > 1 else (None, None)
+            rows = FpRowsFn.apply(points2, idx, w, points1, kp)          # interpolation + concatenation + padding: one launch
+        else:
+            if S == 1:
+                interp = points2.expand(B, N, D2).reshape(B * N, D2)
+            else:
+                idx, w = ops.three_nn(xyz1, xyz2)
+                interp = ThreeInterpolateFn.apply(points2, idx, w)
+            parts = [interp]
+            if points1 is not None:
+                parts.append(points1.reshape(B * N, D1))
+            if kp > D1 + D2:
+                parts.append(_z(interp, B * N, kp - D1 - D2))
+            rows = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
         if len(self.mlp_convs) == 0:
             return rows[:, :D1 + D2].reshape(B, N, -1)
         w0 = _pack_weight(self.mlp_convs[0], [(D1, D1 + D2), (0, D1)], kp)

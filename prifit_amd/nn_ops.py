@@ -987,6 +987,37 @@ class GroupGatherFn(torch.autograd.Function):
         return dfeat, None, None, None, None, None
 
 
+class FpRowsFn(torch.autograd.Function):
+    """[interpolated | points1 | 0-pad] rows of a feature-propagation MLP, [B N, kp], in one launch (prifit_fp_rows).
+    apply(points2 [B,S,D2], idx [B,N,3] or None (S == 1), weight, points1 [B,N,D1] or None, kp)."""
+
+    @staticmethod
+    def forward(ctx, points2, idx, weight, points1, kp):
+        points2 = points2.contiguous()
+        B, S, D2 = points2.shape
+        N = idx.shape[1] if idx is not None else points1.shape[1]
+        D1 = 0 if points1 is None else points1.shape[-1]
+        p1 = None if points1 is None else points1.contiguous()
+        out = torch.empty(B * N, kp, dtype=torch.float32, device=points2.device)
+        call("prifit_fp_rows", ptr(points2), ptr(idx), ptr(weight), ptr(p1), B, N, S, D2, D1, kp, ptr(out), cur_stream())
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, N, S, D2, D1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        idx, weight = ctx.saved_tensors
+        B, N, S, D2, D1 = ctx.dims
+        g = g.contiguous()
+        if idx is None:      # S == 1: the gradient of the broadcast
+            dp2 = g[:, :D2].reshape(B, N, D2).sum(dim=1, keepdim=True)
+        else:
+            dp2 = ops.three_interpolate_bwd(g, 0, idx, weight, B, S, D2)
+        dp1 = g[:, D2:D2 + D1].reshape(B, N, D1) if D1 else None
+        return dp2, None, None, dp1, None
+
+
 class ThreeInterpolateFn(torch.autograd.Function):
     """interpolated[(b,n), :] = sum_j w[b,n,j] * points2[b, idx[b,n,j], :]"""
 
