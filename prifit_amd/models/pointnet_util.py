@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from .. import ops
 from .. import arena as zero_pool
 from .._lib import call, cur_stream, ptr, query
-from ..nn_ops import (FpRowsFn, GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
+from ..nn_ops import (ConcatWindowsFn, FpRowsFn, GatherLinearFn, GroupGatherFn, LinearFn, SAGroupDirectFn, SAGroupGatherFn, SharedMLPFn,
                       ThreeInterpolateFn, _sa_group_launch, sa_group_supported)
 
 
@@ -604,11 +604,17 @@ class PointNetSetAbstractionMsg(nn.Module):
                                          self.nsample_list, kp, feat_first=True,
                                          fused_gather_bwd=_gather_bwd_ok(mode, self.conv_blocks, N),
                                          first_bns=[b[0] for b in self.bn_blocks] if self.training else None)
+            # the scales write their pooled columns side by side into the level's output (no torch.cat)
+            widths = [blk[-1].weight.shape[0] for blk in self.conv_blocks]
+            wide = torch.empty(B * S, sum(widths), dtype=torch.float32, device=xyz.device)
+            c0 = 0
             for i, K in enumerate(self.nsample_list):
                 cfg = _preact_cfg(_mlp_cfg(self.bn_blocks[i], K, self.training), ys[i][1], ys[i][2])
+                cfg["pool_out"] = wide[:, c0:c0 + widths[i]]
+                c0 += widths[i]
                 pooled.append(SharedMLPFn.apply(ys[i][0], cfg, *_mlp_tensors_preact(self.conv_blocks[i], self.bn_blocks[i],
                                                                                     ys[i][2])))
-            return new_xyz, torch.cat(pooled, dim=-1).reshape(B, S, -1)
+            return new_xyz, ConcatWindowsFn.apply(wide, *pooled).reshape(B, S, -1)
         idxs = ops.ball_query_multi(self.radius_list, self.nsample_list, xyz, new_xyz)  # one pass, all radii
         for i, K in enumerate(self.nsample_list):
             if _use_linearity(self.conv_blocks[i][0], kp):

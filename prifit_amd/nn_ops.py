@@ -343,19 +343,25 @@ class SharedMLPFn(torch.autograd.Function):
         arg = None
         if pool_K:
             G = P // pool_K
-            out = torch.empty(G, CL, dtype=torch.float32, device=dev)
+            # pool_out: a [G, CL] column window of the level's concatenated output (the scales of a multi-scale level write
+            # side by side: no torch.cat); the pool kernels take a leading dimension
+            out = cfg.get("pool_out")
+            if out is None:
+                out = torch.empty(G, CL, dtype=torch.float32, device=dev)
+            elif tuple(out.shape) != (G, CL) or out.stride(1) != 1 or out.dtype != torch.float32 or out.device != x.device:
+                raise ValueError("pool_out must be a [G, C] fp32 column window on the input's device")
             arg = torch.empty(G, CL, dtype=torch.int32, device=dev)
             if cand is not None:
                 call("prifit_pool_from_candidates", ptr(cand), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
-                     ptr(out), _LL(CL), ptr(arg), None, cur_stream())
+                     ptr(out), _LL(out.stride(0)), ptr(arg), None, cur_stream())
             else:
                 call("prifit_pool_fwd", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), G, pool_K, CL, 0, _F(0.0),
-                     ptr(out), _LL(CL), ptr(arg), cur_stream())
+                     ptr(out), _LL(out.stride(0)), ptr(arg), cur_stream())
         else:
             out = torch.empty(P, CL, dtype=torch.float32, device=dev)
             call("prifit_affine_relu", ptr(Ys[-1]), _LL(CL), ptr(prev_aff[0]), ptr(prev_aff[1]), P, CL, 0, _F(0.0),
                  ptr(out), _LL(CL), cur_stream())
-        ctx.cfg = {k: v for k, v in cfg.items() if k not in ("preact_slab", "preact_direct", "preact_gather")}
+        ctx.cfg = {k: v for k, v in cfg.items() if k not in ("preact_slab", "preact_direct", "preact_gather", "pool_out")}
         ctx.preact_gather = gather
         ctx.preact = cfg.get("preact_slab") is not None
         # direct-mode set-abstraction front end: this function owns the gradient of the first conv's weight (tensors[0],
@@ -985,6 +991,25 @@ class GroupGatherFn(torch.autograd.Function):
         gout = gout.contiguous()
         dfeat = ops.group_scatter_add(gout, 0 if order == 0 else 3, idx, B, N, C)
         return dfeat, None, None, None, None, None
+
+
+class ConcatWindowsFn(torch.autograd.Function):
+    """The concatenation of column windows that were written IN PLACE into one buffer (SharedMLPFn cfg["pool_out"]): returns the
+    buffer as a function of the windows -- no copy forward, column slices of the gradient backward.
+    apply(wide [R, sum C_i], *windows) -> [R, sum C_i]."""
+
+    @staticmethod
+    def forward(ctx, wide, *windows):
+        ctx.widths = [w.shape[1] for w in windows]
+        return wide.view_as(wide)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c0 = [], 0
+        for wd in ctx.widths:
+            outs.append(g[:, c0:c0 + wd])
+            c0 += wd
+        return (None, *outs)
 
 
 class FpRowsFn(torch.autograd.Function):
