@@ -348,7 +348,7 @@ class SharedMLPFn(torch.autograd.Function):
             out = cfg.get("pool_out")
             if out is None:
                 out = torch.empty(G, CL, dtype=torch.float32, device=dev)
-            elif tuple(out.shape) != (G, CL) or out.stride(1) != 1 or out.dtype != torch.float32 or out.device != x.device:
+            elif tuple(out.shape) != (G, CL) or out.stride(1) != 1 or out.dtype != torch.float32 or out.device != dev:
                 raise ValueError("pool_out must be a [G, C] fp32 column window on the input's device")
             arg = torch.empty(G, CL, dtype=torch.int32, device=dev)
             if cand is not None:
