@@ -122,6 +122,7 @@ class PackAllFn(torch.autograd.Function):
         call("prifit_pack_cols_multi", n, _ptr_array(ws), ints([w.shape[0] for w in ws]), ints([w.shape[1] for w in ws]),
              _ptr_array([i[0] for i in idx]), ints([len(c) for c in specs]), _ptr_array(outs), cur_stream())
         ctx.idx, ctx.shapes = idx, [tuple(w.shape) for w in ws]
+        ctx.set_materialize_grads(False)      # an output nobody used: None in the backward, its job is skipped
         return tuple(outs)
 
     @staticmethod

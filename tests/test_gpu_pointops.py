@@ -151,3 +151,53 @@ def test_cur_stream_is_the_current_stream(hiplib):
         assert cur_stream() == side.cuda_stream and cur_stream(torch.device("cuda", 0)) == side.cuda_stream
         assert cur_stream("cuda") == side.cuda_stream and cur_stream(0) == side.cuda_stream
     assert (cur_stream() or 0) == torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("B,N,S,D2,D1", [(2, 700, 90, 24, 10), (3, 256, 1, 16, 6), (2, 128, 40, 7, 0), (1, 64, 33, 256, 128)])
+def test_fp_rows_is_interpolate_concat_pad(ops, B, N, S, D2, D1):
+    """prifit_fp_rows (round 6): [interpolated | points1 | 0-pad] rows of a feature-propagation layer in one launch against the
+    three steps it replaces (prifit_three_interpolate / the S == 1 broadcast of models/pointnet_util.py:287-288, torch.cat,
+    zero padding), forward bit for bit (the same products in the same order) and backward through autograd."""
+    from prifit_amd.nn_ops import FpRowsFn, ThreeInterpolateFn
+    gen = torch.Generator().manual_seed(B * N + S)
+    xyz1 = _t(synth.cloud("cube", B, N, 3)).cuda()
+    xyz2 = xyz1[:, :S].contiguous() if S > 1 else xyz1[:, :1].contiguous()
+    p2 = torch.randn(B, S, D2, generator=gen).cuda().requires_grad_(True)
+    p1 = torch.randn(B, N, D1, generator=gen).cuda().requires_grad_(True) if D1 else None
+    kp = (D1 + D2 + 3) // 4 * 4
+    idx, w = ops.three_nn(xyz1, xyz2) if S > 1 else (None, None)
+    rows = FpRowsFn.apply(p2, idx, w, p1, kp)
+    p2r = p2.detach().clone().requires_grad_(True)
+    p1r = p1.detach().clone().requires_grad_(True) if D1 else None
+    interp = ThreeInterpolateFn.apply(p2r, idx, w) if S > 1 else p2r.expand(B, N, D2).reshape(B * N, D2)
+    parts = [interp] + ([p1r.reshape(B * N, D1)] if D1 else []) + ([torch.zeros(B * N, kp - D1 - D2, device="cuda")] if kp > D1 + D2 else [])
+    ref = torch.cat(parts, dim=1)
+    assert rows.shape == (B * N, kp) and torch.equal(rows, ref)
+    G = torch.randn(B * N, kp, generator=gen).cuda()
+    (rows * G).sum().backward()
+    (ref * G).sum().backward()
+    torch.testing.assert_close(p2.grad, p2r.grad, rtol=1e-5, atol=1e-5)      # (atomics in the scatter: rounding order)
+    if D1:
+        assert torch.equal(p1.grad, p1r.grad)
+
+
+def test_pack_cols_multi_equals_single_launches(hiplib):
+    """prifit_pack_cols_multi / prifit_unpack_cols_multi (round 6): several column-packed weights in one launch per direction
+    against PackColsFn one by one -- copies and fixed-order sums: bit for bit; maps with zero columns and repeated sources."""
+    from prifit_amd.models.pointnet_util import PackAllFn, PackColsFn
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(64, 6), (128, 131), (196, 323), (16, 3), (256, 515)]
+    maps = [(3, 4, 5, 0, 1, 2, -1, -1), tuple(range(3, 131)) + (0, 1, 2) + (-1,), tuple(range(3, 323)) + (0, 1, 2, -1),
+            (0, 0, 1, 2), tuple(range(512, 515)) + tuple(range(0, 512)) + (-1,)]
+    ws = [torch.randn(s, generator=gen).cuda().requires_grad_(True) for s in shapes]
+    wr = [w.detach().clone().requires_grad_(True) for w in ws]
+    outs = PackAllFn.apply(tuple(maps), *ws)
+    refs = [PackColsFn.apply(w, m) for w, m in zip(wr, maps)]
+    Gs = [torch.randn(o.shape, generator=gen).cuda() for o in outs]
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+    sum((o * g).sum() for o, g in zip(outs[:-1], Gs[:-1])).backward()       # (the last output unused: its job is skipped)
+    sum((r * g).sum() for r, g in zip(refs[:-1], Gs[:-1])).backward()
+    for a, b in zip(ws[:-1], wr[:-1]):
+        assert torch.equal(a.grad, b.grad)
+    assert ws[-1].grad is None
