@@ -1,5 +1,5 @@
 """Stand-alone timing of the symmetric chord-distance kernel (2 - 2 X X^T, [24, 2048, 128]) and of the kNN selections of the
-DGCNN graphs under the library that is installed (A/B: swap prifit_amd/lib/libprifit_hip.so between runs)."""
+DGCNN graphs (A/B: another build of the library through PRIFIT_LIB; the product library is never overwritten)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
